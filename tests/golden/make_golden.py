@@ -1,0 +1,295 @@
+"""
+Golden-vector generator.  Run ONCE in the build container (where /root/reference is mounted):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference package (pure Python; netCDF4 / h5py are absent in the image and only used by
+file loaders, so empty stand-in modules are registered first -- SURVEY.md 8c), feeds it the seeded
+inputs of tests/golden/inputs.py and stores inputs' seeds + reference OUTPUTS as .npz fixtures next to
+this script.  Nothing of the reference (source, bytecode, pickles of its classes) is written; only
+arrays of numbers.  The GPU box never runs this script and never needs /root/reference.
+"""
+
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import inputs  # noqa: E402
+
+for _name, _attr in (('netCDF4', 'Dataset'), ('h5py', 'File')):
+    if _name not in sys.modules:
+        _mod = types.ModuleType(_name)
+        setattr(_mod, _attr, None)
+        sys.modules[_name] = _mod
+sys.dont_write_bytecode = True
+sys.path.insert(0, '/root/reference')
+import grates  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('{0:28s} {1:9.1f} KB'.format(name, os.path.getsize(path) / 1024))
+
+
+def geographic_colat(step):
+    g = grates.grid.GeographicGrid(step, step)
+    return grates.utilities.colatitude(g.parallels, g.semimajor_axis, g.flattening)
+
+
+# ---- G1 / G2: Legendre functions ---------------------------------------------------------------
+def g1_g2():
+    out = {}
+    for N, step, stride in ((5, 10.0, 1), (60, 1.0, 15), (96, 0.25, 72), (180, 0.5, 90)):
+        colat = np.concatenate((geographic_colat(step)[::stride], inputs.SPECIAL_COLAT))
+        out['colat_{0}'.format(N)] = colat
+        out['pnm_{0}'.format(N)] = grates.utilities.legendre_functions(N, colat)
+        for m in sorted({0, 1, N // 2, N}):
+            out['pnm_order_{0}_{1}'.format(N, m)] = grates.utilities.legendre_functions_per_order(N, m, colat)
+    # first 0.5-degree parallel at N=180 (underflow case SURVEY.md 5.3)
+    out['pnm_0'] = grates.utilities.legendre_functions(0, np.array([0.3, 1.2]))
+    save('g1_legendre', **out)
+
+
+# ---- G3: trigonometric functions -----------------------------------------------------------------
+def g3():
+    out = {}
+    for N, step, stride in ((20, 15.0, 1), (96, 0.25, 240)):
+        lon = grates.grid.GeographicGrid(step, step).meridians[::stride]
+        out['lon_{0}'.format(N)] = lon
+        out['cs_{0}'.format(N)] = grates.utilities.trigonometric_functions(N, lon)
+    lon, lat = inputs.scattered_points(3, 7)
+    colat = 0.5 * np.pi - lat
+    out['ynm_lon'], out['ynm_colat'] = lon, colat
+    out['ynm_12'] = grates.utilities.spherical_harmonics(12, colat, lon)
+    save('g3_trig', **out)
+
+
+# ---- G4: index maps (bit-exact integers) ------------------------------------------------------------
+def g4():
+    out = {}
+    for nmin, nmax in ((0, 5), (2, 5), (0, 60), (2, 96), (0, 180), (3, 3)):
+        tag = '{0}_{1}'.format(nmin, nmax)
+        # ravel an array whose entries are their own flat index: the result IS the gather map
+        flat = np.arange((nmax + 1) ** 2, dtype=np.int64).reshape(nmax + 1, nmax + 1)
+        out['ravel_' + tag] = grates.utilities.ravel_coefficients(flat, nmin, nmax)
+        seq = grates.gravityfield.CoefficientSequenceDegreeWise(nmin, nmax)
+        out['seq_' + tag] = np.array([(c.basis_function, c.degree, c.order) for c in seq.coefficients], dtype=np.int64)
+        if nmax <= 60:
+            vec = np.arange(seq.coefficient_count, dtype=np.int64) + 1
+            out['unravel_' + tag] = grates.utilities.unravel_coefficients(vec, nmin, nmax)
+            for m in sorted({0, 1, nmax // 2, nmax}):
+                out['vidx_{0}_{1}'.format(tag, m)] = seq.vector_indices(order=m)
+                if m > 0:
+                    out['vidx_{0}_{1}_c'.format(tag, m)] = seq.vector_indices(order=m, cs='c')
+                    out['vidx_{0}_{1}_s'.format(tag, m)] = seq.vector_indices(order=m, cs='s')
+    # 3d ravel / 2d unravel, ravel with array smaller than max_degree
+    arr3 = np.arange(3 * 36, dtype=np.int64).reshape(3, 6, 6)
+    out['ravel3d_1_5'] = grates.utilities.ravel_coefficients(arr3, 1, 5)
+    out['ravel_short_0_8'] = grates.utilities.ravel_coefficients(arr3[0], 0, 8)
+    out['unravel2d_1_5'] = grates.utilities.unravel_coefficients(out['ravel3d_1_5'], 1, 5)
+    for n, mo in ((0, None), (4, None), (7, 3)):
+        r, c = grates.gravityfield.degree_indices(n, max_order=mo)
+        out['degidx_{0}_{1}'.format(n, mo)] = np.vstack((r, c))
+    for N, m in ((6, 0), (6, 2), (6, 6)):
+        r, c = grates.gravityfield.order_indices(N, m)
+        out['ordidx_{0}_{1}'.format(N, m)] = np.vstack((r, c))
+    save('g4_index', **out)
+
+
+# ---- G5: ellipsoid geometry + grids ------------------------------------------------------------------
+def g5():
+    out = {}
+    for step in (1.0, 0.25):
+        g = grates.grid.GeographicGrid(step, step)
+        tag = str(step).replace('.', 'p')
+        out['parallels_' + tag] = g.parallels
+        out['meridians_' + tag] = g.meridians
+        out['colat_' + tag] = grates.utilities.colatitude(g.parallels, g.semimajor_axis, g.flattening)
+        out['radius_' + tag] = grates.utilities.geocentric_radius(g.parallels, g.semimajor_axis, g.flattening)
+        out['area_rowsum_' + tag] = g.area.reshape(g.parallels.size, -1).sum(axis=1)
+    g = grates.grid.GeographicGrid(2.0, 5.0)
+    out['geo_2_5_meridians'], out['geo_2_5_parallels'], out['geo_2_5_area'] = g.meridians, g.parallels, g.area
+    out['geo_2_5_lon'], out['geo_2_5_lat'] = g.longitude, g.latitude
+    gg = grates.grid.GaussGrid(31)
+    out['gauss31_meridians'], out['gauss31_parallels'], out['gauss31_area'] = gg.meridians, gg.parallels, gg.area
+    rg = grates.grid.RegularGrid(np.linspace(-3.0, 3.0, 7), np.linspace(1.4, -1.4, 5))
+    out['regular_area'] = rg.area
+    save('g5_geometry', **out)
+
+
+# ---- G6: kernel tables ---------------------------------------------------------------------------------
+def g6():
+    out = {}
+    g = grates.grid.GeographicGrid(1.0, 1.0)
+    lat = g.parallels[::24]
+    colat = grates.utilities.colatitude(lat, g.semimajor_axis, g.flattening)
+    r = grates.utilities.geocentric_radius(lat, g.semimajor_axis, g.flattening)
+    out['lat'], out['colat'], out['r'] = lat, colat, r
+    for name in ('ewh', 'potential', 'geoid', 'obp', 'surface_density', 'anomaly', 'deformation', 'uplift'):
+        ker = grates.kernel.get_kernel(name)
+        out['inv_' + name] = ker.inverse_coefficients(0, 180, r, colat)
+        out['coef_' + name] = ker.coefficients(2, 40, r, colat)
+    ker = grates.kernel.get_kernel('ewh')
+    out['ewh_scalar'] = ker.coefficients(0, 10)
+    out['ewh_coefficient_7'] = ker.coefficient(7, r, colat)
+    out['ewh_inverse_coefficient_0'] = ker.inverse_coefficient(0, r, colat)
+    out['ewh_coef_array_2_6'] = ker.coefficient_array(2, 6)      # multi-point call raises upstream (broadcast bug)
+    out['ewh_inv_array_2_6'] = ker.inverse_coefficient_array(2, 6)
+    for frame in ('CE', 'CM', 'CF'):
+        k, h, l = grates.data.load_love_numbers(frame=frame)
+        out['love_' + frame] = np.vstack((k[0:257], h[0:257], l[0:257]))
+    for radius in (0, 200, 300, 500):
+        out['gauss_{0}'.format(radius)] = grates.kernel.Gauss(radius).coefficients(0, 200)
+    out['gauss_20_ext'] = grates.kernel.Gauss(20).coefficients(1000, 1100)   # exercises the >1024 extension
+    out['gauss_300_psi'] = np.linspace(0, 0.3, 7)
+    out['gauss_300_eval'] = grates.kernel.Gauss(300).evaluate(0, 100, out['gauss_300_psi'])
+    out['normal_gravity'] = grates.gravityfield.GRS80.normal_gravity(r, colat)
+    out['normal_gravity_eq_pole'] = np.array([grates.gravityfield.GRS80.normal_gravity(6378137.0, np.pi / 2)[0],
+                                              grates.gravityfield.GRS80.normal_gravity(6378137.0 * (1 - grates.gravityfield.GRS80.flattening), 0.0)[0]])
+    out['grs80_flattening'] = np.array([grates.gravityfield.GRS80.flattening])
+    out['grs80_anm_col0'] = grates.gravityfield.GRS80.anm[:, 0]
+    out['wgs84_J2'] = np.array([grates.gravityfield.WGS84.J2])
+    save('g6_kernel', **out)
+
+
+# ---- G7: synthesis -----------------------------------------------------------------------------------------
+def potential_coefficients(anm):
+    gf = grates.gravityfield.PotentialCoefficients()
+    gf.anm = anm.copy()
+    return gf
+
+
+def g7():
+    out = {}
+    # C1: d/o 60, Gaussian 300 km, 1 degree, ewh (BASELINE config 1)
+    gf = potential_coefficients(inputs.coefficients(1000, 60))
+    filtered = grates.filter.Gaussian(300).filter(gf)
+    grid = filtered.to_grid(grates.grid.GeographicGrid(1.0, 1.0), kernel='ewh')
+    out['c1_filtered_anm'] = filtered.anm
+    out['c1_grid'] = grid.value_array
+    # C2 unit: d/o 96 -> 0.25 degree, two epochs, strided sample + row sums
+    for e in (0, 1):
+        gf = potential_coefficients(inputs.coefficients(1000 + e, 96))
+        va = gf.to_grid(grates.grid.GeographicGrid(0.25, 0.25), kernel='ewh').value_array
+        out['c2_sample_{0}'.format(e)] = va[::9, ::11].copy()
+        out['c2_rowsum_{0}'.format(e)] = va.sum(axis=1)
+        out['c2_maxabs_{0}'.format(e)] = np.array([np.abs(va).max()])
+    # potential kernel on a Gauss grid
+    gf = potential_coefficients(inputs.coefficients(7, 60))
+    out['gauss61_potential'] = gf.to_grid(grates.grid.GaussGrid(61), kernel='potential').value_array
+    # other kernels, small grid
+    gf = potential_coefficients(inputs.coefficients(8, 30))
+    for name in ('geoid', 'obp', 'potential', 'ewh'):
+        out['n30_5deg_' + name] = gf.to_grid(grates.grid.GeographicGrid(5.0, 5.0), kernel=name).value_array
+    # non-default GM / R
+    gf = grates.gravityfield.PotentialCoefficients(GM=3.986004418e14, R=6378137.0)
+    gf.anm = inputs.coefficients(9, 30)
+    out['n30_5deg_gmr'] = gf.to_grid(grates.grid.GeographicGrid(5.0, 5.0), kernel='ewh').value_array
+    # point-list fallback (no .parallels attribute -> AttributeError path)
+    lon, lat = inputs.scattered_points(11, 1000)
+    gf = potential_coefficients(inputs.coefficients(12, 40))
+    out['points_ewh'] = gf.to_grid(grates.grid.IrregularGrid(lon, lat), kernel='ewh').values
+    # non-symmetric regular grid (general path)
+    mer = np.array([-3.0, -2.2, -0.4, 0.1, 0.9, 2.5, 3.1])
+    par = np.array([1.3, 1.0, 0.2, -0.5, -1.45])
+    out['asym_meridians'], out['asym_parallels'] = mer, par
+    out['asym_potential'] = potential_coefficients(inputs.coefficients(13, 25)).to_grid(grates.grid.RegularGrid(mer, par), kernel='potential').value_array
+    save('g7_synthesis', **out)
+
+
+# ---- G8: analysis ----------------------------------------------------------------------------------------------
+def g8():
+    out = {}
+    grid = potential_coefficients(inputs.coefficients(21, 60)).to_grid(grates.grid.GeographicGrid(1.0, 1.0), kernel='potential')
+    out['n60_1deg_anm'] = grid.to_potential_coefficients(0, 60, kernel='potential').anm
+    grid = potential_coefficients(inputs.coefficients(22, 30)).to_grid(grates.grid.GaussGrid(31), kernel='ewh')
+    out['gauss31_values'] = grid.value_array
+    out['gauss31_anm_ewh_2_30'] = grid.to_potential_coefficients(2, 30, kernel='ewh').anm
+    # analysis of arbitrary (non band-limited) values
+    g = grates.grid.GeographicGrid(5.0, 5.0)
+    g.values = np.random.default_rng(23).standard_normal(g.point_count)
+    out['n20_5deg_random_anm'] = g.to_potential_coefficients(0, 20, kernel='potential').anm
+    out['n8_5deg_analysis_matrix'] = g.analysis_matrix(1, 8, 'potential')
+    out['n8_5deg_synthesis_matrix'] = g.synthesis_matrix(1, 8, 'ewh')
+    save('g8_analysis', **out)
+
+
+# ---- G9: covariance propagation -------------------------------------------------------------------------------------
+def g9():
+    out = {}
+    cov = inputs.spd_covariance(31, 41 * 41)
+    out['n40_2deg_ewh'] = grates.grid.GeographicGrid(2.0, 2.0).covariance_propagation(cov, 0, 40, kernel='ewh')
+    cov = inputs.spd_covariance(32, 21 * 21 - 4)
+    out['n20_5deg_min2_potential'] = grates.grid.GeographicGrid(5.0, 5.0).covariance_propagation(cov, 2, 20, kernel='potential')
+    cov = inputs.spd_covariance(33, 21 * 21)
+    g = grates.grid.GeographicGrid(5.0, 5.0)
+    out['n20_5deg_ewh'] = g.covariance_propagation(cov, 0, 20, kernel='ewh')
+    A = g.synthesis_matrix(0, 20, 'ewh')
+    out['n20_5deg_ewh_einsum'] = np.sqrt(np.einsum('ij,jk,ik->i', A, cov, A))
+    lon, lat = inputs.scattered_points(34, 300)
+    out['points_n20_ewh'] = grates.grid.IrregularGrid(lon, lat).covariance_propagation(cov, 0, 20, kernel='ewh')
+    save('g9_covariance', **out)
+
+
+# ---- G10: filters ----------------------------------------------------------------------------------------------------------
+def g10():
+    out = {}
+    gf = potential_coefficients(inputs.coefficients(41, 60))
+    out['gaussian_300_n60'] = grates.filter.Gaussian(300).filter(gf).anm
+    out['gaussian_500_matrix_2_12_diag'] = np.diag(grates.filter.Gaussian(500).matrix(2, 12))
+    for nmax, ngf in ((20, 20), (120, 120), (120, 96)):
+        blocks = inputs.orderwise_random_blocks(42, nmax)
+        flt = grates.filter.OrderWiseFilter(blocks)
+        gf = potential_coefficients(inputs.coefficients(43, ngf))
+        out['orderwise_{0}_{1}'.format(nmax, ngf)] = flt.filter(gf).anm
+        if nmax == 20:
+            out['orderwise_20_matrix_0_20'] = flt.matrix(0, 20)
+            out['orderwise_20_matrix_2_14'] = flt.matrix(2, 14)
+    # DDK construction from synthetic SPD normals (the real ddk_normal_blocks.npz is absent from the mount)
+    for nmax, level in ((20, 5), (20, 3)):
+        normals = inputs.orderwise_normal_blocks(44, nmax)
+        grates.filter.DDKGeneric._blocked_normals = staticmethod(lambda normals=normals: normals)
+        ddk = grates.filter.DDK(level)
+        gf = potential_coefficients(inputs.coefficients(45, nmax))
+        out['ddk{0}_n{1}'.format(level, nmax)] = ddk.filter(gf).anm
+        out['ddk{0}_n{1}_matrix'.format(level, nmax)] = ddk.matrix(2, nmax)
+        gen = grates.filter.DDKGeneric(level)
+        out['ddkgeneric{0}_n{1}'.format(level, nmax)] = gen.filter(gf).anm
+    # dense matrix filter
+    W = np.random.default_rng(46).standard_normal((21 * 21 - 4, 21 * 21 - 4)) / 21
+    gm = grates.filter.GeneralMatrix(W, 2, 20)
+    out['general_2_20_n20'] = gm.filter(potential_coefficients(inputs.coefficients(47, 20))).anm
+    out['general_2_20_n14'] = gm.filter(potential_coefficients(inputs.coefficients(47, 14))).anm
+    out['general_matrix_3_18'] = gm.matrix(3, 18)
+    # time series -> array
+    series = []
+    import datetime
+    for e in range(4):
+        gf = potential_coefficients(inputs.coefficients(50 + e, 6))
+        gf.epoch = datetime.datetime(2010, 1 + e, 15)
+        series.append(gf)
+    out['timeseries_array'] = grates.gravityfield.TimeSeries(series[::-1]).to_array()
+    # PotentialCoefficients arithmetic
+    a = grates.gravityfield.PotentialCoefficients(GM=3.986004418e14, R=6378137.0)
+    a.anm = inputs.coefficients(60, 8)
+    b = potential_coefficients(inputs.coefficients(61, 12))
+    out['pc_add'] = (a + b).anm
+    out['pc_sub'] = (b - a).anm
+    out['pc_mul'] = (a * 2.5).anm
+    out['pc_slice'] = b.slice(min_degree=2, max_degree=10, min_order=1, max_order=6, step_degree=2).anm
+    out['pc_values'] = b.values
+    d, amp = b.degree_amplitudes(kernel='ewh')
+    out['pc_degree_amplitudes'] = amp
+    save('g10_filter', **out)
+
+
+if __name__ == '__main__':
+    only = sys.argv[1:]
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10):
+        if not only or fn.__name__ in only:
+            fn()
