@@ -1,0 +1,81 @@
+"""
+ctypes binding of libshg.so (include/shg.h).  There is no CPU fallback: if the library is missing or a
+call fails, an exception is raised.
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libshg.so')
+
+c_double_p = ctypes.c_void_p     # device or host pointer passed as integer address
+c_plan_p = ctypes.c_void_p
+
+
+class ShgError(RuntimeError):
+    """A libshg call returned a non-zero status."""
+
+    def __init__(self, function, status, message):
+        super().__init__('{0} failed with status {1}: {2}'.format(function, status, message))
+        self.function = function
+        self.status = status
+
+
+# name -> argument types (all functions return int, except the two string getters)
+PROTOTYPES = {
+    'shg_plan_create': [ctypes.POINTER(c_plan_p), ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int],
+    'shg_plan_destroy': [c_plan_p],
+    'shg_plan_set_chunk': [c_plan_p, ctypes.c_int],
+    'shg_plan_info': [c_plan_p, ctypes.POINTER(ctypes.c_int64)],
+    'shg_synthesis': [c_plan_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_synthesis_points': [ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_legendre': [ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_legendre_order': [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_trigonometric': [ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_ravel': [c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_unravel': [c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_covprop_diag': [c_plan_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_covprop_points': [ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_degree_scale': [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_orderwise_filter': [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_dense_filter': [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_dgemm': [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
+    'shg_analysis': [c_plan_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+}
+STRING_GETTERS = ('shg_last_error', 'shg_version')
+
+_lib = None
+
+
+def load():
+    """Load libshg.so (once).  Raises ImportError with build instructions when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('libshg.so not found at {0}: build it with `make -C grates_amd/csrc` or '
+                          '`python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback.'.format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)            # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    for name in STRING_GETTERS:
+        getattr(lib, name).restype = ctypes.c_char_p
+        getattr(lib, name).argtypes = []
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an int-returning libshg function and raise ShgError on failure."""
+    lib = load()
+    status = getattr(lib, name)(*args)
+    if status != 0:
+        raise ShgError(name, status, lib.shg_last_error().decode())
+    return status
+
+
+def version():
+    return load().shg_version().decode()

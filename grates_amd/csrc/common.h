@@ -1,0 +1,79 @@
+// Shared declarations of libshg (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/shg.h"
+
+namespace shg {
+
+int fail(int code, const char* fmt, ...);
+
+#define SHG_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return shg::fail(SHG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),   \
+                             __FILE__, __LINE__);                                                  \
+    } while (0)
+
+#define SHG_REQUIRE(cond, ...)                                                                     \
+    do {                                                                                           \
+        if (!(cond)) return shg::fail(SHG_ERR_INVALID, __VA_ARGS__);                               \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// packed order-major index of (n, m), n >= m:  off(m) + n - m,  off(m) = m (N+1) - m (m-1) / 2
+__host__ __device__ inline int order_offset(int N, int m) { return m * (N + 1) - (m * (m - 1)) / 2; }
+__host__ __device__ inline int packed_count(int N) { return (N + 1) * (N + 2) / 2; }
+
+constexpr int kEpochTile = 8;    // epochs handled together by one wave of the Legendre stage
+constexpr int kLatTile = 64;     // parallels per wave of the Legendre stage (lane <-> parallel)
+
+}  // namespace shg
+
+// Device-resident tables of one (degree, parallels, kn, meridians) configuration.
+struct shg_plan {
+    int device = 0;
+    int N = 0, nlat = 0, nlon = 0;
+    int ldlat = 0;          // nlat rounded up to 64: leading dimension of per-parallel tables / F
+    bool sym4 = false;      // 4-fold longitude symmetry path
+    int ngroups = 1;        // 4 (sym4) or 1
+    int goff[5] = {0, 0, 0, 0, 0};   // first K slot of each group (multiples of 4), goff[ngroups] = K
+    int K = 0;              // total K slots of the longitude stage (multiple of 4)
+    int ncol = 0;           // output columns per group: nlon/4 (sym4) or nlon
+    int ncoltiles = 0;      // ceil(ncol / 16)
+    int chunk = 16;         // epochs per pass
+
+    // device tables
+    double* ct = nullptr;       // [ldlat] cos(colat)
+    double* st = nullptr;       // [ldlat] sin(colat)
+    double* pmm = nullptr;      // [N+1][ldlat] sectorial seeds P_mm(theta_i)
+    double* knT = nullptr;      // [N+1][ldlat] kn transposed
+    double* arec = nullptr;     // [packed] recursion factor a_nm
+    double* brec = nullptr;     // [packed] recursion factor b_nm
+    double* trig = nullptr;     // [ncoltiles][K][16] cos/sin table, column-tile major
+    double* lon = nullptr;      // [nlon]
+    double* colat = nullptr;    // [nlat]
+    // covariance-propagation tables (built lazily)
+    double* pk_deg = nullptr;   // [nlat][Pfull] kn-scaled P_nm in degree-wise order (nmin = 0)
+    double* cs_slot = nullptr;  // [2N+1][nlon] cos/sin per slot (0, 1c, 1s, 2c, 2s, ...)
+    // workspace
+    double* cpk = nullptr;      // [packed][2][chunk_pad] repacked coefficients of one pass
+    double* F = nullptr;        // [chunk][K][ldlat] output of the Legendre stage
+    int chunk_alloc = 0;
+    void* aux = nullptr;        // analysis tables (analysis.hip)
+};
+
+namespace shg {
+int plan_alloc_workspace(shg_plan* p);
+void plan_free_aux(shg_plan* p);
+}  // namespace shg

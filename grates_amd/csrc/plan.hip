@@ -1,0 +1,204 @@
+// Plan creation: host-side generation of the small per-plan tables (recursion factors, sectorial
+// seeds, cos/sin tables) and their upload.  Table arithmetic keeps the reference's expression order
+// (grates/utilities.py:41-54) so that the Legendre values are bit-identical to the NumPy ones.
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "common.h"
+
+namespace shg {
+
+static thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+// a_nm / b_nm of  P_nm = (a_nm t) P_(n-1)m - b_nm P_(n-2)m   in packed order-major layout.
+//   n == m     : unused (seed), a = b = 0
+//   n == m + 1 : a = sqrt(2n + 1), b = 0                                    utilities.py:45-47
+//   n >= m + 2 : a = sqrt((2n-1)/(n-m) (2n+1)/(n+m)),
+//                b = sqrt((2n+1)/(2n-3) (n-m-1)/(n-m) (n+m-1)/(n+m))        utilities.py:49-54
+void recursion_tables(int N, std::vector<double>& a, std::vector<double>& b) {
+    a.assign(packed_count(N), 0.0);
+    b.assign(packed_count(N), 0.0);
+    for (int m = 0; m <= N; ++m) {
+        for (int ni = m + 1; ni <= N; ++ni) {
+            const int idx = order_offset(N, m) + ni - m;
+            const double n = ni, mm = m;
+            if (ni == m + 1) {
+                a[idx] = std::sqrt((double)(2 * ni + 1));
+            } else {
+                a[idx] = std::sqrt((2.0 * n - 1.0) / (n - mm) * (2.0 * n + 1.0) / (n + mm));
+                b[idx] = std::sqrt((2.0 * n + 1.0) / (2.0 * n - 3.0) * (n - mm - 1.0) / (n - mm) * (n + mm - 1.0) / (n + mm));
+            }
+        }
+    }
+}
+
+static int upload(double** dst, const std::vector<double>& src) {
+    SHG_HIP(hipMalloc((void**)dst, std::max<size_t>(src.size(), 1) * sizeof(double)));
+    if (!src.empty()) SHG_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice));
+    return SHG_OK;
+}
+
+// True when meridians obey lon[nlon-1-j] = -lon[j], lon[nlon/2-1-j] = -pi - lon[j], lon[nlon/2+j] = lon[j] + pi
+// to within a few ulp of pi (any equi-angular cell-centred grid, grates/grid.py:1149, 1186).
+static bool has_fourfold_symmetry(int nlon, const double* lon) {
+    if (nlon < 4 || nlon % 4 != 0) return false;
+    const double tol = 2e-15;
+    const double pi = 3.14159265358979323846;
+    for (int j = 0; j < nlon / 4; ++j) {
+        if (std::fabs(lon[nlon - 1 - j] + lon[j]) > tol) return false;
+        if (std::fabs(lon[nlon / 2 - 1 - j] + pi + lon[j]) > tol) return false;
+        if (std::fabs(lon[nlon / 2 + j] - pi - lon[j]) > tol) return false;
+    }
+    return true;
+}
+
+int plan_alloc_workspace(shg_plan* p) {
+    if (p->chunk_alloc == p->chunk && p->F) return SHG_OK;
+    if (p->cpk) (void)hipFree(p->cpk);
+    if (p->F) (void)hipFree(p->F);
+    p->cpk = p->F = nullptr;
+    const int chunk_pad = round_up(p->chunk, kEpochTile);
+    const size_t ncpk = (size_t)packed_count(p->N) * 2 * chunk_pad;
+    const size_t nF = (size_t)chunk_pad * p->K * p->ldlat;
+    if (hipMalloc((void**)&p->cpk, ncpk * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->F, nF * sizeof(double)) != hipSuccess)
+        return fail(SHG_ERR_NOMEM, "workspace allocation failed (%zu + %zu doubles)", ncpk, nF);
+    // padding slots / padding epochs must hold finite numbers: they meet zero table rows in the MFMA
+    SHG_HIP(hipMemset(p->cpk, 0, ncpk * sizeof(double)));
+    SHG_HIP(hipMemset(p->F, 0, nF * sizeof(double)));
+    p->chunk_alloc = p->chunk;
+    return SHG_OK;
+}
+
+}  // namespace shg
+
+using namespace shg;
+
+extern "C" const char* shg_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* shg_version(void) { return "libshg 0.1 (gfx950)"; }
+
+extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* colat_h, const double* kn_h,
+                               int nlon, const double* lon_h, int device) {
+    SHG_REQUIRE(out != nullptr, "shg_plan_create: out is NULL");
+    *out = nullptr;
+    SHG_REQUIRE(N >= 0 && N <= 2047, "shg_plan_create: degree %d out of range [0, 2047]", N);
+    SHG_REQUIRE(nlat > 0 && nlon > 0, "shg_plan_create: empty grid (%d x %d)", nlat, nlon);
+    SHG_REQUIRE(colat_h && kn_h && lon_h, "shg_plan_create: NULL table pointer");
+    SHG_HIP(hipSetDevice(device));
+
+    shg_plan* p = new shg_plan();
+    p->device = device;
+    p->N = N;
+    p->nlat = nlat;
+    p->nlon = nlon;
+    p->ldlat = round_up(nlat, kLatTile);
+    p->sym4 = has_fourfold_symmetry(nlon, lon_h);
+
+    // ---- K slots of the longitude stage
+    if (p->sym4) {
+        const int cnt[4] = {N / 2 + 1, (N + 1) / 2, N / 2, (N + 1) / 2};   // cos even, cos odd, sin even, sin odd
+        p->ngroups = 4;
+        p->goff[0] = 0;
+        for (int g = 0; g < 4; ++g) p->goff[g + 1] = p->goff[g] + round_up(cnt[g], 4);
+        p->ncol = nlon / 4;
+    } else {
+        p->ngroups = 1;
+        p->goff[0] = 0;
+        p->goff[1] = round_up(2 * N + 1, 4);
+        p->ncol = nlon;
+    }
+    p->K = p->goff[p->ngroups];
+    p->ncoltiles = ceil_div(p->ncol, 16);
+
+    // ---- per-parallel tables, padded to ldlat with zeros
+    std::vector<double> ct(p->ldlat, 0.0), st(p->ldlat, 0.0);
+    std::vector<double> pmm((size_t)(N + 1) * p->ldlat, 0.0), knT((size_t)(N + 1) * p->ldlat, 0.0);
+    for (int i = 0; i < nlat; ++i) {
+        ct[i] = std::cos(colat_h[i]);
+        st[i] = std::sin(colat_h[i]);
+        double pv = 1.0;                                             // P_00
+        pmm[i] = pv;
+        for (int n = 1; n <= N; ++n) {
+            if (n == 1)
+                pv = std::sqrt(3.0) * st[i];                         // utilities.py:39
+            else
+                pv = std::sqrt((2.0 * n + 1.0) / (2.0 * n)) * st[i] * pv;   // utilities.py:42-43
+            pmm[(size_t)n * p->ldlat + i] = pv;
+        }
+        for (int n = 0; n <= N; ++n) knT[(size_t)n * p->ldlat + i] = kn_h[(size_t)i * (N + 1) + n];
+    }
+    std::vector<double> a, b;
+    recursion_tables(N, a, b);
+
+    // ---- cos/sin table [coltile][K][16]
+    std::vector<double> trig((size_t)p->ncoltiles * p->K * 16, 0.0);
+    auto put = [&](int slot, int m, bool sine) {
+        for (int j = 0; j < p->ncol; ++j) {
+            const double arg = (double)m * lon_h[j];                 // utilities.py:272-273: cos(m * lon)
+            trig[((size_t)(j / 16) * p->K + slot) * 16 + (j % 16)] = sine ? std::sin(arg) : std::cos(arg);
+        }
+    };
+    if (p->sym4) {
+        for (int m = 0; m <= N; ++m) {
+            put(p->goff[m & 1] + m / 2, m, false);
+            if (m >= 1) put(p->goff[2 + (m & 1)] + ((m & 1) ? m / 2 : m / 2 - 1), m, true);
+        }
+    } else {
+        for (int m = 0; m <= N; ++m) {
+            put(m, m, false);
+            if (m >= 1) put(N + m, m, true);
+        }
+    }
+
+    int rc = SHG_OK;
+    if ((rc = upload(&p->ct, ct)) || (rc = upload(&p->st, st)) || (rc = upload(&p->pmm, pmm)) ||
+        (rc = upload(&p->knT, knT)) || (rc = upload(&p->arec, a)) || (rc = upload(&p->brec, b)) ||
+        (rc = upload(&p->trig, trig)) ||
+        (rc = upload(&p->lon, std::vector<double>(lon_h, lon_h + nlon))) ||
+        (rc = upload(&p->colat, std::vector<double>(colat_h, colat_h + nlat)))) {
+        shg_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return SHG_OK;
+}
+
+extern "C" int shg_plan_destroy(shg_plan* p) {
+    if (!p) return SHG_OK;
+    double* ptrs[] = {p->ct, p->st, p->pmm, p->knT, p->arec, p->brec, p->trig, p->lon, p->colat,
+                      p->pk_deg, p->cs_slot, p->cpk, p->F};
+    for (double* q : ptrs)
+        if (q) (void)hipFree(q);
+    plan_free_aux(p);
+    delete p;
+    return SHG_OK;
+}
+
+extern "C" int shg_plan_set_chunk(shg_plan* p, int epochs_per_pass) {
+    SHG_REQUIRE(p != nullptr, "shg_plan_set_chunk: NULL plan");
+    SHG_REQUIRE(epochs_per_pass >= 1 && epochs_per_pass <= 4096, "shg_plan_set_chunk: %d out of range", epochs_per_pass);
+    p->chunk = epochs_per_pass;
+    return SHG_OK;
+}
+
+extern "C" int shg_plan_info(const shg_plan* p, int64_t which[6]) {
+    SHG_REQUIRE(p != nullptr && which != nullptr, "shg_plan_info: NULL argument");
+    which[0] = p->N;
+    which[1] = p->nlat;
+    which[2] = p->nlon;
+    which[3] = p->sym4 ? 1 : 0;
+    which[4] = p->chunk;
+    which[5] = p->K;
+    return SHG_OK;
+}

@@ -1,0 +1,275 @@
+"""
+Device engine: thin Python wrappers around libshg.  Arrays live on the GPU as torch tensors (fp64,
+contiguous); every routine hands raw device pointers and the current HIP stream to the C ABI.
+
+Nothing in here computes on the CPU: without the library or without a GPU the calls raise.
+"""
+
+import ctypes
+import hashlib
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError('grates_amd: no GPU visible -- the hot path runs on MI355X only (there is no CPU fallback)')
+    _lib.load()
+    return torch
+
+
+def device(index=None):
+    torch = require_gpu()
+    return torch.device('cuda', torch.cuda.current_device() if index is None else index)
+
+
+def to_device(x, dev=None):
+    """fp64 contiguous device tensor from ndarray / tensor / scalar sequence."""
+    torch = require_gpu()
+    dev = device() if dev is None else dev
+    if isinstance(x, torch.Tensor):
+        return x.to(device=dev, dtype=torch.float64).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64))).to(dev)
+
+
+def to_host(t):
+    return t.detach().cpu().numpy()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _host_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Plan:
+    """
+    Device tables for one (max_degree, parallels, kn table, meridians) configuration
+    (shg_plan_create).  `colat` [nlat] geocentric colatitudes, `kn` [nlat, N+1], `meridians` [nlon].
+    """
+
+    def __init__(self, max_degree, colat, kn, meridians, device_index=None):
+        torch = require_gpu()
+        self.device = device(device_index)
+        self.max_degree = int(max_degree)
+        colat = np.ascontiguousarray(colat, dtype=np.float64)
+        kn = np.ascontiguousarray(kn, dtype=np.float64)
+        meridians = np.ascontiguousarray(meridians, dtype=np.float64)
+        if kn.shape != (colat.size, self.max_degree + 1):
+            raise ValueError('kn must have shape (nlat, max_degree + 1), got {0}'.format(kn.shape))
+        self.nlat, self.nlon = colat.size, meridians.size
+        self._handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.call('shg_plan_create', ctypes.byref(self._handle), self.max_degree, self.nlat, _host_ptr(colat),
+                      _host_ptr(kn), self.nlon, _host_ptr(meridians), self.device.index)
+
+    def __del__(self):
+        handle = getattr(self, '_handle', None)
+        if handle is not None and handle.value:
+            try:
+                _lib.load().shg_plan_destroy(handle)
+            except Exception:
+                pass
+            self._handle = ctypes.c_void_p()
+
+    def info(self):
+        arr = (ctypes.c_int64 * 6)()
+        _lib.call('shg_plan_info', self._handle, arr)
+        return {'max_degree': arr[0], 'nlat': arr[1], 'nlon': arr[2], 'fourfold_symmetry': bool(arr[3]),
+                'epochs_per_pass': arr[4], 'k_slots': arr[5]}
+
+    def set_chunk(self, epochs_per_pass):
+        _lib.call('shg_plan_set_chunk', self._handle, int(epochs_per_pass))
+
+    def synthesis(self, anm, out=None):
+        """anm [B, N+1, N+1] (or [N+1, N+1]) -> grid [B, nlat, nlon] (device tensor)."""
+        torch = _torch()
+        x = to_device(anm, self.device)
+        single = x.dim() == 2
+        if single:
+            x = x.unsqueeze(0)
+        n1 = self.max_degree + 1
+        if x.dim() != 3 or x.shape[1] != n1 or x.shape[2] != n1:
+            raise ValueError('coefficient batch must have shape (B, {0}, {0}), got {1}'.format(n1, tuple(x.shape)))
+        B = x.shape[0]
+        if out is None:
+            out = torch.empty((B, self.nlat, self.nlon), dtype=torch.float64, device=self.device)
+        elif tuple(out.shape) != (B, self.nlat, self.nlon) or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError('out must be a contiguous fp64 tensor of shape {0}'.format((B, self.nlat, self.nlon)))
+        with torch.cuda.device(self.device):
+            _lib.call('shg_synthesis', self._handle, _ptr(x), B, _ptr(out), _stream())
+        return out[0] if single else out
+
+    def covariance_propagation(self, cov, min_degree, lat0=0, lat1=None):
+        """cov [P, P] degree-wise -> sigma [(lat1-lat0)*nlon] for the band of parallels [lat0, lat1)."""
+        torch = _torch()
+        lat1 = self.nlat if lat1 is None else lat1
+        c = to_device(cov, self.device)
+        P = (self.max_degree + 1) ** 2 - min_degree ** 2
+        if c.dim() != 2 or c.shape[0] != P or c.shape[1] != P:
+            raise ValueError('covariance matrix must have shape ({0}, {0}), got {1}'.format(P, tuple(c.shape)))
+        out = torch.empty(((lat1 - lat0) * self.nlon,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.call('shg_covprop_diag', self._handle, _ptr(c), int(min_degree), int(lat0), int(lat1), _ptr(out), _stream())
+        return out
+
+    def analysis(self, grid, area, min_degree):
+        """grid [B, nlat, nlon], area [nlat, nlon] -> anm [B, N+1, N+1]."""
+        torch = _torch()
+        g = to_device(grid, self.device)
+        single = g.dim() == 2
+        if single:
+            g = g.unsqueeze(0)
+        a = to_device(area, self.device).reshape(self.nlat, self.nlon)
+        n1 = self.max_degree + 1
+        out = torch.zeros((g.shape[0], n1, n1), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.call('shg_analysis', self._handle, _ptr(g), _ptr(a), int(min_degree), g.shape[0], _ptr(out), _stream())
+        return out[0] if single else out
+
+
+_plan_cache = {}
+_PLAN_CACHE_LIMIT = 8
+
+
+def cached_plan(max_degree, colat, kn, meridians):
+    """Plans are cached by content so that repeated to_grid calls reuse the device tables."""
+    torch = require_gpu()
+    h = hashlib.blake2b(digest_size=16)
+    for a in (np.int64(max_degree), np.int64(torch.cuda.current_device()), colat, kn, meridians):
+        h.update(np.ascontiguousarray(a).tobytes())
+    key = h.hexdigest()
+    plan = _plan_cache.get(key)
+    if plan is None:
+        if len(_plan_cache) >= _PLAN_CACHE_LIMIT:
+            _plan_cache.pop(next(iter(_plan_cache)))
+        plan = Plan(max_degree, colat, kn, meridians)
+        _plan_cache[key] = plan
+    return plan
+
+
+def clear_plan_cache():
+    _plan_cache.clear()
+
+
+# ---------------------------------------------------------------------------------------------------
+# table functions / index maps
+# ---------------------------------------------------------------------------------------------------
+
+def legendre_functions(max_degree, colat):
+    torch = require_gpu()
+    th = to_device(np.atleast_1d(colat))
+    out = torch.empty((th.numel(), max_degree + 1, max_degree + 1), dtype=torch.float64, device=th.device)
+    _lib.call('shg_legendre', int(max_degree), _ptr(th), th.numel(), _ptr(out), _stream())
+    return out
+
+
+def legendre_functions_per_order(max_degree, order, colat):
+    torch = require_gpu()
+    th = to_device(np.atleast_1d(colat))
+    out = torch.empty((th.numel(), max_degree + 1 - order), dtype=torch.float64, device=th.device)
+    _lib.call('shg_legendre_order', int(max_degree), int(order), _ptr(th), th.numel(), _ptr(out), _stream())
+    return out
+
+
+def trigonometric_functions(max_degree, lon):
+    torch = require_gpu()
+    lam = to_device(np.atleast_1d(lon))
+    out = torch.empty((lam.numel(), max_degree + 1, max_degree + 1), dtype=torch.float64, device=lam.device)
+    _lib.call('shg_trigonometric', int(max_degree), _ptr(lam), lam.numel(), _ptr(out), _stream())
+    return out
+
+
+def ravel(arr, min_degree, max_degree):
+    """arr [B, Na+1, Na+1] device tensor -> [B, P] degree-wise."""
+    torch = require_gpu()
+    x = to_device(arr)
+    B, na = x.shape[0], x.shape[-1] - 1
+    P = (max_degree + 1) ** 2 - min_degree ** 2
+    out = torch.empty((B, max(P, 0)), dtype=torch.float64, device=x.device)
+    _lib.call('shg_ravel', _ptr(x), B, na, int(min_degree), int(max_degree), _ptr(out), _stream())
+    return out
+
+
+def unravel(vec, min_degree, max_degree):
+    """vec [B, P] device tensor -> [B, nmax+1, nmax+1]."""
+    torch = require_gpu()
+    v = to_device(vec)
+    B = v.shape[0]
+    out = torch.empty((B, max_degree + 1, max_degree + 1), dtype=torch.float64, device=v.device)
+    _lib.call('shg_unravel', _ptr(v), B, int(min_degree), int(max_degree), _ptr(out), _stream())
+    return out
+
+
+def degree_scale(anm, weights, first_degree):
+    """anm [B, N+1, N+1] scaled by weights[n] for every degree n >= first_degree."""
+    torch = require_gpu()
+    x = to_device(anm)
+    N = x.shape[-1] - 1
+    w = to_device(weights)
+    if w.numel() != N + 1:
+        raise ValueError('weights must have max_degree + 1 entries')
+    out = torch.empty_like(x)
+    _lib.call('shg_degree_scale', _ptr(w), N, int(first_degree), _ptr(x), x.shape[0], _ptr(out), _stream())
+    return out
+
+
+def synthesis_points(max_degree, colat, lon, kn, anm):
+    """Point-list synthesis: colat/lon [npts], kn [npts, N+1], anm [B, N+1, N+1] -> [B, npts]."""
+    torch = require_gpu()
+    th, lam, k, x = to_device(colat), to_device(lon), to_device(kn), to_device(anm)
+    out = torch.empty((x.shape[0], th.numel()), dtype=torch.float64, device=x.device)
+    _lib.call('shg_synthesis_points', int(max_degree), _ptr(th), _ptr(lam), _ptr(k), th.numel(), _ptr(x), x.shape[0], _ptr(out), _stream())
+    return out
+
+
+def covprop_points(max_degree, colat, lon, kn, cov, min_degree):
+    torch = require_gpu()
+    th, lam, k, c = to_device(colat), to_device(lon), to_device(kn), to_device(cov)
+    out = torch.empty((th.numel(),), dtype=torch.float64, device=c.device)
+    _lib.call('shg_covprop_points', int(max_degree), _ptr(th), _ptr(lam), _ptr(k), th.numel(), _ptr(c), int(min_degree), _ptr(out), _stream())
+    return out
+
+
+def orderwise_filter(blocks_packed, block_offsets, block_max_degree, anm):
+    """blocks_packed: 1d device tensor, block_offsets: int64 device tensor [2Nb+1]; anm [B, N+1, N+1]."""
+    torch = require_gpu()
+    x = to_device(anm)
+    out = torch.empty_like(x)
+    _lib.call('shg_orderwise_filter', _ptr(blocks_packed), _ptr(block_offsets), int(block_max_degree), x.shape[-1] - 1,
+              _ptr(x), x.shape[0], _ptr(out), _stream())
+    return out
+
+
+def dense_filter(W, X):
+    """Y = W @ X, W [P, P], X [P, T] device tensors."""
+    torch = require_gpu()
+    W, X = to_device(W), to_device(X)
+    out = torch.empty_like(X)
+    _lib.call('shg_dense_filter', _ptr(W), W.shape[0], _ptr(X), X.shape[1], _ptr(out), _stream())
+    return out
+
+
+def dgemm(A, B):
+    """C = A @ B on the fp64 MFMA GEMM (row-major device tensors)."""
+    torch = require_gpu()
+    A, B = to_device(A), to_device(B)
+    M, K = A.shape
+    N = B.shape[1]
+    out = torch.empty((M, N), dtype=torch.float64, device=A.device)
+    _lib.call('shg_dgemm', M, N, K, _ptr(A), K, _ptr(B), N, _ptr(out), N, _stream())
+    return out

@@ -1,0 +1,515 @@
+"""
+Point distributions on the ellipsoid with the interface of ``grates.grid``: the ``Grid`` base class with
+its area-weighted statistics (grates/grid.py:92-507), ``RegularGrid`` (:510-839), ``IrregularGrid``
+(:842-1120), ``GeographicGrid`` (:1123-1162) and ``GaussGrid`` (:1165-1204), plus the coordinate helpers the
+kernels need.  Reuter / geodesic / mascon grids, basins and point-in-polygon tests are host-side geometry
+and out of scope.
+
+Heavy operators -- ``to_potential_coefficients`` (analysis), ``covariance_propagation``,
+``synthesis_matrix`` / ``analysis_matrix`` -- run on the GPU through libshg.
+"""
+
+import abc
+
+import numpy as np
+
+from . import engine, kernel as _kernel, utilities
+from . import gravityfield as _gravityfield
+
+_GM = 3.9860044150e+14
+_R = 6.3781363000e+06
+
+
+class Grid(metaclass=abc.ABCMeta):
+    """Base interface for point collections."""
+
+    @abc.abstractmethod
+    def copy(self):
+        pass
+
+    @property
+    @abc.abstractmethod
+    def semimajor_axis(self):
+        pass
+
+    @property
+    @abc.abstractmethod
+    def flattening(self):
+        pass
+
+    @property
+    @abc.abstractmethod
+    def longitude(self):
+        pass
+
+    @property
+    @abc.abstractmethod
+    def latitude(self):
+        pass
+
+    @property
+    @abc.abstractmethod
+    def area(self):
+        pass
+
+    @abc.abstractmethod
+    def values(self):
+        pass
+
+    @abc.abstractmethod
+    def point_count(self):
+        pass
+
+    @property
+    def size(self):
+        return self.point_count
+
+    @property
+    def colatitude(self):
+        return utilities.colatitude(self.latitude, self.semimajor_axis, self.flattening)
+
+    def is_compatible(self, other):
+        """True if both grids have numerically equal point coordinates."""
+        if self.point_count == other.point_count:
+            return np.allclose(self.longitude, other.longitude) and np.allclose(self.latitude, other.latitude)
+        return False
+
+    def cartesian_coordinates(self):
+        return geodetic2cartesian(self.longitude, self.latitude, h=0, a=self.semimajor_axis, f=self.flattening)
+
+    # ---- area-weighted statistics (grates/grid.py:174-260) -------------------------------------------------
+    def __weights(self, mask):
+        if mask is None:
+            mask = np.ones(self.point_count, dtype=bool)
+        areas = self.area
+        w = np.ones(np.count_nonzero(mask)) if areas is None else areas[mask]
+        return mask, w
+
+    def mean(self, mask=None):
+        mask, w = self.__weights(mask)
+        return np.sum(w * self.values[mask]) / np.sum(w)
+
+    def rms(self, mask=None):
+        mask, w = self.__weights(mask)
+        return np.sqrt(np.sum(w * self.values[mask] ** 2) / np.sum(w))
+
+    def std(self, mask=None):
+        mask, w = self.__weights(mask)
+        centred = self.values[mask] - self.mean(mask)
+        return np.sqrt(np.sum(w * centred ** 2) / np.sum(w))
+
+    def distance_matrix(self):
+        """Spherical distance [rad] between all pairs of grid points."""
+        lon, lat = self.longitude, self.latitude
+        return spherical_distance(lon[:, np.newaxis], lat[:, np.newaxis], lon[np.newaxis, :], lat[np.newaxis, :], r=1)
+
+    # ---- linear operators ------------------------------------------------------------------------------------------
+    @abc.abstractmethod
+    def synthesis_matrix_per_order(self, m, min_degree, max_degree, kernel, GM, R):
+        pass
+
+    def synthesis_matrix(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
+        """Dense operator A (points x coefficients, degree-wise columns) mapping coefficients to grid values
+        (grates/grid.py:412-443)."""
+        colat, lon, kn = self._point_tables(kernel, max_degree, GM, R)
+        Y = engine.trigonometric_functions(max_degree, lon)
+        Y *= engine.legendre_functions(max_degree, colat)
+        Y *= _degree_scale_array(kn, max_degree)
+        return engine.to_host(engine.ravel(Y, min_degree, max_degree))
+
+    @abc.abstractmethod
+    def analysis_matrix(self, min_degree, max_degree, kernel, GM, R):
+        pass
+
+    def window_matrix(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
+        """W = (F * values) A with the grid values as window function (grates/grid.py:472-475)."""
+        F = engine.to_device(self.analysis_matrix(min_degree, max_degree, kernel, GM, R))
+        F *= engine.to_device(self.values)
+        return engine.to_host(engine.dgemm(F, engine.to_device(self.synthesis_matrix(min_degree, max_degree, kernel, GM, R))))
+
+    def to_potential_coefficients(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
+        """Spherical harmonic analysis through the full analysis matrix (grates/grid.py:498-507)."""
+        if self.values is None:
+            raise ValueError('grid has no values to propagate to potential coefficients')
+        F = engine.to_device(self.analysis_matrix(min_degree, max_degree, kernel, GM, R))
+        x = engine.dgemm(F, engine.to_device(self.values).reshape(-1, 1))
+        coeffs = _gravityfield.PotentialCoefficients(GM, R)
+        coeffs.anm = utilities.unravel_coefficients(engine.to_host(x).ravel(), min_degree, max_degree)
+        return coeffs
+
+    def _point_tables(self, kernel, max_degree, GM, R):
+        colat, _, kn = _gravityfield.surface_factors(_kernel.get_kernel(kernel), max_degree, self.latitude, GM, R,
+                                                     self.semimajor_axis, self.flattening)
+        return colat, self.longitude, kn
+
+
+def _degree_scale_array(kn, max_degree):
+    """Device tensor [k, N+1, N+1] holding kn[k, degree of slot]."""
+    torch = engine.require_gpu()
+    t = engine.to_device(kn)
+    idx = torch.arange(max_degree + 1, device=t.device)
+    deg = torch.maximum(idx[:, None], idx[None, :])
+    return t[:, deg]
+
+
+class RegularGrid(Grid):
+    """
+    Regular global point distribution given by meridians (longitudes) and parallels (latitudes, north to
+    south) in radians on the ellipsoid (a, f).  `value_array` is (parallels, meridians).
+    """
+
+    def __init__(self, meridians, parallels, area_elements=None, a=6378137.0, f=298.2572221010**-1):
+        self.parallels = parallels
+        self.meridians = meridians
+        self.__a = a
+        self.__f = f
+        if area_elements is None:
+            lon_edges = np.concatenate(([-np.pi], self.meridians[0:-1] + 0.5 * np.diff(self.meridians), [np.pi]))
+            lat_edges = np.concatenate(([0.5 * np.pi], self.parallels[0:-1] + 0.5 * np.diff(self.parallels), [-0.5 * np.pi]))
+            area_elements = 2.0 * (np.sin(np.abs(np.diff(lat_edges)) * 0.5) * np.cos(self.parallels))[:, np.newaxis] * np.diff(lon_edges)
+        self.__areas = area_elements
+        self.value_array = None
+        self.epoch = None
+
+    def copy(self):
+        grid = RegularGrid(self.meridians.copy(), self.parallels.copy(), self.__areas.copy(), self.semimajor_axis, self.flattening)
+        if self.value_array is not None:
+            grid.values = self.values.copy()
+        grid.epoch = self.epoch
+        return grid
+
+    def to_regular(self, threshold=1e-6):
+        if threshold <= 0:
+            raise ValueError('threshold should be positive (got {0:e})'.format(threshold))
+        return self.copy()
+
+    @property
+    def semimajor_axis(self):
+        return self.__a
+
+    @property
+    def flattening(self):
+        return self.__f
+
+    @property
+    def point_count(self):
+        return self.parallels.size * self.meridians.size
+
+    @property
+    def longitude(self):
+        return np.tile(self.meridians, self.parallels.size)
+
+    @property
+    def latitude(self):
+        return np.repeat(self.parallels, self.meridians.size)
+
+    @property
+    def area(self):
+        return self.__areas.ravel()
+
+    @property
+    def values(self):
+        if self.value_array is not None:
+            return self.value_array.ravel()
+
+    @values.setter
+    def values(self, val):
+        if val is None:
+            self.value_array = None
+        elif isinstance(val, np.ndarray):
+            if val.ndim > 1:
+                raise ValueError("unable to assign values of dimension {0:d} to grid".format(val.ndim))
+            if val.size != self.point_count:
+                raise ValueError("unable to assign values of size {0:d} to grid with {1:d} points".format(val.size, self.point_count))
+            self.value_array = np.reshape(val, (self.parallels.size, self.meridians.size))
+        else:
+            raise ValueError("grid values must be either None or " + str(np.ndarray))
+
+    # ---- tables ----------------------------------------------------------------------------------------------------
+    def _parallel_tables(self, kernel, max_degree, GM, R):
+        return _gravityfield.surface_factors(_kernel.get_kernel(kernel), max_degree, self.parallels, GM, R,
+                                             self.semimajor_axis, self.flattening)
+
+    def _plan(self, kernel, max_degree, GM, R):
+        colat, _, kn = self._parallel_tables(kernel, max_degree, GM, R)
+        return engine.cached_plan(max_degree, colat, kn, self.meridians)
+
+    def synthesis_matrix_per_order(self, m, min_degree, max_degree, kernel, GM, R):
+        """Operator block of order m (rows parallel-major): one matrix for m = 0, a (cosine, sine) tuple
+        otherwise; columns are degrees max(m, min_degree)..max_degree (grates/grid.py:653-663)."""
+        torch = engine.require_gpu()
+        colat, _, kn = self._parallel_tables(kernel, max_degree, GM, R)
+        Pm = engine.legendre_functions_per_order(max_degree, m, colat) * engine.to_device(kn[:, m:])
+        Pm = Pm[:, max(min_degree - m, 0):]
+        nlon = self.meridians.size
+        if m == 0:
+            return engine.to_host(Pm.repeat_interleave(nlon, dim=0))
+        lam = engine.to_device(m * self.meridians)
+        Ac = (Pm[:, None, :] * torch.cos(lam)[None, :, None]).reshape(-1, Pm.shape[1])
+        As = (Pm[:, None, :] * torch.sin(lam)[None, :, None]).reshape(-1, Pm.shape[1])
+        return engine.to_host(Ac), engine.to_host(As)
+
+    def analysis_matrix(self, min_degree, max_degree, kernel, GM=_GM, R=_R):
+        """Dense analysis operator (coefficients x points), assembled by applying the per-order
+        least-squares analysis to unit grids on the GPU (grates/grid.py:698-730)."""
+        torch = engine.require_gpu()
+        plan = self._plan(kernel, max_degree, GM, R)
+        area = engine.to_device(self.area).reshape(self.parallels.size, self.meridians.size)
+        M = self.point_count
+        P = (max_degree + 1) ** 2 - min_degree ** 2
+        out = torch.empty((P, M), dtype=torch.float64, device=area.device)
+        block = 256
+        for i0 in range(0, M, block):
+            i1 = min(i0 + block, M)
+            unit = torch.zeros((i1 - i0, M), dtype=torch.float64, device=area.device)
+            unit[torch.arange(i1 - i0), torch.arange(i0, i1)] = 1.0
+            anm = plan.analysis(unit.reshape(i1 - i0, self.parallels.size, self.meridians.size), area, min_degree)
+            out[:, i0:i1] = engine.ravel(anm, min_degree, max_degree).T
+        return engine.to_host(out)
+
+    def to_potential_coefficients(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
+        """Area-weighted least-squares analysis, order by order, on the GPU (grates/grid.py:774-790)."""
+        if self.values is None:
+            raise ValueError('grid has no values to propagate to potential coefficients')
+        plan = self._plan(kernel, max_degree, GM, R)
+        anm = plan.analysis(self.value_array, self.area.reshape(self.parallels.size, self.meridians.size), min_degree)
+        coeffs = _gravityfield.PotentialCoefficients(GM, R)
+        coeffs.anm = engine.to_host(anm)
+        return coeffs
+
+    def covariance_propagation(self, covariance_matrix, min_degree, max_degree, kernel='potential', GM=_GM, R=_R,
+                               parallel_range=None):
+        """
+        Standard deviation of the gridded functional given the coefficient covariance matrix in degree-wise
+        order: sqrt(diag(A Sigma A^T)) with A generated on the fly (grates/grid.py:817-839).  Sets and returns
+        the grid values.  `parallel_range=(i0, i1)` (extension) restricts the computation to a latitude band
+        and returns only that band without touching the grid values.
+        """
+        plan = self._plan(kernel, max_degree, GM, R)
+        if parallel_range is not None:
+            return engine.to_host(plan.covariance_propagation(covariance_matrix, min_degree, parallel_range[0], parallel_range[1]))
+        sigma = engine.to_host(plan.covariance_propagation(covariance_matrix, min_degree))
+        self.values = sigma
+        return sigma.copy()
+
+
+class IrregularGrid(Grid):
+    """Arbitrary point list given by longitude / latitude pairs [rad]."""
+
+    def __init__(self, longitude, latitude, area_element=None, a=6378137.0, f=298.2572221010**-1):
+        self.__lons = longitude
+        self.__lats = latitude
+        self.__areas = np.full(self.__lons.size, 4 * np.pi / self.__lons.size) if area_element is None else area_element
+        self.__a = a
+        self.__f = f
+        self.__values = None
+        self.epoch = None
+
+    def copy(self):
+        grid = IrregularGrid(self.__lons.copy(), self.__lats.copy(), self.__areas.copy(), self.semimajor_axis, self.flattening)
+        if self.__values is not None:
+            grid.values = self.values.copy()
+        grid.epoch = self.epoch
+        return grid
+
+    @property
+    def semimajor_axis(self):
+        return self.__a
+
+    @property
+    def flattening(self):
+        return self.__f
+
+    @property
+    def longitude(self):
+        return self.__lons
+
+    @property
+    def latitude(self):
+        return self.__lats
+
+    @property
+    def area(self):
+        return self.__areas
+
+    @property
+    def values(self):
+        return self.__values
+
+    @values.setter
+    def values(self, val):
+        if val is None:
+            self.__values = None
+        elif isinstance(val, np.ndarray):
+            if val.ndim > 1:
+                raise ValueError("unable to assign values of dimension {0:d} to grid".format(val.ndim))
+            if val.size != self.point_count:
+                raise ValueError("unable to assign values of size {0:d} to grid with {1:d} points".format(val.size, self.point_count))
+            self.__values = val
+        else:
+            raise ValueError("grid values must be either None or " + str(np.ndarray))
+
+    @property
+    def point_count(self):
+        return self.__lons.size
+
+    def to_regular(self, threshold=1e-6):
+        """Coerce into a RegularGrid if the points form meridians x parallels (grates/grid.py:886-914)."""
+        if threshold <= 0:
+            raise ValueError('threshold should be positive (got {0:e})'.format(threshold))
+        threshold /= self.semimajor_axis
+
+        def clusters(sorted_values):
+            out, k = [], 0
+            while k < sorted_values.size and len(out) < self.point_count:
+                out.append(sorted_values[k])
+                k += np.searchsorted(sorted_values[k + 1:], sorted_values[k] + threshold) + 1
+            return out
+
+        meridians = clusters(np.sort(self.longitude))
+        parallels = clusters(np.sort(self.latitude))
+        if len(meridians) * len(parallels) != self.point_count:
+            raise ValueError('grid cannot be coerced to a regular sampling')
+        grid = RegularGrid(np.array(meridians), np.array(parallels[::-1]), a=self.semimajor_axis, f=self.flattening)
+        if self.values is not None:
+            import scipy.spatial
+            tree = scipy.spatial.cKDTree(np.vstack((self.longitude, self.latitude)).T)
+            _, index = tree.query(np.vstack((grid.longitude, grid.latitude)).T)
+            grid.values = self.values[index]
+        return grid
+
+    def synthesis_matrix_per_order(self, m, min_degree, max_degree, kernel, GM, R):
+        """Operator block of order m for a point list (grates/grid.py:981-991)."""
+        torch = engine.require_gpu()
+        colat, lon, kn = self._point_tables(kernel, max_degree, GM, R)
+        Pm = engine.legendre_functions_per_order(max_degree, m, colat) * engine.to_device(kn[:, m:])
+        Pm = Pm[:, max(min_degree - m, 0):]
+        if m == 0:
+            return engine.to_host(Pm)
+        lam = engine.to_device(m * lon)
+        return engine.to_host(Pm * torch.cos(lam)[:, None]), engine.to_host(Pm * torch.sin(lam)[:, None])
+
+    def analysis_matrix(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
+        """(A^T W A)^-1 A^T W with W = diag(area) (grates/grid.py:1015-1017); the normal matrix and the
+        right-hand side are formed with the fp64 MFMA GEMM, the small dense solve runs on the device."""
+        torch = engine.require_gpu()
+        A = engine.to_device(self.synthesis_matrix(min_degree, max_degree, kernel, GM, R))
+        sw = torch.sqrt(engine.to_device(self.area))
+        A = A * sw[:, None]
+        At = A.T.contiguous()
+        normal = engine.dgemm(At, A)
+        return engine.to_host(torch.linalg.solve(normal, At * sw[None, :]))
+
+    def covariance_propagation(self, covariance_matrix, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
+        """Point-list covariance propagation (grates/grid.py:1096-1120).  Sets and returns the grid values."""
+        colat, lon, kn = self._point_tables(kernel, max_degree, GM, R)
+        sigma = engine.to_host(engine.covprop_points(max_degree, colat, lon, kn, covariance_matrix, min_degree))
+        self.values = sigma
+        return sigma.copy()
+
+
+class GeographicGrid(RegularGrid):
+    """
+    Global geographic grid with step sizes dlon, dlat in degrees; points are pixel centres
+    (grates/grid.py:1141-1153).
+    """
+
+    def __init__(self, dlon=0.5, dlat=0.5, a=6378137.0, f=298.2572221010**-1):
+        self.__dlon = dlon
+        self.__dlat = dlat
+        nlons = 360 / dlon
+        nlats = 180 / dlat
+        meridians = np.linspace(-np.pi + dlon / 180 * np.pi * 0.5, np.pi - dlon / 180 * np.pi * 0.5, int(nlons))
+        parallels = -np.linspace(-np.pi * 0.5 + dlat / 180 * np.pi * 0.5, np.pi * 0.5 - dlat / 180 * np.pi * 0.5, int(nlats))
+        areas = np.tile(2.0 * dlon / 180 * np.pi * np.sin(dlat * 0.5 / 180 * np.pi) * np.cos(parallels)[:, np.newaxis], (1, meridians.size))
+        super(GeographicGrid, self).__init__(meridians, parallels, areas, a, f)
+
+    def copy(self):
+        grid = GeographicGrid(self.__dlon, self.__dlat, self.semimajor_axis, self.flattening)
+        if self.values is not None:
+            grid.values = self.values.copy()
+        grid.epoch = self.epoch
+        return grid
+
+
+class GaussGrid(RegularGrid):
+    """
+    Gaussian grid: parallels at the roots of the Legendre polynomial of degree parallel_count (mapped from
+    the unit sphere onto the ellipsoid), 2 * parallel_count meridians (grates/grid.py:1181-1195).
+    """
+
+    def __init__(self, parallel_count, a=6378137.0, f=298.2572221010**-1):
+        from scipy.special import roots_legendre
+        zeros, weights, _ = roots_legendre(parallel_count, mu=True)
+        dlon = np.pi / parallel_count
+        meridians = np.linspace(-np.pi + dlon * 0.5, np.pi - dlon * 0.5, 2 * parallel_count)
+        cosine_theta = -zeros
+        sine_theta = np.sqrt(1 - cosine_theta ** 2)
+        parallels = np.arctan2(cosine_theta, (1 - f) ** 2 * sine_theta)
+        areas = np.tile(dlon * weights[:, np.newaxis], (1, meridians.size))
+        super(GaussGrid, self).__init__(meridians, parallels, areas, a, f)
+
+    def copy(self):
+        grid = GaussGrid(self.parallels.size, self.semimajor_axis, self.flattening)
+        if self.value_array is not None:
+            grid.values = self.values.copy()
+        grid.epoch = self.epoch
+        return grid
+
+
+# -------------------------------------------------------------------------------------------------------
+# coordinate helpers (grates/grid.py:1893-2044)
+# -------------------------------------------------------------------------------------------------------
+
+def spherical_distance(lon1, lat1, lon2, lat2, r=6378136.3):
+    """Great-circle distance on a sphere of radius r (Vincenty form of the arc)."""
+    dlon = lon2 - lon1
+    y = np.sqrt((np.cos(lat2) * np.sin(dlon)) ** 2 + (np.cos(lat1) * np.sin(lat2) - np.sin(lat1) * np.cos(lat2) * np.cos(dlon)) ** 2)
+    x = np.sin(lat1) * np.sin(lat2) + np.cos(lat1) * np.cos(lat2) * np.cos(dlon)
+    return np.arctan2(y, x) * r
+
+
+def spherical2cartesian(r, colatitude, lon):
+    xyz = np.empty((np.asarray(lon).size, 3))
+    xyz[:, 0] = r * np.sin(colatitude) * np.cos(lon)
+    xyz[:, 1] = r * np.sin(colatitude) * np.sin(lon)
+    xyz[:, 2] = r * np.cos(colatitude)
+    return xyz
+
+
+def cartesian2spherical(xyz):
+    """(r, colatitude, longitude) of cartesian triples (m, 3)."""
+    r = np.sqrt(np.sum(xyz ** 2, axis=1))
+    colat = np.arctan2(np.sqrt(np.sum(xyz[:, 0:2] ** 2, axis=1)), xyz[:, 2])
+    lon = np.arctan2(xyz[:, 1], xyz[:, 0])
+    return r, colat, lon
+
+
+def geodetic2cartesian(lon, lat, h=0, a=6378137.0, f=298.2572221010**-1):
+    """Cartesian coordinates (m, 3) from geodetic longitude, latitude [rad] and ellipsoidal height [m]."""
+    if f == 0.0:
+        return spherical2cartesian(a + h, np.pi * 0.5 - lat, lon)
+    e2 = 2 * f - f ** 2
+    nu = a / np.sqrt(1 - e2 * np.sin(lat) ** 2)
+    return np.vstack(((nu + h) * np.cos(lat) * np.cos(lon), (nu + h) * np.cos(lat) * np.sin(lon), ((1 - e2) * nu + h) * np.sin(lat))).T
+
+
+def cartesian2geodetic(xyz, a=6378137.0, f=298.2572221010**-1, max_iter=10, threshold=1e-6):
+    """Geodetic longitude, latitude [rad] and height [m] by fixed-point iteration of Bowring's equation
+    (grates/grid.py:1984-2008)."""
+    if f == 0.0:
+        r, colat, lon = cartesian2spherical(xyz)
+        return lon, np.pi * 0.5 - colat, r - a
+    e2 = 2 * f - f ** 2
+    z = xyz[:, -1]
+    p2 = xyz[:, 0] ** 2 + xyz[:, 1] ** 2
+    h_previous = 0
+    k = (1 - e2) ** -1
+    for _ in range(max_iter):
+        c = np.power(p2 + (1 - e2) * z ** 2 * k ** 2, 1.5) / (a * e2)
+        k = 1 + (p2 + (1 - e2) * z ** 2 * k ** 3) / (c - p2)
+        h = (k ** -1 - (1 - e2)) * np.sqrt(p2 + z ** 2 * k ** 2) / e2
+        if np.max(np.abs(h - h_previous)) < threshold:
+            break
+        h_previous = h
+    return np.arctan2(xyz[:, 1], xyz[:, 0]), np.arctan2(k * z, np.sqrt(p2)), h

@@ -1,0 +1,146 @@
+/*
+ * shg.h -- C ABI of libshg: spherical-harmonic synthesis / analysis / covariance propagation / filter
+ *          kernels for AMD MI355X (gfx950, CDNA4).
+ *
+ * This is the drop-in boundary for the hot path of akvas/grates.  The reference is
+ * pure Python and has no FFI of its own; every entry point below names the reference function whose inner
+ * loop it replaces (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative shg_status; shg_last_error() gives the message of
+ *     the last failure on the calling thread.  No exception crosses the boundary.
+ *   - pointers named *_h are HOST pointers (read during the call, not retained); all other array
+ *     pointers are DEVICE pointers to contiguous fp64 / int arrays owned by the caller
+ *     (e.g. torch.Tensor.data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous with
+ *     respect to the host; a plan may have only one operation in flight at a time (it owns workspace).
+ *   - coefficient arrays use the reference packing  anm[n][m] = C_nm (m <= n),  anm[m-1][n] = S_nm (m >= 1)
+ *     (grates/gravityfield.py:156-159); "degree-wise" vectors use  index(C,n,0) = n^2 - nmin^2,
+ *     index(C,n,m) = n^2 + 2m - 1 - nmin^2,  index(S,n,m) = n^2 + 2m - nmin^2  (grates/utilities.py:331-343).
+ *   - grids are [nlat][nlon] row-major, parallels north to south (grates/grid.py:609-625, 1146-1151).
+ */
+#ifndef SHG_H
+#define SHG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct shg_plan shg_plan;
+
+typedef enum {
+    SHG_OK = 0,
+    SHG_ERR_INVALID = -1,   /* bad argument (NULL pointer, negative size, degree mismatch ...) */
+    SHG_ERR_HIP = -2,       /* a HIP runtime call failed                                        */
+    SHG_ERR_NOMEM = -3,     /* workspace allocation failed                                      */
+    SHG_ERR_UNSUPPORTED = -4
+} shg_status;
+
+/* ------------------------------------------------------------------------------------------------
+ * Plan: per-(degree, parallels, kernel table, meridians) tables held on the device.
+ *   replaces the per-call table rebuild of PotentialCoefficients.to_grid
+ *   (grates/gravityfield.py:353-365: colatitude/radius -> kn, legendre_functions, trigonometric_functions).
+ *
+ *   N        maximum degree
+ *   colat_h  [nlat] geocentric colatitude of every parallel                  (grates/utilities.py:438-459)
+ *   kn_h     [nlat][N+1] per-parallel degree factors (1/k_n)(R/r)^(n+1) GM/R  (grates/gravityfield.py:356)
+ *   lon_h    [nlon] longitude of every meridian
+ * ------------------------------------------------------------------------------------------------ */
+int shg_plan_create(shg_plan** out, int N, int nlat, const double* colat_h, const double* kn_h,
+                    int nlon, const double* lon_h, int device);
+int shg_plan_destroy(shg_plan* plan);
+
+/* Number of epochs processed per internal pass (workspace is sized for it).  Default 16. */
+int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
+
+/* Introspection: which[0]=N, [1]=nlat, [2]=nlon, [3]=1 if the 4-fold longitude symmetry path is active,
+ * [4]=epochs per pass, [5]=K slots of the longitude stage. */
+int shg_plan_info(const shg_plan* plan, int64_t which[6]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthesis  V[b][i][j] = sum_nm kn[i][n] P_nm(theta_i) (C_nm[b] cos m lon_j + S_nm[b] sin m lon_j)
+ *   replaces PotentialCoefficients.to_grid, regular-grid branch   (grates/gravityfield.py:352-368)
+ *   anm  [B][N+1][N+1]      grid  [B][nlat][nlon]
+ * ------------------------------------------------------------------------------------------------ */
+int shg_synthesis(shg_plan* plan, const double* anm, int B, double* grid, void* stream);
+
+/* Point-list synthesis, one thread block per block of points
+ *   replaces PotentialCoefficients.to_grid, AttributeError branch  (grates/gravityfield.py:370-388)
+ *   colat, lon [npts]; kn [npts][N+1]; anm [B][N+1][N+1]; values [B][npts]                            */
+int shg_synthesis_points(int N, const double* colat, const double* lon, const double* kn, int npts,
+                         const double* anm, int B, double* values, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Parity hooks for the table functions
+ *   shg_legendre          utilities.legendre_functions            (grates/utilities.py:13-59)
+ *                         colat [k] -> pnm [k][N+1][N+1] (packed, sine slots mirrored)
+ *   shg_legendre_order    utilities.legendre_functions_per_order   (grates/utilities.py:62-115)
+ *                         colat [k] -> pm [k][N+1-m]   (uses s = sqrt(1 - t^2))
+ *   shg_trigonometric     utilities.trigonometric_functions        (grates/utilities.py:249-275)
+ *                         lon [k] -> cs [k][N+1][N+1]
+ * ------------------------------------------------------------------------------------------------ */
+int shg_legendre(int N, const double* colat, int k, double* pnm, void* stream);
+int shg_legendre_order(int N, int m, const double* colat, int k, double* pm, void* stream);
+int shg_trigonometric(int N, const double* lon, int k, double* cs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Degree-wise ravel / unravel of batches (integer index maps applied on the device)
+ *   replaces utilities.ravel_coefficients / unravel_coefficients   (grates/utilities.py:310-411)
+ *   and TimeSeries.to_array                                        (grates/gravityfield.py:964-980)
+ *   arr [B][Na+1][Na+1]  <->  vec [B][(nmax+1)^2 - nmin^2]; degrees > Na read as zero / are dropped.
+ * ------------------------------------------------------------------------------------------------ */
+int shg_ravel(const double* arr, int B, int Na, int nmin, int nmax, double* vec, void* stream);
+int shg_unravel(const double* vec, int B, int nmin, int nmax, double* arr /* [B][nmax+1][nmax+1], zero-filled */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Covariance propagation  sigma[i*nlon + j] = sqrt(a_ij^T Sigma a_ij),  a_ij = row of the synthesis matrix
+ *   replaces RegularGrid.covariance_propagation                     (grates/grid.py:817-839)
+ *   cov    [P][P] degree-wise order, P = (N+1)^2 - nmin^2 (only N == plan degree is accepted)
+ *   sigma  [(lat1-lat0)*nlon]  for the band of parallels lat0 <= i < lat1 (latitude-band sharding)
+ *   The A rows are generated on the fly (never materialised); A*Sigma runs on v_mfma_f64_16x16x4_f64.
+ * ------------------------------------------------------------------------------------------------ */
+int shg_covprop_diag(shg_plan* plan, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream);
+
+/* Point-list variant  (grates/grid.py:1096-1120): colat, lon [npts]; kn [npts][N+1]; sigma [npts] */
+int shg_covprop_points(int N, const double* colat, const double* lon, const double* kn, int npts,
+                       const double* cov, int nmin, double* sigma, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Filters
+ *   shg_degree_scale      Gaussian.filter / Butterworth.filter degree-wise scaling (grates/filter.py:61-72)
+ *                         anm_out[b][slot of degree n] = w[n] * anm_in   for n >= nfirst, copied below
+ *   shg_orderwise_filter  OrderWiseFilter.filter                      (grates/filter.py:175-191)
+ *                         blocks packed back to back in the reference list order
+ *                         [order0_cos, order1_cos, order1_sin, ...], block k row-major with leading
+ *                         dimension block_dim[k] = Nb+1-m; block_off [2Nb+1] offsets in doubles.
+ *                         Coefficients of degree N <= Nb are filtered with the leading (N+1-m)^2 sub-block;
+ *                         degrees 0 and 1 are restored from the input.
+ *   shg_dense_filter      GeneralMatrix.filter core  Y = W X           (grates/filter.py:473-474)
+ *                         W [P][P], X [P][T] (epoch fastest), Y [P][T]; fp64 MFMA GEMM.
+ * ------------------------------------------------------------------------------------------------ */
+int shg_degree_scale(const double* w /* [N+1] device */, int N, int nfirst, const double* anm_in, int B,
+                     double* anm_out, void* stream);
+int shg_orderwise_filter(const double* blocks_packed, const int64_t* block_off, int Nb, int N,
+                         const double* anm_in, int B, double* anm_out, void* stream);
+int shg_dense_filter(const double* W, int P, const double* X, int T, double* Y, void* stream);
+
+/* General fp64 MFMA GEMM  C[M][N] = A[M][K] B[K][N]  (row-major, leading dimensions in elements). */
+int shg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Analysis (area-weighted least squares per order)
+ *   replaces RegularGrid.to_potential_coefficients                    (grates/grid.py:665-696, 752-790)
+ *   grid [B][nlat][nlon]; area [nlat][nlon]; anm [B][N+1][N+1] (degrees < nmin left zero)
+ * ------------------------------------------------------------------------------------------------ */
+int shg_analysis(shg_plan* plan, const double* grid, const double* area, int nmin, int B, double* anm, void* stream);
+
+const char* shg_last_error(void);
+const char* shg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHG_H */

@@ -1,0 +1,78 @@
+"""
+CPU checks of the drop-in boundary: libshg.so loads and exports every symbol include/shg.h declares, the
+product package never touches oracle/, and compute entry points fail loudly without a GPU.
+"""
+
+import ast
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'shg.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(shg_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from grates_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), 'libshg.so does not export ' + name
+    # the ctypes prototype table covers the same set
+    assert sorted(list(_lib.PROTOTYPES) + list(_lib.STRING_GETTERS)) == names
+    assert 'gfx950' in _lib.version()
+
+
+def test_error_reporting_without_gpu_calls():
+    from grates_amd import _lib
+    lib = _lib.load()
+    # argument validation happens before any HIP call
+    assert lib.shg_plan_set_chunk(None, 4) == -1
+    assert b'NULL plan' in lib.shg_last_error()
+    with pytest.raises(_lib.ShgError) as err:
+        _lib.call('shg_legendre_order', 3, 5, None, 1, None, None)
+    assert 'order exceeds maximum degree' in str(err.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'grates_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if not fn.endswith('.py'):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, fn)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or '']
+                for n in names:
+                    assert not n.startswith('oracle') and 'shg_oracle' not in n, '{0} imports {1}'.format(fn, n)
+    for dirpath, _, files in os.walk(os.path.join(pkg, 'csrc')):
+        for fn in files:
+            if fn.endswith(('.hip', '.h', '.cpp')):
+                assert 'oracle' not in open(os.path.join(dirpath, fn)).read()
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import grates_amd as ga
+    gf = ga.gravityfield.PotentialCoefficients(max_degree=4)
+    with pytest.raises(RuntimeError, match='no GPU'):
+        gf.to_grid(ga.grid.GeographicGrid(30, 30), 'potential')
+    with pytest.raises(RuntimeError, match='no GPU'):
+        ga.utilities.legendre_functions(4, np.array([0.3]))
+    with pytest.raises(RuntimeError, match='no GPU'):
+        ga.filter.Gaussian(300).filter(gf)

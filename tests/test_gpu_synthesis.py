@@ -1,0 +1,192 @@
+"""
+GPU parity of the synthesis path (rows a8-a11 of SURVEY.md 8a): PotentialCoefficients.to_grid and the batched
+engine against the reference's golden vectors and against the CPU oracle on seeded inputs.
+Tolerance (north_star / SURVEY.md 8d): max|d| / max|ref| <= 1e-12.
+"""
+
+import datetime
+
+import numpy as np
+import pytest
+
+import grates_amd as ga
+import inputs
+from conftest import relerr
+from oracle import shg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def love():
+    return ga.data.load_love_numbers()[0]
+
+
+def make_pc(anm, **kw):
+    gf = ga.gravityfield.PotentialCoefficients(**kw)
+    gf.anm = anm.copy()
+    return gf
+
+
+def test_config1_gaussian_then_grid(golden):
+    """BASELINE config 1: d/o 60, 300 km Gaussian, 1 degree grid, ewh."""
+    g = golden('g7_synthesis')
+    gf = make_pc(inputs.coefficients(1000, 60))
+    filtered = ga.filter.Gaussian(300).filter(gf)
+    np.testing.assert_allclose(filtered.anm, g['c1_filtered_anm'], rtol=1e-15, atol=0)
+    grid_in = ga.grid.GeographicGrid(1.0, 1.0)
+    out = filtered.to_grid(grid_in, kernel='ewh')
+    assert type(out) is ga.grid.GeographicGrid and out is not grid_in and grid_in.values is None
+    assert out.value_array.shape == (180, 360)
+    assert relerr(out.value_array, g['c1_grid']) < TOL
+
+
+def test_config2_unit_two_epochs(golden):
+    """d/o 96 -> 0.25 degree, the unit of the headline metric, against reference samples."""
+    g = golden('g7_synthesis')
+    grid = ga.grid.GeographicGrid(0.25, 0.25)
+    batch = np.stack([inputs.coefficients(1000 + e, 96) for e in (0, 1)])
+    values = ga.engine.to_host(ga.gravityfield.synthesize(batch, grid, 'ewh'))
+    assert values.shape == (2, 720, 1440)
+    for e in (0, 1):
+        assert relerr(values[e][::9, ::11], g['c2_sample_{0}'.format(e)]) < TOL
+        assert relerr(values[e].sum(axis=1), g['c2_rowsum_{0}'.format(e)]) < 1e-11
+        assert abs(np.abs(values[e]).max() - g['c2_maxabs_{0}'.format(e)][0]) < TOL * g['c2_maxabs_{0}'.format(e)][0]
+    info = ga.engine.cached_plan(96, *_tables(grid, 96, 'ewh')).info()
+    assert info['fourfold_symmetry'] and info['nlat'] == 720 and info['nlon'] == 1440
+
+
+def _tables(grid, N, kernel, GM=3.9860044150e+14, R=6.3781363000e+06):
+    colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel(kernel), N, grid.parallels, GM, R, grid.semimajor_axis, grid.flattening)
+    return colat, kn, grid.meridians
+
+
+def test_kernels_grids_and_constants(golden):
+    g = golden('g7_synthesis')
+    out = make_pc(inputs.coefficients(7, 60)).to_grid(ga.grid.GaussGrid(61), kernel='potential')
+    assert type(out) is ga.grid.GaussGrid
+    assert relerr(out.value_array, g['gauss61_potential']) < TOL
+    gf = make_pc(inputs.coefficients(8, 30))
+    for name in ('geoid', 'obp', 'potential', 'ewh'):
+        out = gf.to_grid(ga.grid.GeographicGrid(5.0, 5.0), kernel=name)
+        assert relerr(out.value_array, g['n30_5deg_' + name]) < TOL, name
+    gf = make_pc(inputs.coefficients(9, 30), GM=3.986004418e14, R=6378137.0)
+    assert relerr(gf.to_grid(ga.grid.GeographicGrid(5.0, 5.0), kernel='ewh').value_array, g['n30_5deg_gmr']) < TOL
+
+
+def test_general_path_asymmetric_grid(golden):
+    """Meridians without the 4-fold symmetry take the general longitude stage."""
+    g = golden('g7_synthesis')
+    grid = ga.grid.RegularGrid(g['asym_meridians'], g['asym_parallels'])
+    out = make_pc(inputs.coefficients(13, 25)).to_grid(grid, kernel='potential')
+    assert relerr(out.value_array, g['asym_potential']) < TOL
+    plan = ga.engine.cached_plan(25, *_tables(grid, 25, 'potential'))
+    assert not plan.info()['fourfold_symmetry']
+
+
+@pytest.mark.parametrize('N,dlon,dlat', [(0, 30, 30), (1, 30, 30), (2, 90, 45), (3, 10, 20), (17, 4.5, 3), (33, 2, 2), (64, 1, 2.5), (120, 1, 1)])
+def test_against_oracle_shapes(N, dlon, dlat):
+    """Seeded inputs, many degree / grid shapes (ragged tiles, tiny grids, nlon % 4 != 0 -> general path)."""
+    grid = ga.grid.GeographicGrid(dlon, dlat)
+    anm = inputs.coefficients(100 + N, N)
+    ref = orc.synthesis_regular(anm, grid.meridians, grid.parallels, orc.KernelTable('ewh', love()))
+    out = make_pc(anm).to_grid(grid, 'ewh')
+    assert relerr(out.value_array, ref) < TOL
+
+
+def test_nlon_not_multiple_of_four_and_odd_sizes():
+    pot = orc.KernelTable('potential')
+    for nlon, nlat in ((6, 3), (10, 7), (37, 19), (50, 1), (1, 5)):
+        mer = np.linspace(-np.pi, np.pi, nlon, endpoint=False) + np.pi / nlon
+        par = np.linspace(1.5, -1.5, nlat) if nlat > 1 else np.array([0.3])
+        grid = ga.grid.RegularGrid(mer, par)
+        anm = inputs.coefficients(nlon, 9)
+        ref = orc.synthesis_regular(anm, mer, par, pot)
+        assert relerr(make_pc(anm).to_grid(grid, 'potential').value_array, ref) < TOL
+
+
+def test_batch_sizes_and_chunking():
+    """Batches that are not multiples of the epoch tile / pass size; results independent of the chunking."""
+    grid = ga.grid.GeographicGrid(3.0, 3.0)
+    N = 40
+    ker = orc.KernelTable('ewh', love())
+    batch = np.stack([inputs.coefficients(500 + e, N) for e in range(21)])
+    ref = np.stack([orc.synthesis_regular(batch[e], grid.meridians, grid.parallels, ker) for e in range(21)])
+    plan = ga.engine.Plan(N, *_tables(grid, N, 'ewh'))
+    for chunk in (16, 1, 5, 8, 64):
+        plan.set_chunk(chunk)
+        for B in (1, 7, 8, 9, 21):
+            out = ga.engine.to_host(plan.synthesis(batch[0:B]))
+            assert out.shape == (B, 60, 120)
+            assert relerr(out, ref[0:B]) < TOL, (chunk, B)
+    assert plan.synthesis(batch[0:0]).shape == (0, 60, 120)
+    single = ga.engine.to_host(plan.synthesis(batch[3]))
+    assert single.shape == (60, 120) and relerr(single, ref[3]) < TOL
+    with pytest.raises(ValueError):
+        plan.synthesis(np.zeros((2, N, N)))
+
+
+def test_linearity_and_zero_input():
+    grid = ga.grid.GeographicGrid(2.0, 2.0)
+    a, b = inputs.coefficients(1, 50), inputs.coefficients(2, 50)
+    va = make_pc(a).to_grid(grid, 'potential').value_array
+    vb = make_pc(b).to_grid(grid, 'potential').value_array
+    vab = make_pc(2.0 * a - 3.0 * b).to_grid(grid, 'potential').value_array
+    assert relerr(vab, 2.0 * va - 3.0 * vb) < TOL
+    assert np.all(make_pc(np.zeros((51, 51))).to_grid(grid, 'potential').value_array == 0.0)
+    # degree-0 only: constant GM/R * (R/r) on every parallel
+    c = np.zeros((51, 51))
+    c[0, 0] = 1.0
+    v = make_pc(c).to_grid(grid, 'potential').value_array
+    r = orc.geocentric_radius(grid.parallels)
+    np.testing.assert_allclose(v, np.repeat((3.9860044150e+14 / r)[:, None], 180, axis=1), rtol=1e-14)
+
+
+def test_time_series_to_grid():
+    series = []
+    for e in range(5):
+        gf = make_pc(inputs.coefficients(70 + e, 20))
+        gf.epoch = datetime.datetime(2012, 1 + e, 1)
+        series.append(gf)
+    ts = ga.gravityfield.TimeSeries(series)
+    grid = ga.grid.GeographicGrid(10, 10)
+    grids = ts.to_grid(grid, 'ewh')
+    assert len(grids) == 5 and all(type(x) is ga.grid.GeographicGrid for x in grids)
+    ker = orc.KernelTable('ewh', love())
+    for gf, out in zip(series, grids):
+        assert out.epoch == gf.epoch
+        assert relerr(out.value_array, orc.synthesis_regular(gf.anm, grid.meridians, grid.parallels, ker)) < TOL
+    t = ts.to_grid(grid, 'ewh', as_tensor=True)
+    assert t.is_cuda and tuple(t.shape) == (5, 18, 36)
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 at full size (240 x d/o 96 -> 0.25 degree): size-independent properties."""
+    import torch
+    grid = ga.grid.GeographicGrid(0.25, 0.25)
+    B, N = 240, 96
+    rng = np.random.default_rng(2024)
+    batch = torch.from_numpy(rng.standard_normal((B, N + 1, N + 1)) * 1e-10).cuda()
+    out = ga.gravityfield.synthesize(batch, grid, 'ewh')
+    assert tuple(out.shape) == (B, 720, 1440) and bool(torch.isfinite(out).all())
+    # (1) a few epochs against the oracle
+    ker = orc.KernelTable('ewh', love())
+    for e in (0, 113, 239):
+        ref = orc.synthesis_regular(batch[e].cpu().numpy(), grid.meridians, grid.parallels, ker)
+        assert relerr(out[e].cpu().numpy(), ref) < TOL
+    # (2) linearity across the batch: synth(sum_b w_b x_b) == sum_b w_b synth(x_b)
+    w = torch.from_numpy(rng.standard_normal(B)).cuda()
+    combo = ga.gravityfield.synthesize((w[:, None, None] * batch).sum(dim=0, keepdim=True), grid, 'ewh')[0]
+    lin = (w[:, None, None] * out).sum(dim=0)
+    assert float((combo - lin).abs().max() / lin.abs().max()) < 1e-11
+    # (3) permutation of the batch permutes the output (no cross-epoch leakage, chunk boundaries)
+    perm = torch.randperm(B, device='cuda')
+    out_p = ga.gravityfield.synthesize(batch[perm], grid, 'ewh')
+    assert bool((out_p == out[perm]).all())
+    # (4) mean over longitude only sees order 0:  mean_j V[i, j] = sum_n kn P_n0 C_n0
+    zonal = batch.clone()
+    idx = torch.arange(N + 1, device='cuda')
+    mask = torch.zeros((N + 1, N + 1), dtype=torch.bool, device='cuda')
+    mask[:, 0] = True
+    zon = ga.gravityfield.synthesize(zonal * mask, grid, 'ewh')
+    assert float((out.mean(dim=2) - zon[:, :, 0]).abs().max() / out.abs().max()) < 1e-12
