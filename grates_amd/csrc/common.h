@@ -71,9 +71,24 @@ struct shg_plan {
     double* F = nullptr;        // [chunk][K][ldlat] output of the Legendre stage
     int chunk_alloc = 0;
     void* aux = nullptr;        // analysis tables (analysis.hip)
+
+    // optional per-kernel event timing (shg_plan_profile)
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events;    // pairs (start, stop)
+    std::vector<int> prof_kinds;
+    size_t prof_used = 0;                   // number of pairs in use
 };
 
 namespace shg {
 int plan_alloc_workspace(shg_plan* p);
 void plan_free_aux(shg_plan* p);
+
+// RAII event pair around one kernel launch (no-op unless profiling is enabled on the plan)
+struct ProfileScope {
+    shg_plan* p;
+    hipStream_t stream;
+    hipEvent_t stop = nullptr;
+    ProfileScope(shg_plan* plan, int kind, hipStream_t s);
+    ~ProfileScope();
+};
 }  // namespace shg

@@ -81,9 +81,54 @@ int plan_alloc_workspace(shg_plan* p) {
     return SHG_OK;
 }
 
+ProfileScope::ProfileScope(shg_plan* plan, int kind, hipStream_t s) : p(plan), stream(s) {
+    if (!p || !p->profiling) return;
+    if (p->prof_used * 2 + 2 > p->prof_events.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        p->prof_events.push_back(a);
+        p->prof_events.push_back(b);
+        p->prof_kinds.push_back(kind);
+    }
+    p->prof_kinds[p->prof_used] = kind;
+    (void)hipEventRecord(p->prof_events[p->prof_used * 2], stream);
+    stop = p->prof_events[p->prof_used * 2 + 1];
+    p->prof_used++;
+}
+
+ProfileScope::~ProfileScope() {
+    if (stop) (void)hipEventRecord(stop, stream);
+}
+
 }  // namespace shg
 
 using namespace shg;
+
+extern "C" int shg_plan_profile(shg_plan* p, int enable) {
+    SHG_REQUIRE(p != nullptr, "shg_plan_profile: NULL plan");
+    p->profiling = enable != 0;
+    return SHG_OK;
+}
+
+extern "C" int shg_plan_profile_read(shg_plan* p, double ms[SHG_PROFILE_KINDS], int64_t launches[SHG_PROFILE_KINDS]) {
+    SHG_REQUIRE(p != nullptr && ms != nullptr && launches != nullptr, "shg_plan_profile_read: NULL argument");
+    for (int k = 0; k < SHG_PROFILE_KINDS; ++k) {
+        ms[k] = 0.0;
+        launches[k] = 0;
+    }
+    for (size_t e = 0; e < p->prof_used; ++e) {
+        SHG_HIP(hipEventSynchronize(p->prof_events[e * 2 + 1]));
+        float t = 0.f;
+        SHG_HIP(hipEventElapsedTime(&t, p->prof_events[e * 2], p->prof_events[e * 2 + 1]));
+        const int k = p->prof_kinds[e];
+        if (k >= 0 && k < SHG_PROFILE_KINDS) {
+            ms[k] += t;
+            launches[k] += 1;
+        }
+    }
+    p->prof_used = 0;
+    return SHG_OK;
+}
 
 extern "C" const char* shg_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* shg_version(void) { return "libshg 0.1 (gfx950)"; }
@@ -180,6 +225,7 @@ extern "C" int shg_plan_destroy(shg_plan* p) {
                       p->pk_deg, p->cs_slot, p->cpk, p->F};
     for (double* q : ptrs)
         if (q) (void)hipFree(q);
+    for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
     plan_free_aux(p);
     delete p;
     return SHG_OK;

@@ -247,10 +247,16 @@ extern "C" int shg_synthesis(shg_plan* p, const double* anm, int B, double* grid
     for (int c0 = 0; c0 < B; c0 += p->chunk) {
         const int nb = std::min(p->chunk, B - c0);
         const int nbt = ceil_div(nb, kEpochTile);
-        hipLaunchKernelGGL(pack_coefficients_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, N, nb, Bpad,
-                           anm + (size_t)c0 * E, p->cpk);
-        hipLaunchKernelGGL(legendre_stage_kernel, dim3(p->ldlat / kLatTile, N + 1, nbt), dim3(64), 0, stream, N, p->ldlat,
-                           p->K, Bpad, map, p->ct, p->pmm, p->knT, p->arec, p->brec, p->cpk, p->F);
+        {
+            ProfileScope ps(p, 0, stream);
+            hipLaunchKernelGGL(pack_coefficients_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, N, nb, Bpad,
+                               anm + (size_t)c0 * E, p->cpk);
+        }
+        {
+            ProfileScope ps(p, 1, stream);
+            hipLaunchKernelGGL(legendre_stage_kernel, dim3(p->ldlat / kLatTile, N + 1, nbt), dim3(64), 0, stream, N, p->ldlat,
+                               p->K, Bpad, map, p->ct, p->pmm, p->knT, p->arec, p->brec, p->cpk, p->F);
+        }
         LonParams L;
         L.nlat = p->nlat;
         L.nlon = p->nlon;
@@ -264,6 +270,7 @@ extern "C" int shg_synthesis(shg_plan* p, const double* anm, int B, double* grid
         L.trig = p->trig;
         L.G = grid + (size_t)c0 * p->nlat * p->nlon;
         dim3 grid_dim(ceil_div(L.total_rt, 4), ceil_div(p->ncoltiles, 4));
+        ProfileScope ps(p, 2, stream);
         if (p->sym4)
             hipLaunchKernelGGL(lon_stage_kernel<4>, grid_dim, dim3(256), 0, stream, L);
         else

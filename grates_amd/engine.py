@@ -95,6 +95,19 @@ class Plan:
     def set_chunk(self, epochs_per_pass):
         _lib.call('shg_plan_set_chunk', self._handle, int(epochs_per_pass))
 
+    PROFILE_KINDS = ('pack_coefficients', 'legendre_stage', 'lon_stage', 'covprop', 'analysis_lon', 'analysis_solve', 'k6', 'k7')
+
+    def profile(self, enable=True):
+        """Record HIP events around every kernel this plan launches (on the launching stream)."""
+        _lib.call('shg_plan_profile', self._handle, 1 if enable else 0)
+
+    def profile_read(self):
+        """{kernel: (total_ms, launches)} since the last read; synchronises the recorded events."""
+        ms = (ctypes.c_double * 8)()
+        n = (ctypes.c_int64 * 8)()
+        _lib.call('shg_plan_profile_read', self._handle, ms, n)
+        return {name: (ms[k], n[k]) for k, name in enumerate(self.PROFILE_KINDS) if n[k] > 0}
+
     def synthesis(self, anm, out=None):
         """anm [B, N+1, N+1] (or [N+1, N+1]) -> grid [B, nlat, nlon] (device tensor)."""
         torch = _torch()

@@ -60,6 +60,14 @@ int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
  * [4]=epochs per pass, [5]=K slots of the longitude stage. */
 int shg_plan_info(const shg_plan* plan, int64_t which[6]);
 
+/* Per-kernel timing with HIP events recorded on the caller's stream around every kernel a plan launches.
+ * kinds: 0 pack_coefficients, 1 legendre_stage, 2 lon_stage, 3 covprop, 4 analysis_lon, 5 analysis_solve.
+ * shg_plan_profile_read synchronises the recorded events, returns accumulated milliseconds and launch
+ * counts per kind since the last read, and resets the accumulators. */
+#define SHG_PROFILE_KINDS 8
+int shg_plan_profile(shg_plan* plan, int enable);
+int shg_plan_profile_read(shg_plan* plan, double ms[SHG_PROFILE_KINDS], int64_t launches[SHG_PROFILE_KINDS]);
+
 /* ------------------------------------------------------------------------------------------------
  * Synthesis  V[b][i][j] = sum_nm kn[i][n] P_nm(theta_i) (C_nm[b] cos m lon_j + S_nm[b] sin m lon_j)
  *   replaces PotentialCoefficients.to_grid, regular-grid branch   (grates/gravityfield.py:352-368)
