@@ -187,7 +187,7 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
     recursion_tables(N, a, b);
 
     // ---- cos/sin table [coltile][K][16]
-    std::vector<double> trig((size_t)p->ncoltiles * p->K * 16, 0.0);
+    std::vector<double> trig((size_t)round_up(p->ncoltiles, 8) * p->K * 16, 0.0);   // padded to whole column blocks
     auto put = [&](int slot, int m, bool sine) {
         for (int j = 0; j < p->ncol; ++j) {
             const double arg = (double)m * lon_h[j];                 // utilities.py:272-273: cos(m * lon)
@@ -222,7 +222,7 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
 extern "C" int shg_plan_destroy(shg_plan* p) {
     if (!p) return SHG_OK;
     double* ptrs[] = {p->ct, p->st, p->pmm, p->knT, p->arec, p->brec, p->trig, p->lon, p->colat,
-                      p->pk_deg, p->cs_slot, p->cpk, p->F};
+                      p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->cpk4};
     for (double* q : ptrs)
         if (q) (void)hipFree(q);
     for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
@@ -238,7 +238,15 @@ extern "C" int shg_plan_set_chunk(shg_plan* p, int epochs_per_pass) {
     return SHG_OK;
 }
 
-extern "C" int shg_plan_info(const shg_plan* p, int64_t which[6]) {
+extern "C" int shg_plan_set_path(shg_plan* p, int path) {
+    SHG_REQUIRE(p != nullptr, "shg_plan_set_path: NULL plan");
+    SHG_REQUIRE(path >= 0 && path <= 2, "shg_plan_set_path: path %d not in {0, 1, 2}", path);
+    SHG_REQUIRE(path != 2 || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
+    p->path = path;
+    return SHG_OK;
+}
+
+extern "C" int shg_plan_info(const shg_plan* p, int64_t which[8]) {
     SHG_REQUIRE(p != nullptr && which != nullptr, "shg_plan_info: NULL argument");
     which[0] = p->N;
     which[1] = p->nlat;
@@ -246,5 +254,6 @@ extern "C" int shg_plan_info(const shg_plan* p, int64_t which[6]) {
     which[3] = p->sym4 ? 1 : 0;
     which[4] = p->chunk;
     which[5] = p->K;
+    which[6] = (p->path == 2 || (p->path == 0 && fused_chunk_for(p) != 0)) ? 1 : 0;
     return SHG_OK;
 }

@@ -87,10 +87,14 @@ class Plan:
             self._handle = ctypes.c_void_p()
 
     def info(self):
-        arr = (ctypes.c_int64 * 6)()
+        arr = (ctypes.c_int64 * 8)()
         _lib.call('shg_plan_info', self._handle, arr)
         return {'max_degree': arr[0], 'nlat': arr[1], 'nlon': arr[2], 'fourfold_symmetry': bool(arr[3]),
-                'epochs_per_pass': arr[4], 'k_slots': arr[5]}
+                'epochs_per_pass': arr[4], 'k_slots': arr[5], 'fused': bool(arr[6])}
+
+    def set_path(self, path):
+        """'auto', 'staged' (three kernels) or 'fused' (single kernel)."""
+        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2}[path])
 
     def set_chunk(self, epochs_per_pass):
         _lib.call('shg_plan_set_chunk', self._handle, int(epochs_per_pass))

@@ -56,9 +56,13 @@ int shg_plan_destroy(shg_plan* plan);
 /* Number of epochs processed per internal pass (workspace is sized for it).  Default 16. */
 int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
 
+/* Synthesis path: 0 = automatic, 1 = three-kernel path (pack, Legendre stage, longitude stage; any grid,
+ * any degree), 2 = single fused kernel (4-fold symmetric meridians, K <= 224 i.e. degree <= 110). */
+int shg_plan_set_path(shg_plan* plan, int path);
+
 /* Introspection: which[0]=N, [1]=nlat, [2]=nlon, [3]=1 if the 4-fold longitude symmetry path is active,
- * [4]=epochs per pass, [5]=K slots of the longitude stage. */
-int shg_plan_info(const shg_plan* plan, int64_t which[6]);
+ * [4]=epochs per pass, [5]=K slots of the longitude stage, [6]=1 if synthesis uses the fused kernel, [7]=0. */
+int shg_plan_info(const shg_plan* plan, int64_t which[8]);
 
 /* Per-kernel timing with HIP events recorded on the caller's stream around every kernel a plan launches.
  * kinds: 0 pack_coefficients, 1 legendre_stage, 2 lon_stage, 3 covprop, 4 analysis_lon, 5 analysis_solve.

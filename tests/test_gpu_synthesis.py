@@ -190,3 +190,32 @@ def test_full_size_properties_config2():
     mask[:, 0] = True
     zon = ga.gravityfield.synthesize(zonal * mask, grid, 'ewh')
     assert float((out.mean(dim=2) - zon[:, :, 0]).abs().max() / out.abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize('N,dlon,dlat', [(0, 30, 30), (1, 30, 30), (2, 90, 45), (3, 10, 20), (17, 4.5, 3), (64, 1, 2.5), (96, 0.5, 0.5), (110, 1, 1)])
+def test_fused_and_staged_paths(N, dlon, dlat):
+    """Both synthesis paths (single fused kernel / three staged kernels) against the oracle, ragged batch sizes."""
+    grid = ga.grid.GeographicGrid(dlon, dlat)
+    ker = orc.KernelTable('ewh', love())
+    B = 7
+    batch = np.stack([inputs.coefficients(900 + N * 10 + e, N) for e in range(B)])
+    ref = np.stack([orc.synthesis_regular(batch[e], grid.meridians, grid.parallels, ker) for e in range(B)])
+    plan = ga.engine.Plan(N, *_tables(grid, N, 'ewh'))
+    assert plan.info()['fourfold_symmetry'] and plan.info()['fused']
+    for path in ('fused', 'staged'):
+        plan.set_path(path)
+        assert plan.info()['fused'] == (path == 'fused')
+        for nb in (1, 3, 4, 5, 7):
+            out = ga.engine.to_host(plan.synthesis(batch[0:nb]))
+            assert relerr(out, ref[0:nb]) < TOL, (path, nb)
+
+
+def test_fused_path_limits():
+    grid = ga.grid.GeographicGrid(2, 2)
+    plan = ga.engine.Plan(120, *_tables(grid, 120, 'potential'))
+    assert not plan.info()['fused']            # K = 248 > 224: falls back to the staged kernels
+    with pytest.raises(ga._lib.ShgError):
+        plan.set_path('fused')
+    g7 = ga.grid.RegularGrid(np.array([-3.0, -2.2, -0.4, 0.1, 0.9, 2.5, 3.1]), np.array([1.3, 1.0, 0.2, -0.5]))
+    plan = ga.engine.Plan(10, *_tables(g7, 10, 'potential'))
+    assert not plan.info()['fused'] and not plan.info()['fourfold_symmetry']
