@@ -155,7 +155,8 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
         const int cnt[4] = {N / 2 + 1, (N + 1) / 2, N / 2, (N + 1) / 2};   // cos even, cos odd, sin even, sin odd
         p->ngroups = 4;
         p->goff[0] = 0;
-        for (int g = 0; g < 4; ++g) p->goff[g + 1] = p->goff[g] + round_up(cnt[g], 4);
+        // groups padded to whole bodies of 4 MFMA k-steps (16 slots): the fused kernel then needs no remainder handling
+        for (int g = 0; g < 4; ++g) p->goff[g + 1] = p->goff[g] + round_up(cnt[g], 16);
         p->ncol = nlon / 4;
     } else {
         p->ngroups = 1;
@@ -187,7 +188,8 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
     recursion_tables(N, a, b);
 
     // ---- cos/sin table [coltile][K][16]
-    std::vector<double> trig((size_t)round_up(p->ncoltiles, 8) * p->K * 16, 0.0);   // padded to whole column blocks
+    // padded to whole column blocks of the fused kernel plus one chunk of rows (its prefetch is unconditional)
+    std::vector<double> trig(((size_t)round_up(p->ncoltiles, 8) * p->K + 16) * 16, 0.0);
     auto put = [&](int slot, int m, bool sine) {
         for (int j = 0; j < p->ncol; ++j) {
             const double arg = (double)m * lon_h[j];                 // utilities.py:272-273: cos(m * lon)

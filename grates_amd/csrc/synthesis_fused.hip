@@ -8,17 +8,20 @@
 //     B operand = plan table PK_m[n][i] = kn[i][n] P_nm(theta_i)  (what the reference forms at
 //     grates/gravityfield.py:358-362), both read as MFMA fragments straight from L2.
 //     The result lands in the LDS panel As[slot(m, c/s)][row = epoch * 16 + parallel].
-//   phase 2 (longitude stage on MFMA): panel (64 x K) times the cos/sin table, streamed through a
-//     double-buffered LDS ring in chunks of CHUNK K-slots, 8 column tiles (128 quarter-columns) at a time;
-//     the four longitude images of every quarter-column are formed in registers and stored.
+//   phase 2 (longitude stage on MFMA): wave w owns column tile cb * 8 + w of every block of 8 column tiles
+//     (64 panel rows x 16 quarter-columns).  A fragments come from the read-only LDS panel, B fragments
+//     (cos/sin table) straight from L2 through a register ring that runs one body (16 MFMAs) ahead; there is
+//     no barrier after the panel is complete.  The four longitude images of every quarter-column are formed
+//     in registers and stored with 16-byte stores.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace shg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kPanelStride = 80;    // 64 rows + 16 pad: k-rows of one fragment read fall on disjoint LDS banks
-constexpr int kTrigStride = 144;    // 128 columns + 16 pad
+constexpr int kPanelStride = 80;    // 64 rows + 16 pad: the 4 k-rows of one fragment read fall on disjoint LDS banks
 
 // ------------------------------------------------------------------------------------------------
 // plan-time table  PK[(m, n)][i] = kn[i][n] * P_nm(theta_i)   (order-major packed, parallel fastest)
@@ -68,25 +71,38 @@ __global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, c
 
 struct FusedParams {
     int N, nlat, nlon, ldlat, K, ncol, B, nit, Ppk, ncb;   // nit = 16-parallel tiles, ncb = column blocks (8 tiles each)
-    int goff[5];
+    int goff[5];              // first K slot of each (cos/sin, m even/odd) group; every group is a multiple of 16 slots
     int gcount[4];            // used slots per group (the rest up to goff[g+1] is zero padding)
+    int dbg;                  // experiment switches (SHG_DEBUG): 1 no stores, 2 no Legendre phase, 4 no longitude phase, 8 no longitude MFMAs
     const double* cpk4;
     const double* pk;
     const double* trig;       // [ncb * 8][K][16]
     double* G;
 };
 
-template <int CHUNK>
+// One work item of phase 1: 4 k-steps (16 degrees) of order m starting at local degree index k0.
+struct LegendreItem {
+    int m, k0;
+    __device__ bool valid(int N) const { return m <= N; }
+    __device__ LegendreItem next(int N) const {
+        LegendreItem r = {m, k0 + 16};
+        if (r.k0 >= N + 1 - m) {
+            r.m = m + 8;
+            r.k0 = 0;
+        }
+        return r;
+    }
+};
+
 __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
-    extern __shared__ double lds[];
-    double* As = lds;                                  // [K][kPanelStride]
-    double* Bs = lds + (size_t)P.K * kPanelStride;     // [2][CHUNK][kTrigStride]
+    extern __shared__ double As[];                     // panel [K][kPanelStride]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int bt = blockIdx.x % ((P.B + 3) / 4);       // epoch tile fastest: neighbouring blocks share the PK slab
-    const int it = blockIdx.x / ((P.B + 3) / 4);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: keeps the order loops on the scalar unit
+    const int nbt = (P.B + 3) >> 2;
+    const int bt = blockIdx.x % nbt;                   // epoch tile fastest: neighbouring blocks share the PK slab
+    const int it = blockIdx.x / nbt;
     const int i0 = it * 16;
     const int fr = lane & 15, fk = lane >> 4;
 
@@ -95,155 +111,211 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         for (int s = P.goff[g] + P.gcount[g]; s < P.goff[g + 1]; ++s)
             if (tid < 64) As[s * kPanelStride + tid] = 0.0;
 
-    // ---- phase 1: Legendre stage, orders distributed over the 8 waves
-    {
+    // ---- phase 1: Legendre stage.  Orders are distributed over the 8 waves; items of 4 k-steps are double
+    //      buffered in two named register sets so that the fragments of item t+1 are in flight while item t runs.
+    if (!(P.dbg & 2)) {
         const double* pkcol = P.pk + i0 + fr;
-        const double* cf = P.cpk4 + (size_t)bt * P.Ppk * 8 + fr;
+        const double* cf = P.cpk4 + (size_t)bt * P.Ppk * 8 + (fr & 7);    // rows 8-15 of the A operand are masked to zero
         const bool arow = fr < 8;
-        for (int m = wave; m <= P.N; m += 8) {
-            const int off = order_offset(P.N, m);
-            const int cnt = P.N + 1 - m;
-            double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            for (int k0 = 0; k0 < cnt; k0 += 16) {
-                double a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int nl = k0 + u * 4 + fk;
-                    const bool ok = nl < cnt;
-                    a[u] = (ok && arow) ? cf[(size_t)(off + nl) * 8] : 0.0;
-                    b[u] = ok ? pkcol[(size_t)(off + nl) * P.ldlat] : 0.0;
-                }
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
-            }
-            // C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15  ->  reg 0 = C part of epoch (lane >> 4),
-            // reg 1 = S part; panel row = epoch * 16 + parallel = lane
-            const int sc = P.goff[m & 1] + (m >> 1);
-            As[sc * kPanelStride + lane] = acc0[0] + acc1[0];
-            if (m >= 1) {
-                const int ss = P.goff[2 + (m & 1)] + ((m & 1) ? (m >> 1) : (m >> 1) - 1);
-                As[ss * kPanelStride + lane] = acc0[1] + acc1[1];
+        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+
+#define SHG_P1_ISSUE(item, A0, A1, A2, A3, B0, B1, B2, B3)                                   \
+    do {                                                                                     \
+        const int off_ = order_offset(P.N, (item).m);                                        \
+        const int last_ = P.N - (item).m;                                                    \
+        const int n0_ = min((item).k0 + fk, last_), n1_ = min((item).k0 + 4 + fk, last_);    \
+        const int n2_ = min((item).k0 + 8 + fk, last_), n3_ = min((item).k0 + 12 + fk, last_); \
+        A0 = cf[(size_t)(off_ + n0_) * 8];                                                   \
+        B0 = pkcol[(size_t)(off_ + n0_) * P.ldlat];                                          \
+        A1 = cf[(size_t)(off_ + n1_) * 8];                                                   \
+        B1 = pkcol[(size_t)(off_ + n1_) * P.ldlat];                                          \
+        A2 = cf[(size_t)(off_ + n2_) * 8];                                                   \
+        B2 = pkcol[(size_t)(off_ + n2_) * P.ldlat];                                          \
+        A3 = cf[(size_t)(off_ + n3_) * 8];                                                   \
+        B3 = pkcol[(size_t)(off_ + n3_) * P.ldlat];                                          \
+    } while (0)
+
+#define SHG_P1_CONSUME(item, nxt, A0, A1, A2, A3, B0, B1, B2, B3)                                                   \
+    do {                                                                                                            \
+        const int cnt_ = P.N + 1 - (item).m;                                                                        \
+        const double a0_ = (arow && (item).k0 + fk < cnt_) ? A0 : 0.0;                                              \
+        const double a1_ = (arow && (item).k0 + 4 + fk < cnt_) ? A1 : 0.0;                                          \
+        const double a2_ = (arow && (item).k0 + 8 + fk < cnt_) ? A2 : 0.0;                                          \
+        const double a3_ = (arow && (item).k0 + 12 + fk < cnt_) ? A3 : 0.0;                                         \
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0_, B0, acc0, 0, 0, 0);                                        \
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_, B1, acc1, 0, 0, 0);                                        \
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2_, B2, acc0, 0, 0, 0);                                        \
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3_, B3, acc1, 0, 0, 0);                                        \
+        if ((nxt).m != (item).m) {                                                                                  \
+            /* C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15: reg 0 = cosine part of epoch (lane >> 4),  */ \
+            /* reg 1 = sine part; panel row = epoch * 16 + parallel = lane                                        */ \
+            const int m_ = (item).m;                                                                                \
+            As[(P.goff[m_ & 1] + (m_ >> 1)) * kPanelStride + lane] = acc0[0] + acc1[0];                             \
+            if (m_ >= 1)                                                                                            \
+                As[(P.goff[2 + (m_ & 1)] + ((m_ & 1) ? (m_ >> 1) : (m_ >> 1) - 1)) * kPanelStride + lane] = acc0[1] + acc1[1]; \
+            acc0 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
+            acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
+        }                                                                                                           \
+    } while (0)
+
+        double xa0 = 0, xa1 = 0, xa2 = 0, xa3 = 0, xb0 = 0, xb1 = 0, xb2 = 0, xb3 = 0;     // register set X
+        double ya0 = 0, ya1 = 0, ya2 = 0, ya3 = 0, yb0 = 0, yb1 = 0, yb2 = 0, yb3 = 0;     // register set Y
+        // The prefetch is issued unconditionally (an exhausted sequence re-reads its last item): a branch around
+        // the loads makes the compiler's vmcnt bookkeeping conservative and serialises load and MFMA.
+        LegendreItem cur = {wave, 0};
+        if (cur.valid(P.N)) {
+            SHG_P1_ISSUE(cur, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
+            while (true) {
+                LegendreItem nx = cur.next(P.N);
+                const bool nx_ok = nx.valid(P.N);
+                const LegendreItem ld1 = nx_ok ? nx : cur;
+                SHG_P1_ISSUE(ld1, ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3);
+                SHG_P1_CONSUME(cur, nx, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
+                if (!nx_ok) break;
+                cur = nx.next(P.N);
+                const bool cur_ok = cur.valid(P.N);
+                const LegendreItem ld2 = cur_ok ? cur : nx;
+                SHG_P1_ISSUE(ld2, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
+                SHG_P1_CONSUME(nx, cur, ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3);
+                if (!cur_ok) break;
             }
         }
+#undef SHG_P1_ISSUE
+#undef SHG_P1_CONSUME
     }
+    __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
 
     // ---- phase 2: longitude stage
-    const int wr = wave >> 2, wc = wave & 3;           // 2 x 4 waves, wave tile 32 rows x 32 quarter-columns
-    // staging of one chunk: CHUNK slots x 8 tiles x 128 B = CHUNK * 64 pieces of 16 B; 512 threads
-    constexpr int kPieces = CHUNK * 64 / 512;          // 2 (CHUNK 16) or 1 (CHUNK 8)
-    const int st_q = (tid & 7) * 2;                    // double offset inside the 16-column row
-    const int st_tile = (tid >> 3) & 7;
-    const int st_slot = tid >> 6;                      // 0..7 (+8 for the second piece)
-
-    // flat list of chunks: (cb, g, k0) in lexicographic order
-    int cb = 0, g = 0, k0 = P.goff[0];
-    auto advance = [&](int& cb_, int& g_, int& k0_) {
-        k0_ += CHUNK;
-        while (k0_ >= P.goff[g_ + 1]) {       // also skips empty groups (tiny degrees)
-            ++g_;
-            if (g_ == 4) {
-                g_ = 0;
-                ++cb_;
-                if (cb_ >= P.ncb) return;
-            }
-            k0_ = P.goff[g_];
-        }
-    };
-    double2 stage[kPieces];
-    auto load_chunk = [&](int cb_, int g_, int k0_) {
-#pragma unroll
-        for (int h = 0; h < kPieces; ++h) {
-            const int s = st_slot + 8 * h;
-            stage[h] = make_double2(0.0, 0.0);
-            if (cb_ < P.ncb && k0_ + s < P.goff[g_ + 1])
-                stage[h] = *reinterpret_cast<const double2*>(P.trig + ((size_t)(cb_ * 8 + st_tile) * P.K + k0_ + s) * 16 + st_q);
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int h = 0; h < kPieces; ++h) {
-            const int s = st_slot + 8 * h;
-            *reinterpret_cast<double2*>(&Bs[((size_t)buf * CHUNK + s) * kTrigStride + st_tile * 16 + st_q]) = stage[h];
-        }
-    };
-
-    load_chunk(cb, g, k0);
-    store_chunk(0);
-    __syncthreads();          // panel (phase 1) and chunk 0 visible
-
-    double4_t acc[4][2][2];
-    int buf = 0;
-    for (int ccb = 0; ccb < P.ncb; ++ccb) {
+    const int nbody = P.K >> 4;                        // bodies of 4 k-steps; every group is a whole number of bodies
+    const bool pair_stores = (P.ncol & 1) == 0;
+    const int par = fr & 1;
+    const double* tbase = P.trig + ((size_t)wave * P.K + fk) * 16 + fr;      // + cb * cb_stride + body * 256 + u * 64
+    const size_t cb_stride = (size_t)8 * P.K * 16;
+    double ring0, ring1, ring2, ring3;                 // B fragments of the current body
+    {
+        const double* t0 = tbase;
+        ring0 = t0[0];
+        ring1 = t0[64];
+        ring2 = t0[128];
+        ring3 = t0[192];
+    }
+    for (int ccb = 0; ccb < P.ncb && !(P.dbg & 4); ++ccb) {
+        double4_t acc[4][4];
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) acc[gg][a][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            for (int rt = 0; rt < 4; ++rt) acc[gg][rt] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
-            for (int kk = P.goff[gg]; kk < P.goff[gg + 1]; kk += CHUNK) {
-                // prefetch the next chunk of the flat sequence into registers
-                int ncb_ = cb, ng_ = g, nk_ = k0;
-                advance(ncb_, ng_, nk_);
-                load_chunk(ncb_, ng_, nk_);
-                const int nsteps = min(CHUNK, P.goff[gg + 1] - kk) >> 2;
-                const double* Bb = Bs + (size_t)buf * CHUNK * kTrigStride;
-                for (int ks = 0; ks < nsteps; ++ks) {
-                    const double* arow = As + (size_t)(kk + ks * 4 + fk) * kPanelStride + fr;
-                    const double* brow = Bb + (size_t)(ks * 4 + fk) * kTrigStride + wc * 32 + fr;
-                    const double a0 = arow[(wr * 2 + 0) * 16], a1 = arow[(wr * 2 + 1) * 16];
-                    const double b0 = brow[0], b1 = brow[16];
-                    acc[gg][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[gg][0][0], 0, 0, 0);
-                    acc[gg][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[gg][0][1], 0, 0, 0);
-                    acc[gg][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[gg][1][0], 0, 0, 0);
-                    acc[gg][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[gg][1][1], 0, 0, 0);
+            for (int body = P.goff[gg] >> 4; body < (P.goff[gg + 1] >> 4) && !(P.dbg & 8); ++body) {
+                // next body of the flat (column block, body) sequence; clamped at the very end
+                int nb_ = body + 1, ncb_ = ccb;
+                if (nb_ == nbody) {
+                    nb_ = 0;
+                    ncb_ = min(ccb + 1, P.ncb - 1);
                 }
-                store_chunk(buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
-                cb = ncb_;
-                g = ng_;
-                k0 = nk_;
+                const double* tn = tbase + (size_t)ncb_ * cb_stride + (size_t)nb_ * 256;
+                // B fragments of the NEXT body: issued now, consumed a whole body (16 MFMAs) later
+                const double nx0 = tn[0], nx1 = tn[64], nx2 = tn[128], nx3 = tn[192];
+                const double* ap = As + (size_t)(body * 16 + fk) * kPanelStride + fr;
+                double a0[4], a1[4];
+#define SHG_READ_A(dst, u)                                                     \
+    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) dst[rt] = ap[(u) * 4 * kPanelStride + rt * 16]
+#define SHG_MFMA4(src, ring)                                                   \
+    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) acc[gg][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(src[rt], ring, acc[gg][rt], 0, 0, 0)
+                // hand-scheduled: the A fragments of k-step u+1 are read while k-step u runs
+                SHG_READ_A(a0, 0);
+                SHG_READ_A(a1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                SHG_MFMA4(a0, ring0);
+                __builtin_amdgcn_sched_barrier(0);
+                SHG_READ_A(a0, 2);
+                SHG_MFMA4(a1, ring1);
+                __builtin_amdgcn_sched_barrier(0);
+                SHG_READ_A(a1, 3);
+                SHG_MFMA4(a0, ring2);
+                __builtin_amdgcn_sched_barrier(0);
+                SHG_MFMA4(a1, ring3);
+                __builtin_amdgcn_sched_barrier(0);
+                ring0 = nx0;
+                ring1 = nx1;
+                ring2 = nx2;
+                ring3 = nx3;
+#undef SHG_READ_A
+#undef SHG_MFMA4
             }
         }
         // epilogue of this column block: four longitude images per quarter-column
+        //   lon_j: E + O,  -lon_j (column nlon-1-j): E - O,  -pi - lon_j (nlon/2-1-j): Ee - Eo - Oe + Oo,
+        //   lon_j + pi (nlon/2+j): Ee - Eo + Oe - Oo
+        const int jt = (ccb * 8 + wave) * 16;
+        if (jt >= P.ncol) continue;                               // uniform per wave (padding tile)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int b = bt * 4 + wr * 2 + a;
+        for (int rt = 0; rt < 4; ++rt) {
+            const int b = bt * 4 + rt;
             if (b >= P.B) continue;
+            double img[4][4];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int j = (ccb * 8 + wc * 2 + c) * 16 + fr;
+            for (int r = 0; r < 4; ++r) {
+                const double ee = acc[0][rt][r], eo = acc[1][rt][r], oe = acc[2][rt][r], oo = acc[3][rt][r];
+                const double s1 = ee + eo, s2 = ee - eo, d1 = oe + oo, d2 = oe - oo;
+                img[0][r] = s1 + d1;
+                img[1][r] = s1 - d1;
+                img[2][r] = s2 - d2;
+                img[3][r] = s2 + d2;
+            }
+            if (P.dbg & 1) {
+                if (img[0][0] != 1.2345e-300) continue;
+            }
+            if (pair_stores) {
+                // lanes (2q, 2q+1) hold adjacent columns: swap halves so that every lane owns two rows x two
+                // adjacent columns and stores 16 bytes
+                const int jc = jt + (fr & ~1);
+                const bool jok = jc < P.ncol;
+                const int ia = i0 + fk + (par ? 8 : 0), ib = ia + 4;
+                double* rowa = P.G + ((size_t)b * P.nlat + ia) * P.nlon;
+                double* rowb = P.G + ((size_t)b * P.nlat + ib) * P.nlon;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double r0 = __shfl_xor(par ? img[t][0] : img[t][2], 1);
+                    const double r1 = __shfl_xor(par ? img[t][1] : img[t][3], 1);
+                    const double a_lo = par ? r0 : img[t][0], a_hi = par ? img[t][2] : r0;
+                    const double b_lo = par ? r1 : img[t][1], b_hi = par ? img[t][3] : r1;
+                    int col;
+                    bool ascending;
+                    if (t == 0) { col = jc; ascending = true; }
+                    else if (t == 1) { col = P.nlon - 2 - jc; ascending = false; }
+                    else if (t == 2) { col = P.nlon / 2 - 2 - jc; ascending = false; }
+                    else { col = P.nlon / 2 + jc; ascending = true; }
+                    if (jok && ia < P.nlat)
+                        *reinterpret_cast<double2*>(rowa + col) = ascending ? make_double2(a_lo, a_hi) : make_double2(a_hi, a_lo);
+                    if (jok && ib < P.nlat)
+                        *reinterpret_cast<double2*>(rowb + col) = ascending ? make_double2(b_lo, b_hi) : make_double2(b_hi, b_lo);
+                }
+            } else {
+                const int j = jt + fr;
                 if (j >= P.ncol) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = i0 + fk + 4 * r;
                     if (i >= P.nlat) continue;
                     double* row = P.G + ((size_t)b * P.nlat + i) * P.nlon;
-                    const double ee = acc[0][a][c][r], eo = acc[1][a][c][r], oe = acc[2][a][c][r], oo = acc[3][a][c][r];
-                    const double s1 = ee + eo, s2 = ee - eo, d1 = oe + oo, d2 = oe - oo;
-                    row[j] = s1 + d1;
-                    row[P.nlon - 1 - j] = s1 - d1;
-                    row[P.nlon / 2 - 1 - j] = s2 - d2;
-                    row[P.nlon / 2 + j] = s2 + d2;
+                    row[j] = img[0][r];
+                    row[P.nlon - 1 - j] = img[1][r];
+                    row[P.nlon / 2 - 1 - j] = img[2][r];
+                    row[P.nlon / 2 + j] = img[3][r];
                 }
             }
         }
     }
 }
 
-static size_t fused_lds_bytes(int K, int chunk) { return ((size_t)K * kPanelStride + 2 * (size_t)chunk * kTrigStride) * sizeof(double); }
+static size_t fused_lds_bytes(int K) { return (size_t)K * kPanelStride * sizeof(double); }
 
-// 0: not applicable, 16 / 8: chunk size to use
+// non-zero when the fused kernel applies: 4-fold symmetric meridians and a panel that fits the 160 KiB LDS
 int fused_chunk_for(const shg_plan* p) {
-    if (!p->sym4) return 0;
-    const size_t limit = 160 * 1024;
-    if (fused_lds_bytes(p->K, 16) <= limit) return 16;
-    if (fused_lds_bytes(p->K, 8) <= limit) return 8;
-    return 0;
+    if (!p->sym4 || (p->K & 15)) return 0;
+    return fused_lds_bytes(p->K) <= 160 * 1024 ? 16 : 0;
 }
 
 int build_pk_table(shg_plan* p, hipStream_t stream) {
@@ -258,8 +330,7 @@ int build_pk_table(shg_plan* p, hipStream_t stream) {
 }
 
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
-    const int chunk = fused_chunk_for(p);
-    if (chunk == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
+    if (fused_chunk_for(p) == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
     int rc = build_pk_table(p, stream);
     if (rc) return rc;
     const int nbt = ceil_div(B, 4);
@@ -295,20 +366,17 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     const int N = p->N;
     const int cnt[4] = {N / 2 + 1, (N + 1) / 2, N / 2, (N + 1) / 2};
     for (int g = 0; g < 4; ++g) P.gcount[g] = cnt[g];
+    const char* dbg_env = getenv("SHG_DEBUG");
+    P.dbg = dbg_env ? atoi(dbg_env) : 0;
     P.cpk4 = p->cpk4;
     P.pk = p->pk;
     P.trig = p->trig;
     P.G = grid;
-    const size_t lds = fused_lds_bytes(p->K, chunk);
+    const size_t lds = fused_lds_bytes(p->K);
     const dim3 grid_dim((unsigned)(nbt * P.nit));
     ProfileScope ps(p, 2, stream);
-    if (chunk == 16) {
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(synthesis_fused_kernel<16>, grid_dim, dim3(512), lds, stream, P);
-    } else {
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(synthesis_fused_kernel<8>, grid_dim, dim3(512), lds, stream, P);
-    }
+    SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(synthesis_fused_kernel, grid_dim, dim3(512), lds, stream, P);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }

@@ -192,7 +192,7 @@ def test_full_size_properties_config2():
     assert float((out.mean(dim=2) - zon[:, :, 0]).abs().max() / out.abs().max()) < 1e-12
 
 
-@pytest.mark.parametrize('N,dlon,dlat', [(0, 30, 30), (1, 30, 30), (2, 90, 45), (3, 10, 20), (17, 4.5, 3), (64, 1, 2.5), (96, 0.5, 0.5), (110, 1, 1)])
+@pytest.mark.parametrize('N,dlon,dlat', [(0, 30, 30), (1, 30, 30), (2, 90, 45), (3, 10, 20), (17, 4.5, 3), (64, 1, 2.5), (96, 0.5, 0.5), (110, 1, 1), (126, 1.5, 1.5)])
 def test_fused_and_staged_paths(N, dlon, dlat):
     """Both synthesis paths (single fused kernel / three staged kernels) against the oracle, ragged batch sizes."""
     grid = ga.grid.GeographicGrid(dlon, dlat)
@@ -212,8 +212,8 @@ def test_fused_and_staged_paths(N, dlon, dlat):
 
 def test_fused_path_limits():
     grid = ga.grid.GeographicGrid(2, 2)
-    plan = ga.engine.Plan(120, *_tables(grid, 120, 'potential'))
-    assert not plan.info()['fused']            # K = 248 > 224: falls back to the staged kernels
+    plan = ga.engine.Plan(140, *_tables(grid, 140, 'potential'))
+    assert not plan.info()['fused']            # K = 4 * 80 = 320 > 256: falls back to the staged kernels
     with pytest.raises(ga._lib.ShgError):
         plan.set_path('fused')
     g7 = ga.grid.RegularGrid(np.array([-3.0, -2.2, -0.4, 0.1, 0.9, 2.5, 3.1]), np.array([1.3, 1.0, 0.2, -0.5]))
