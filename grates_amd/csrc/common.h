@@ -66,6 +66,9 @@ struct shg_plan {
     // covariance-propagation tables (built lazily)
     double* pk_deg = nullptr;   // [nlat][Pfull] kn-scaled P_nm in degree-wise order (nmin = 0)
     double* cs_slot = nullptr;  // [2N+1][nlon] cos/sin per slot (0, 1c, 1s, 2c, 2s, ...)
+    int* rslot = nullptr;       // [Pfull] rank inside its degree of every degree-wise index
+    double* cov_partial = nullptr;   // [column blocks][band rows] partial row sums of the covariance kernel
+    size_t cov_partial_size = 0;
     // workspace
     double* cpk = nullptr;      // [packed][2][chunk_pad] repacked coefficients of one pass
     double* F = nullptr;        // [chunk][K][ldlat] output of the Legendre stage

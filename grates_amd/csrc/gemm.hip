@@ -1,0 +1,393 @@
+// fp64 MFMA GEMM (v_mfma_f64_16x16x4_f64) in two flavours that share one main loop:
+//   MODE_PLAIN    C[M][N] = A[M][K] B[K][N]                      shg_dgemm, shg_dense_filter (grates/filter.py:473-474)
+//   MODE_COVPROP  sigma2[r] = sum_c (A Sigma)[r][c] A[r][c]        shg_covprop_diag            (grates/grid.py:833-835)
+//                 with the rows of A = synthesis matrix generated on the fly:
+//                 A[(i, j)][p] = PK[i][p] * CS[slot(p)][j]         (grates/grid.py:825-834: F = cs * Pnm[k])
+//                 A (68 GB at d/o 180 / 0.5 deg) is never materialised, only M doubles leave the kernel.
+//
+// Block tile 128 x 128, BK = 16, 4 waves as 2 x 2, wave tile 64 x 64 (16 accumulators).  Global -> register
+// prefetch of the next K tile overlaps the 64 MFMAs of the current one; one barrier per K tile.
+#include "common.h"
+
+namespace shg {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDA = 17;     // As[row][k], 17-double rows: the 16 rows x 4 k of one fragment read hit distinct banks
+constexpr int LDB = 144;    // Bs[k][col], 128 + 16 pad
+
+enum { MODE_PLAIN = 0, MODE_COVPROP = 1 };
+
+struct GemmParams {
+    int M, N, K;
+    const double* A;
+    int lda;
+    const double* B;
+    int ldb;
+    double* C;
+    int ldc;
+    // covariance propagation
+    const double* pkd;      // [nlat][ldp]  kn-scaled Legendre functions in degree-wise order (min_degree 0)
+    int ldp;
+    const double* csr;      // [2N+1][nlon] 1, cos(lon), sin(lon), cos(2 lon), ... : row = rank of the coefficient inside its degree
+    const int* rslot;       // [ldp] rank inside the degree of every degree-wise index
+    int ldcs;               // leading dimension of csr (nlon, or the point count for point lists)
+    long long idiv, jmod;   // flat row R -> table row R / idiv, table column R % jmod (regular grid: both nlon)
+    int p_off;              // min_degree^2: first degree-wise index covered by the covariance matrix
+    long long row0;         // first flat grid row (lat0 * nlon) of the band
+    double* partial;        // [gridDim.x][M] per-column-block partial row sums
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmParams P) {
+    extern __shared__ double gemm_lds[];
+    double (*As)[BM * LDA] = reinterpret_cast<double (*)[BM * LDA]>(gemm_lds);                       // [2][BM * LDA]
+    double (*Bs)[BK * LDB] = reinterpret_cast<double (*)[BK * LDB]>(gemm_lds + 2 * BM * LDA);        // [2][BK * LDB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fk = lane >> 4;
+    // column block is the slow grid dimension: the blocks resident at one time share the same B panel in L2
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+
+    // ---- A tile fetch assignment
+    // PLAIN: 128 rows x 8 pieces of 16 B; piece p = tid + 256 h: row = p >> 3, k = (p & 7) * 2
+    // COVPROP: element e = tid + 256 h: row = e & 127 (fixed per thread), k = e >> 7
+    double areg[8];
+    long long cov_i = 0;
+    int cov_j = 0;
+    bool cov_row_ok = false;
+    if (MODE == MODE_COVPROP) {
+        const int row = tid & 127;
+        cov_row_ok = m0 + row < P.M;
+        const long long R = P.row0 + m0 + (cov_row_ok ? row : 0);
+        cov_i = R / P.idiv;
+        cov_j = (int)(R % P.jmod);
+    }
+    auto fetch_a = [&](int k0) {
+        if (MODE == MODE_PLAIN) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int p = tid + 256 * h;
+                const int row = p >> 3, k = (p & 7) * 2;
+                const int gr = m0 + row, gk = k0 + k;
+                double v0 = 0.0, v1 = 0.0;
+                if (gr < P.M) {
+                    const double* src = P.A + (size_t)gr * P.lda + gk;
+                    if (gk + 1 < P.K && ((P.lda & 1) == 0)) {
+                        const double2 t = *reinterpret_cast<const double2*>(src);
+                        v0 = t.x;
+                        v1 = t.y;
+                    } else {
+                        if (gk < P.K) v0 = src[0];
+                        if (gk + 1 < P.K) v1 = src[1];
+                    }
+                }
+                areg[2 * h] = v0;
+                areg[2 * h + 1] = v1;
+            }
+        } else {
+            const int kb = tid >> 7;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const int gk = k0 + 2 * h + kb;
+                double v = 0.0;
+                if (cov_row_ok && gk < P.K) {
+                    const int pf = gk + P.p_off;
+                    v = P.pkd[cov_i * P.ldp + pf] * P.csr[(size_t)P.rslot[pf] * P.ldcs + cov_j];
+                }
+                areg[h] = v;
+            }
+        }
+    };
+    auto store_a = [&](int buf) {
+        if (MODE == MODE_PLAIN) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int p = tid + 256 * h;
+                const int row = p >> 3, k = (p & 7) * 2;
+                As[buf][row * LDA + k] = areg[2 * h];
+                As[buf][row * LDA + k + 1] = areg[2 * h + 1];
+            }
+        } else {
+            const int row = tid & 127, kb = tid >> 7;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) As[buf][row * LDA + 2 * h + kb] = areg[h];
+        }
+    };
+    // ---- B tile: 16 rows x 128 cols = 1024 pieces of 16 B; piece p = tid + 256 h: k = p >> 6, col = (p & 63) * 2
+    double2 breg[4];
+    const bool b_vec = (P.ldb & 1) == 0;
+    auto fetch_b = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int p = tid + 256 * h;
+            const int k = p >> 6, col = (p & 63) * 2;
+            const int gk = k0 + k, gc = n0 + col;
+            double2 v = make_double2(0.0, 0.0);
+            if (gk < P.K) {
+                const double* src = P.B + (size_t)gk * P.ldb + gc;
+                if (gc + 1 < P.N && b_vec) {
+                    v = *reinterpret_cast<const double2*>(src);
+                } else {
+                    if (gc < P.N) v.x = src[0];
+                    if (gc + 1 < P.N) v.y = src[1];
+                }
+            }
+            breg[h] = v;
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int p = tid + 256 * h;
+            const int k = p >> 6, col = (p & 63) * 2;
+            *reinterpret_cast<double2*>(&Bs[buf][k * LDB + col]) = breg[h];
+        }
+    };
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    fetch_a(0);
+    fetch_b(0);
+    store_a(0);
+    store_b(0);
+    __syncthreads();
+
+    const int ntiles = (P.K + BK - 1) / BK;
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) {
+            fetch_a((t + 1) * BK);
+            fetch_b((t + 1) * BK);
+        }
+        const double* Ab = As[buf] + (wr * 64 + fr) * LDA + fk;
+        const double* Bb = Bs[buf] + fk * LDB + wc * 64 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = Ab[a * 16 * LDA + ks * 4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[b] = Bb[ks * 4 * LDB + b * 16];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) {
+            store_a(buf ^ 1);
+            store_b(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
+    if (MODE == MODE_PLAIN) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = m0 + wr * 64 + a * 16 + fk + 4 * r;
+                if (gr >= P.M) continue;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int gc = n0 + wc * 64 + b * 16 + fr;
+                    if (gc < P.N) P.C[(size_t)gr * P.ldc + gc] = acc[a][b][r];
+                }
+            }
+    } else {
+        // row-dot of the (A Sigma) tile with the matching A tile, reduced over the 128 columns of the block
+        double* red = As[0];                // reuse: [128 rows][2 column halves]
+        int colslot[4];
+        bool colok[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gc = n0 + wc * 64 + b * 16 + fr;
+            colok[b] = gc < P.N;
+            colslot[b] = P.rslot[(colok[b] ? gc : 0) + P.p_off];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * 64 + a * 16 + fk + 4 * r;
+                const bool rok = m0 + row < P.M;
+                const long long R = P.row0 + m0 + (rok ? row : 0);
+                const long long gi = R / P.idiv;
+                const int gj = (int)(R % P.jmod);
+                double s = 0.0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (rok && colok[b]) {
+                        const int pf = n0 + wc * 64 + b * 16 + fr + P.p_off;
+                        const double aval = P.pkd[gi * P.ldp + pf] * P.csr[(size_t)colslot[b] * P.ldcs + gj];
+                        s = fma(acc[a][b][r], aval, s);
+                    }
+                }
+                // reduce over the 16 lanes that hold the 16 columns of a tile row
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 8);
+                if (fr == 0) red[row * 2 + wc] = s;
+            }
+        __syncthreads();
+        if (tid < BM && m0 + tid < P.M) P.partial[(size_t)blockIdx.x * P.M + m0 + tid] = red[tid * 2] + red[tid * 2 + 1];
+    }
+}
+
+__global__ void covprop_reduce_kernel(int M, int nparts, const double* __restrict__ partial, double* __restrict__ sigma) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    double s = 0.0;
+    for (int c = 0; c < nparts; ++c) s += partial[(size_t)c * M + r];
+    sigma[r] = sqrt(s);                                     // grates/grid.py:837-839
+}
+
+// PKD[i][p] = PK[(m, n)][i] rearranged to the degree-wise index p (min_degree 0); CSR[r][j]; rslot[p]
+__global__ void covprop_tables_kernel(int N, int nlat, int nlon, int ldlat, const double* __restrict__ pk,
+                                      const double* __restrict__ lon, double* __restrict__ pkd, double* __restrict__ csr,
+                                      int* __restrict__ rslot) {
+    const int P = (N + 1) * (N + 1);
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < (long long)nlat * P) {
+        const int i = (int)(tid / P), p = (int)(tid % P);
+        int n = (int)sqrt((double)p);
+        while ((n + 1) * (n + 1) <= p) ++n;
+        while (n * n > p) --n;
+        const int r = p - n * n;
+        const int m = (r + 1) >> 1;
+        pkd[tid] = pk[(size_t)(order_offset(N, m) + n - m) * ldlat + i];
+        if (i == 0) rslot[p] = r;
+    }
+    if (tid < (long long)(2 * N + 1) * nlon) {
+        const int r = (int)(tid / nlon), j = (int)(tid % nlon);
+        const int m = (r + 1) >> 1;
+        const double arg = (double)m * lon[j];
+        csr[tid] = (r == 0) ? 1.0 : ((r & 1) ? cos(arg) : sin(arg));
+    }
+}
+
+static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream) {
+    const dim3 grid(ceil_div(P.N, BN), ceil_div(P.M, BM));
+    const size_t lds = (size_t)(2 * BM * LDA + 2 * BK * LDB) * sizeof(double);      // 71.7 KB: two blocks per CU
+    if (mode == MODE_PLAIN) {
+        SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gemm_f64_kernel<MODE_PLAIN>, grid, dim3(256), lds, stream, P);
+    } else {
+        SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_COVPROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gemm_f64_kernel<MODE_COVPROP>, grid, dim3(256), lds, stream, P);
+    }
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+// sigma[r] = sqrt(a_r^T Sigma a_r) for M rows whose A entries are products of two table entries
+int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
+                    long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
+                    hipStream_t stream) {
+    GemmParams G = {};
+    G.M = M;
+    G.N = Pn;
+    G.K = Pn;
+    G.B = cov;
+    G.ldb = Pn;
+    G.pkd = pkd;
+    G.ldp = ldp;
+    G.csr = csr;
+    G.ldcs = ldcs;
+    G.rslot = rslot;
+    G.idiv = idiv;
+    G.jmod = jmod;
+    G.p_off = p_off;
+    G.row0 = row0;
+    G.partial = partial;
+    {
+        ProfileScope ps(prof, 3, stream);
+        int rc = launch_gemm(MODE_COVPROP, G, stream);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(covprop_reduce_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, stream, M, ceil_div(Pn, BN), partial, sigma);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+}  // namespace shg
+
+using namespace shg;
+
+extern "C" int shg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, void* stream_) {
+    SHG_REQUIRE(M >= 0 && N >= 0 && K >= 0, "shg_dgemm: negative dimension");
+    if (M == 0 || N == 0) return SHG_OK;
+    SHG_REQUIRE(A && B && C, "shg_dgemm: NULL pointer");
+    SHG_REQUIRE(lda >= K && ldb >= N && ldc >= N, "shg_dgemm: leading dimension too small");
+    GemmParams P = {};
+    P.M = M;
+    P.N = N;
+    P.K = K;
+    P.A = A;
+    P.lda = lda;
+    P.B = B;
+    P.ldb = ldb;
+    P.C = C;
+    P.ldc = ldc;
+    return launch_gemm(MODE_PLAIN, P, (hipStream_t)stream_);
+}
+
+extern "C" int shg_dense_filter(const double* W, int Pn, const double* X, int T, double* Y, void* stream_) {
+    SHG_REQUIRE(Pn >= 0 && T >= 0, "shg_dense_filter: negative dimension");
+    return shg_dgemm(Pn, T, Pn, W, Pn, X, T, Y, T, stream_);
+}
+
+extern "C" int shg_covprop_diag(shg_plan* p, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream_) {
+    SHG_REQUIRE(p != nullptr, "shg_covprop_diag: NULL plan");
+    SHG_REQUIRE(nmin >= 0 && nmin <= p->N + 1, "shg_covprop_diag: min_degree %d out of range", nmin);
+    SHG_REQUIRE(lat0 >= 0 && lat1 <= p->nlat && lat0 <= lat1, "shg_covprop_diag: bad band [%d, %d)", lat0, lat1);
+    if (lat0 == lat1) return SHG_OK;
+    SHG_REQUIRE(sigma != nullptr, "shg_covprop_diag: NULL output");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int Pfull = (p->N + 1) * (p->N + 1);
+    const int Pn = Pfull - nmin * nmin;
+    const long long M = (long long)(lat1 - lat0) * p->nlon;
+    SHG_REQUIRE(M < (1LL << 31), "shg_covprop_diag: band too large");
+    SHG_REQUIRE(Pn == 0 || cov != nullptr, "shg_covprop_diag: NULL covariance");
+
+    int rc = build_pk_table(p, stream);
+    if (rc) return rc;
+    if (!p->pk_deg) {
+        if (hipMalloc((void**)&p->pk_deg, (size_t)p->nlat * Pfull * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&p->cs_slot, (size_t)(2 * p->N + 1) * p->nlon * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&p->rslot, (size_t)Pfull * sizeof(int)) != hipSuccess)
+            return fail(SHG_ERR_NOMEM, "covariance propagation tables: allocation failed");
+        const long long work = std::max<long long>((long long)p->nlat * Pfull, (long long)(2 * p->N + 1) * p->nlon);
+        hipLaunchKernelGGL(covprop_tables_kernel, dim3((unsigned)ceil_div64(work, 256)), dim3(256), 0, stream, p->N, p->nlat, p->nlon,
+                           p->ldlat, p->pk, p->lon, p->pk_deg, p->cs_slot, p->rslot);
+        SHG_HIP(hipGetLastError());
+    }
+    const int ncolblocks = std::max(1, ceil_div(Pn, BN));
+    const size_t need = (size_t)ncolblocks * M;
+    if (need > p->cov_partial_size) {
+        if (p->cov_partial) {
+            SHG_HIP(hipStreamSynchronize(stream));
+            (void)hipFree(p->cov_partial);
+            p->cov_partial = nullptr;
+        }
+        if (hipMalloc((void**)&p->cov_partial, need * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "covariance propagation workspace (%zu doubles)", need);
+        p->cov_partial_size = need;
+    }
+    if (Pn == 0) {
+        SHG_HIP(hipMemsetAsync(sigma, 0, M * sizeof(double), stream));
+        return SHG_OK;
+    }
+    return covprop_generic(p->pk_deg, Pfull, p->cs_slot, p->nlon, p->rslot, p->nlon, p->nlon, (long long)lat0 * p->nlon, (int)M, cov, Pn,
+                           nmin * nmin, p->cov_partial, sigma, p, stream);
+}

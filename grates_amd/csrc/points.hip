@@ -1,0 +1,168 @@
+// Point-list paths (irregular grids): every point carries its own colatitude, longitude and kn row.
+//   shg_synthesis_points   replaces grates/gravityfield.py:370-388 (blocks of 512 points, spherical_harmonics + dgemv)
+//   shg_covprop_points     replaces grates/grid.py:1096-1120       (blocks of 256 points, F Sigma F^T diagonal)
+// Synthesis: lane <-> point, column recursion of P_nm in registers, coefficients fetched with wave-uniform
+// scalar loads, 4 epochs per pass.  Covariance: per-point tables feed the same fp64 MFMA kernel as the regular grid.
+#include "common.h"
+
+namespace shg {
+
+constexpr int kPtEpochs = 4;
+
+__device__ inline double rec_a_pt(int ni, int mi) {
+    const double n = ni, m = mi;
+    if (ni == mi + 1) return sqrt((double)(2 * ni + 1));
+    return sqrt((2.0 * n - 1.0) / (n - m) * (2.0 * n + 1.0) / (n + m));
+}
+__device__ inline double rec_b_pt(int ni, int mi) {
+    const double n = ni, m = mi;
+    if (ni == mi + 1) return 0.0;
+    return sqrt((2.0 * n + 1.0) / (2.0 * n - 3.0) * (n - m - 1.0) / (n - m) * (n + m - 1.0) / (n + m));
+}
+
+__global__ __launch_bounds__(64) void synthesis_points_kernel(int N, int npts, int B, const double* __restrict__ colat,
+                                                              const double* __restrict__ lon, const double* __restrict__ kn,
+                                                              const double* __restrict__ anm, double* __restrict__ values) {
+    const int pt = blockIdx.x * 64 + threadIdx.x;
+    const int b0 = blockIdx.y * kPtEpochs;
+    const bool ok = pt < npts;
+    const int q = ok ? pt : 0;
+    const double th = colat[q], lam = lon[q];
+    const double t = cos(th), st = sin(th);
+    const double* knp = kn + (size_t)q * (N + 1);
+    const size_t E = (size_t)(N + 1) * (N + 1);
+    double acc[kPtEpochs];
+#pragma unroll
+    for (int bb = 0; bb < kPtEpochs; ++bb) acc[bb] = 0.0;
+    double pmm = 1.0;
+    for (int m = 0; m <= N; ++m) {
+        if (m == 1)
+            pmm = sqrt(3.0) * st;
+        else if (m >= 2)
+            pmm = sqrt((2.0 * m + 1.0) / (2.0 * m)) * st * pmm;
+        const double arg = (double)m * lam;
+        const double cm = cos(arg), sm = sin(arg);
+        double p1 = pmm, p2 = 0.0;
+        for (int n = m; n <= N; ++n) {
+            if (n > m) {
+                const double p = (rec_a_pt(n, m) * t) * p1 - rec_b_pt(n, m) * p2;
+                p2 = p1;
+                p1 = p;
+            }
+            const double pk = p1 * knp[n];
+            const double yc = pk * cm, ys = pk * sm;
+#pragma unroll
+            for (int bb = 0; bb < kPtEpochs; ++bb) {
+                const int b = min(b0 + bb, B - 1);
+                const double* a = anm + (size_t)b * E;                 // wave-uniform addresses: scalar loads
+                acc[bb] = fma(yc, a[(size_t)n * (N + 1) + m], acc[bb]);
+                if (m >= 1) acc[bb] = fma(ys, a[(size_t)(m - 1) * (N + 1) + n], acc[bb]);
+            }
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int bb = 0; bb < kPtEpochs; ++bb)
+            if (b0 + bb < B) values[(size_t)(b0 + bb) * npts + pt] = acc[bb];
+    }
+}
+
+// per-point tables of the covariance kernel: pkd[pt][p] (degree-wise, min_degree 0), csr[r][pt]
+__global__ void covprop_point_tables_kernel(int N, int npts, const double* __restrict__ colat, const double* __restrict__ lon,
+                                            const double* __restrict__ kn, double* __restrict__ pkd, double* __restrict__ csr,
+                                            int* __restrict__ rslot) {
+    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= npts) return;
+    const int P = (N + 1) * (N + 1);
+    const double th = colat[pt], lam = lon[pt];
+    const double t = cos(th), st = sin(th);
+    double pmm = 1.0;
+    for (int m = 0; m <= N; ++m) {
+        if (m == 1)
+            pmm = sqrt(3.0) * st;
+        else if (m >= 2)
+            pmm = sqrt((2.0 * m + 1.0) / (2.0 * m)) * st * pmm;
+        const double arg = (double)m * lam;
+        if (m == 0) {
+            csr[pt] = 1.0;
+        } else {
+            csr[(size_t)(2 * m - 1) * npts + pt] = cos(arg);
+            csr[(size_t)(2 * m) * npts + pt] = sin(arg);
+        }
+        double p1 = pmm, p2 = 0.0;
+        for (int n = m; n <= N; ++n) {
+            if (n > m) {
+                const double p = (rec_a_pt(n, m) * t) * p1 - rec_b_pt(n, m) * p2;
+                p2 = p1;
+                p1 = p;
+            }
+            const double pk = p1 * kn[(size_t)pt * (N + 1) + n];
+            const int base = n * n;
+            if (m == 0) {
+                pkd[(size_t)pt * P + base] = pk;
+            } else {
+                pkd[(size_t)pt * P + base + 2 * m - 1] = pk;
+                pkd[(size_t)pt * P + base + 2 * m] = pk;
+            }
+            if (pt == 0) {
+                if (m == 0) {
+                    rslot[base] = 0;
+                } else {
+                    rslot[base + 2 * m - 1] = 2 * m - 1;
+                    rslot[base + 2 * m] = 2 * m;
+                }
+            }
+        }
+    }
+}
+
+int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
+                    long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
+                    hipStream_t stream);
+
+}  // namespace shg
+
+using namespace shg;
+
+extern "C" int shg_synthesis_points(int N, const double* colat, const double* lon, const double* kn, int npts, const double* anm,
+                                    int B, double* values, void* stream_) {
+    SHG_REQUIRE(N >= 0 && npts >= 0 && B >= 0, "shg_synthesis_points: negative size");
+    if (npts == 0 || B == 0) return SHG_OK;
+    SHG_REQUIRE(colat && lon && kn && anm && values, "shg_synthesis_points: NULL pointer");
+    hipLaunchKernelGGL(synthesis_points_kernel, dim3(ceil_div(npts, 64), ceil_div(B, kPtEpochs)), dim3(64), 0, (hipStream_t)stream_, N,
+                       npts, B, colat, lon, kn, anm, values);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+extern "C" int shg_covprop_points(int N, const double* colat, const double* lon, const double* kn, int npts, const double* cov,
+                                  int nmin, double* sigma, void* stream_) {
+    SHG_REQUIRE(N >= 0 && npts >= 0 && nmin >= 0 && nmin <= N + 1, "shg_covprop_points: bad size");
+    if (npts == 0) return SHG_OK;
+    SHG_REQUIRE(colat && lon && kn && sigma, "shg_covprop_points: NULL pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int Pfull = (N + 1) * (N + 1);
+    const int Pn = Pfull - nmin * nmin;
+    if (Pn == 0) {
+        SHG_HIP(hipMemsetAsync(sigma, 0, (size_t)npts * sizeof(double), stream));
+        return SHG_OK;
+    }
+    SHG_REQUIRE(cov != nullptr, "shg_covprop_points: NULL covariance");
+    double *pkd = nullptr, *csr = nullptr, *partial = nullptr;
+    int* rslot = nullptr;
+    const int ncolblocks = ceil_div(Pn, 128);
+    if (hipMallocAsync((void**)&pkd, (size_t)npts * Pfull * sizeof(double), stream) != hipSuccess ||
+        hipMallocAsync((void**)&csr, (size_t)(2 * N + 1) * npts * sizeof(double), stream) != hipSuccess ||
+        hipMallocAsync((void**)&rslot, (size_t)Pfull * sizeof(int), stream) != hipSuccess ||
+        hipMallocAsync((void**)&partial, (size_t)ncolblocks * npts * sizeof(double), stream) != hipSuccess)
+        return fail(SHG_ERR_NOMEM, "shg_covprop_points: workspace allocation failed");
+    hipLaunchKernelGGL(covprop_point_tables_kernel, dim3(ceil_div(npts, 64)), dim3(64), 0, stream, N, npts, colat, lon, kn, pkd, csr, rslot);
+    int rc = covprop_generic(pkd, Pfull, csr, npts, rslot, 1, (long long)1 << 40, 0, npts, cov, Pn, nmin * nmin, partial, sigma, nullptr, stream);
+    (void)hipFreeAsync(pkd, stream);
+    (void)hipFreeAsync(csr, stream);
+    (void)hipFreeAsync(rslot, stream);
+    (void)hipFreeAsync(partial, stream);
+    if (rc) return rc;
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}

@@ -1,0 +1,96 @@
+"""
+GPU parity of covariance propagation (rows a14 / a15 of SURVEY.md 8a) and of the fp64 MFMA GEMM it runs on.
+Tolerance for sigma: 1e-11 relative (square root of a P^2-term sum).
+"""
+
+import numpy as np
+import pytest
+
+import grates_amd as ga
+import inputs
+from conftest import relerr
+from oracle import shg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL_SIGMA = 1e-11
+
+
+def love():
+    return ga.data.load_love_numbers()[0]
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (16, 16, 4), (128, 128, 16), (130, 70, 33), (257, 129, 100), (64, 300, 7), (500, 3, 511)])
+def test_dgemm_against_numpy(M, N, K):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K)
+    A, B = rng.standard_normal((M, K)), rng.standard_normal((K, N))
+    C = ga.engine.to_host(ga.engine.dgemm(A, B))
+    assert C.shape == (M, N)
+    assert relerr(C, A @ B) < 1e-14
+
+
+def test_dgemm_layout_with_asymmetric_operand():
+    # A = I with an asymmetric B catches transposed fragment layouts
+    n = 48
+    B = np.arange(n * n, dtype=float).reshape(n, n)
+    np.testing.assert_array_equal(ga.engine.to_host(ga.engine.dgemm(np.eye(n), B)), B)
+    np.testing.assert_array_equal(ga.engine.to_host(ga.engine.dgemm(B, np.eye(n))), B)
+
+
+def test_golden_regular_grids(golden):
+    g = golden('g9_covariance')
+    grid = ga.grid.GeographicGrid(2.0, 2.0)
+    s = grid.covariance_propagation(inputs.spd_covariance(31, 41 * 41), 0, 40, kernel='ewh')
+    assert s.shape == (16200,) and relerr(s, g['n40_2deg_ewh']) < TOL_SIGMA
+    np.testing.assert_array_equal(grid.values, s)                      # the method also sets the grid values
+    grid = ga.grid.GeographicGrid(5.0, 5.0)
+    s = grid.covariance_propagation(inputs.spd_covariance(32, 21 * 21 - 4), 2, 20, kernel='potential')
+    assert relerr(s, g['n20_5deg_min2_potential']) < TOL_SIGMA
+    cov = inputs.spd_covariance(33, 21 * 21)
+    s = grid.covariance_propagation(cov, 0, 20, kernel='ewh')
+    assert relerr(s, g['n20_5deg_ewh']) < TOL_SIGMA
+    assert relerr(s, g['n20_5deg_ewh_einsum']) < TOL_SIGMA
+    band = grid.covariance_propagation(cov, 0, 20, kernel='ewh', parallel_range=(3, 7))
+    np.testing.assert_array_equal(band, s[3 * 72:7 * 72])              # latitude-band sharding is bit-reproducible
+    with pytest.raises(ValueError):
+        grid.covariance_propagation(cov[:-1, :-1], 0, 20)
+
+
+def test_golden_point_list(golden):
+    g = golden('g9_covariance')
+    lon, lat = inputs.scattered_points(34, 300)
+    grid = ga.grid.IrregularGrid(lon, lat)
+    s = grid.covariance_propagation(inputs.spd_covariance(33, 21 * 21), 0, 20, kernel='ewh')
+    assert relerr(s, g['points_n20_ewh']) < TOL_SIGMA
+    np.testing.assert_array_equal(grid.values, s)
+
+
+@pytest.mark.parametrize('N,nmin,dlon,dlat', [(3, 0, 30, 30), (12, 3, 7.5, 10), (33, 0, 3, 4), (60, 2, 2, 3)])
+def test_against_oracle(N, nmin, dlon, dlat):
+    """Ragged tiles: P and the number of grid rows are not multiples of the 128 x 128 block tile."""
+    grid = ga.grid.GeographicGrid(dlon, dlat)
+    P = (N + 1) ** 2 - nmin ** 2
+    cov = inputs.spd_covariance(200 + N, P)
+    ref = orc.covariance_propagation_regular(cov, nmin, N, grid.meridians, grid.parallels, orc.KernelTable('ewh', love()))
+    s = grid.covariance_propagation(cov, nmin, N, kernel='ewh')
+    assert relerr(s, ref) < TOL_SIGMA
+
+
+def test_properties_identity_and_scaling():
+    """Size-independent properties: Sigma = I gives the row norm of the synthesis matrix; sigma scales with sqrt(c)."""
+    N = 50
+    grid = ga.grid.GeographicGrid(2.0, 2.0)
+    P = (N + 1) ** 2
+    s1 = grid.covariance_propagation(np.eye(P), 0, N, kernel='potential')
+    unit = np.zeros((N + 1, N + 1))
+    ker = orc.KernelTable('potential')
+    colat, _, kn = orc.kn_table(ker, N, grid.parallels, orc.GM_DEFAULT, orc.R_DEFAULT)
+    Pnm = orc.scale_packed_by_degree(orc.legendre_functions(N, colat), kn)
+    # sum_p a_p^2 = sum_nm (kn P_nm)^2 (cos^2 + sin^2) = sum over the packed array with order-0 entries counted once
+    w = np.ones((N + 1, N + 1))
+    w[np.triu_indices(N + 1, 1)] = 0.0                   # sine slots: cos^2 + sin^2 = 1 is already in the cosine slot
+    ref = np.sqrt(np.einsum('knm,nm->k', Pnm ** 2, w))
+    assert relerr(s1.reshape(90, 180), np.repeat(ref[:, None], 180, axis=1)) < 1e-12
+    cov = inputs.spd_covariance(5, P)
+    a = grid.covariance_propagation(cov, 0, N, kernel='potential')
+    b = grid.covariance_propagation(4.0 * cov, 0, N, kernel='potential')
+    np.testing.assert_allclose(b, 2.0 * a, rtol=1e-14)

@@ -1,0 +1,97 @@
+"""
+GPU parity of the filters (rows a16-a19 of SURVEY.md 8a): order-wise block filter (DDK family) and dense matrix
+filter against the golden vectors of the reference.  Tolerance: 1e-13 relative.
+"""
+
+import numpy as np
+import pytest
+
+import grates_amd as ga
+import inputs
+from conftest import relerr
+from oracle import shg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-13
+
+
+def make_pc(anm):
+    gf = ga.gravityfield.PotentialCoefficients()
+    gf.anm = anm.copy()
+    return gf
+
+
+@pytest.mark.parametrize('nmax,ngf', [(20, 20), (120, 120), (120, 96)])
+def test_orderwise_filter_golden(golden, nmax, ngf):
+    g = golden('g10_filter')
+    flt = ga.filter.OrderWiseFilter(inputs.orderwise_random_blocks(42, nmax))
+    gf = make_pc(inputs.coefficients(43, ngf))
+    out = flt.filter(gf)
+    assert out is not gf and out.max_degree == ngf
+    np.testing.assert_array_equal(gf.anm, inputs.coefficients(43, ngf))
+    assert relerr(out.anm, g['orderwise_{0}_{1}'.format(nmax, ngf)]) < TOL
+    np.testing.assert_array_equal(out.anm[0:2, 0:2], gf.anm[0:2, 0:2])       # degrees 0 and 1 restored
+
+
+def test_orderwise_errors_and_batch():
+    flt = ga.filter.OrderWiseFilter(inputs.orderwise_random_blocks(42, 20))
+    with pytest.raises(ValueError):
+        flt.filter(make_pc(inputs.coefficients(1, 21)))
+    with pytest.raises(TypeError):
+        flt.filter(np.zeros((3, 3)))
+    blocks = inputs.orderwise_random_blocks(42, 20)
+    batch = np.stack([inputs.coefficients(300 + e, 17) for e in range(37)])
+    out = ga.engine.to_host(flt.filter_batch(batch))
+    for e in (0, 13, 36):
+        assert relerr(out[e], orc.orderwise_filter(batch[e], blocks)) < TOL
+    # the block filter and its dense matrix are the same operator on degrees >= 2 (input without degrees 0, 1)
+    W = flt.matrix(2, 17)
+    x_in = batch[5].copy()
+    x_in[0:2, 0:2] = 0.0
+    y = ga.engine.to_host(flt.filter_batch(x_in[np.newaxis]))[0]
+    assert relerr(orc.ravel_coefficients(y, 2, 17), W @ orc.ravel_coefficients(x_in, 2, 17)) < TOL
+
+
+def test_ddk_from_synthetic_normals(golden):
+    """DDK construction + application (config 3 operator) with synthetic SPD normals; the published blocks are absent."""
+    g = golden('g10_filter')
+    normals = inputs.orderwise_normal_blocks(44, 20)
+    ga.filter.DDKGeneric._blocked_normals = staticmethod(lambda: normals)
+    try:
+        gf = make_pc(inputs.coefficients(45, 20))
+        for level in (5, 3):
+            assert relerr(ga.filter.DDK(level).filter(gf).anm, g['ddk{0}_n20'.format(level)]) < 1e-12
+            assert relerr(ga.filter.DDKGeneric(level).filter(gf).anm, g['ddkgeneric{0}_n20'.format(level)]) < 1e-12
+    finally:
+        ga.filter.DDKGeneric._blocked_normals = staticmethod(lambda: ga.data.ddk_normal_blocks())
+
+
+def test_general_matrix_filter(golden):
+    g = golden('g10_filter')
+    W = np.random.default_rng(46).standard_normal((21 * 21 - 4, 21 * 21 - 4)) / 21
+    gm = ga.filter.GeneralMatrix(W, 2, 20)
+    out = gm.filter(make_pc(inputs.coefficients(47, 20)))
+    assert relerr(out.anm, g['general_2_20_n20']) < TOL
+    out14 = gm.filter(make_pc(inputs.coefficients(47, 14)))
+    assert out14.anm.shape == g['general_2_20_n14'].shape
+    assert relerr(out14.anm, g['general_2_20_n14']) < TOL
+    batch = np.stack([inputs.coefficients(400 + e, 20) for e in range(9)])
+    res = ga.engine.to_host(gm.filter_batch(batch))
+    for e in range(9):
+        assert relerr(res[e], orc.general_matrix_filter(batch[e], W, 2, 20)) < TOL
+
+
+def test_config3_ddk5_time_series_d120():
+    """BASELINE config 3: DDK5-type filter applied to a d/o-120 time series, block form vs full-matrix multiply."""
+    nmax, T = 120, 24
+    normals = inputs.orderwise_normal_blocks(44, nmax)
+    blocks = orc.ddk_blocks(normals, 5)
+    flt = ga.filter.OrderWiseFilter(blocks)
+    batch = np.stack([inputs.coefficients(600 + e, nmax) for e in range(T)])
+    batch[:, 0:2, 0:2] = 0.0          # GRACE-type series carry no degree 0 / 1; the dense form ignores them as inputs
+    out_blocks = ga.engine.to_host(flt.filter_batch(batch))
+    for e in (0, 11, 23):
+        assert relerr(out_blocks[e], orc.orderwise_filter(batch[e], blocks)) < TOL
+    dense = ga.filter.GeneralMatrix(flt.matrix(2, nmax), 2, nmax)             # 14637 x 14637 full normal-type matrix
+    out_dense = ga.engine.to_host(dense.filter_batch(batch))
+    assert relerr(out_dense, out_blocks) < 1e-12

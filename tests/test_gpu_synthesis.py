@@ -219,3 +219,24 @@ def test_fused_path_limits():
     g7 = ga.grid.RegularGrid(np.array([-3.0, -2.2, -0.4, 0.1, 0.9, 2.5, 3.1]), np.array([1.3, 1.0, 0.2, -0.5]))
     plan = ga.engine.Plan(10, *_tables(g7, 10, 'potential'))
     assert not plan.info()['fused'] and not plan.info()['fourfold_symmetry']
+
+
+def test_point_list_path(golden):
+    """Grids without .parallels take the point-list kernel (AttributeError dispatch of the reference)."""
+    g = golden('g7_synthesis')
+    lon, lat = inputs.scattered_points(11, 1000)
+    grid = ga.grid.IrregularGrid(lon, lat)
+    out = make_pc(inputs.coefficients(12, 40)).to_grid(grid, kernel='ewh')
+    assert type(out) is ga.grid.IrregularGrid and grid.values is None
+    assert relerr(out.values, g['points_ewh']) < TOL
+    batch = np.stack([inputs.coefficients(12 + e, 40) for e in range(6)])
+    vals = ga.engine.to_host(ga.gravityfield.synthesize(batch, grid, 'ewh'))
+    ker = orc.KernelTable('ewh', love())
+    for e in (0, 5):
+        assert relerr(vals[e], orc.synthesis_points(batch[e], lon, lat, ker)) < TOL
+    # the same points given as a regular grid agree with the separable path
+    reg = ga.grid.GeographicGrid(10, 10)
+    irr = ga.grid.IrregularGrid(reg.longitude, reg.latitude)
+    a = make_pc(batch[0]).to_grid(reg, 'ewh').values
+    b = make_pc(batch[0]).to_grid(irr, 'ewh').values
+    assert relerr(a, b) < TOL
