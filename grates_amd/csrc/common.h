@@ -78,7 +78,6 @@ struct shg_plan {
     double* cpk4 = nullptr;     // [ceil(B/4)][packed][2][4] repacked coefficients of the whole batch
     size_t cpk4_size = 0;
     int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel
-    void* aux = nullptr;        // analysis tables (analysis.hip)
 
     // optional per-kernel event timing (shg_plan_profile)
     bool profiling = false;
@@ -92,7 +91,6 @@ int plan_alloc_workspace(shg_plan* p);
 int fused_chunk_for(const shg_plan* p);
 int build_pk_table(shg_plan* p, hipStream_t stream);
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
-void plan_free_aux(shg_plan* p);
 
 // RAII event pair around one kernel launch (no-op unless profiling is enabled on the plan)
 struct ProfileScope {

@@ -253,28 +253,39 @@ __global__ void covprop_reduce_kernel(int M, int nparts, const double* __restric
     sigma[r] = sqrt(s);                                     // grates/grid.py:837-839
 }
 
-// PKD[i][p] = PK[(m, n)][i] rearranged to the degree-wise index p (min_degree 0); CSR[r][j]; rslot[p]
-__global__ void covprop_tables_kernel(int N, int nlat, int nlon, int ldlat, const double* __restrict__ pk,
-                                      const double* __restrict__ lon, double* __restrict__ pkd, double* __restrict__ csr,
-                                      int* __restrict__ rslot) {
+// PKD[i][p] = PK[(m, n)][i] rearranged to the degree-wise index p (min_degree 0); rslot[p] = rank inside the degree
+__global__ void covprop_pkd_kernel(int N, int nlat, int ldlat, const double* __restrict__ pk, double* __restrict__ pkd,
+                                   int* __restrict__ rslot) {
     const int P = (N + 1) * (N + 1);
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < (long long)nlat * P) {
-        const int i = (int)(tid / P), p = (int)(tid % P);
-        int n = (int)sqrt((double)p);
-        while ((n + 1) * (n + 1) <= p) ++n;
-        while (n * n > p) --n;
-        const int r = p - n * n;
-        const int m = (r + 1) >> 1;
-        pkd[tid] = pk[(size_t)(order_offset(N, m) + n - m) * ldlat + i];
-        if (i == 0) rslot[p] = r;
-    }
-    if (tid < (long long)(2 * N + 1) * nlon) {
-        const int r = (int)(tid / nlon), j = (int)(tid % nlon);
-        const int m = (r + 1) >> 1;
-        const double arg = (double)m * lon[j];
-        csr[tid] = (r == 0) ? 1.0 : ((r & 1) ? cos(arg) : sin(arg));
-    }
+    if (tid >= (long long)nlat * P) return;
+    const int i = (int)(tid / P), p = (int)(tid % P);
+    int n = (int)sqrt((double)p);
+    while ((n + 1) * (n + 1) <= p) ++n;
+    while (n * n > p) --n;
+    const int r = p - n * n;
+    const int m = (r + 1) >> 1;
+    pkd[tid] = pk[(size_t)(order_offset(N, m) + n - m) * ldlat + i];
+    if (i == 0) rslot[p] = r;
+}
+
+// CSR[r][j]: r = 0 -> 1, r = 2m-1 -> cos(m lon_j), r = 2m -> sin(m lon_j)
+__global__ void cs_table_kernel(int N, int nlon, const double* __restrict__ lon, double* __restrict__ csr) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long long)(2 * N + 1) * nlon) return;
+    const int r = (int)(tid / nlon), j = (int)(tid % nlon);
+    const int m = (r + 1) >> 1;
+    const double arg = (double)m * lon[j];
+    csr[tid] = (r == 0) ? 1.0 : ((r & 1) ? cos(arg) : sin(arg));
+}
+
+int covprop_build_cs_table(shg_plan* p, hipStream_t stream) {
+    if (p->cs_slot) return SHG_OK;
+    const long long n = (long long)(2 * p->N + 1) * p->nlon;
+    if (hipMalloc((void**)&p->cs_slot, (size_t)n * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "cos/sin table allocation failed");
+    hipLaunchKernelGGL(cs_table_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, stream, p->N, p->nlon, p->lon, p->cs_slot);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
 }
 
 static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream) {
@@ -363,14 +374,14 @@ extern "C" int shg_covprop_diag(shg_plan* p, const double* cov, int nmin, int la
 
     int rc = build_pk_table(p, stream);
     if (rc) return rc;
+    rc = covprop_build_cs_table(p, stream);
+    if (rc) return rc;
     if (!p->pk_deg) {
         if (hipMalloc((void**)&p->pk_deg, (size_t)p->nlat * Pfull * sizeof(double)) != hipSuccess ||
-            hipMalloc((void**)&p->cs_slot, (size_t)(2 * p->N + 1) * p->nlon * sizeof(double)) != hipSuccess ||
             hipMalloc((void**)&p->rslot, (size_t)Pfull * sizeof(int)) != hipSuccess)
             return fail(SHG_ERR_NOMEM, "covariance propagation tables: allocation failed");
-        const long long work = std::max<long long>((long long)p->nlat * Pfull, (long long)(2 * p->N + 1) * p->nlon);
-        hipLaunchKernelGGL(covprop_tables_kernel, dim3((unsigned)ceil_div64(work, 256)), dim3(256), 0, stream, p->N, p->nlat, p->nlon,
-                           p->ldlat, p->pk, p->lon, p->pk_deg, p->cs_slot, p->rslot);
+        hipLaunchKernelGGL(covprop_pkd_kernel, dim3((unsigned)ceil_div64((long long)p->nlat * Pfull, 256)), dim3(256), 0, stream, p->N,
+                           p->nlat, p->ldlat, p->pk, p->pk_deg, p->rslot);
         SHG_HIP(hipGetLastError());
     }
     const int ncolblocks = std::max(1, ceil_div(Pn, BN));

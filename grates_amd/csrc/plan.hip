@@ -229,7 +229,6 @@ extern "C" int shg_plan_destroy(shg_plan* p) {
     for (double* q : ptrs)
         if (q) (void)hipFree(q);
     for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
-    plan_free_aux(p);
     delete p;
     return SHG_OK;
 }
