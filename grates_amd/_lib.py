@@ -42,7 +42,9 @@ PROTOTYPES = {
     'shg_covprop_points': [ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_degree_scale': [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_orderwise_filter': [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_ddk_blocks': [c_double_p, c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_void_p],
     'shg_dense_filter': [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_spd_solve': [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_dgemm': [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
     'shg_analysis': [c_plan_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
 }

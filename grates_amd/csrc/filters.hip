@@ -55,3 +55,109 @@ extern "C" int shg_orderwise_filter(const double* blocks_packed, const int64_t* 
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// DDK block construction:  W_k = (N_k + diag(w[m:]))^-1 N_k  for every order-wise normal block
+// (replaces the 2 Nb + 1 dense solves of DDK.__init__ / DDKGeneric.__init__, grates/filter.py:252-255, 344-347).
+// N_k + D is symmetric positive definite (normal matrix plus positive power-law weights): one workgroup per
+// block does an in-place Cholesky factorisation and 2 triangular solves with all columns of N_k as right-hand sides.
+// ------------------------------------------------------------------------------------------------
+namespace shg {
+
+// in-place right-looking Cholesky of the lower triangle of L [d][d] by one workgroup of 256 threads
+__device__ void cholesky_inplace(double* L, int d, int tid) {
+    for (int k = 0; k < d; ++k) {
+        if (tid == 0) L[k * d + k] = sqrt(L[k * d + k]);
+        __syncthreads();
+        const double piv = L[k * d + k];
+        for (int r = k + 1 + tid; r < d; r += 256) L[r * d + k] /= piv;
+        __syncthreads();
+        const int t = d - k - 1;
+        for (int e = tid; e < t * t; e += 256) {
+            const int r = k + 1 + e / t, c = k + 1 + e % t;
+            if (c <= r) L[r * d + c] = fma(-L[r * d + k], L[c * d + k], L[r * d + c]);
+        }
+        __syncthreads();
+    }
+}
+
+// X <- (L L^T)^-1 X for the ncol columns of X [d][ldx]: one thread per column
+__device__ void cholesky_solve_columns(const double* L, double* X, int d, int ncol, int ldx, int tid) {
+    for (int col = tid; col < ncol; col += 256) {
+        for (int k = 0; k < d; ++k) {
+            double acc = X[(size_t)k * ldx + col];
+            for (int j = 0; j < k; ++j) acc = fma(-L[k * d + j], X[(size_t)j * ldx + col], acc);
+            X[(size_t)k * ldx + col] = acc / L[k * d + k];
+        }
+        for (int k = d - 1; k >= 0; --k) {
+            double acc = X[(size_t)k * ldx + col];
+            for (int j = k + 1; j < d; ++j) acc = fma(-L[j * d + k], X[(size_t)j * ldx + col], acc);
+            X[(size_t)k * ldx + col] = acc / L[k * d + k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ddk_blocks_kernel(int Nb, const double* __restrict__ normals, const long long* __restrict__ off,
+                                                         const double* __restrict__ weights, double* __restrict__ work,
+                                                         double* __restrict__ out) {
+    const int kb = blockIdx.x;
+    const int m = (kb + 1) >> 1;
+    const int d = Nb + 1 - m;
+    const int tid = threadIdx.x;
+    const double* Nk = normals + off[kb];
+    double* L = work + off[kb];
+    double* X = out + off[kb];
+    for (int e = tid; e < d * d; e += 256) {
+        const int r = e / d, c = e % d;
+        L[e] = Nk[e] + (r == c ? weights[m + r] : 0.0);
+        X[e] = Nk[e];
+    }
+    __syncthreads();
+    cholesky_inplace(L, d, tid);
+    cholesky_solve_columns(L, X, d, d, d, tid);
+}
+
+// X = A^-1 B for one symmetric positive definite A [n][n] and B [n][k]; column tiles of B go to different workgroups,
+// each of which factors its own copy of A (small systems: least-squares normal equations of point lists).
+__global__ __launch_bounds__(256) void spd_solve_kernel(int n, int k, const double* __restrict__ A, const double* __restrict__ Bm,
+                                                        double* __restrict__ work, double* __restrict__ X) {
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * 256;
+    const int nc = min(256, k - c0);
+    double* L = work + (size_t)blockIdx.x * n * n;
+    for (int e = tid; e < n * n; e += 256) L[e] = A[e];
+    for (int e = tid; e < n * nc; e += 256) {
+        const int r = e / nc, c = e % nc;
+        X[(size_t)r * k + c0 + c] = Bm[(size_t)r * k + c0 + c];
+    }
+    __syncthreads();
+    cholesky_inplace(L, n, tid);
+    cholesky_solve_columns(L, X + c0, n, nc, k, tid);
+}
+
+}  // namespace shg
+
+extern "C" int shg_ddk_blocks(const double* normals_packed, const int64_t* block_off, int Nb, const double* weights, double* work,
+                              double* blocks_out, void* stream_) {
+    SHG_REQUIRE(Nb >= 0, "shg_ddk_blocks: negative degree");
+    SHG_REQUIRE(normals_packed && block_off && weights && work && blocks_out, "shg_ddk_blocks: NULL pointer");
+    hipLaunchKernelGGL(shg::ddk_blocks_kernel, dim3(2 * Nb + 1), dim3(256), 0, (hipStream_t)stream_, Nb, normals_packed,
+                       (const long long*)block_off, weights, work, blocks_out);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+extern "C" int shg_spd_solve(const double* A, int n, const double* Bm, int k, double* X, void* stream_) {
+    SHG_REQUIRE(n >= 0 && k >= 0, "shg_spd_solve: negative size");
+    if (n == 0 || k == 0) return SHG_OK;
+    SHG_REQUIRE(A && Bm && X, "shg_spd_solve: NULL pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nblocks = ceil_div(k, 256);
+    double* work = nullptr;
+    if (hipMallocAsync((void**)&work, (size_t)nblocks * n * n * sizeof(double), stream) != hipSuccess)
+        return fail(SHG_ERR_NOMEM, "shg_spd_solve: workspace allocation failed");
+    hipLaunchKernelGGL(shg::spd_solve_kernel, dim3(nblocks), dim3(256), 0, stream, n, k, A, Bm, work, X);
+    (void)hipFreeAsync(work, stream);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}

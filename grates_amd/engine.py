@@ -272,12 +272,36 @@ def orderwise_filter(blocks_packed, block_offsets, block_max_degree, anm):
     return out
 
 
+def ddk_blocks(normal_blocks, weights):
+    """W_k = (N_k + diag(w[m:]))^-1 N_k for a list of order-wise normal blocks (host ndarrays) -> list of ndarrays."""
+    torch = require_gpu()
+    nb = normal_blocks[0].shape[0] - 1
+    sizes = np.array([b.size for b in normal_blocks], dtype=np.int64)
+    offsets = np.concatenate(([0], np.cumsum(sizes)[:-1])).astype(np.int64)
+    packed = to_device(np.concatenate([np.ascontiguousarray(b, dtype=np.float64).ravel() for b in normal_blocks]))
+    off = torch.from_numpy(offsets).to(packed.device)
+    work, out = torch.empty_like(packed), torch.empty_like(packed)
+    w = to_device(weights)
+    _lib.call('shg_ddk_blocks', _ptr(packed), _ptr(off), int(nb), _ptr(w), _ptr(work), _ptr(out), _stream())
+    host = to_host(out)
+    return [host[o:o + s].reshape(b.shape).copy() for o, s, b in zip(offsets, sizes, normal_blocks)]
+
+
 def dense_filter(W, X):
     """Y = W @ X, W [P, P], X [P, T] device tensors."""
     torch = require_gpu()
     W, X = to_device(W), to_device(X)
     out = torch.empty_like(X)
     _lib.call('shg_dense_filter', _ptr(W), W.shape[0], _ptr(X), X.shape[1], _ptr(out), _stream())
+    return out
+
+
+def spd_solve(A, B):
+    """X = A^-1 B for symmetric positive definite A (device Cholesky)."""
+    torch = require_gpu()
+    A, B = to_device(A), to_device(B)
+    out = torch.empty_like(B)
+    _lib.call('shg_spd_solve', _ptr(A), A.shape[0], _ptr(B), B.shape[1], _ptr(out), _stream())
     return out
 
 

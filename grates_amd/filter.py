@@ -1,7 +1,8 @@
 """
 Spatial filters with the interface of ``grates.filter``: ``Gaussian`` (grates/filter.py:31-95),
 ``Butterworth`` (:98-130), ``OrderWiseFilter`` (:133-222), ``DDKGeneric`` / ``DDK`` (:225-349),
-``BlockedNormalsVDK`` (:352-427) and ``GeneralMatrix`` (:430-509).
+``BlockedNormalsVDK`` (:352-427) and ``GeneralMatrix`` (:430-509).  ``VDK`` (one-off dense solve whose upstream
+``filter`` is broken) and ``FilterKernel`` are out of scope.
 
 ``filter(gravityfield)`` keeps the reference semantics (new object, input untouched); every filter also
 offers ``filter_batch(anm_batch)`` which filters a whole [T, N+1, N+1] stack of epochs in one GPU call --
@@ -144,13 +145,9 @@ class OrderWiseFilter(SpatialFilter):
 
 
 def _regularised_blocks(normals, weights):
-    """(N_m + diag(w[m:]))^-1 N_m for every order-wise normal block (grates/filter.py:252-255)."""
-    nmax = normals[0].shape[0] - 1
-    out = []
-    for block in normals:
-        m = nmax + 1 - block.shape[0]
-        out.append(np.linalg.solve(block + np.diag(weights[m:]), block))
-    return out
+    """(N_m + diag(w[m:]))^-1 N_m for every order-wise normal block (grates/filter.py:252-255), all blocks in one
+    device launch (Cholesky per block: N_m + diag(w) is symmetric positive definite)."""
+    return engine.ddk_blocks(normals, weights)
 
 
 class DDKGeneric(OrderWiseFilter):
@@ -262,19 +259,3 @@ class GeneralMatrix(SpatialFilter):
         idx_source, idx_target = _gravityfield.CoefficientSequence.reorder_indices(source, target)
         W[np.ix_(idx_target, idx_target)] = self.__W[np.ix_(idx_source, idx_source)].copy()
         return W
-
-
-class VDK(GeneralMatrix):
-    """
-    VDK filter (Horvath et al. 2018): W = (N + K)^-1 N with Kaula regularisation K = diag(scale n^power) on a
-    full normal equation matrix in degree-wise order (grates/filter.py:512-573; the upstream `filter`
-    fails on a name-mangled attribute, here the GeneralMatrix path is used).
-    """
-
-    def __init__(self, normal_equation_matrix, min_degree, max_degree, kaula_scale, kaula_power):
-        degrees = _gravityfield.CoefficientSequenceDegreeWise(min_degree, max_degree).as_array()[:, 1].astype(float)
-        kaula = kaula_scale * degrees ** kaula_power
-        torch = engine.require_gpu()
-        N = engine.to_device(normal_equation_matrix)
-        W = torch.linalg.solve(N + torch.diag(engine.to_device(kaula)), N)
-        super(VDK, self).__init__(engine.to_host(W), min_degree, max_degree)

@@ -391,14 +391,14 @@ class IrregularGrid(Grid):
 
     def analysis_matrix(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
         """(A^T W A)^-1 A^T W with W = diag(area) (grates/grid.py:1015-1017); the normal matrix and the
-        right-hand side are formed with the fp64 MFMA GEMM, the small dense solve runs on the device."""
+        right-hand side are formed with the fp64 MFMA GEMM, the normal equations are solved by a device Cholesky."""
         torch = engine.require_gpu()
         A = engine.to_device(self.synthesis_matrix(min_degree, max_degree, kernel, GM, R))
         sw = torch.sqrt(engine.to_device(self.area))
         A = A * sw[:, None]
         At = A.T.contiguous()
         normal = engine.dgemm(At, A)
-        return engine.to_host(torch.linalg.solve(normal, At * sw[None, :]))
+        return engine.to_host(engine.spd_solve(normal, (At * sw[None, :]).contiguous()))
 
     def covariance_propagation(self, covariance_matrix, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
         """Point-list covariance propagation (grates/grid.py:1096-1120).  Sets and returns the grid values."""

@@ -139,6 +139,17 @@ int shg_orderwise_filter(const double* blocks_packed, const int64_t* block_off, 
                          const double* anm_in, int B, double* anm_out, void* stream);
 int shg_dense_filter(const double* W, int P, const double* X, int T, double* Y, void* stream);
 
+/* DDK block construction  W_k = (N_k + diag(w[m:]))^-1 N_k  for all 2Nb+1 order-wise normal blocks
+ *   replaces the dense solves of DDK.__init__ / DDKGeneric.__init__      (grates/filter.py:252-255, 344-347)
+ *   normals_packed / blocks_out / work: blocks back to back as in shg_orderwise_filter (work: scratch of the
+ *   same size); weights [Nb+1] device array (w_0 = 1, w_n = scale n^4). */
+int shg_ddk_blocks(const double* normals_packed, const int64_t* block_off, int Nb, const double* weights, double* work,
+                   double* blocks_out, void* stream);
+
+/* X = A^-1 B for a symmetric positive definite A [n][n], B / X [n][k] (Cholesky on the device)
+ *   replaces the normal-equation solve of IrregularGrid.analysis_matrix   (grates/grid.py:1015-1017) */
+int shg_spd_solve(const double* A, int n, const double* B, int k, double* X, void* stream);
+
 /* General fp64 MFMA GEMM  C[M][N] = A[M][K] B[K][N]  (row-major, leading dimensions in elements). */
 int shg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, void* stream);
 

@@ -60,7 +60,9 @@ def test_ddk_from_synthetic_normals(golden):
     try:
         gf = make_pc(inputs.coefficients(45, 20))
         for level in (5, 3):
-            assert relerr(ga.filter.DDK(level).filter(gf).anm, g['ddk{0}_n20'.format(level)]) < 1e-12
+            ddk = ga.filter.DDK(level)
+            assert relerr(ddk.filter(gf).anm, g['ddk{0}_n20'.format(level)]) < 1e-12
+            assert relerr(ddk.matrix(2, 20), g['ddk{0}_n20_matrix'.format(level)]) < 1e-12
             assert relerr(ga.filter.DDKGeneric(level).filter(gf).anm, g['ddkgeneric{0}_n20'.format(level)]) < 1e-12
     finally:
         ga.filter.DDKGeneric._blocked_normals = staticmethod(lambda: ga.data.ddk_normal_blocks())
