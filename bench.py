@@ -61,6 +61,78 @@ def cpu_baseline(sample_epochs, batch_host, grid):
                 sample_epochs, EPOCHS, MAX_DEGREE, GRID_STEP, dt)}
 
 
+COV_DEGREE = 180
+COV_GRID_STEP = 0.5
+MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (spec); measured 77.3 TFLOP/s (profiles/r01_microbench.txt)
+
+
+def covariance_leg(args, rank, world, barrier):
+    """d/o-180 covariance propagation to a 0.5 degree grid (BASELINE config 4), a band of parallels per GPU:
+    sigma = sqrt(diag(A Sigma A^T)) with A generated on the fly, A Sigma on fp64 MFMA.  Flops = 2 M P^2 + 2 M P."""
+    import torch
+    import torch.distributed as dist
+    import grates_amd as ga
+    N = COV_DEGREE
+    grid = ga.grid.GeographicGrid(COV_GRID_STEP, COV_GRID_STEP)
+    nlat, nlon = grid.parallels.size, grid.meridians.size
+    P = (N + 1) ** 2
+    colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel(KERNEL), N, grid.parallels, 3.9860044150e+14, 6.3781363000e+06,
+                                                   grid.semimajor_axis, grid.flattening)
+    plan = ga.engine.Plan(N, colat, kn, grid.meridians)
+    # synthetic SPD covariance, generated on the device (8.59 GB, never shipped): symmetric random + dominant diagonal
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    cov = torch.rand((P, P), dtype=torch.float64, device='cuda', generator=gen)
+    cov = (cov + cov.T) * (0.5e-22 / P)
+    cov.diagonal().add_(2e-22)
+    band = min(args.cov_parallels, nlat // world)
+    lat0 = rank * (nlat // world)                     # each rank works inside its own latitude band of the full sharding
+    lat1 = lat0 + band
+    plan.covariance_propagation(cov, 0, lat0, lat0 + 1)          # warm-up: builds the plan tables
+    barrier()
+    plan.profile(True)
+    plan.profile_read()
+    t0 = time.perf_counter()
+    sigma = plan.covariance_propagation(cov, 0, lat0, lat1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = plan.profile_read()
+    plan.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    M = band * nlon
+    flops = 2.0 * M * P * P + 2.0 * M * P
+    if rank != 0:
+        return None
+    k_ms, k_n = prof.get('covprop', (0.0, 0))
+    achieved = flops / (k_ms * 1e-3) / 1e12 if k_n else None
+    out = {
+        'metric': 'full-covariance propagation d/o 180 -> 0.5 deg grid', 'value': world * flops / elapsed / 1e9, 'unit': 'GFLOP/s',
+        'n_gpus': world, 'config': {'workload': 'd/o {0} (P = {1}, Sigma {2:.2f} GB replicated), {3} of {4} parallels x {5} meridians per GPU'.format(
+            N, P, P * P * 8 / 1e9, band, nlat, nlon), 'flops_per_gpu': flops, 'full_grid_flops': 2.0 * nlat * nlon * P * (P + 1.0)},
+        'seconds': elapsed,
+        'roofline': {'kernel': 'gemm_f64_kernel<MODE_COVPROP>', 'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F64_PEAK_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': (achieved / MFMA_F64_PEAK_TFLOPS) if achieved else None, 'traffic': None,
+                     'avg_launch_ms': k_ms / max(k_n, 1)},
+        'sigma_checksum': float(sigma.sum().item()),
+    }
+    if world == 1 and args.cov_cpu_parallels > 0:
+        from oracle import shg_oracle as orc
+        ker = orc.KernelTable(KERNEL, ga.data.load_love_numbers()[0])
+        cov_host = cov.cpu().numpy()
+        t0 = time.perf_counter()
+        ref = orc.covariance_propagation_regular(cov_host, 0, N, grid.meridians, grid.parallels, ker, parallel_range=(lat0, lat0 + args.cov_cpu_parallels))
+        dt = time.perf_counter() - t0
+        mc = args.cov_cpu_parallels * nlon
+        got = sigma[0:mc].cpu().numpy()
+        out['cpu_baseline'] = {'value': (2.0 * mc * P * P + 2.0 * mc * P) / dt / 1e9, 'unit': 'GFLOP/s', 'cores': os.cpu_count(), 'kind': 'port',
+                               'sample': '{0} of {1} parallels at full P (NumPy oracle, per-parallel F @ Sigma), {2:.1f} s incl. table setup'.format(
+                                   args.cov_cpu_parallels, nlat, dt),
+                               'max_rel_diff_vs_gpu': float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))}
+    return out
+
+
 def pmc_traffic():
     """HBM bytes per lon_stage launch from the committed rocprofv3 --pmc summary, if there is one."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -79,6 +151,8 @@ def main():
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass (0 = library default)')
     ap.add_argument('--cpu-sample', type=int, default=16, help='solutions timed on the CPU baseline (0 = skip)')
+    ap.add_argument('--cov-parallels', type=int, default=8, help='parallels of the d/o-180 covariance-propagation leg per GPU (0 = skip)')
+    ap.add_argument('--cov-cpu-parallels', type=int, default=1, help='parallels of the covariance CPU baseline (0 = skip)')
     args = ap.parse_args()
 
     import torch
@@ -141,6 +215,7 @@ def main():
     if rank == 0:
         info = plan.info()
         per_solution = algorithmic_bytes_per_solution(MAX_DEGREE, nlat, nlon)
+        main_kernel = 'synthesis_fused_kernel' if info['fused'] else 'lon_stage_kernel<4>'
         lon_ms, lon_launches = prof.get('lon_stage', (0.0, 0))
         launches_per_step = lon_launches / max(args.steps, 1)
         epochs_per_launch = B / max(launches_per_step, 1e-9)
@@ -163,9 +238,9 @@ def main():
             'config': {'workload': 'batch of {0} monthly solutions d/o {1} -> {2} deg GeographicGrid ({3}x{4}), kernel {5}, per GPU'.format(
                 B, MAX_DEGREE, GRID_STEP, nlat, nlon, KERNEL),
                 'max_degree': MAX_DEGREE, 'epochs_per_gpu': B, 'grid': [nlat, nlon], 'parallelism': 'epochs sharded over {0} GPU(s), no collective'.format(world),
-                'epochs_per_pass': info['epochs_per_pass'], 'fourfold_symmetry': info['fourfold_symmetry']},
+                'fused_kernel': info['fused'], 'fourfold_symmetry': info['fourfold_symmetry']},
             'roofline': {
-                'kernel': 'lon_stage_kernel<4>', 'bound': 'hbm',
+                'kernel': main_kernel, 'bound': 'hbm',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
                 'traffic': pmc_traffic(),
@@ -179,6 +254,13 @@ def main():
             line['cpu_baseline'] = cpu_baseline(min(args.cpu_sample, B), batch_host, grid)
         else:
             line['cpu_baseline'] = None
+
+    # ---- second half of the metric: full-covariance propagation GFLOP/s (d/o 180 -> 0.5 deg, latitude bands)
+    del out, batch
+    torch.cuda.empty_cache()
+    cov = covariance_leg(args, rank, world, barrier) if args.cov_parallels > 0 else None
+    if rank == 0:
+        line['covariance'] = cov
         print(json.dumps(line), flush=True)
 
     if world > 1:

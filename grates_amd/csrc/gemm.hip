@@ -40,7 +40,7 @@ struct GemmParams {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmParams P) {
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      // 2 waves per SIMD: two blocks per CU
     extern __shared__ double gemm_lds[];
     double (*As)[BM * LDA] = reinterpret_cast<double (*)[BM * LDA]>(gemm_lds);                       // [2][BM * LDA]
     double (*Bs)[BK * LDB] = reinterpret_cast<double (*)[BK * LDB]>(gemm_lds + 2 * BM * LDA);        // [2][BK * LDB]
@@ -50,9 +50,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmParams P) {
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, fk = lane >> 4;
-    // column block is the slow grid dimension: the blocks resident at one time share the same B panel in L2
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    // PLAIN: column block fastest.  COVPROP: row block fastest -- the blocks resident at one time then walk the same
+    // 33 MB column panel of Sigma together and it is fetched from HBM once instead of once per row block.
+    const int m0 = (MODE == MODE_PLAIN ? blockIdx.y : blockIdx.x) * BM;
+    const int n0 = (MODE == MODE_PLAIN ? blockIdx.x : blockIdx.y) * BN;
+    const int colblock = MODE == MODE_PLAIN ? blockIdx.x : blockIdx.y;
 
     // ---- A tile fetch assignment
     // PLAIN: 128 rows x 8 pieces of 16 B; piece p = tid + 256 h: row = p >> 3, k = (p & 7) * 2
@@ -68,6 +70,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmParams P) {
         cov_i = R / P.idiv;
         cov_j = (int)(R % P.jmod);
     }
+    int cov_deg = 0;     // degree of the first degree-wise index of the K tile being fetched (tracked incrementally)
+    const double* cov_pk = MODE == MODE_COVPROP ? P.pkd + cov_i * P.ldp : nullptr;
+    const double* cov_cs = MODE == MODE_COVPROP ? P.csr + cov_j : nullptr;
     auto fetch_a = [&](int k0) {
         if (MODE == MODE_PLAIN) {
 #pragma unroll
@@ -91,16 +96,24 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmParams P) {
                 areg[2 * h + 1] = v1;
             }
         } else {
+            // degree-wise index p = n^2 + r: the rank r inside the degree selects the cos/sin row; it is derived
+            // arithmetically (no index-table load in front of the gather)
             const int kb = tid >> 7;
+            const int p0 = k0 + P.p_off;
+            while ((cov_deg + 1) * (cov_deg + 1) <= p0) ++cov_deg;
+            int n = cov_deg, r = p0 + kb - cov_deg * cov_deg;          // element h is index p0 + kb + 2 h
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                const int gk = k0 + 2 * h + kb;
-                double v = 0.0;
-                if (cov_row_ok && gk < P.K) {
-                    const int pf = gk + P.p_off;
-                    v = P.pkd[cov_i * P.ldp + pf] * P.csr[(size_t)P.rslot[pf] * P.ldcs + cov_j];
+                while (r > 2 * n) {
+                    r -= 2 * n + 1;
+                    ++n;
                 }
-                areg[h] = v;
+                const int gk = k0 + 2 * h + kb;
+                const bool ok = cov_row_ok && gk < P.K;
+                const int pf = ok ? gk + P.p_off : P.p_off;
+                const double v = cov_pk[pf] * cov_cs[(size_t)(ok ? r : 0) * P.ldcs];
+                areg[h] = ok ? v : 0.0;
+                r += 2;
             }
         }
     };
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmParams P) {
                 if (fr == 0) red[row * 2 + wc] = s;
             }
         __syncthreads();
-        if (tid < BM && m0 + tid < P.M) P.partial[(size_t)blockIdx.x * P.M + m0 + tid] = red[tid * 2] + red[tid * 2 + 1];
+        if (tid < BM && m0 + tid < P.M) P.partial[(size_t)colblock * P.M + m0 + tid] = red[tid * 2] + red[tid * 2 + 1];
     }
 }
 
@@ -289,7 +302,7 @@ int covprop_build_cs_table(shg_plan* p, hipStream_t stream) {
 }
 
 static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream) {
-    const dim3 grid(ceil_div(P.N, BN), ceil_div(P.M, BM));
+    const dim3 grid = mode == MODE_PLAIN ? dim3(ceil_div(P.N, BN), ceil_div(P.M, BM)) : dim3(ceil_div(P.M, BM), ceil_div(P.N, BN));
     const size_t lds = (size_t)(2 * BM * LDA + 2 * BK * LDB) * sizeof(double);      // 71.7 KB: two blocks per CU
     if (mode == MODE_PLAIN) {
         SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
