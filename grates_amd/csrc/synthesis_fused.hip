@@ -80,6 +80,15 @@ struct FusedParams {
     double* G;
 };
 
+// value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1, 0, 3, 2]: two VALU moves, no LDS crossbar
+__device__ inline double swap_neighbour(double x) {
+    const long long bits = __builtin_bit_cast(long long, x);
+    const int lo = (int)bits, hi = (int)(bits >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned int)lo2);
+}
+
 // One work item of phase 1: 4 k-steps (16 degrees) of order m starting at local degree index k0.
 struct LegendreItem {
     int m, k0;
@@ -277,8 +286,8 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
                 double* rowb = P.G + ((size_t)b * P.nlat + ib) * P.nlon;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const double r0 = __shfl_xor(par ? img[t][0] : img[t][2], 1);
-                    const double r1 = __shfl_xor(par ? img[t][1] : img[t][3], 1);
+                    const double r0 = swap_neighbour(par ? img[t][0] : img[t][2]);
+                    const double r1 = swap_neighbour(par ? img[t][1] : img[t][3]);
                     const double a_lo = par ? r0 : img[t][0], a_hi = par ? img[t][2] : r0;
                     const double b_lo = par ? r1 : img[t][1], b_hi = par ? img[t][3] : r1;
                     int col;
