@@ -66,7 +66,7 @@ COV_GRID_STEP = 0.5
 MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (spec); measured 77.3 TFLOP/s (profiles/r01_microbench.txt)
 
 
-def covariance_leg(args, rank, world, barrier):
+def covariance_leg(args, rank, world, barrier, reduce_device='cuda'):
     """d/o-180 covariance propagation to a 0.5 degree grid (BASELINE config 4), a band of parallels per GPU:
     sigma = sqrt(diag(A Sigma A^T)) with A generated on the fly, A Sigma on fp64 MFMA.  Flops = 2 M P^2 + 2 M P."""
     import torch
@@ -98,7 +98,7 @@ def covariance_leg(args, rank, world, barrier):
     prof = plan.profile_read()
     plan.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     M = band * nlon
@@ -152,6 +152,8 @@ def main():
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass (0 = library default)')
     ap.add_argument('--cpu-sample', type=int, default=16, help='solutions timed on the CPU baseline (0 = skip)')
     ap.add_argument('--cov-parallels', type=int, default=8, help='parallels of the d/o-180 covariance-propagation leg per GPU (0 = skip)')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only to rehearse on one GPU)")
+    ap.add_argument('--same-device', action='store_true', help='rehearsal: map every rank to cuda:0 (with --backend gloo)')
     ap.add_argument('--cov-cpu-parallels', type=int, default=1, help='parallels of the covariance CPU baseline (0 = skip)')
     args = ap.parse_args()
 
@@ -165,10 +167,16 @@ def main():
         raise SystemExit('WORLD_SIZE={0} does not match --gpus {1}'.format(world, args.gpus))
     if args.gpus > 1 and world == 1:
         raise SystemExit('--gpus {0} needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node {0} bench.py ...'.format(args.gpus))
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    reduce_device = 'cuda' if args.backend == 'nccl' else 'cpu'
 
     import grates_amd as ga
 
@@ -208,7 +216,7 @@ def main():
     plan.profile(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -258,7 +266,7 @@ def main():
     # ---- second half of the metric: full-covariance propagation GFLOP/s (d/o 180 -> 0.5 deg, latitude bands)
     del out, batch
     torch.cuda.empty_cache()
-    cov = covariance_leg(args, rank, world, barrier) if args.cov_parallels > 0 else None
+    cov = covariance_leg(args, rank, world, barrier, reduce_device) if args.cov_parallels > 0 else None
     if rank == 0:
         line['covariance'] = cov
         print(json.dumps(line), flush=True)
