@@ -39,7 +39,7 @@ struct GemmParams {
     double* partial;        // [gridDim.x][M] per-column-block partial row sums
 };
 
-template <int MODE>
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      // 2 waves per SIMD: two blocks per CU
     extern __shared__ double gemm_lds[];
     double (*As)[BM * LDA] = reinterpret_cast<double (*)[BM * LDA]>(gemm_lds);                       // [2][BM * LDA]
@@ -56,111 +56,124 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     const int n0 = (MODE == MODE_PLAIN ? blockIdx.x : blockIdx.y) * BN;
     const int colblock = MODE == MODE_PLAIN ? blockIdx.x : blockIdx.y;
 
-    // ---- A tile fetch assignment
-    // PLAIN: 128 rows x 8 pieces of 16 B; piece p = tid + 256 h: row = p >> 3, k = (p & 7) * 2
-    // COVPROP: element e = tid + 256 h: row = e & 127 (fixed per thread), k = e >> 7
+    // ---- operand fetch.  Full K tiles are fetched without any bounds test: row / column indices beyond the matrix are
+    //      clamped to valid addresses (the garbage only reaches rows / columns that are never stored), so the main loop
+    //      is branch free and the compiler can keep the prefetch in flight across the MFMAs.  Only the last partial
+    //      K tile zero-fills.
+    // PLAIN A: 128 rows x 8 pieces of 2 doubles; piece h of a thread: row = (tid >> 3) + 32 h, k = (tid & 7) * 2
+    // COVPROP A: element h of a thread: row = tid & 127 (fixed), k = (tid >> 7) + 2 h, generated from two small tables
+    // B: 16 k-rows x 64 pieces of 2 doubles; piece h: k = (tid >> 6) + 4 h, col = (tid & 63) * 2
     double areg[8];
-    long long cov_i = 0;
-    int cov_j = 0;
-    bool cov_row_ok = false;
-    if (MODE == MODE_COVPROP) {
-        const int row = tid & 127;
-        cov_row_ok = m0 + row < P.M;
-        const long long R = P.row0 + m0 + (cov_row_ok ? row : 0);
-        cov_i = R / P.idiv;
-        cov_j = (int)(R % P.jmod);
+    double2 breg[4];
+    const int a_kk = (tid & 7) * 2;
+    const double* a_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (MODE == MODE_PLAIN) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) a_ptr[h] = P.A + (size_t)min(m0 + (tid >> 3) + 32 * h, P.M - 1) * P.lda + a_kk;
     }
+    const double* cov_pk = nullptr;
+    const double* cov_cs = nullptr;
     int cov_deg = 0;     // degree of the first degree-wise index of the K tile being fetched (tracked incrementally)
-    const double* cov_pk = MODE == MODE_COVPROP ? P.pkd + cov_i * P.ldp : nullptr;
-    const double* cov_cs = MODE == MODE_COVPROP ? P.csr + cov_j : nullptr;
-    auto fetch_a = [&](int k0) {
+    if (MODE == MODE_COVPROP) {
+        const long long R = P.row0 + min(m0 + (tid & 127), P.M - 1);
+        cov_pk = P.pkd + (R / P.idiv) * P.ldp + P.p_off;
+        cov_cs = P.csr + (R % P.jmod);
+    }
+    const int b_k = tid >> 6;
+    const int b_col = (tid & 63) * 2;
+    const int b_c0 = VEC ? min(n0 + b_col, P.N - 2) : min(n0 + b_col, P.N - 1);
+    const int b_c1 = min(n0 + b_col + 1, P.N - 1);
+    const double* b_ptr0 = P.B + b_c0;
+    const double* b_ptr1 = P.B + b_c1;
+
+    auto fetch_full = [&](int k0) {
         if (MODE == MODE_PLAIN) {
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const int p = tid + 256 * h;
-                const int row = p >> 3, k = (p & 7) * 2;
-                const int gr = m0 + row, gk = k0 + k;
-                double v0 = 0.0, v1 = 0.0;
-                if (gr < P.M) {
-                    const double* src = P.A + (size_t)gr * P.lda + gk;
-                    if (gk + 1 < P.K && ((P.lda & 1) == 0)) {
-                        const double2 t = *reinterpret_cast<const double2*>(src);
-                        v0 = t.x;
-                        v1 = t.y;
-                    } else {
-                        if (gk < P.K) v0 = src[0];
-                        if (gk + 1 < P.K) v1 = src[1];
-                    }
+                if (VEC) {
+                    const double2 t = *reinterpret_cast<const double2*>(a_ptr[h] + k0);
+                    areg[2 * h] = t.x;
+                    areg[2 * h + 1] = t.y;
+                } else {
+                    areg[2 * h] = a_ptr[h][k0];
+                    areg[2 * h + 1] = a_ptr[h][k0 + 1];
                 }
-                areg[2 * h] = v0;
-                areg[2 * h + 1] = v1;
             }
         } else {
-            // degree-wise index p = n^2 + r: the rank r inside the degree selects the cos/sin row; it is derived
-            // arithmetically (no index-table load in front of the gather)
-            const int kb = tid >> 7;
+            // degree-wise index p = n^2 + r: the rank r inside the degree selects the cos/sin row (derived arithmetically)
             const int p0 = k0 + P.p_off;
             while ((cov_deg + 1) * (cov_deg + 1) <= p0) ++cov_deg;
-            int n = cov_deg, r = p0 + kb - cov_deg * cov_deg;          // element h is index p0 + kb + 2 h
+            int n = cov_deg, r = p0 + (tid >> 7) - cov_deg * cov_deg;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
                 while (r > 2 * n) {
                     r -= 2 * n + 1;
                     ++n;
                 }
-                const int gk = k0 + 2 * h + kb;
-                const bool ok = cov_row_ok && gk < P.K;
-                const int pf = ok ? gk + P.p_off : P.p_off;
-                const double v = cov_pk[pf] * cov_cs[(size_t)(ok ? r : 0) * P.ldcs];
-                areg[h] = ok ? v : 0.0;
+                areg[h] = cov_pk[k0 + 2 * h + (tid >> 7)] * cov_cs[(size_t)r * P.ldcs];
                 r += 2;
             }
         }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const size_t row = (size_t)(k0 + b_k + 4 * h) * P.ldb;
+            if (VEC)
+                breg[h] = *reinterpret_cast<const double2*>(b_ptr0 + row);
+            else
+                breg[h] = make_double2(b_ptr0[row], b_ptr1[row]);
+        }
     };
-    auto store_a = [&](int buf) {
+    // last partial K tile: same addresses with k clamped, entries beyond K zeroed
+    auto fetch_tail = [&](int k0) {
         if (MODE == MODE_PLAIN) {
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const int p = tid + 256 * h;
-                const int row = p >> 3, k = (p & 7) * 2;
-                As[buf][row * LDA + k] = areg[2 * h];
-                As[buf][row * LDA + k + 1] = areg[2 * h + 1];
+                const int k1 = k0 + a_kk;                               // a_ptr already points at column a_kk
+                const double v0 = a_ptr[h][min(k1, P.K - 1) - a_kk];
+                const double v1 = a_ptr[h][min(k1 + 1, P.K - 1) - a_kk];
+                areg[2 * h] = k1 < P.K ? v0 : 0.0;
+                areg[2 * h + 1] = k1 + 1 < P.K ? v1 : 0.0;
+            }
+        } else {
+            const int p0 = k0 + P.p_off;
+            while ((cov_deg + 1) * (cov_deg + 1) <= p0) ++cov_deg;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const int gk = k0 + 2 * h + (tid >> 7);
+                const int kc = min(gk, P.K - 1);
+                int n = cov_deg, r = kc + P.p_off - cov_deg * cov_deg;
+                while (r > 2 * n) {
+                    r -= 2 * n + 1;
+                    ++n;
+                }
+                const double v = cov_pk[kc] * cov_cs[(size_t)r * P.ldcs];
+                areg[h] = gk < P.K ? v : 0.0;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int gk = k0 + b_k + 4 * h;
+            const size_t row = (size_t)min(gk, P.K - 1) * P.ldb;
+            const double x = b_ptr0[row];
+            const double y = VEC ? b_ptr0[row + 1] : b_ptr1[row];
+            breg[h] = gk < P.K ? make_double2(x, y) : make_double2(0.0, 0.0);
+        }
+    };
+    auto stage = [&](int buf) {
+        if (MODE == MODE_PLAIN) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int row = (tid >> 3) + 32 * h;
+                As[buf][row * LDA + a_kk] = areg[2 * h];
+                As[buf][row * LDA + a_kk + 1] = areg[2 * h + 1];
             }
         } else {
             const int row = tid & 127, kb = tid >> 7;
 #pragma unroll
             for (int h = 0; h < 8; ++h) As[buf][row * LDA + 2 * h + kb] = areg[h];
         }
-    };
-    // ---- B tile: 16 rows x 128 cols = 1024 pieces of 16 B; piece p = tid + 256 h: k = p >> 6, col = (p & 63) * 2
-    double2 breg[4];
-    const bool b_vec = (P.ldb & 1) == 0;
-    auto fetch_b = [&](int k0) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int p = tid + 256 * h;
-            const int k = p >> 6, col = (p & 63) * 2;
-            const int gk = k0 + k, gc = n0 + col;
-            double2 v = make_double2(0.0, 0.0);
-            if (gk < P.K) {
-                const double* src = P.B + (size_t)gk * P.ldb + gc;
-                if (gc + 1 < P.N && b_vec) {
-                    v = *reinterpret_cast<const double2*>(src);
-                } else {
-                    if (gc < P.N) v.x = src[0];
-                    if (gc + 1 < P.N) v.y = src[1];
-                }
-            }
-            breg[h] = v;
-        }
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int p = tid + 256 * h;
-            const int k = p >> 6, col = (p & 63) * 2;
-            *reinterpret_cast<double2*>(&Bs[buf][k * LDB + col]) = breg[h];
-        }
+        for (int h = 0; h < 4; ++h) *reinterpret_cast<double2*>(&Bs[buf][(b_k + 4 * h) * LDB + b_col]) = breg[h];
     };
 
     double4_t acc[4][4];
@@ -169,19 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    fetch_a(0);
-    fetch_b(0);
-    store_a(0);
-    store_b(0);
-    __syncthreads();
-
-    const int ntiles = (P.K + BK - 1) / BK;
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) {
-            fetch_a((t + 1) * BK);
-            fetch_b((t + 1) * BK);
-        }
+    auto compute = [&](int buf) {
         const double* Ab = As[buf] + (wr * 64 + fr) * LDA + fk;
         const double* Bb = Bs[buf] + fk * LDB + wc * 64 + fr;
 #pragma unroll
@@ -196,12 +197,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        if (t + 1 < ntiles) {
-            store_a(buf ^ 1);
-            store_b(buf ^ 1);
-        }
+    };
+
+    const int nfull = P.K / BK;
+    const bool has_tail = (P.K % BK) != 0;
+    if (nfull > 0)
+        fetch_full(0);
+    else
+        fetch_tail(0);
+    stage(0);
+    __syncthreads();
+    for (int t = 0; t + 1 < nfull; ++t) {             // branch-free steady state
+        fetch_full((t + 1) * BK);
+        compute(t & 1);
+        stage((t + 1) & 1);
         __syncthreads();
     }
+    if (nfull > 0) {
+        if (has_tail) fetch_tail(nfull * BK);
+        compute((nfull - 1) & 1);
+        if (has_tail) stage(nfull & 1);
+        __syncthreads();
+    }
+    if (has_tail) compute(nfull & 1);
+    __syncthreads();
 
     // ---- epilogue.  C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
     if (MODE == MODE_PLAIN) {
@@ -304,13 +323,20 @@ int covprop_build_cs_table(shg_plan* p, hipStream_t stream) {
 static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream) {
     const dim3 grid = mode == MODE_PLAIN ? dim3(ceil_div(P.N, BN), ceil_div(P.M, BM)) : dim3(ceil_div(P.M, BM), ceil_div(P.N, BN));
     const size_t lds = (size_t)(2 * BM * LDA + 2 * BK * LDB) * sizeof(double);      // 71.7 KB: two blocks per CU
+    // 16-byte operand loads need even leading dimensions / sizes and 16-byte aligned bases
+    const bool vec = (P.ldb % 2 == 0) && (P.N % 2 == 0) && ((uintptr_t)P.B % 16 == 0) &&
+                     (mode != MODE_PLAIN || ((P.lda % 2 == 0) && (P.K % 2 == 0) && ((uintptr_t)P.A % 16 == 0)));
+#define SHG_GEMM_LAUNCH(M_, V_)                                                                                                \
+    do {                                                                                                                        \
+        SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<M_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((gemm_f64_kernel<M_, V_>), grid, dim3(256), lds, stream, P);                                         \
+    } while (0)
     if (mode == MODE_PLAIN) {
-        SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(gemm_f64_kernel<MODE_PLAIN>, grid, dim3(256), lds, stream, P);
+        if (vec) SHG_GEMM_LAUNCH(MODE_PLAIN, true); else SHG_GEMM_LAUNCH(MODE_PLAIN, false);
     } else {
-        SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_COVPROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(gemm_f64_kernel<MODE_COVPROP>, grid, dim3(256), lds, stream, P);
+        if (vec) SHG_GEMM_LAUNCH(MODE_COVPROP, true); else SHG_GEMM_LAUNCH(MODE_COVPROP, false);
     }
+#undef SHG_GEMM_LAUNCH
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
@@ -347,6 +373,10 @@ int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, con
 
 }  // namespace shg
 
+namespace shg {
+int covprop_rows(shg_plan* p, const double* cov, int Pn, int p_off, int lat0, int lat1, double* partial, hipStream_t stream);
+}
+
 using namespace shg;
 
 extern "C" int shg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, void* stream_) {
@@ -354,6 +384,10 @@ extern "C" int shg_dgemm(int M, int N, int K, const double* A, int lda, const do
     if (M == 0 || N == 0) return SHG_OK;
     SHG_REQUIRE(A && B && C, "shg_dgemm: NULL pointer");
     SHG_REQUIRE(lda >= K && ldb >= N && ldc >= N, "shg_dgemm: leading dimension too small");
+    if (K == 0) {
+        SHG_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)N * sizeof(double), M, (hipStream_t)stream_));
+        return SHG_OK;
+    }
     GemmParams P = {};
     P.M = M;
     P.N = N;
@@ -410,6 +444,16 @@ extern "C" int shg_covprop_diag(shg_plan* p, const double* cov, int nmin, int la
     }
     if (Pn == 0) {
         SHG_HIP(hipMemsetAsync(sigma, 0, M * sizeof(double), stream));
+        return SHG_OK;
+    }
+    // Two kernels: covprop_rows (covprop.hip) keeps row tiles inside one parallel (operand tiles are plain table rows) but
+    // pads every parallel to a multiple of 128 meridians; the general kernel generates A element-wise and wastes nothing.
+    const int padded = round_up(p->nlon, 128);
+    if ((padded - p->nlon) * 25 <= p->nlon) {                 // padding waste <= 4 %
+        rc = covprop_rows(p, cov, Pn, nmin * nmin, lat0, lat1, p->cov_partial, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(covprop_reduce_kernel, dim3(ceil_div((int)M, 256)), dim3(256), 0, stream, (int)M, ncolblocks, p->cov_partial, sigma);
+        SHG_HIP(hipGetLastError());
         return SHG_OK;
     }
     return covprop_generic(p->pk_deg, Pfull, p->cs_slot, p->nlon, p->rslot, p->nlon, p->nlon, (long long)lat0 * p->nlon, (int)M, cov, Pn,

@@ -94,3 +94,16 @@ def test_properties_identity_and_scaling():
     a = grid.covariance_propagation(cov, 0, N, kernel='potential')
     b = grid.covariance_propagation(4.0 * cov, 0, N, kernel='potential')
     np.testing.assert_allclose(b, 2.0 * a, rtol=1e-14)
+
+
+def test_row_tiled_kernel_on_128_multiple_grid():
+    """Grids whose meridian count is a multiple of 128 take the row-tiled kernel (covprop.hip); others the general one."""
+    N, nmin = 30, 2
+    mer = np.linspace(-np.pi, np.pi, 256, endpoint=False) + np.pi / 256
+    par = np.linspace(1.5, -1.5, 9)
+    grid = ga.grid.RegularGrid(mer, par)
+    P = (N + 1) ** 2 - nmin ** 2
+    cov = inputs.spd_covariance(321, P)
+    ref = orc.covariance_propagation_regular(cov, nmin, N, mer, par, orc.KernelTable('potential'))
+    s = grid.covariance_propagation(cov, nmin, N, kernel='potential')
+    assert relerr(s, ref) < TOL_SIGMA
