@@ -150,6 +150,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass (0 = library default)')
+    ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'panel'], help='synthesis kernel path')
     ap.add_argument('--cpu-sample', type=int, default=16, help='solutions timed on the CPU baseline (0 = skip)')
     ap.add_argument('--cov-parallels', type=int, default=8, help='parallels of the d/o-180 covariance-propagation leg per GPU (0 = skip)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only to rehearse on one GPU)")
@@ -187,6 +188,8 @@ def main():
     plan = ga.engine.Plan(MAX_DEGREE, colat, kn, grid.meridians)
     if args.chunk > 0:
         plan.set_chunk(args.chunk)
+    if args.path != 'auto':
+        plan.set_path(args.path)
 
     # synthetic monthly solutions: default_rng(1000 + e) N(0,1) * 1e-10, distinct per rank
     B = args.epochs

@@ -77,7 +77,10 @@ struct shg_plan {
     double* pk = nullptr;       // [packed + 4][ldlat] kn-scaled Legendre table, built on first use
     double* cpk4 = nullptr;     // [ceil(B/4)][packed][2][4] repacked coefficients of the whole batch
     size_t cpk4_size = 0;
-    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel
+    int cpk4_variant = 0;       // layout the workspace was last zero-initialised for
+    double* panel = nullptr;    // two-kernel synthesis: [B/4][nit][K][64] Legendre-stage output in LDS-image order
+    size_t panel_size = 0;
+    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel, 3 Legendre kernel + longitude kernel
 
     // optional per-kernel event timing (shg_plan_profile)
     bool profiling = false;

@@ -224,7 +224,7 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
 extern "C" int shg_plan_destroy(shg_plan* p) {
     if (!p) return SHG_OK;
     double* ptrs[] = {p->ct, p->st, p->pmm, p->knT, p->arec, p->brec, p->trig, p->lon, p->colat,
-                      p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->cpk4, p->cov_partial};
+                      p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->cpk4, p->cov_partial, p->panel};
     if (p->rslot) (void)hipFree(p->rslot);
     for (double* q : ptrs)
         if (q) (void)hipFree(q);
@@ -242,8 +242,8 @@ extern "C" int shg_plan_set_chunk(shg_plan* p, int epochs_per_pass) {
 
 extern "C" int shg_plan_set_path(shg_plan* p, int path) {
     SHG_REQUIRE(p != nullptr, "shg_plan_set_path: NULL plan");
-    SHG_REQUIRE(path >= 0 && path <= 2, "shg_plan_set_path: path %d not in {0, 1, 2}", path);
-    SHG_REQUIRE(path != 2 || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
+    SHG_REQUIRE(path >= 0 && path <= 3, "shg_plan_set_path: path %d not in {0, 1, 2, 3}", path);
+    SHG_REQUIRE(path < 2 || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
     p->path = path;
     return SHG_OK;
 }
@@ -256,6 +256,7 @@ extern "C" int shg_plan_info(const shg_plan* p, int64_t which[8]) {
     which[3] = p->sym4 ? 1 : 0;
     which[4] = p->chunk;
     which[5] = p->K;
-    which[6] = (p->path == 2 || (p->path == 0 && fused_chunk_for(p) != 0)) ? 1 : 0;
+    which[6] = (p->path >= 2 || (p->path == 0 && fused_chunk_for(p) != 0)) ? 1 : 0;
+    which[7] = p->path;
     return SHG_OK;
 }

@@ -77,6 +77,7 @@ struct FusedParams {
     const double* cpk4;
     const double* pk;
     const double* trig;       // [ncb * 8][K][16]
+    const double* panel;      // two-kernel variant: [B/4][nit][K][64] panels written by legendre_mfma_kernel
     double* G;
 };
 
@@ -103,6 +104,7 @@ struct LegendreItem {
     }
 };
 
+template <bool FROM_PANEL>
 __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     extern __shared__ double As[];                     // panel [K][kPanelStride]
 
@@ -116,13 +118,30 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     const int fr = lane & 15, fk = lane >> 4;
 
     // ---- zero the padding slots of the panel
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4 && !FROM_PANEL; ++g)
         for (int s = P.goff[g] + P.gcount[g]; s < P.goff[g + 1]; ++s)
             if (tid < 64) As[s * kPanelStride + tid] = 0.0;
 
+    // ---- two-kernel variant: the panel was computed by legendre_mfma_kernel; copy the contiguous K x 64 image into LDS
+    if (FROM_PANEL) {
+        const double* src = P.panel + ((size_t)bt * P.nit + it) * P.K * 64;
+        for (int p0 = 0; p0 < P.K * 32; p0 += 512 * 4) {          // 4 pieces of 16 B per thread in flight
+            double2 v[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int p = min(p0 + h * 512 + tid, P.K * 32 - 1);
+                v[h] = *reinterpret_cast<const double2*>(src + 2 * p);
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int p = p0 + h * 512 + tid;
+                if (p < P.K * 32) *reinterpret_cast<double2*>(&As[(p >> 5) * kPanelStride + (p & 31) * 2]) = v[h];
+            }
+        }
+    }
     // ---- phase 1: Legendre stage.  Orders are distributed over the 8 waves; items of 4 k-steps are double
     //      buffered in two named register sets so that the fragments of item t+1 are in flight while item t runs.
-    if (!(P.dbg & 2)) {
+    if (!FROM_PANEL && !(P.dbg & 2)) {
         const double* pkcol = P.pk + i0 + fr;
         const double* cf = P.cpk4 + (size_t)bt * P.Ppk * 8 + (fr & 7);    // rows 8-15 of the A operand are masked to zero
         const bool arow = fr < 8;
@@ -319,6 +338,70 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-kernel variant, stage 1: Legendre stage as its own high-occupancy kernel (no LDS, ~40 VGPRs, 8 waves per SIMD hide the
+// L2 latency that the fused kernel exposes).  One wave = (8 epochs, 16 parallels, one order m):
+//   D[(c/s, epoch)][parallel] = sum_n coef[(c/s, epoch)][n] * PK_m[n][parallel]       all 16 MFMA rows are used
+// and the result is written in the exact LDS image of the longitude kernel, [B/4][nit][K][64] (512 contiguous bytes per store).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_coefficients8_kernel(int N, int B, const double* __restrict__ anm, double* __restrict__ cpk8) {
+    const int E = (N + 1) * (N + 1);
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int bt = blockIdx.y;
+    const int r = e / (N + 1), c = e % (N + 1);
+    int idx, cs;
+    if (c <= r) {
+        idx = order_offset(N, c) + r - c;
+        cs = 0;
+    } else {
+        idx = order_offset(N, r + 1) + c - (r + 1);
+        cs = 1;
+    }
+    double* dst = cpk8 + (((size_t)bt * packed_count(N) + idx) * 2 + cs) * 8;
+#pragma unroll
+    for (int bb = 0; bb < 8; bb += 2) {
+        const double v0 = (bt * 8 + bb < B) ? anm[(size_t)(bt * 8 + bb) * E + e] : 0.0;
+        const double v1 = (bt * 8 + bb + 1 < B) ? anm[(size_t)(bt * 8 + bb + 1) * E + e] : 0.0;
+        *reinterpret_cast<double2*>(dst + bb) = make_double2(v0, v1);
+    }
+}
+
+__global__ __launch_bounds__(256) void legendre_mfma_kernel(int N, int ldlat, int K, int nit, int Ppk, int g0, int g1, int g2, int g3,
+                                                            const double* __restrict__ cpk8, const double* __restrict__ pk,
+                                                            double* __restrict__ panel) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.y * 4 + wave;
+    if (m > N) return;
+    const int it = blockIdx.x % nit, bt8 = blockIdx.x / nit;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int off = order_offset(N, m);
+    const int cnt = N + 1 - m;
+    const double* a_base = cpk8 + ((size_t)bt8 * Ppk + off) * 16 + fr;      // + n_local * 16
+    const double* b_base = pk + (size_t)off * ldlat + it * 16 + fr;         // + n_local * ldlat
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < cnt; k0 += 8) {
+        const int n0 = k0 + fk, n1 = k0 + 4 + fk;
+        const int c0 = min(n0, cnt - 1), c1 = min(n1, cnt - 1);
+        const double a0 = a_base[(size_t)c0 * 16], a1 = a_base[(size_t)c1 * 16];
+        const double b0 = b_base[(size_t)c0 * ldlat], b1 = b_base[(size_t)c1 * ldlat];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(n0 < cnt ? a0 : 0.0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(n1 < cnt ? a1 : 0.0, b1, acc1, 0, 0, 0);
+    }
+    // C/D layout: row = (lane >> 4) + 4 reg = c/s * 8 + epoch, col = lane & 15 = parallel.
+    //   reg 0: cosine, epochs 0-3; reg 1: cosine, epochs 4-7; reg 2: sine, epochs 0-3; reg 3: sine, epochs 4-7
+    // panel row = (epoch & 3) * 16 + parallel = lane, epoch tile of 4 = bt8 * 2 + (reg & 1)
+    const int sc = (m & 1 ? g0 : 0) + (m >> 1);                                       // group offsets are multiples of 16
+    const int ss = g0 + g1 + (m & 1 ? g2 : 0) + ((m & 1) ? (m >> 1) : (m >> 1) - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r >= 2 && m == 0) break;
+        const int slot = r >= 2 ? ss : sc;
+        panel[(((size_t)(bt8 * 2 + (r & 1)) * nit + it) * K + slot) * 64 + lane] = acc0[r] + acc1[r];
+    }
+}
+
 static size_t fused_lds_bytes(int K) { return (size_t)K * kPanelStride * sizeof(double); }
 
 // non-zero when the fused kernel applies: 4-fold symmetric meridians and a panel that fits the 160 KiB LDS
@@ -338,13 +421,18 @@ int build_pk_table(shg_plan* p, hipStream_t stream) {
     return SHG_OK;
 }
 
+// variant 2: single fused kernel; variant 3: Legendre stage as its own kernel + longitude kernel reading the panels
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
     if (fused_chunk_for(p) == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
+    const bool two_kernel = p->path == 3;
     int rc = build_pk_table(p, stream);
     if (rc) return rc;
     const int nbt = ceil_div(B, 4);
+    const int nbt8 = ceil_div(B, 8);
     const int Ppk = packed_count(p->N);
-    const size_t need = (size_t)nbt * Ppk * 8;
+    const int nit = ceil_div(p->nlat, 16);
+    // coefficient workspace: [nbt][Ppk][2][4] (fused) or [nbt8][Ppk][2][8] (two-kernel): same size per epoch
+    const size_t need = (size_t)std::max(nbt, 2 * nbt8) * Ppk * 8;
     if (need > p->cpk4_size) {
         if (p->cpk4) {
             SHG_HIP(hipStreamSynchronize(stream));
@@ -353,13 +441,13 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
         }
         if (hipMalloc((void**)&p->cpk4, need * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "coefficient workspace allocation failed");
         p->cpk4_size = need;
-        SHG_HIP(hipMemsetAsync(p->cpk4, 0, need * sizeof(double), stream));   // sine slots of order 0 stay zero
+    }
+    // sine slots of order 0 are never written by the pack kernels and must read as zero (layouts differ per variant)
+    if (p->cpk4_variant != (two_kernel ? 3 : 2)) {
+        SHG_HIP(hipMemsetAsync(p->cpk4, 0, p->cpk4_size * sizeof(double), stream));
+        p->cpk4_variant = two_kernel ? 3 : 2;
     }
     const int E = (p->N + 1) * (p->N + 1);
-    {
-        ProfileScope ps(p, 0, stream);
-        hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, anm, p->cpk4);
-    }
     FusedParams P;
     P.N = p->N;
     P.nlat = p->nlat;
@@ -368,7 +456,7 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.K = p->K;
     P.ncol = p->ncol;
     P.B = B;
-    P.nit = ceil_div(p->nlat, 16);
+    P.nit = nit;
     P.Ppk = Ppk;
     P.ncb = ceil_div(p->ncoltiles, 8);
     for (int g = 0; g < 5; ++g) P.goff[g] = p->goff[g];
@@ -380,12 +468,44 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.cpk4 = p->cpk4;
     P.pk = p->pk;
     P.trig = p->trig;
+    P.panel = nullptr;
     P.G = grid;
     const size_t lds = fused_lds_bytes(p->K);
     const dim3 grid_dim((unsigned)(nbt * P.nit));
-    ProfileScope ps(p, 2, stream);
-    SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(synthesis_fused_kernel, grid_dim, dim3(512), lds, stream, P);
+    if (two_kernel) {
+        const size_t pneed = (size_t)2 * nbt8 * nit * p->K * 64;
+        if (pneed > p->panel_size) {
+            if (p->panel) {
+                SHG_HIP(hipStreamSynchronize(stream));
+                (void)hipFree(p->panel);
+                p->panel = nullptr;
+            }
+            if (hipMalloc((void**)&p->panel, pneed * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "panel workspace allocation failed (%zu doubles)", pneed);
+            p->panel_size = pneed;
+            SHG_HIP(hipMemsetAsync(p->panel, 0, pneed * sizeof(double), stream));      // padding slots stay zero
+        }
+        {
+            ProfileScope ps(p, 0, stream);
+            hipLaunchKernelGGL(pack_coefficients8_kernel, dim3(ceil_div(E, 256), nbt8), dim3(256), 0, stream, p->N, B, anm, p->cpk4);
+        }
+        {
+            ProfileScope ps(p, 1, stream);
+            hipLaunchKernelGGL(legendre_mfma_kernel, dim3((unsigned)(nbt8 * nit), ceil_div(N + 1, 4)), dim3(256), 0, stream, N, p->ldlat, p->K, nit,
+                               Ppk, p->goff[1], p->goff[2] - p->goff[1], p->goff[3] - p->goff[2], p->goff[4] - p->goff[3], p->cpk4, p->pk, p->panel);
+        }
+        P.panel = p->panel;
+        ProfileScope ps(p, 2, stream);
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(synthesis_fused_kernel<true>, grid_dim, dim3(512), lds, stream, P);
+    } else {
+        {
+            ProfileScope ps(p, 0, stream);
+            hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, anm, p->cpk4);
+        }
+        ProfileScope ps(p, 2, stream);
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(synthesis_fused_kernel<false>, grid_dim, dim3(512), lds, stream, P);
+    }
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }

@@ -93,8 +93,8 @@ class Plan:
                 'epochs_per_pass': arr[4], 'k_slots': arr[5], 'fused': bool(arr[6])}
 
     def set_path(self, path):
-        """'auto', 'staged' (three kernels) or 'fused' (single kernel)."""
-        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2}[path])
+        """'auto', 'staged' (three kernels, any grid), 'fused' (single kernel) or 'panel' (Legendre kernel + longitude kernel)."""
+        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'panel': 3}[path])
 
     def set_chunk(self, epochs_per_pass):
         _lib.call('shg_plan_set_chunk', self._handle, int(epochs_per_pass))

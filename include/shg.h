@@ -56,8 +56,9 @@ int shg_plan_destroy(shg_plan* plan);
 /* Number of epochs processed per internal pass (workspace is sized for it).  Default 16. */
 int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
 
-/* Synthesis path: 0 = automatic, 1 = three-kernel path (pack, Legendre stage, longitude stage; any grid,
- * any degree), 2 = single fused kernel (4-fold symmetric meridians, K <= 224 i.e. degree <= 110). */
+/* Synthesis path: 0 = automatic, 1 = three-kernel path (pack, Legendre stage, longitude stage; any grid, any degree),
+ * 2 = single fused kernel, 3 = Legendre-stage kernel + longitude kernel exchanging LDS-image panels
+ * (2 and 3: 4-fold symmetric meridians, degree <= 126). */
 int shg_plan_set_path(shg_plan* plan, int path);
 
 /* Introspection: which[0]=N, [1]=nlat, [2]=nlon, [3]=1 if the 4-fold longitude symmetry path is active,

@@ -202,9 +202,9 @@ def test_fused_and_staged_paths(N, dlon, dlat):
     ref = np.stack([orc.synthesis_regular(batch[e], grid.meridians, grid.parallels, ker) for e in range(B)])
     plan = ga.engine.Plan(N, *_tables(grid, N, 'ewh'))
     assert plan.info()['fourfold_symmetry'] and plan.info()['fused']
-    for path in ('fused', 'staged'):
+    for path in ('fused', 'panel', 'staged'):
         plan.set_path(path)
-        assert plan.info()['fused'] == (path == 'fused')
+        assert plan.info()['fused'] == (path != 'staged')
         for nb in (1, 3, 4, 5, 7):
             out = ga.engine.to_host(plan.synthesis(batch[0:nb]))
             assert relerr(out, ref[0:nb]) < TOL, (path, nb)
