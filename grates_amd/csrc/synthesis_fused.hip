@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_, B1, acc1, 0, 0, 0);                                        \
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2_, B2, acc0, 0, 0, 0);                                        \
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3_, B3, acc1, 0, 0, 0);                                        \
-        if ((nxt).m != (item).m) {                                                                                  \
+        if ((nxt).m != (item).m && (item).m <= P.N) {                                                               \
             /* C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15: reg 0 = cosine part of epoch (lane >> 4),  */ \
             /* reg 1 = sine part; panel row = epoch * 16 + parallel = lane                                        */ \
             const int m_ = (item).m;                                                                                \
@@ -188,25 +188,24 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
 
         double xa0 = 0, xa1 = 0, xa2 = 0, xa3 = 0, xb0 = 0, xb1 = 0, xb2 = 0, xb3 = 0;     // register set X
         double ya0 = 0, ya1 = 0, ya2 = 0, ya3 = 0, yb0 = 0, yb1 = 0, yb2 = 0, yb3 = 0;     // register set Y
-        // The prefetch is issued unconditionally (an exhausted sequence re-reads its last item): a branch around
-        // the loads makes the compiler's vmcnt bookkeeping conservative and serialises load and MFMA.
+        // Counted loop, two items per trip, loads issued unconditionally (an exhausted sequence re-reads a valid item and
+        // its MFMAs see a zero A operand): no branch around loads and a single loop exit keep the compiler's vmcnt
+        // bookkeeping exact, so the fragments of item t+1 really are in flight while item t runs.
+        int nitems = 0;
+        for (int m = wave; m <= P.N; m += 8) nitems += (P.N + 1 - m + 15) >> 4;
         LegendreItem cur = {wave, 0};
-        if (cur.valid(P.N)) {
-            SHG_P1_ISSUE(cur, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
-            while (true) {
-                LegendreItem nx = cur.next(P.N);
-                const bool nx_ok = nx.valid(P.N);
-                const LegendreItem ld1 = nx_ok ? nx : cur;
-                SHG_P1_ISSUE(ld1, ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3);
-                SHG_P1_CONSUME(cur, nx, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
-                if (!nx_ok) break;
-                cur = nx.next(P.N);
-                const bool cur_ok = cur.valid(P.N);
-                const LegendreItem ld2 = cur_ok ? cur : nx;
-                SHG_P1_ISSUE(ld2, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
-                SHG_P1_CONSUME(nx, cur, ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3);
-                if (!cur_ok) break;
-            }
+        const LegendreItem first = cur;
+        if (nitems > 0) SHG_P1_ISSUE(cur, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
+        for (int trip = 0; trip < (nitems + 1) / 2; ++trip) {
+            const LegendreItem nx = cur.next(P.N);
+            const LegendreItem ld1 = nx.valid(P.N) ? nx : first;
+            SHG_P1_ISSUE(ld1, ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3);
+            SHG_P1_CONSUME(cur, nx, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
+            const LegendreItem nn = nx.next(P.N);
+            const LegendreItem ld2 = nn.valid(P.N) ? nn : first;
+            SHG_P1_ISSUE(ld2, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
+            SHG_P1_CONSUME(nx, nn, ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3);
+            cur = nn;
         }
 #undef SHG_P1_ISSUE
 #undef SHG_P1_CONSUME
