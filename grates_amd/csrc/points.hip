@@ -7,6 +7,8 @@
 
 namespace shg {
 
+void recursion_tables(int N, std::vector<double>& a, std::vector<double>& b);   // plan.hip
+
 constexpr int kPtEpochs = 4;
 
 __device__ inline double rec_a_pt(int ni, int mi) {
@@ -22,6 +24,7 @@ __device__ inline double rec_b_pt(int ni, int mi) {
 
 __global__ __launch_bounds__(64) void synthesis_points_kernel(int N, int npts, int B, const double* __restrict__ colat,
                                                               const double* __restrict__ lon, const double* __restrict__ kn,
+                                                              const double* __restrict__ arec, const double* __restrict__ brec,
                                                               const double* __restrict__ anm, double* __restrict__ values) {
     const int pt = blockIdx.x * 64 + threadIdx.x;
     const int b0 = blockIdx.y * kPtEpochs;
@@ -43,9 +46,10 @@ __global__ __launch_bounds__(64) void synthesis_points_kernel(int N, int npts, i
         const double arg = (double)m * lam;
         const double cm = cos(arg), sm = sin(arg);
         double p1 = pmm, p2 = 0.0;
+        const int off = order_offset(N, m);
         for (int n = m; n <= N; ++n) {
             if (n > m) {
-                const double p = (rec_a_pt(n, m) * t) * p1 - rec_b_pt(n, m) * p2;
+                const double p = (arec[off + n - m] * t) * p1 - brec[off + n - m] * p2;     // wave-uniform table entries
                 p2 = p1;
                 p1 = p;
             }
@@ -129,8 +133,17 @@ extern "C" int shg_synthesis_points(int N, const double* colat, const double* lo
     SHG_REQUIRE(N >= 0 && npts >= 0 && B >= 0, "shg_synthesis_points: negative size");
     if (npts == 0 || B == 0) return SHG_OK;
     SHG_REQUIRE(colat && lon && kn && anm && values, "shg_synthesis_points: NULL pointer");
-    hipLaunchKernelGGL(synthesis_points_kernel, dim3(ceil_div(npts, 64), ceil_div(B, kPtEpochs)), dim3(64), 0, (hipStream_t)stream_, N,
-                       npts, B, colat, lon, kn, anm, values);
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<double> a, b;
+    recursion_tables(N, a, b);                       // same host-built factors as the plans (reference expression order)
+    double* tab = nullptr;
+    if (hipMallocAsync((void**)&tab, 2 * a.size() * sizeof(double), stream) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_synthesis_points: table allocation failed");
+    SHG_HIP(hipMemcpyAsync(tab, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    SHG_HIP(hipMemcpyAsync(tab + a.size(), b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    SHG_HIP(hipStreamSynchronize(stream));           // the host vectors go out of scope
+    hipLaunchKernelGGL(synthesis_points_kernel, dim3(ceil_div(npts, 64), ceil_div(B, kPtEpochs)), dim3(64), 0, stream, N, npts, B, colat, lon,
+                       kn, tab, tab + a.size(), anm, values);
+    (void)hipFreeAsync(tab, stream);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
