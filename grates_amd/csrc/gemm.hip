@@ -382,12 +382,14 @@ using namespace shg;
 extern "C" int shg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, void* stream_) {
     SHG_REQUIRE(M >= 0 && N >= 0 && K >= 0, "shg_dgemm: negative dimension");
     if (M == 0 || N == 0) return SHG_OK;
-    SHG_REQUIRE(A && B && C, "shg_dgemm: NULL pointer");
-    SHG_REQUIRE(lda >= K && ldb >= N && ldc >= N, "shg_dgemm: leading dimension too small");
-    if (K == 0) {
+    SHG_REQUIRE(C != nullptr, "shg_dgemm: NULL output pointer");
+    SHG_REQUIRE(ldc >= N, "shg_dgemm: leading dimension too small");
+    if (K == 0) {                                     // empty sum: C = 0
         SHG_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)N * sizeof(double), M, (hipStream_t)stream_));
         return SHG_OK;
     }
+    SHG_REQUIRE(A && B, "shg_dgemm: NULL pointer");
+    SHG_REQUIRE(lda >= K && ldb >= N, "shg_dgemm: leading dimension too small");
     GemmParams P = {};
     P.M = M;
     P.N = N;

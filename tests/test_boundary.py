@@ -76,3 +76,15 @@ def test_compute_fails_loudly_without_gpu():
         ga.utilities.legendre_functions(4, np.array([0.3]))
     with pytest.raises(RuntimeError, match='no GPU'):
         ga.filter.Gaussian(300).filter(gf)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/shg.h is the C ABI: it must compile as C without any HIP / C++ header."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('gcc not available')
+    src = tmp_path / 'use_shg.c'
+    src.write_text('#include "shg.h"\nint main(void) { shg_plan* p = 0; return shg_plan_destroy(p) + (int)sizeof(shg_status) * 0; }\n')
+    subprocess.run([gcc, '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)], check=True)
