@@ -74,10 +74,14 @@ struct shg_plan {
     double* F = nullptr;        // [chunk][K][ldlat] output of the Legendre stage
     int chunk_alloc = 0;
     // fused synthesis path (synthesis_fused.hip)
-    double* pk = nullptr;       // [packed + 4][ldlat] kn-scaled Legendre table, built on first use
-    double* cpk4 = nullptr;     // [ceil(B/4)][packed][2][4] repacked coefficients of the whole batch
+    double* pk = nullptr;       // [packed + 4][ldlat] kn-scaled Legendre table (two-kernel variant), built on first use
+    double* pkf = nullptr;      // [nit][Qtot][64 lanes][2] the same table in MFMA-fragment order (fused kernel), built on first use
+    int* qoff = nullptr;        // [N+2] first row-octet of every order in the fragment-ordered tables; qoff[N+1] = Qtot
+    int Qtot = 0;
+    double* cpk4 = nullptr;     // repacked coefficients of the whole batch: [ceil(B/4)][Qtot][32][2] (fused) or [ceil(B/8)][packed][2][8]
     size_t cpk4_size = 0;
     int cpk4_variant = 0;       // layout the workspace was last zero-initialised for
+    size_t cpk4_zeroed = 0;
     double* panel = nullptr;    // two-kernel synthesis: [B/4][nit][K][64] Legendre-stage output in LDS-image order
     size_t panel_size = 0;
     int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel, 3 Legendre kernel + longitude kernel

@@ -20,6 +20,7 @@
 namespace shg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kPanelStride = 80;    // 64 rows + 16 pad: the 4 k-rows of one fragment read fall on disjoint LDS banks
 
@@ -45,28 +46,53 @@ __global__ __launch_bounds__(64) void pk_table_kernel(int N, int ldlat, const do
     }
 }
 
-// coefficients of 4 epochs side by side:  cpk4[bt][(m, n)][c/s][4]
-__global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, const double* __restrict__ anm,
-                                                                  double* __restrict__ cpk4) {
+// The same table in MFMA-fragment order.  Order m owns ceil((N+1-m)/8) "row octets" (8 degrees = 2 k-steps) starting at
+// octet qoff[m]; octet o of parallel tile it is 64 lanes x 2 doubles, lane = fk * 16 + fr holding
+//   PK[(m, m + 8 j + 4 s + fk)][16 it + fr]   for s = 0, 1       (zero beyond degree N)
+// so that one 16-byte load per lane fetches the B fragments of two k-steps and a wave reads 1 KB contiguous.
+__global__ __launch_bounds__(64) void pkf_table_kernel(int N, int ldlat, int nit, int Qtot, const int* __restrict__ qoff,
+                                                       const double* __restrict__ ct, const double* __restrict__ pmm,
+                                                       const double* __restrict__ knT, const double* __restrict__ arec,
+                                                       const double* __restrict__ brec, double* __restrict__ pkf) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nit * 16) return;
+    const int m = blockIdx.y;
+    const int off = order_offset(N, m);
+    const double t = ct[i];
+    double* dst = pkf + (((size_t)(i >> 4) * Qtot + qoff[m]) * 64 + (i & 15)) * 2;      // + octet * 128 + fk * 32 + s
+    double p1 = pmm[(size_t)m * ldlat + i], p2 = 0.0;
+    dst[0] = p1 * knT[(size_t)m * ldlat + i];
+    for (int n = m + 1; n <= N; ++n) {
+        const int idx = off + n - m, nl = n - m;
+        const double p = (arec[idx] * t) * p1 - brec[idx] * p2;      // grates/utilities.py:52-54, no contraction
+        p2 = p1;
+        p1 = p;
+        dst[(size_t)(nl >> 3) * 128 + (nl & 3) * 32 + ((nl >> 2) & 1)] = p * knT[(size_t)n * ldlat + i];
+    }
+}
+
+// coefficients of 4 epochs in MFMA-fragment order:  cpk4[bt][octet][fk * 8 + c/s * 4 + epoch][s]  (A operand rows 0-3 =
+// C_nm of the 4 epochs, rows 4-7 = S_nm; rows 8-15 are zero and not stored)
+__global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, int Qtot, const int* __restrict__ qoff,
+                                                                  const double* __restrict__ anm, double* __restrict__ cpk4) {
     const int E = (N + 1) * (N + 1);
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
     const int bt = blockIdx.y;
     const int r = e / (N + 1), c = e % (N + 1);
-    int idx, cs;
+    int m, nl, cs;
     if (c <= r) {
-        idx = order_offset(N, c) + r - c;
+        m = c;
+        nl = r - c;
         cs = 0;
     } else {
-        idx = order_offset(N, r + 1) + c - (r + 1);
+        m = r + 1;
+        nl = c - (r + 1);
         cs = 1;
     }
-    double v[4];
+    double* dst = cpk4 + (((size_t)bt * Qtot + qoff[m] + (nl >> 3)) * 32 + (nl & 3) * 8 + cs * 4) * 2 + ((nl >> 2) & 1);
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) v[bb] = (bt * 4 + bb < B) ? anm[(size_t)(bt * 4 + bb) * E + e] : 0.0;
-    double* dst = cpk4 + (((size_t)bt * packed_count(N) + idx) * 2 + cs) * 4;
-    *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
-    *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
+    for (int bb = 0; bb < 4; ++bb) dst[bb * 2] = (bt * 4 + bb < B) ? anm[(size_t)(bt * 4 + bb) * E + e] : 0.0;
 }
 
 struct FusedParams {
@@ -74,8 +100,10 @@ struct FusedParams {
     int goff[5];              // first K slot of each (cos/sin, m even/odd) group; every group is a multiple of 16 slots
     int gcount[4];            // used slots per group (the rest up to goff[g+1] is zero padding)
     int dbg;                  // experiment switches (SHG_DEBUG): 1 no stores, 2 no Legendre phase, 4 no longitude phase, 8 no longitude MFMAs
-    const double* cpk4;
-    const double* pk;
+    int Qtot;                 // row octets of the fragment-ordered tables
+    const int* qoff;          // [N+2]
+    const double* cpk4;       // [nbt][Qtot][32][2]
+    const double* pkf;        // [nit][Qtot][64][2]
     const double* trig;       // [ncb * 8][K][16]
     const double* panel;      // two-kernel variant: [B/4][nit][K][64] panels written by legendre_mfma_kernel
     double* G;
@@ -90,15 +118,15 @@ __device__ inline double swap_neighbour(double x) {
     return __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned int)lo2);
 }
 
-// One work item of phase 1: 4 k-steps (16 degrees) of order m starting at local degree index k0.
+// One work item of phase 1: two row octets (4 k-steps, 16 degrees) of order m starting at octet j0 of that order.
 struct LegendreItem {
-    int m, k0;
+    int m, j0;
     __device__ bool valid(int N) const { return m <= N; }
     __device__ LegendreItem next(int N) const {
-        LegendreItem r = {m, k0 + 16};
-        if (r.k0 >= N + 1 - m) {
+        LegendreItem r = {m, j0 + 2};
+        if (r.j0 * 8 >= N + 1 - m) {
             r.m = m + 8;
-            r.k0 = 0;
+            r.j0 = 0;
         }
         return r;
     }
@@ -142,38 +170,31 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     // ---- phase 1: Legendre stage.  Orders are distributed over the 8 waves; items of 4 k-steps are double
     //      buffered in two named register sets so that the fragments of item t+1 are in flight while item t runs.
     if (!FROM_PANEL && !(P.dbg & 2)) {
-        const double* pkcol = P.pk + i0 + fr;
-        const double* cf = P.cpk4 + (size_t)bt * P.Ppk * 8 + (fr & 7);    // rows 8-15 of the A operand are masked to zero
-        const bool arow = fr < 8;
+        const double* pkb = P.pkf + ((size_t)it * P.Qtot * 64 + lane) * 2;                       // + octet * 128
+        const double* cf = P.cpk4 + ((size_t)bt * P.Qtot * 32 + fk * 8 + (fr & 7)) * 2;          // + octet * 64
+        const bool arow = fr < 8;                                     // rows 8-15 of the A operand are zero
         double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 
-#define SHG_P1_ISSUE(item, A0, A1, A2, A3, B0, B1, B2, B3)                                   \
+        // 16-byte fragment loads: A and B of two k-steps per load, 1 KB (B) / 512 B (A) contiguous per wave
+#define SHG_P1_ISSUE(item, ALO, AHI, BLO, BHI)                                               \
     do {                                                                                     \
-        const int off_ = order_offset(P.N, (item).m);                                        \
-        const int last_ = P.N - (item).m;                                                    \
-        const int n0_ = min((item).k0 + fk, last_), n1_ = min((item).k0 + 4 + fk, last_);    \
-        const int n2_ = min((item).k0 + 8 + fk, last_), n3_ = min((item).k0 + 12 + fk, last_); \
-        A0 = cf[(size_t)(off_ + n0_) * 8];                                                   \
-        B0 = pkcol[(size_t)(off_ + n0_) * P.ldlat];                                          \
-        A1 = cf[(size_t)(off_ + n1_) * 8];                                                   \
-        B1 = pkcol[(size_t)(off_ + n1_) * P.ldlat];                                          \
-        A2 = cf[(size_t)(off_ + n2_) * 8];                                                   \
-        B2 = pkcol[(size_t)(off_ + n2_) * P.ldlat];                                          \
-        A3 = cf[(size_t)(off_ + n3_) * 8];                                                   \
-        B3 = pkcol[(size_t)(off_ + n3_) * P.ldlat];                                          \
+        const int q_ = (P.N + 8 - (item).m) >> 3;                                            \
+        const int o0_ = P.qoff[(item).m] + (item).j0;                                        \
+        const int o1_ = o0_ + ((item).j0 + 1 < q_ ? 1 : 0);                                  \
+        ALO = *reinterpret_cast<const double2*>(cf + (size_t)o0_ * 64);                      \
+        BLO = *reinterpret_cast<const double2*>(pkb + (size_t)o0_ * 128);                    \
+        AHI = *reinterpret_cast<const double2*>(cf + (size_t)o1_ * 64);                      \
+        BHI = *reinterpret_cast<const double2*>(pkb + (size_t)o1_ * 128);                    \
     } while (0)
 
-#define SHG_P1_CONSUME(item, nxt, A0, A1, A2, A3, B0, B1, B2, B3)                                                   \
+#define SHG_P1_CONSUME(item, nxt, ALO, AHI, BLO, BHI)                                                               \
     do {                                                                                                            \
-        const int cnt_ = P.N + 1 - (item).m;                                                                        \
-        const double a0_ = (arow && (item).k0 + fk < cnt_) ? A0 : 0.0;                                              \
-        const double a1_ = (arow && (item).k0 + 4 + fk < cnt_) ? A1 : 0.0;                                          \
-        const double a2_ = (arow && (item).k0 + 8 + fk < cnt_) ? A2 : 0.0;                                          \
-        const double a3_ = (arow && (item).k0 + 12 + fk < cnt_) ? A3 : 0.0;                                         \
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0_, B0, acc0, 0, 0, 0);                                        \
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_, B1, acc1, 0, 0, 0);                                        \
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2_, B2, acc0, 0, 0, 0);                                        \
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3_, B3, acc1, 0, 0, 0);                                        \
+        const bool lo_ = arow && (item).m <= P.N;                                                                   \
+        const bool hi_ = lo_ && ((item).j0 + 1) * 8 < P.N + 1 - (item).m;                                           \
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.x : 0.0, BLO.x, acc0, 0, 0, 0);                       \
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.y : 0.0, BLO.y, acc1, 0, 0, 0);                       \
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.x : 0.0, BHI.x, acc0, 0, 0, 0);                       \
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.y : 0.0, BHI.y, acc1, 0, 0, 0);                       \
         if ((nxt).m != (item).m && (item).m <= P.N) {                                                               \
             /* C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15: reg 0 = cosine part of epoch (lane >> 4),  */ \
             /* reg 1 = sine part; panel row = epoch * 16 + parallel = lane                                        */ \
@@ -186,25 +207,26 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         }                                                                                                           \
     } while (0)
 
-        double xa0 = 0, xa1 = 0, xa2 = 0, xa3 = 0, xb0 = 0, xb1 = 0, xb2 = 0, xb3 = 0;     // register set X
-        double ya0 = 0, ya1 = 0, ya2 = 0, ya3 = 0, yb0 = 0, yb1 = 0, yb2 = 0, yb3 = 0;     // register set Y
+        double2 xal = {0, 0}, xah = {0, 0}, xbl = {0, 0}, xbh = {0, 0};     // register set X
+        double2 yal = {0, 0}, yah = {0, 0}, ybl = {0, 0}, ybh = {0, 0};     // register set Y
         // Counted loop, two items per trip, loads issued unconditionally (an exhausted sequence re-reads a valid item and
         // its MFMAs see a zero A operand): no branch around loads and a single loop exit keep the compiler's vmcnt
-        // bookkeeping exact, so the fragments of item t+1 really are in flight while item t runs.
+        // bookkeeping exact, so the fragments of item t+1 really are in flight while item t runs.  (Three items in
+        // flight measured no faster: the stage is bound by L2 -> CU throughput, not by latency.)
         int nitems = 0;
         for (int m = wave; m <= P.N; m += 8) nitems += (P.N + 1 - m + 15) >> 4;
         LegendreItem cur = {wave, 0};
         const LegendreItem first = cur;
-        if (nitems > 0) SHG_P1_ISSUE(cur, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
+        if (nitems > 0) SHG_P1_ISSUE(cur, xal, xah, xbl, xbh);
         for (int trip = 0; trip < (nitems + 1) / 2; ++trip) {
             const LegendreItem nx = cur.next(P.N);
             const LegendreItem ld1 = nx.valid(P.N) ? nx : first;
-            SHG_P1_ISSUE(ld1, ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3);
-            SHG_P1_CONSUME(cur, nx, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
+            SHG_P1_ISSUE(ld1, yal, yah, ybl, ybh);
+            SHG_P1_CONSUME(cur, nx, xal, xah, xbl, xbh);
             const LegendreItem nn = nx.next(P.N);
             const LegendreItem ld2 = nn.valid(P.N) ? nn : first;
-            SHG_P1_ISSUE(ld2, xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3);
-            SHG_P1_CONSUME(nx, nn, ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3);
+            SHG_P1_ISSUE(ld2, xal, xah, xbl, xbh);
+            SHG_P1_CONSUME(nx, nn, yal, yah, ybl, ybh);
             cur = nn;
         }
 #undef SHG_P1_ISSUE
@@ -314,10 +336,10 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
                     else if (t == 1) { col = P.nlon - 2 - jc; ascending = false; }
                     else if (t == 2) { col = P.nlon / 2 - 2 - jc; ascending = false; }
                     else { col = P.nlon / 2 + jc; ascending = true; }
-                    if (jok && ia < P.nlat)
-                        *reinterpret_cast<double2*>(rowa + col) = ascending ? make_double2(a_lo, a_hi) : make_double2(a_hi, a_lo);
-                    if (jok && ib < P.nlat)
-                        *reinterpret_cast<double2*>(rowb + col) = ascending ? make_double2(b_lo, b_hi) : make_double2(b_hi, b_lo);
+                    const double2_t va = ascending ? (double2_t){a_lo, a_hi} : (double2_t){a_hi, a_lo};
+                    const double2_t vb = ascending ? (double2_t){b_lo, b_hi} : (double2_t){b_hi, b_lo};
+                    if (jok && ia < P.nlat) *reinterpret_cast<double2_t*>(rowa + col) = va;
+                    if (jok && ib < P.nlat) *reinterpret_cast<double2_t*>(rowb + col) = vb;
                 }
             } else {
                 const int j = jt + fr;
@@ -420,18 +442,41 @@ int build_pk_table(shg_plan* p, hipStream_t stream) {
     return SHG_OK;
 }
 
+// fragment-ordered table of the fused kernel (and the octet offsets both fragment-ordered tables share)
+int build_pkf_table(shg_plan* p, hipStream_t stream) {
+    if (p->pkf) return SHG_OK;
+    const int N = p->N, nit = ceil_div(p->nlat, 16);
+    std::vector<int> qoff(N + 2);
+    int q = 0;
+    for (int m = 0; m <= N; ++m) {
+        qoff[m] = q;
+        q += (N + 1 - m + 7) / 8;
+    }
+    qoff[N + 1] = q;
+    p->Qtot = q;
+    if (!p->qoff && hipMalloc((void**)&p->qoff, qoff.size() * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "octet table allocation failed");
+    SHG_HIP(hipMemcpy(p->qoff, qoff.data(), qoff.size() * sizeof(int), hipMemcpyHostToDevice));
+    const size_t n = (size_t)nit * q * 128;
+    if (hipMalloc((void**)&p->pkf, n * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "PK table allocation failed (%zu doubles)", n);
+    SHG_HIP(hipMemsetAsync(p->pkf, 0, n * sizeof(double), stream));
+    hipLaunchKernelGGL(pkf_table_kernel, dim3(p->ldlat / 64, N + 1), dim3(64), 0, stream, N, p->ldlat, nit, q, p->qoff, p->ct, p->pmm,
+                       p->knT, p->arec, p->brec, p->pkf);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
 // variant 2: single fused kernel; variant 3: Legendre stage as its own kernel + longitude kernel reading the panels
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
     if (fused_chunk_for(p) == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
     const bool two_kernel = p->path == 3;
-    int rc = build_pk_table(p, stream);
+    int rc = two_kernel ? build_pk_table(p, stream) : build_pkf_table(p, stream);
     if (rc) return rc;
     const int nbt = ceil_div(B, 4);
     const int nbt8 = ceil_div(B, 8);
     const int Ppk = packed_count(p->N);
     const int nit = ceil_div(p->nlat, 16);
-    // coefficient workspace: [nbt][Ppk][2][4] (fused) or [nbt8][Ppk][2][8] (two-kernel): same size per epoch
-    const size_t need = (size_t)std::max(nbt, 2 * nbt8) * Ppk * 8;
+    // coefficient workspace: [nbt][Qtot][32][2] (fused) or [nbt8][Ppk][2][8] (two-kernel)
+    const size_t need = two_kernel ? (size_t)nbt8 * Ppk * 16 : (size_t)nbt * p->Qtot * 64;
     if (need > p->cpk4_size) {
         if (p->cpk4) {
             SHG_HIP(hipStreamSynchronize(stream));
@@ -440,11 +485,14 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
         }
         if (hipMalloc((void**)&p->cpk4, need * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "coefficient workspace allocation failed");
         p->cpk4_size = need;
+        p->cpk4_zeroed = 0;
     }
-    // sine slots of order 0 are never written by the pack kernels and must read as zero (layouts differ per variant)
-    if (p->cpk4_variant != (two_kernel ? 3 : 2)) {
+    // sine slots of order 0 and the padding rows of the octets are never written by the pack kernels and must read as
+    // zero (layouts differ per variant)
+    if (need > 0 && (p->cpk4_variant != (two_kernel ? 3 : 2) || p->cpk4_zeroed < need)) {
         SHG_HIP(hipMemsetAsync(p->cpk4, 0, p->cpk4_size * sizeof(double), stream));
         p->cpk4_variant = two_kernel ? 3 : 2;
+        p->cpk4_zeroed = p->cpk4_size;
     }
     const int E = (p->N + 1) * (p->N + 1);
     FusedParams P;
@@ -464,8 +512,10 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     for (int g = 0; g < 4; ++g) P.gcount[g] = cnt[g];
     const char* dbg_env = getenv("SHG_DEBUG");
     P.dbg = dbg_env ? atoi(dbg_env) : 0;
+    P.Qtot = p->Qtot;
+    P.qoff = p->qoff;
     P.cpk4 = p->cpk4;
-    P.pk = p->pk;
+    P.pkf = p->pkf;
     P.trig = p->trig;
     P.panel = nullptr;
     P.G = grid;
@@ -499,7 +549,7 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     } else {
         {
             ProfileScope ps(p, 0, stream);
-            hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, anm, p->cpk4);
+            hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, p->qoff, anm, p->cpk4);
         }
         ProfileScope ps(p, 2, stream);
         SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
