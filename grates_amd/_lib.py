@@ -46,6 +46,10 @@ PROTOTYPES = {
     'shg_dense_filter': [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_spd_solve': [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_dgemm': [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
+    'shg_gemm': [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int,
+                 ctypes.c_double, c_double_p, ctypes.c_int, ctypes.c_void_p],
+    'shg_potrf': [ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
+    'shg_trtri': [ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
     'shg_analysis': [c_plan_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
 }
 STRING_GETTERS = ('shg_last_error', 'shg_version')

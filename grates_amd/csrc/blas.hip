@@ -1,0 +1,477 @@
+// Dense fp64 building blocks of the block-banded normal-equation solver (grates/lstsq.py:698-883), all on fp64 MFMA:
+//   shg_gemm        C = alpha op(A) op(B) + beta C     (op = identity / transpose, batched, optional upper-tiles-only)
+//   shg_potrf       A = U^T U in place (upper)         replaces scipy.linalg.cholesky(..., lower=False)   lstsq.py:713
+//   shg_trtri       X = U^-1 (upper triangular)        replaces scipy.linalg.solve_triangular / inv       lstsq.py:716, 807, 835, 856
+// Triangular solves with a d x d block become GEMMs with the explicit inverse of the d x d factor, which is built
+// from exact 128 x 128 diagonal-block inverses by recursive doubling:
+//   [U11 U12; 0 U22]^-1 = [X11, -X11 U12 X22; 0, X22].
+//
+// Blocked right-looking Cholesky, nb = 128: leaf factorisation + leaf inverse in LDS (one workgroup), row panel
+// U12 = U11^-T A12 and trailing update A22 -= U12^T U12 as MFMA GEMMs (upper tiles only).
+#include "common.h"
+
+namespace shg {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int XM = 128, XN = 128, XK = 16;
+constexpr int XLR = 17;      // [row][k] staging: 17-double rows (operand contiguous along k in memory)
+constexpr int XLK = 144;     // [k][row] staging: 128 + 16 pad (operand contiguous along its row / column index)
+constexpr int XBUF = 2304;   // doubles per operand buffer: max(128 * 17, 16 * 144)
+
+struct GemmExParams {
+    int M, N, K;
+    const double* A;
+    int lda;
+    long long strideA;
+    const double* B;
+    int ldb;
+    long long strideB;
+    double* C;
+    int ldc;
+    long long strideC;
+    double alpha, beta;
+    int upper_only;           // skip output tiles that lie entirely below the diagonal
+};
+
+// TA: A is stored [K][M] (op(A) = A^T);  TB: B is stored [N][K] (op(B) = B^T).  Row-major everywhere.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
+    extern __shared__ double gemm_ex_lds[];
+    double* As0 = gemm_ex_lds;                  // [2][XBUF]
+    double* Bs0 = gemm_ex_lds + 2 * XBUF;       // [2][XBUF]
+
+    const int m0 = blockIdx.y * XM, n0 = blockIdx.x * XN;
+    if (P.upper_only && m0 >= n0 + XN) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fk = lane >> 4;
+    const double* A = P.A + (size_t)blockIdx.z * P.strideA;
+    const double* B = P.B + (size_t)blockIdx.z * P.strideB;
+    double* C = P.C + (size_t)blockIdx.z * P.strideC;
+
+    // staging roles of a thread
+    //   k-contiguous operand  ([row][k] in memory):  piece h: row = (tid >> 3) + 32 h, k = (tid & 7) * 2, 2 elements
+    //   row-contiguous operand ([k][row] in memory): piece h: k = (tid >> 6) + 4 h, row = (tid & 63) * 2, 2 elements
+    // Indices beyond the matrix are clamped to valid addresses (the values only reach rows / columns that are never
+    // stored); only the last partial K tile zero-fills.
+    const int r_row = tid >> 3, r_k = (tid & 7) * 2;
+    const int k_k = tid >> 6, k_row = (tid & 63) * 2;
+    double areg[8], breg[8];
+    // base pointers of the steady state (k = 0): R-type operand: 4 row pointers; K-type operand: 2 column pointers
+    const double* ar[4];
+    const double* br[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        ar[h] = TA ? nullptr : A + (size_t)min(m0 + r_row + 32 * h, P.M - 1) * P.lda + r_k;
+        br[h] = TB ? B + (size_t)min(n0 + r_row + 32 * h, P.N - 1) * P.ldb + r_k : nullptr;
+    }
+    const double* ak0 = A + (size_t)k_k * P.lda + min(m0 + k_row, P.M - 1);
+    const double* ak1 = A + (size_t)k_k * P.lda + min(m0 + k_row + 1, P.M - 1);
+    const double* bk0 = B + (size_t)k_k * P.ldb + min(n0 + k_row, P.N - 1);
+    const double* bk1 = B + (size_t)k_k * P.ldb + min(n0 + k_row + 1, P.N - 1);
+    const size_t lda4 = (size_t)4 * P.lda, ldb4 = (size_t)4 * P.ldb;
+
+    auto fetch_full = [&](int k0) {
+        if (!TA) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                areg[2 * h] = ar[h][k0];
+                areg[2 * h + 1] = ar[h][k0 + 1];
+            }
+        } else {
+            const size_t o = (size_t)k0 * P.lda;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                areg[2 * h] = ak0[o + h * lda4];
+                areg[2 * h + 1] = ak1[o + h * lda4];
+            }
+        }
+        if (TB) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                breg[2 * h] = br[h][k0];
+                breg[2 * h + 1] = br[h][k0 + 1];
+            }
+        } else {
+            const size_t o = (size_t)k0 * P.ldb;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                breg[2 * h] = bk0[o + h * ldb4];
+                breg[2 * h + 1] = bk1[o + h * ldb4];
+            }
+        }
+    };
+    // last partial K tile: same addresses with k clamped, entries beyond K zeroed
+    auto fetch_tail = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int ka = k0 + r_k, kb = ka + 1;                         // R-type: a thread's two k indices
+            const int ca = min(ka, P.K - 1) - r_k, cb = min(kb, P.K - 1) - r_k;
+            const int kk = k0 + k_k + 4 * h;                              // K-type: the k row of piece h
+            const size_t ok = (size_t)(min(kk, P.K - 1) - k_k);
+            if (!TA) {
+                const double v0 = ar[h][ca], v1 = ar[h][cb];
+                areg[2 * h] = ka < P.K ? v0 : 0.0;
+                areg[2 * h + 1] = kb < P.K ? v1 : 0.0;
+            } else {
+                const double v0 = ak0[ok * P.lda], v1 = ak1[ok * P.lda];
+                areg[2 * h] = kk < P.K ? v0 : 0.0;
+                areg[2 * h + 1] = kk < P.K ? v1 : 0.0;
+            }
+            if (TB) {
+                const double v0 = br[h][ca], v1 = br[h][cb];
+                breg[2 * h] = ka < P.K ? v0 : 0.0;
+                breg[2 * h + 1] = kb < P.K ? v1 : 0.0;
+            } else {
+                const double v0 = bk0[ok * P.ldb], v1 = bk1[ok * P.ldb];
+                breg[2 * h] = kk < P.K ? v0 : 0.0;
+                breg[2 * h + 1] = kk < P.K ? v1 : 0.0;
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        double* As = As0 + buf * XBUF;
+        double* Bs = Bs0 + buf * XBUF;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (!TA) {
+                As[(r_row + 32 * h) * XLR + r_k] = areg[2 * h];
+                As[(r_row + 32 * h) * XLR + r_k + 1] = areg[2 * h + 1];
+            } else {
+                *reinterpret_cast<double2*>(&As[(k_k + 4 * h) * XLK + k_row]) = make_double2(areg[2 * h], areg[2 * h + 1]);
+            }
+            if (TB) {
+                Bs[(r_row + 32 * h) * XLR + r_k] = breg[2 * h];
+                Bs[(r_row + 32 * h) * XLR + r_k + 1] = breg[2 * h + 1];
+            } else {
+                *reinterpret_cast<double2*>(&Bs[(k_k + 4 * h) * XLK + k_row]) = make_double2(breg[2 * h], breg[2 * h + 1]);
+            }
+        }
+    };
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    auto compute = [&](int buf) {
+        const double* As = As0 + buf * XBUF;
+        const double* Bs = Bs0 + buf * XBUF;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                af[a] = TA ? As[(ks * 4 + fk) * XLK + wr * 64 + a * 16 + fr] : As[(wr * 64 + a * 16 + fr) * XLR + ks * 4 + fk];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                bf[b] = TB ? Bs[(wc * 64 + b * 16 + fr) * XLR + ks * 4 + fk] : Bs[(ks * 4 + fk) * XLK + wc * 64 + b * 16 + fr];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    const int nfull = P.K / XK;
+    const bool has_tail = (P.K % XK) != 0;
+    if (nfull > 0)
+        fetch_full(0);
+    else
+        fetch_tail(0);
+    stage(0);
+    __syncthreads();
+    for (int t = 0; t + 1 < nfull; ++t) {             // branch-free steady state
+        fetch_full((t + 1) * XK);
+        compute(t & 1);
+        stage((t + 1) & 1);
+        __syncthreads();
+    }
+    if (nfull > 0) {
+        if (has_tail) fetch_tail(nfull * XK);
+        compute((nfull - 1) & 1);
+        if (has_tail) stage(nfull & 1);
+        __syncthreads();
+    }
+    if (has_tail) compute(nfull & 1);
+
+    // epilogue.  C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = m0 + wr * 64 + a * 16 + fk + 4 * r;
+            if (gr >= P.M) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int gc = n0 + wc * 64 + b * 16 + fr;
+                if (gc >= P.N) continue;
+                double* c = C + (size_t)gr * P.ldc + gc;
+                const double v = P.alpha * acc[a][b][r];
+                *c = P.beta == 0.0 ? v : fma(P.beta, *c, v);
+            }
+        }
+}
+
+__global__ void scale_kernel(int M, int N, double beta, double* __restrict__ C, int ldc, long long strideC) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    double* p = C + (size_t)blockIdx.z * strideC + (size_t)blockIdx.y * ldc + c;
+    *p = beta == 0.0 ? 0.0 : beta * *p;
+}
+
+int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
+            long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || batch <= 0) return SHG_OK;
+    GemmExParams P;
+    P.M = M;
+    P.N = N;
+    P.K = K;
+    P.A = A;
+    P.lda = lda;
+    P.strideA = strideA;
+    P.B = B;
+    P.ldb = ldb;
+    P.strideB = strideB;
+    P.C = C;
+    P.ldc = ldc;
+    P.strideC = strideC;
+    P.alpha = alpha;
+    P.beta = beta;
+    P.upper_only = upper_only ? 1 : 0;
+    if (K <= 0) {                      // empty sum: C = beta C
+        hipLaunchKernelGGL(scale_kernel, dim3(ceil_div(N, 256), M, batch), dim3(256), 0, stream, M, N, beta, C, ldc, strideC);
+        SHG_HIP(hipGetLastError());
+        return SHG_OK;
+    }
+    const dim3 grid(ceil_div(N, XN), ceil_div(M, XM), batch);
+    const size_t lds = (size_t)4 * XBUF * sizeof(double);          // 73.7 KB: two workgroups per CU
+#define SHG_GEMM_EX(TA_, TB_)                                                                                                     \
+    do {                                                                                                                           \
+        SHG_HIP(hipFuncSetAttribute((const void*)gemm_ex_kernel<TA_, TB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((gemm_ex_kernel<TA_, TB_>), grid, dim3(256), lds, stream, P);                                           \
+    } while (0)
+    if (ta) {
+        if (tb) SHG_GEMM_EX(true, true); else SHG_GEMM_EX(true, false);
+    } else {
+        if (tb) SHG_GEMM_EX(false, true); else SHG_GEMM_EX(false, false);
+    }
+#undef SHG_GEMM_EX
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// leaf: one n x n diagonal block (n <= 128) in LDS, one workgroup
+//   mode bit 0: factor the upper triangle in place (A = U^T U) and write U back (strictly lower part of the block zeroed)
+//   mode bit 1: invert the (factored or given) upper triangular block into Xout[n][ldx]
+// ------------------------------------------------------------------------------------------------
+constexpr int LEAF = 128;
+constexpr int LLD = LEAF + 1;
+
+__global__ __launch_bounds__(256) void leaf_kernel(int n, double* __restrict__ A, int lda, long long strideA, double* __restrict__ X,
+                                                   int ldx, long long strideX, int mode, int* __restrict__ info, int info_base) {
+    extern __shared__ double U[];                       // [n][LLD]
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    A += (size_t)blockIdx.x * strideA;
+    if (X) X += (size_t)blockIdx.x * strideX;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < n * n; e += 256) {
+        const int r = e / n, c = e % n;
+        U[r * LLD + c] = c >= r ? A[(size_t)r * lda + c] : 0.0;
+    }
+    __syncthreads();
+    if (mode & 1) {
+        // right-looking elimination with the row scaling deferred: step k uses the unscaled pivot row,
+        //   U[i][c] -= U[k][i] U[k][c] / U[k][k]   (k < i <= c),   one barrier per step
+        const int ty = tid >> 4, tx = tid & 15;
+        for (int k = 0; k < n; ++k) {
+            const double piv = U[k * LLD + k];
+            if (!(piv > 0.0)) {                          // not positive definite (also catches NaN); uniform: all threads read the same value
+                if (tid == 0) bad = k + 1;
+                break;
+            }
+            const double inv = 1.0 / piv;
+            for (int i = k + 1 + ty; i < n; i += 16) {
+                const double f = U[k * LLD + i] * inv;
+                for (int c = k + 1 + tx; c < n; c += 16)
+                    if (c >= i) U[i * LLD + c] = fma(-f, U[k * LLD + c], U[i * LLD + c]);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        if (bad) {
+            if (tid == 0 && info) atomicCAS(info, 0, info_base + (int)blockIdx.x * LEAF + bad);
+            return;
+        }
+        // scale the rows: U[k][c] /= sqrt(d_k)
+        for (int e = tid; e < n * n; e += 256) {
+            const int r = e / n, c = e % n;
+            if (c >= r) {
+                const double s = sqrt(U[r * LLD + r]);
+                // the diagonal entry is read by other threads of the same row: write it last, after a barrier
+                if (c > r) U[r * LLD + c] = U[r * LLD + c] / s;
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < n; r += 256) U[r * LLD + r] = sqrt(U[r * LLD + r]);
+        __syncthreads();
+        for (int e = tid; e < n * n; e += 256) {
+            const int r = e / n, c = e % n;
+            A[(size_t)r * lda + c] = U[r * LLD + c];   // strictly lower part: zeros
+        }
+    }
+    if (mode & 2) {
+        // in-place inversion of the upper triangular block, column by column (unblocked LAPACK trti2 scheme):
+        //   x_jj = 1 / u_jj;   x[0:j, j] = -x_jj * X[0:j, 0:j] u[0:j, j]   with the already inverted leading block
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const double xjj = 1.0 / U[j * LLD + j];
+            double v = 0.0;
+            const int i = tid;                            // one thread per row (n <= 128 < 256)
+            if (i < j) {
+                for (int k = i; k < j; ++k) v = fma(U[i * LLD + k], U[k * LLD + j], v);     // X[i][k] (k >= i) times u[k][j]
+                v = -v * xjj;
+            }
+            __syncthreads();
+            if (i < j) U[i * LLD + j] = v;
+            if (i == j) U[j * LLD + j] = xjj;
+            __syncthreads();
+        }
+        for (int e = tid; e < n * n; e += 256) {
+            const int r = e / n, c = e % n;
+            X[(size_t)r * ldx + c] = U[r * LLD + c];   // strictly lower part: zeros
+        }
+    }
+}
+
+static int launch_leaf(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, int batch, int mode, int* info,
+                       int info_base, hipStream_t stream) {
+    const size_t lds = (size_t)n * LLD * sizeof(double);
+    SHG_HIP(hipFuncSetAttribute((const void*)leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LEAF * LLD * sizeof(double))));
+    hipLaunchKernelGGL(leaf_kernel, dim3(batch), dim3(256), lds, stream, n, A, lda, strideA, X, ldx, strideX, mode, info, info_base);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+__global__ void zero_lower_kernel(int n, double* __restrict__ A, int lda) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)n * n) return;
+    const int r = (int)(e / n), c = (int)(e % n);
+    if (c < r) A[(size_t)r * lda + c] = 0.0;
+}
+
+// X = U^-1 for an upper triangular U [n][ldu]; X [n][ldx] (the strictly lower part of X is set to zero); work: n * 128 doubles
+int trtri_upper(int n, const double* U, int ldu, double* X, int ldx, double* work, hipStream_t stream) {
+    if (n <= 0) return SHG_OK;
+    SHG_HIP(hipMemset2DAsync(X, (size_t)ldx * sizeof(double), 0, (size_t)n * sizeof(double), n, stream));
+    // leaves: X_kk = U_kk^-1 for all diagonal blocks at once (the ragged last one separately)
+    const int nfullb = n / LEAF, rest = n % LEAF;
+    int rc;
+    // the leaf kernel reads its block from "A" and writes the inverse to "X": copy U's diagonal blocks through X itself
+    // (mode 2 reads A = U diagonal block, which it does not modify)
+    if (nfullb > 0) {
+        rc = launch_leaf(LEAF, const_cast<double*>(U), ldu, (long long)LEAF * (ldu + 1), X, ldx, (long long)LEAF * (ldx + 1), nfullb, 2, nullptr, 0,
+                         stream);
+        if (rc) return rc;
+    }
+    if (rest > 0) {
+        const size_t o = (size_t)nfullb * LEAF;
+        rc = launch_leaf(rest, const_cast<double*>(U) + o * (ldu + 1), ldu, 0, X + o * (ldx + 1), ldx, 0, 1, 2, nullptr, 0, stream);
+        if (rc) return rc;
+    }
+    // recursive doubling: units of size s are complete; merge neighbours (a, a + s) into units of 2 s:
+    //   X12 = -X11 (U12 X22)
+    for (int s = LEAF; s < n; s *= 2) {
+        for (int a = 0; a + s < n; a += 2 * s) {
+            const int n2 = std::min(s, n - (a + s));             // right unit (may be ragged)
+            const double* U12 = U + (size_t)a * ldu + (a + s);
+            const double* X11 = X + (size_t)a * ldx + a;
+            const double* X22 = X + (size_t)(a + s) * ldx + (a + s);
+            double* X12 = X + (size_t)a * ldx + (a + s);
+            // T[s][n2] = U12 X22   (work, ld = n2)
+            rc = gemm_ex(false, false, s, n2, n2, 1.0, U12, ldu, 0, X22, ldx, 0, 0.0, work, n2, 0, 1, false, stream);
+            if (rc) return rc;
+            rc = gemm_ex(false, false, s, n2, s, -1.0, X11, ldx, 0, work, n2, 0, 0.0, X12, ldx, 0, 1, false, stream);
+            if (rc) return rc;
+        }
+    }
+    return SHG_OK;
+}
+
+// A = U^T U in place (upper triangle referenced, strictly lower triangle zeroed); work: 128 * 128 doubles; info (device int,
+// may be NULL): set to the 1-based index of the first non-positive pivot
+int potrf_upper(int n, double* A, int lda, double* work, int* info, hipStream_t stream) {
+    int rc;
+    for (int k0 = 0; k0 < n; k0 += LEAF) {
+        const int kb = std::min(LEAF, n - k0);
+        double* Akk = A + (size_t)k0 * lda + k0;
+        const int restn = n - k0 - kb;
+        rc = launch_leaf(kb, Akk, lda, 0, work, kb, 0, 1, restn > 0 ? 3 : 1, info, k0, stream);
+        if (rc) return rc;
+        if (restn > 0) {
+            double* A12 = Akk + kb;
+            // U12 = U11^-T A12 (in place: every workgroup reads only the column tile it overwrites)
+            rc = gemm_ex(true, false, kb, restn, kb, 1.0, work, kb, 0, A12, lda, 0, 0.0, A12, lda, 0, 1, false, stream);
+            if (rc) return rc;
+            // A22 -= U12^T U12 (upper tiles)
+            double* A22 = A + (size_t)(k0 + kb) * lda + (k0 + kb);
+            rc = gemm_ex(true, false, restn, restn, kb, -1.0, A12, lda, 0, A12, lda, 0, 1.0, A22, lda, 0, 1, true, stream);
+            if (rc) return rc;
+        }
+    }
+    if (n > 1) {
+        hipLaunchKernelGGL(zero_lower_kernel, dim3((unsigned)ceil_div64((long long)n * n, 256)), dim3(256), 0, stream, n, A, lda);
+        SHG_HIP(hipGetLastError());
+    }
+    return SHG_OK;
+}
+
+}  // namespace shg
+
+using namespace shg;
+
+extern "C" int shg_gemm(int transa, int transb, int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb,
+                        double beta, double* C, int ldc, void* stream) {
+    SHG_REQUIRE(M >= 0 && N >= 0 && K >= 0, "shg_gemm: negative dimension");
+    if (M == 0 || N == 0) return SHG_OK;
+    SHG_REQUIRE(C != nullptr && ldc >= N, "shg_gemm: bad output");
+    if (K > 0) {
+        SHG_REQUIRE(A && B, "shg_gemm: NULL pointer");
+        SHG_REQUIRE(lda >= (transa ? M : K) && ldb >= (transb ? K : N), "shg_gemm: leading dimension too small");
+    }
+    return gemm_ex(transa != 0, transb != 0, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, false, (hipStream_t)stream);
+}
+
+extern "C" int shg_potrf(int n, double* A, int lda, int* info, void* stream_) {
+    SHG_REQUIRE(n >= 0, "shg_potrf: negative size");
+    if (n == 0) return SHG_OK;
+    SHG_REQUIRE(A != nullptr && lda >= n, "shg_potrf: bad matrix");
+    hipStream_t stream = (hipStream_t)stream_;
+    double* work = nullptr;
+    if (hipMallocAsync((void**)&work, (size_t)LEAF * LEAF * sizeof(double), stream) != hipSuccess)
+        return fail(SHG_ERR_NOMEM, "shg_potrf: workspace allocation failed");
+    if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
+    const int rc = potrf_upper(n, A, lda, work, info, stream);
+    (void)hipFreeAsync(work, stream);
+    return rc;
+}
+
+extern "C" int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream_) {
+    SHG_REQUIRE(n >= 0, "shg_trtri: negative size");
+    if (n == 0) return SHG_OK;
+    SHG_REQUIRE(U && X && ldu >= n && ldx >= n, "shg_trtri: bad matrix");
+    SHG_REQUIRE(U != X, "shg_trtri: in-place inversion is not supported");
+    hipStream_t stream = (hipStream_t)stream_;
+    double* work = nullptr;
+    if (hipMallocAsync((void**)&work, (size_t)n * n / 2 * sizeof(double) + 1024, stream) != hipSuccess)
+        return fail(SHG_ERR_NOMEM, "shg_trtri: workspace allocation failed");
+    const int rc = trtri_upper(n, U, ldu, X, ldx, work, stream);
+    (void)hipFreeAsync(work, stream);
+    return rc;
+}

@@ -314,3 +314,54 @@ def dgemm(A, B):
     out = torch.empty((M, N), dtype=torch.float64, device=A.device)
     _lib.call('shg_dgemm', M, N, K, _ptr(A), K, _ptr(B), N, _ptr(out), N, _stream())
     return out
+
+
+def gemm(A, B, transa=False, transb=False, alpha=1.0, beta=0.0, out=None):
+    """out = alpha op(A) op(B) + beta out on the fp64 MFMA GEMM; A, B, out are 2-d row-major device tensors
+    (row strides are honoured, the last dimension must be contiguous)."""
+    torch = require_gpu()
+    A, B = to_device(A), to_device(B)
+    for t in (A, B):
+        if t.dim() != 2 or (t.numel() > 0 and t.shape[1] > 1 and t.stride(1) != 1):
+            raise ValueError('gemm operands must be two-dimensional with a contiguous last dimension')
+    M = A.shape[1] if transa else A.shape[0]
+    K = A.shape[0] if transa else A.shape[1]
+    Kb = B.shape[1] if transb else B.shape[0]
+    N = B.shape[0] if transb else B.shape[1]
+    if K != Kb:
+        raise ValueError('gemm: inner dimensions differ ({0} vs {1})'.format(K, Kb))
+    if out is None:
+        if beta != 0.0:
+            raise ValueError('gemm: beta != 0 needs an output tensor')
+        out = torch.empty((M, N), dtype=torch.float64, device=A.device)
+    elif tuple(out.shape) != (M, N) or (N > 1 and out.stride(1) != 1):
+        raise ValueError('gemm: output must be ({0}, {1}) with a contiguous last dimension'.format(M, N))
+    _lib.call('shg_gemm', int(transa), int(transb), M, N, K, float(alpha), _ptr(A), max(A.stride(0), 1), _ptr(B), max(B.stride(0), 1),
+              float(beta), _ptr(out), max(out.stride(0), 1), _stream())
+    return out
+
+
+def potrf(A, check=True):
+    """Upper Cholesky factor U (A = U^T U) of a symmetric positive definite device matrix, in place; the strictly lower
+    triangle is zeroed.  Raises numpy.linalg.LinAlgError like scipy.linalg.cholesky when a pivot is not positive."""
+    torch = require_gpu()
+    if A.dim() != 2 or A.shape[0] != A.shape[1] or (A.shape[1] > 1 and A.stride(1) != 1):
+        raise ValueError('potrf: square matrix with a contiguous last dimension expected')
+    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    _lib.call('shg_potrf', A.shape[0], _ptr(A), max(A.stride(0), 1), _ptr(info), _stream())
+    if check:
+        k = int(info.item())
+        if k:
+            import numpy as np
+            raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(k))
+    return A
+
+
+def trtri(U):
+    """Inverse of an upper triangular device matrix (new tensor)."""
+    torch = require_gpu()
+    if U.dim() != 2 or U.shape[0] != U.shape[1] or (U.shape[1] > 1 and U.stride(1) != 1):
+        raise ValueError('trtri: square matrix with a contiguous last dimension expected')
+    X = torch.empty((U.shape[0], U.shape[0]), dtype=torch.float64, device=U.device)
+    _lib.call('shg_trtri', U.shape[0], _ptr(U), max(U.stride(0), 1), _ptr(X), max(X.stride(0), 1), _stream())
+    return X

@@ -155,6 +155,24 @@ int shg_spd_solve(const double* A, int n, const double* B, int k, double* X, voi
 int shg_dgemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dense block operations of the block-banded normal-equation solver ("Kalman smoother", grates/lstsq.py:698-883).
+ * The reference loops over the non-zero blocks of a BlockMatrix in Python and calls NumPy / SciPy LAPACK per block;
+ * the replacement keeps those loops on the host and runs every block operation on the device:
+ *   shg_gemm    C = alpha op(A) op(B) + beta C, row-major, transX != 0 -> operand stored transposed
+ *               replaces the `@` products of blocks          (grates/lstsq.py:679, 711, 743-748, 770-774, 805, 815, 846, 860-882)
+ *   shg_potrf   A = U^T U in place, upper triangle referenced, strictly lower triangle zeroed on exit; *info (device int,
+ *               may be NULL) receives the 1-based index of the first non-positive pivot, 0 on success
+ *               replaces scipy.linalg.cholesky(lower=False)  (grates/lstsq.py:713; numpy.linalg.cholesky lstsq.py:197)
+ *   shg_trtri   X = U^-1 for an upper triangular U (X != U; strictly lower triangle of X zeroed).  Triangular solves
+ *               with a factor block are GEMMs with this inverse
+ *               replaces scipy.linalg.solve_triangular / inv (grates/lstsq.py:716, 807, 817, 835, 839, 856, 868)
+ * ------------------------------------------------------------------------------------------------ */
+int shg_gemm(int transa, int transb, int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb,
+             double beta, double* C, int ldc, void* stream);
+int shg_potrf(int n, double* A, int lda, int* info, void* stream);
+int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Analysis (area-weighted least squares per order)
  *   replaces RegularGrid.to_potential_coefficients                    (grates/grid.py:665-696, 752-790)
  *   grid [B][nlat][nlon]; area [nlat][nlon]; anm [B][N+1][N+1] (degrees < nmin left zero)

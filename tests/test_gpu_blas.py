@@ -1,0 +1,103 @@
+"""
+GPU parity of the dense block operations behind the block-banded normal-equation solver:
+shg_gemm / shg_potrf / shg_trtri against NumPy / SciPy on the same seeded inputs.
+Tolerances: GEMM 1e-13 relative to max|C|; Cholesky factor and triangular inverse 1e-12 relative for the
+well-conditioned seeded matrices used here (cond ~ 1e2).
+"""
+
+import numpy as np
+import pytest
+import scipy.linalg as la
+import torch
+
+import grates_amd as ga
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+eng = ga.engine
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize('ta', [False, True])
+@pytest.mark.parametrize('tb', [False, True])
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (5, 7, 3), (130, 257, 33), (300, 200, 128), (128, 128, 16), (257, 129, 500), (64, 1681, 128)])
+def test_gemm_transposes(ta, tb, M, N, K):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    ref = (A.T if ta else A) @ (B.T if tb else B)
+    out = eng.gemm(dev(A), dev(B), transa=ta, transb=tb).cpu().numpy()
+    assert relerr(out, ref) < 1e-13
+
+
+def test_gemm_alpha_beta_and_views():
+    rng = np.random.default_rng(5)
+    A, B, C = rng.standard_normal((150, 90)), rng.standard_normal((90, 70)), rng.standard_normal((150, 70))
+    out = dev(C)
+    eng.gemm(dev(A), dev(B), alpha=-1.0, beta=1.0, out=out)
+    assert relerr(out.cpu().numpy(), C - A @ B) < 1e-13
+    out = dev(C)
+    eng.gemm(dev(A), dev(B), alpha=0.5, beta=-2.0, out=out)
+    assert relerr(out.cpu().numpy(), 0.5 * A @ B - 2 * C) < 1e-13
+    # strided views: blocks of a larger matrix as operands and as the output
+    big = dev(rng.standard_normal((400, 400)))
+    bh = big.cpu().numpy().copy()
+    eng.gemm(big[10:140, 5:95], big[200:290, 300:370], alpha=1.0, beta=1.0, out=big[150:280, 100:170])
+    bh[150:280, 100:170] += bh[10:140, 5:95] @ bh[200:290, 300:370]
+    assert relerr(big.cpu().numpy(), bh) < 1e-13
+    # K = 0: C = beta C
+    out = dev(C)
+    eng.gemm(dev(np.zeros((150, 0))), dev(np.zeros((0, 70))), beta=3.0, out=out)
+    np.testing.assert_array_equal(out.cpu().numpy(), 3.0 * C)
+    with pytest.raises(ValueError):
+        eng.gemm(dev(A), dev(C))
+    with pytest.raises(ValueError):
+        eng.gemm(dev(A), dev(B), beta=1.0)
+
+
+def spd(seed, n):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, n + 8))
+    return G @ G.T / n + np.eye(n)
+
+
+@pytest.mark.parametrize('n', [1, 2, 17, 127, 128, 129, 300, 640, 1681])
+def test_potrf_and_trtri(n):
+    A = spd(n, n)
+    U = eng.potrf(dev(A)).cpu().numpy()
+    ref = la.cholesky(A, lower=False)
+    assert np.array_equal(np.tril(U, -1), np.zeros_like(U))
+    assert relerr(U, ref) < 1e-12
+    assert relerr(U.T @ U, A) < 1e-13
+    X = eng.trtri(dev(ref)).cpu().numpy()
+    assert np.array_equal(np.tril(X, -1), np.zeros_like(X))
+    assert relerr(X, la.inv(ref)) < 1e-12
+    assert relerr(X @ ref, np.eye(n)) < 1e-12
+
+
+def test_potrf_only_upper_triangle_referenced_and_strided():
+    n = 200
+    A = spd(3, n)
+    junk = A.copy()
+    junk[np.tril_indices(n, -1)] = 1e30                    # scipy.linalg.cholesky(lower=False) never reads it either
+    U = eng.potrf(dev(junk)).cpu().numpy()
+    assert relerr(U, la.cholesky(A, lower=False)) < 1e-12
+    big = dev(np.zeros((300, 300)))
+    big[50:250, 20:220] = dev(A)
+    eng.potrf(big[50:250, 20:220])
+    assert relerr(big[50:250, 20:220].cpu().numpy(), la.cholesky(A, lower=False)) < 1e-12
+    assert float(big[0:50].abs().max()) == 0.0 and float(big[:, 220:].abs().max()) == 0.0
+
+
+def test_potrf_not_positive_definite():
+    A = spd(4, 150)
+    A[140, 140] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.potrf(dev(A))
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.potrf(dev(np.zeros((3, 3))))
+    with pytest.raises(ValueError):
+        eng.potrf(dev(np.zeros((3, 4))))
