@@ -51,3 +51,32 @@ def scattered_points(seed, count):
 
 
 SPECIAL_COLAT = np.array([1e-3, 0.5 * np.pi, np.pi - 1e-3])
+
+
+def var_covariance_function(seed, dim, max_lag):
+    """Covariance function [Sigma_0, ..., Sigma_max_lag] of a stable VAR(1) process x_t = Phi x_{t-1} + w_t
+    (Sigma_k = Phi^k Sigma_0, Sigma_0 from the discrete Lyapunov equation): a valid multivariate covariance
+    function of any dimension for the Yule-Walker construction of grates/lstsq.py:127-167."""
+    import scipy.linalg as la
+    rng = np.random.default_rng(seed)
+    Phi = rng.standard_normal((dim, dim))
+    Phi *= 0.6 / np.max(np.abs(np.linalg.eigvals(Phi)))
+    G = rng.standard_normal((dim, dim + 4))
+    Q = G @ G.T / dim
+    S0 = la.solve_discrete_lyapunov(Phi, Q)
+    S0 = 0.5 * (S0 + S0.T)
+    out = [S0]
+    for _ in range(max_lag):
+        out.append(Phi @ out[-1])
+    return out
+
+
+def observation_normals(seed, epoch_count, dim, scale=1.0):
+    """Per-epoch observation normal equations: (N_t [dim, dim] SPD, n_t [dim, 1], lPl_t, observation count)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(epoch_count):
+        A = rng.standard_normal((dim + 5, dim))
+        l = rng.standard_normal((dim + 5, 1))
+        out.append((A.T @ A * scale, A.T @ l * scale, float(np.sum(l * l) * scale), dim + 5))
+    return out

@@ -288,8 +288,102 @@ def g10():
     save('g10_filter', **out)
 
 
+# ---- G11: block-banded normal equations ("Kalman smoother", lstsq.py) ----------------------------------------------------
+def g11():
+    from grates import lstsq
+    out = {}
+    dim, order, epochs = 6, 2, 7
+    cf = inputs.var_covariance_function(1, dim, order)
+    seq = lstsq.AutoregressiveModelSequence.from_covariance_function(cf)
+    for k in range(order + 1):
+        model = lstsq.AutoregressiveModel.from_covariance_function(cf[0:k + 1])
+        out['var{0}_Q'.format(k)] = model.white_noise_covariance
+        if k:
+            out['var{0}_coefficients'.format(k)] = np.array(model.coefficients)
+        for r in range(k + 1):
+            for c in range(r, k + 1):
+                out['var{0}_normals_{1}{2}'.format(k, r, c)] = model.normal_equation_block(r, c)
+    constraint = seq.normal_equations(epochs)
+    out['constraint_matrix'] = constraint.matrix.to_array()
+    out['covariance_function_back'] = np.array(seq.covariance_function(3))
+
+    # smoother: observation normals of independent epochs + VAR constraint, variance factors (1, 0.5)
+    def observation_system():
+        per_epoch = inputs.observation_normals(2, epochs, dim)
+        idx = np.arange(0, (epochs + 1) * dim, dim)
+        bm = lstsq.BlockMatrix(idx, idx)
+        for t, e in enumerate(per_epoch):
+            bm[t, t] = e[0]
+        return lstsq.NormalEquations(bm, np.vstack([e[1] for e in per_epoch]), sum(e[2] for e in per_epoch), sum(e[3] for e in per_epoch))
+    factors = [1.0, 0.5]
+    parts = [observation_system(), seq.normal_equations(epochs)]
+    combined = lstsq.accumulate_normals(parts, factors)
+    out['combined_matrix'] = combined.matrix.to_array()
+    out['combined_rhs'] = combined.right_hand_side
+    out['combined_lPl'] = np.array(combined.observation_square_sum)
+    out['combined_count'] = np.array(combined.observation_count)
+    np.random.seed(123)
+    x = combined.solve()
+    np.random.seed(123)
+    signs = np.random.randint(0, 2, size=(epochs * dim, 100))
+    signs[signs == 0] = -1
+    out['signs'] = signs.astype(np.int8)
+    out['solution'] = x
+    out['monte_carlo_vectors'] = combined.monte_carlo_vectors
+    out['factor'] = combined.matrix.to_array()
+    out['posterior_sigma'] = np.array(combined.posterior_sigma(x))
+    out['residual_square_sums'] = np.array([p.residual_square_sum(x) for p in parts])
+    out['redundancies'] = np.array([p.redundancy(combined, f) for p, f in zip(parts, factors)])
+    out['variance_factors'] = lstsq.compute_variance_factors(parts, combined, x, factors)
+    combined.compute_covariance(sparse=True)
+    out['sparse_inverse'] = combined.matrix.to_array()
+    again = lstsq.accumulate_normals([observation_system(), seq.normal_equations(epochs)], factors)
+    again.compute_covariance(sparse=False)
+    out['full_inverse'] = again.matrix.to_array()
+
+    # general block matrix: ragged blocks (17 = 5 + 5 + 5 + 2), blocks (0, 3) and (1, 2) empty, fill-in at (1, 2)
+    n = 17
+    A = inputs.spd_covariance(9, n, scale=1.0) + np.eye(n)
+    rows, cols = lstsq.BlockMatrix.compute_block_index(A.shape, 5)
+    out['ragged_index'] = rows
+    A[0:5, 15:17] = 0
+    A[15:17, 0:5] = 0
+    A[5:10, 10:15] = 0
+    A[10:15, 5:10] = 0
+    out['ragged_input'] = A
+    upper = np.triu(A)
+    bm = lstsq.BlockMatrix.from_array(upper, rows, cols)
+    b = np.random.default_rng(10).standard_normal((n, 3))
+    out['ragged_rhs'] = b
+    out['ragged_multiply_symmetric'] = bm.multiply_symmetric(b)
+    out['ragged_diag'] = bm.diag()
+    sq = bm @ bm
+    out['ragged_matmul'] = sq.to_array()
+    bm.cholesky()
+    out['ragged_factor'] = bm.to_array()
+    out['ragged_solve_T'] = bm.solve_triangular(b, transpose=True)
+    out['ragged_solve_N'] = bm.solve_triangular(b, transpose=False)
+    out['ragged_multiply_N'] = bm.multiply_triangular(b, transpose=False)
+    out['ragged_multiply_T'] = bm.multiply_triangular(b, transpose=True)
+    sp = bm.copy()
+    sp.sparse_inverse()
+    out['ragged_sparse_inverse'] = sp.to_array()
+    bm.inverse()
+    out['ragged_inverse'] = bm.to_array()
+
+    # Tikhonov regularisation
+    reg = np.random.default_rng(11).uniform(0.5, 2.0, 12)
+    bias = np.random.default_rng(12).standard_normal((12, 1))
+    tk = lstsq.TikhonovRegularization(reg, [0, 4, 8, 12], bias)
+    out['tikhonov_matrix'] = tk.matrix.to_array()
+    out['tikhonov_rhs'] = tk.right_hand_side
+    out['tikhonov_lPl'] = np.array(tk.observation_square_sum)
+    out['tikhonov_count'] = np.array(tk.observation_count)
+    save('g11_lstsq', **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
         if not only or fn.__name__ in only:
             fn()
