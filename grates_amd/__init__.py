@@ -12,6 +12,7 @@ from . import kernel
 from . import gravityfield
 from . import grid
 from . import filter
+from . import lstsq
 
 __all__ = ['data', 'engine', 'filter', 'gravityfield', 'grid', 'kernel', 'utilities']
 __version__ = '0.1.0'

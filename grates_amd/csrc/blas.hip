@@ -448,6 +448,32 @@ extern "C" int shg_gemm(int transa, int transb, int M, int N, int K, double alph
     return gemm_ex(transa != 0, transb != 0, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, false, (hipStream_t)stream);
 }
 
+namespace shg {
+__global__ void axpby_kernel(int rows, int cols, double alpha, const double* __restrict__ X, int ldx, double beta, double* __restrict__ Y,
+                             int ldy) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols) return;
+    double* y = Y + (size_t)r * ldy + c;
+    const double ax = alpha * X[(size_t)r * ldx + c];
+    *y = beta == 0.0 ? ax : fma(beta, *y, ax);
+}
+}  // namespace shg
+
+extern "C" int shg_axpby(int rows, int cols, double alpha, const double* X, int ldx, double beta, double* Y, int ldy, void* stream) {
+    SHG_REQUIRE(rows >= 0 && cols >= 0, "shg_axpby: negative size");
+    if (rows == 0 || cols == 0) return SHG_OK;
+    SHG_REQUIRE(X && Y && ldx >= cols && ldy >= cols, "shg_axpby: bad operands");
+    SHG_REQUIRE(rows <= 65535 * 1024, "shg_axpby: too many rows");
+    for (int r0 = 0; r0 < rows; r0 += 65535) {
+        const int nr = std::min(65535, rows - r0);
+        hipLaunchKernelGGL(axpby_kernel, dim3(ceil_div(cols, 256), nr), dim3(256), 0, (hipStream_t)stream, nr, cols, alpha,
+                           X + (size_t)r0 * ldx, ldx, beta, Y + (size_t)r0 * ldy, ldy);
+    }
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
 extern "C" int shg_potrf(int n, double* A, int lda, int* info, void* stream_) {
     SHG_REQUIRE(n >= 0, "shg_potrf: negative size");
     if (n == 0) return SHG_OK;

@@ -320,7 +320,8 @@ def gemm(A, B, transa=False, transb=False, alpha=1.0, beta=0.0, out=None):
     """out = alpha op(A) op(B) + beta out on the fp64 MFMA GEMM; A, B, out are 2-d row-major device tensors
     (row strides are honoured, the last dimension must be contiguous)."""
     torch = require_gpu()
-    A, B = to_device(A), to_device(B)
+    A = A if isinstance(A, torch.Tensor) and A.is_cuda and A.dtype == torch.float64 else to_device(A)
+    B = B if isinstance(B, torch.Tensor) and B.is_cuda and B.dtype == torch.float64 else to_device(B)
     for t in (A, B):
         if t.dim() != 2 or (t.numel() > 0 and t.shape[1] > 1 and t.stride(1) != 1):
             raise ValueError('gemm operands must be two-dimensional with a contiguous last dimension')
@@ -365,3 +366,16 @@ def trtri(U):
     X = torch.empty((U.shape[0], U.shape[0]), dtype=torch.float64, device=U.device)
     _lib.call('shg_trtri', U.shape[0], _ptr(U), max(U.stride(0), 1), _ptr(X), max(X.stride(0), 1), _stream())
     return X
+
+
+def axpby(alpha, X, beta, Y):
+    """Y = alpha X + beta Y in place for 2-d device tensors of equal shape (row strides honoured)."""
+    require_gpu()
+    if X.dim() != 2 or tuple(X.shape) != tuple(Y.shape):
+        raise ValueError('axpby: two-dimensional operands of equal shape expected')
+    if X.numel() == 0:
+        return Y
+    if (X.shape[1] > 1 and X.stride(1) != 1) or (Y.shape[1] > 1 and Y.stride(1) != 1):
+        raise ValueError('axpby: contiguous last dimension expected')
+    _lib.call('shg_axpby', X.shape[0], X.shape[1], float(alpha), _ptr(X), max(X.stride(0), 1), float(beta), _ptr(Y), max(Y.stride(0), 1), _stream())
+    return Y

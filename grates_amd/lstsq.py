@@ -1,0 +1,648 @@
+"""
+Block-banded normal equations on the device: the reference's vector-autoregressive constraint models, sparse
+`BlockMatrix` and `NormalEquations` ("Kalman smoother", grates/lstsq.py:12-1149) with the same class and method
+names, argument meaning and error behaviour.  The host keeps the reference's loops over non-zero blocks; every block
+lives in HBM as its own fp64 tensor and every block operation is a libshg call:
+
+    block products                  -> shg_gemm  (fp64 MFMA, transposes / alpha / beta, accumulates in place)
+    scipy.linalg.cholesky           -> shg_potrf (blocked right-looking upper Cholesky)
+    solve_triangular / inv of a
+    diagonal factor block           -> shg_trtri once per diagonal block (cached), then shg_gemm
+    block scaling / accumulation    -> shg_axpby
+
+Vectors may be passed as NumPy arrays (results come back as NumPy arrays, like the reference) or as device tensors
+(results stay on the device).  There is no CPU fallback.
+
+Not built (outside the smoother path): UnscentedTransformSymmetric, teigh, trsvd, robust_least_squares,
+AutoregressiveModel.from_transformed_coefficients (pseudo-inverse).
+"""
+
+import numpy as np
+
+from . import engine
+
+
+def _is_tensor(x):
+    return engine._torch().is_tensor(x)
+
+
+def _dev(x):
+    """fp64 device tensor (copy) of an ndarray / tensor"""
+    torch = engine.require_gpu()
+    if torch.is_tensor(x):
+        return x.to(device=engine.device(), dtype=torch.float64).clone()
+    return engine.to_device(np.asarray(x, dtype=np.float64))
+
+
+def _zeros(shape):
+    torch = engine.require_gpu()
+    return torch.zeros(tuple(int(s) for s in shape), dtype=torch.float64, device=engine.device())
+
+
+def _dot(a, b):
+    """sum of the element-wise product of two [n, k] device tensors (trace of a^T b on the MFMA GEMM)"""
+    return float(np.trace(engine.to_host(engine.gemm(a, b, transa=True))))
+
+
+def _like_input(result, template):
+    return result if _is_tensor(template) else engine.to_host(result)
+
+
+class AutoregressiveModel:
+    """
+    Vector-autoregressive (VAR) model (grates/lstsq.py:12-247).
+
+    Parameters
+    ----------
+    coefficients : list, tuple, ndarray
+        VAR model coefficients
+    covariance_matrix : ndarray
+        covariance matrix of the white noise sequence
+    """
+
+    def __init__(self, coefficients, covariance_matrix):
+        if isinstance(coefficients, np.ndarray):
+            self.__coefficients = tuple(coefficients)
+        else:
+            self.__coefficients = coefficients
+        self.__covariance_matrix = covariance_matrix
+        self.__normal_equation = None
+
+    @property
+    def dimension(self):
+        return self.__covariance_matrix.shape[0]
+
+    @property
+    def order(self):
+        return len(self.__coefficients)
+
+    @property
+    def white_noise_covariance(self):
+        return self.__covariance_matrix
+
+    @property
+    def coefficients(self):
+        return self.__coefficients
+
+    def order_one_representation(self):
+        """grates/lstsq.py:81-99"""
+        if self.order == 1:
+            return self
+        B = np.eye(self.dimension * self.order)
+        for k in range(self.order):
+            B[0:self.dimension, k * self.dimension:(k + 1) * self.dimension] = np.asarray(self.__coefficients[k]).copy()
+        Q = np.zeros(B.shape)
+        Q[0:self.dimension, 0:self.dimension] = np.asarray(self.__covariance_matrix).copy()
+        return AutoregressiveModel(B, Q)
+
+    @staticmethod
+    def from_covariance_function(covariance_function):
+        """Yule-Walker equations solved with the block Cholesky factorisation on the device (grates/lstsq.py:127-167)."""
+        if isinstance(covariance_function, np.ndarray):
+            covariance_function = tuple(covariance_function)
+        model_order = len(covariance_function) - 1
+        if model_order == 0:
+            return AutoregressiveModel((), covariance_function[0])
+
+        dimension = covariance_function[0].shape[0]
+        block_index = [0]
+        while block_index[-1] < model_order * dimension:
+            block_index.append(block_index[-1] + dimension)
+
+        coefficient_matrix = BlockMatrix(block_index, block_index)
+        right_hand_side = np.empty((dimension * model_order, dimension))
+        for row in range(coefficient_matrix.shape[0]):
+            right_hand_side[row * dimension:(row + 1) * dimension, :] = covariance_function[row + 1]
+            for column in range(row, coefficient_matrix.shape[1]):
+                coefficient_matrix[row, column] = np.ascontiguousarray(covariance_function[column - row].T)
+
+        coefficient_matrix.cholesky()
+        rhs = _dev(right_hand_side)
+        x1 = coefficient_matrix.solve_triangular(rhs, transpose=True)
+        x2 = coefficient_matrix.solve_triangular(x1)
+        Q = _dev(covariance_function[0])
+        engine.gemm(x2, rhs, transa=True, alpha=-1.0, beta=1.0, out=Q)
+        return AutoregressiveModel(np.split(engine.to_host(x2).T, model_order, axis=1), engine.to_host(Q))
+
+    @staticmethod
+    def from_sample(sample, order):
+        """grates/lstsq.py:170-190 (as upstream: every lag uses the zero-lag product)"""
+        s = _dev(sample)
+        product = engine.to_host(engine.gemm(s, s, transa=True))
+        covariance_function = [product / (sample.shape[0] - k) for k in range(order + 1)]
+        return AutoregressiveModel.from_covariance_function(covariance_function)
+
+    def __compute_normals(self):
+        """Normal equations of the pseudo-observations of the model (grates/lstsq.py:192-209): W = chol(Q) (upper),
+        observation blocks W^-T B_k (k descending) and -W^-T, normal blocks as their products."""
+        W = engine.potrf(_dev(self.__covariance_matrix))
+        Winv = engine.trtri(W)
+        observation_equations = [engine.gemm(Winv, _dev(B), transa=True) for B in self.__coefficients[::-1]]
+        minus = _zeros(Winv.shape)
+        engine.axpby(-1.0, Winv.t().contiguous(), 0.0, minus)
+        observation_equations.append(minus)
+
+        block_index = [0]
+        while block_index[-1] < (self.order + 1) * self.dimension:
+            block_index.append(block_index[-1] + self.dimension)
+        self.__normal_equation = BlockMatrix(block_index, block_index)
+        for row in range(self.__normal_equation.shape[0]):
+            for column in range(row, self.__normal_equation.shape[1]):
+                self.__normal_equation._set_device(row, column, engine.gemm(observation_equations[row], observation_equations[column], transa=True))
+
+    def normal_equation_block(self, row, column):
+        """normal-equation block (row, column) as ndarray (grates/lstsq.py:211-230)"""
+        return engine.to_host(self._normal_equation_block_device(row, column))
+
+    def _normal_equation_block_device(self, row, column):
+        if self.__normal_equation is None:
+            self.__compute_normals()
+        return self.__normal_equation.device_block(row, column)
+
+    def to_transformed_coefficients(self):
+        """grates/lstsq.py:232-247"""
+        W_inv = engine.trtri(engine.potrf(_dev(self.__covariance_matrix)))
+        transformed = [engine.to_host(engine.gemm(W_inv, _dev(B), alpha=-1.0)) for B in self.__coefficients[::-1]]
+        transformed.append(engine.to_host(W_inv))
+        return np.hstack(transformed)
+
+
+class AutoregressiveModelSequence:
+    """Sequence of VAR models of increasing order, starting from order 0 (grates/lstsq.py:250-411)."""
+
+    def __init__(self, armodels):
+        self.__armodels = armodels
+
+    @staticmethod
+    def from_covariance_function(covariance_function):
+        return AutoregressiveModelSequence([AutoregressiveModel.from_covariance_function(covariance_function[0:k + 1])
+                                            for k in range(len(covariance_function))])
+
+    @staticmethod
+    def from_sample(sample, maximum_order):
+        return AutoregressiveModelSequence([AutoregressiveModel.from_sample(sample, order) for order in range(maximum_order + 1)])
+
+    @property
+    def maximum_order(self):
+        return self.__armodels[-1].order
+
+    @property
+    def dimension(self):
+        return self.__armodels[-1].dimension
+
+    def __normals_block(self, epoch_count, row, column):
+        """Block (row, column), row <= column, of the constraint normals of `epoch_count` epochs (grates/lstsq.py:333-362).
+        The reference scans all epoch_count - p window positions; only those with column - p <= index <= row contribute."""
+        N = _zeros((self.dimension, self.dimension))
+        p = self.maximum_order
+        for index in range(max(0, column - p), min(row, epoch_count - p - 1) + 1):
+            engine.axpby(1.0, self.__armodels[-1]._normal_equation_block_device(row - index, column - index), 1.0, N)
+        for order in range(p):
+            if row <= order and column <= order:
+                engine.axpby(1.0, self.__armodels[order]._normal_equation_block_device(row, column), 1.0, N)
+        return N
+
+    def normal_equations(self, epoch_count):
+        """Block-banded inverse covariance matrix of `epoch_count` epochs with zero right-hand side (grates/lstsq.py:364-392).
+        Interior blocks are equal sums; they are formed once and copied."""
+        parameter_count = epoch_count * self.dimension
+        block_index = np.arange(0, parameter_count + self.dimension, self.dimension, dtype=int)
+        normals_matrix = BlockMatrix(block_index, block_index)
+        right_hand_side = np.zeros((parameter_count, 1))
+        p = self.maximum_order
+        interior = {}
+        for row in range(epoch_count):
+            for column in range(row, min(epoch_count, row + p + 1)):
+                if p <= row <= epoch_count - p - 1:          # full window range, no start-up models: depends on the lag only
+                    lag = column - row
+                    if lag not in interior:
+                        interior[lag] = self.__normals_block(epoch_count, row, column)
+                    normals_matrix._set_device(row, column, interior[lag].clone())
+                else:
+                    normals_matrix._set_device(row, column, self.__normals_block(epoch_count, row, column))
+        return NormalEquations(normals_matrix, right_hand_side, 0.0, parameter_count)
+
+    def covariance_function(self, maximum_lag):
+        """grates/lstsq.py:394-411"""
+        normals = self.normal_equations(max(maximum_lag + 1, self.maximum_order + 1))
+        normals.compute_covariance(sparse=False)
+        return [normals.matrix[0, k] for k in range(maximum_lag + 1)]
+
+
+class BlockMatrix:
+    """
+    Sparse rectangular block matrix with device-resident blocks (grates/lstsq.py:414-912).  `matrix[i, j]` returns a host
+    copy of a block (None when the block is empty) and `matrix[i, j] = array` stores a device copy; `device_block(i, j)`
+    gives the tensor itself.
+    """
+
+    def __init__(self, row_index, column_index):
+        self.shape = (len(row_index) - 1, len(column_index) - 1)
+        self.__row_index = row_index
+        self.__column_index = column_index
+        self.__data = {}
+        self.__inverse_factor = {}      # diagonal index -> inverse of the upper triangular factor block
+
+    def copy(self):
+        """Deep copy of BlockMatrix"""
+        output = BlockMatrix(self.__row_index, self.__column_index)
+        for key, block in self.__data.items():
+            output.__data[key] = block.clone()
+        return output
+
+    @staticmethod
+    def compute_block_index(array_shape, block_size):
+        """grates/lstsq.py:437-463"""
+        row_index = [0]
+        while row_index[-1] < array_shape[0]:
+            row_index.append(min(array_shape[0], row_index[-1] + block_size))
+        column_index = [0]
+        while column_index[-1] < array_shape[1]:
+            column_index.append(min(array_shape[1], column_index[-1] + block_size))
+        return np.array(row_index), np.array(column_index)
+
+    @staticmethod
+    def from_array(array, row_index, column_index):
+        """Block matrix from a 2D ndarray; blocks without a non-zero entry stay empty (grates/lstsq.py:466-497)."""
+        if not isinstance(array, np.ndarray):
+            raise ValueError('array must be of type ' + str(np.ndarray))
+        if array.ndim != 2:
+            raise ValueError('array must be a two-dimensional ' + str(np.ndarray))
+        if row_index[-1] != array.shape[0]:
+            raise ValueError("mismatch in array shape in dimension 0 and row block index")
+        if column_index[-1] != array.shape[1]:
+            raise ValueError("mismatch in array shape in dimension 1 and column block index")
+        block_matrix = BlockMatrix(row_index, column_index)
+        for row in range(len(row_index) - 1):
+            for column in range(len(column_index) - 1):
+                block = array[row_index[row]:row_index[row + 1], column_index[column]:column_index[column + 1]]
+                if np.count_nonzero(block):
+                    block_matrix[row, column] = block
+        return block_matrix
+
+    def to_array(self):
+        """2D ndarray (host) of the whole matrix (grates/lstsq.py:499-514)"""
+        array = np.zeros((self.__row_index[-1], self.__column_index[-1]))
+        for (row, column), block in self.__data.items():
+            array[self.__row_slice(row), self.__column_slice(column)] = engine.to_host(block)
+        return array
+
+    def __check_bounds(self, i, j):
+        if i > self.shape[0]:
+            raise IndexError("block index {0} is out of bounds for axis 0 with size {1}".format(i, self.shape[0]))
+        if j > self.shape[1]:
+            raise IndexError("block index {0} is out of bounds for axis 1 with size {1}".format(j, self.shape[1]))
+
+    def __block_shape(self, i, j):
+        return int(self.__row_index[i + 1] - self.__row_index[i]), int(self.__column_index[j + 1] - self.__column_index[j])
+
+    def __row_slice(self, i):
+        return slice(int(self.__row_index[i]), int(self.__row_index[i + 1]), 1)
+
+    def __column_slice(self, i):
+        return slice(int(self.__column_index[i]), int(self.__column_index[i + 1]), 1)
+
+    def __check_item(self, i, j, item):
+        if not (isinstance(item, np.ndarray) or _is_tensor(item)):
+            raise ValueError('Block matrix item must be of type ' + str(np.ndarray))
+        if item.ndim != 2:
+            raise ValueError('Block matrix item must be a two-dimensional ' + str(np.ndarray))
+        if tuple(item.shape) != self.__block_shape(i, j):
+            raise ValueError('Block matrix item at position ({0:d}, {1:d}) must be of size ({2:d}, {3:d}). '
+                             'Got ({4:d}, {5:d}).'.format(i, j, *self.__block_shape(i, j), item.shape[0], item.shape[1]))
+
+    def __setitem__(self, key, value):
+        if not isinstance(key, tuple) and len(key) != 2:
+            raise IndexError("Indices to block matrix must be tuples of length 2")
+        self.__check_bounds(key[0], key[1])
+        self.__check_item(key[0], key[1], value)
+        self._set_device(key[0], key[1], _dev(value))
+
+    def _set_device(self, i, j, tensor):
+        """store a device tensor as block (i, j) without copying it"""
+        self.__data[(int(i), int(j))] = tensor
+        if i == j:
+            self.__inverse_factor.pop(int(i), None)
+
+    def __getitem__(self, key):
+        if not isinstance(key, tuple) and len(key) != 2:
+            raise IndexError("Indices to block matrix must be tuples of length 2")
+        self.__check_bounds(key[0], key[1])
+        block = self.__data.get((int(key[0]), int(key[1])))
+        return None if block is None else engine.to_host(block)
+
+    def device_block(self, i, j):
+        """device tensor of block (i, j), or None"""
+        return self.__data.get((int(i), int(j)))
+
+    def is_nonzero(self, row, column):
+        """whether block (row, column) is stored"""
+        return (int(row), int(column)) in self.__data
+
+    def __nz(self, i, j):
+        return (i, j) in self.__data
+
+    def __matmul__(self, other):
+        """C = A B over the non-zero blocks (grates/lstsq.py:651-681)"""
+        if not isinstance(other, BlockMatrix):
+            raise ValueError("Matrix multiplication not implemented for type {0}".format(type(other)))
+        result = BlockMatrix(self.__row_index, other.__column_index)
+        for i in range(result.shape[0]):
+            for j in range(result.shape[1]):
+                for k in range(self.shape[1]):
+                    if self.__nz(i, k) and other.__nz(k, j):
+                        engine.gemm(self.__data[(i, k)], other.__data[(k, j)], beta=1.0, out=result.__set_block(i, j))
+        return result
+
+    def __set_block(self, i, j):
+        """zero block on first use (grates/lstsq.py:683-696)"""
+        if (i, j) not in self.__data:
+            self.__data[(i, j)] = _zeros(self.__block_shape(i, j))
+        return self.__data[(i, j)]
+
+    def __factor_inverse(self, i):
+        """inverse of the upper triangular diagonal block i (computed once)"""
+        if i not in self.__inverse_factor:
+            self.__inverse_factor[i] = engine.trtri(self.__data[(i, i)])
+        return self.__inverse_factor[i]
+
+    def cholesky(self):
+        """
+        Cholesky factorization N = W^T W in place; only the upper triangle is referenced, afterwards the matrix holds the
+        upper triangular factor W (grates/lstsq.py:698-717).  Raises numpy.linalg.LinAlgError if a diagonal block is not
+        positive definite.
+        """
+        for row in range(self.shape[0]):
+            for r in range(row):
+                if not self.__nz(r, row):
+                    continue
+                for c in range(row, self.shape[1]):
+                    if self.__nz(r, c):
+                        engine.gemm(self.__data[(r, row)], self.__data[(r, c)], transa=True, alpha=-1.0, beta=1.0, out=self.__set_block(row, c))
+            engine.potrf(self.__data[(row, row)])
+            self.__inverse_factor.pop(row, None)
+            columns = [c for c in range(row + 1, self.shape[1]) if self.__nz(row, c)]
+            if columns:
+                Winv = self.__factor_inverse(row)
+                for c in columns:
+                    self.__data[(row, c)] = engine.gemm(Winv, self.__data[(row, c)], transa=True)
+
+    def __vector(self, b):
+        v = _dev(b)
+        return v.reshape(1, -1) if v.dim() == 1 else v
+
+    def multiply_triangular(self, b, transpose=False):
+        """v = W b or v = W^T b with the upper triangular factor (grates/lstsq.py:719-750).  As upstream, the transposed
+        branch assigns instead of accumulating (lstsq.py:743)."""
+        bd = self.__vector(b)
+        v = _zeros(bd.shape)
+        if transpose:
+            for i in range(self.shape[0]):
+                for j in range(i + 1):
+                    if self.__nz(j, i):
+                        engine.gemm(self.__data[(j, i)], bd[self.__row_slice(j)], transa=True, out=v[self.__row_slice(i)])
+        else:
+            for i in range(self.shape[0]):
+                for j in range(i, self.shape[1]):
+                    if self.__nz(i, j):
+                        engine.gemm(self.__data[(i, j)], bd[self.__row_slice(j)], beta=1.0, out=v[self.__row_slice(i)])
+        return _like_input(v, b)
+
+    def multiply_symmetric(self, b):
+        """v = N b for a symmetric matrix of which only the upper triangle is stored (grates/lstsq.py:752-776)"""
+        bd = self.__vector(b)
+        v = _zeros(bd.shape)
+        for i in range(self.shape[0]):
+            if self.__nz(i, i):
+                engine.gemm(self.__data[(i, i)], bd[self.__row_slice(i)], beta=1.0, out=v[self.__row_slice(i)])
+            for j in range(i + 1, self.shape[1]):
+                if self.__nz(i, j):
+                    engine.gemm(self.__data[(i, j)], bd[self.__row_slice(j)], beta=1.0, out=v[self.__row_slice(i)])
+                    engine.gemm(self.__data[(i, j)], bd[self.__row_slice(i)], transa=True, beta=1.0, out=v[self.__row_slice(j)])
+        return _like_input(v, b)
+
+    def solve_triangular(self, b, transpose=False):
+        """Solve W x = b or W^T x = b with the upper triangular block factor (grates/lstsq.py:778-821)."""
+        b_copy = self.__vector(b)
+        x = _zeros(b_copy.shape)
+        if transpose:
+            for row in range(self.shape[0]):
+                for column in range(row):
+                    if self.__nz(column, row):
+                        engine.gemm(self.__data[(column, row)], x[self.__row_slice(column)], transa=True, alpha=-1.0, beta=1.0,
+                                    out=b_copy[self.__row_slice(row)])
+                engine.gemm(self.__factor_inverse(row), b_copy[self.__row_slice(row)], transa=True, out=x[self.__row_slice(row)])
+        else:
+            for row in range(self.shape[0] - 1, -1, -1):
+                for column in range(self.shape[0] - 1, row, -1):
+                    if self.__nz(row, column):
+                        engine.gemm(self.__data[(row, column)], x[self.__row_slice(column)], alpha=-1.0, beta=1.0,
+                                    out=b_copy[self.__row_slice(row)])
+                engine.gemm(self.__factor_inverse(row), b_copy[self.__row_slice(row)], out=x[self.__row_slice(row)])
+        return _like_input(x, b)
+
+    def sparse_inverse(self):
+        """
+        Sparse inverse N^-1 = W^-1 W^-T on the pattern of the Cholesky factor W held by the matrix, in place
+        (grates/lstsq.py:823-846).
+        """
+        for i in range(self.shape[0] - 1, -1, -1):
+            Winv = self.__factor_inverse(i)
+            temporary_row = {}
+            for k in range(i + 1, self.shape[1]):
+                if self.__nz(i, k):
+                    temporary_row[k] = engine.gemm(Winv, self.__data[(i, k)])
+                    self.__data[(i, k)] = _zeros(self.__block_shape(i, k))
+            self._set_device(i, i, engine.gemm(Winv, Winv, transb=True))
+            for j in range(self.shape[0] - 1, i - 1, -1):
+                if not self.__nz(i, j):
+                    continue
+                for k in range(i + 1, self.shape[0]):
+                    if self.__nz(min(k, j), max(k, j)) and k in temporary_row:
+                        if k < j:
+                            engine.gemm(temporary_row[k], self.__data[(k, j)], alpha=-1.0, beta=1.0, out=self.__data[(i, j)])
+                        else:
+                            engine.gemm(temporary_row[k], self.__data[(j, k)], transb=True, alpha=-1.0, beta=1.0, out=self.__data[(i, j)])
+
+    def inverse(self):
+        """
+        Full inverse N^-1 = W^-1 W^-T from the Cholesky factor W held by the matrix, in place, upper triangle
+        (grates/lstsq.py:848-882).
+        """
+        factor_inverse = {j: self.__factor_inverse(j) for j in range(self.shape[0])}
+        for j in range(self.shape[0] - 1, -1, -1):
+            self.__data[(j, j)] = factor_inverse[j]
+            for i in range(j - 1, -1, -1):
+                if self.__nz(i, j):
+                    self.__data[(i, j)] = engine.gemm(self.__data[(i, j)], self.__data[(j, j)])
+                for k in range(i + 1, j):
+                    if self.__nz(i, k) and self.__nz(k, j):
+                        engine.gemm(self.__data[(i, k)], self.__data[(k, j)], beta=1.0, out=self.__set_block(i, j))
+                if self.__nz(i, j):
+                    self.__data[(i, j)] = engine.gemm(factor_inverse[i], self.__data[(i, j)], alpha=-1.0)
+        for i in range(self.shape[0]):
+            self.__data[(i, i)] = engine.gemm(self.__data[(i, i)], self.__data[(i, i)], transb=True)
+            for j in range(i + 1, self.shape[0]):
+                if self.__nz(i, j):
+                    engine.gemm(self.__data[(i, j)], self.__data[(i, j)], transb=True, beta=1.0, out=self.__data[(i, i)])
+                    self.__data[(i, j)] = engine.gemm(self.__data[(i, j)], self.__data[(j, j)], transb=True)
+                for k in range(j + 1, self.shape[0]):
+                    if self.__nz(i, k) and self.__nz(j, k):
+                        engine.gemm(self.__data[(i, k)], self.__data[(j, k)], transb=True, beta=1.0, out=self.__set_block(i, j))
+        self.__inverse_factor.clear()
+
+    def _scale(self, value):
+        """Scale whole matrix with a factor."""
+        for block in self.__data.values():
+            engine.axpby(value, block, 0.0, block)
+        self.__inverse_factor.clear()
+
+    def _axpy(self, factor, other):
+        """Perform self += factor * other."""
+        for key, block in other.__data.items():
+            if key in self.__data:
+                engine.axpby(factor, block, 1.0, self.__data[key])
+            else:
+                self.__data[key] = _zeros(block.shape)
+                engine.axpby(factor, block, 0.0, self.__data[key])
+        self.__inverse_factor.clear()
+
+    def diag(self):
+        """Return copy of main diagonal."""
+        d = np.zeros(min(self.__row_index[-1], self.__column_index[-1]))
+        for idx in range(min(len(self.__row_index), len(self.__column_index)) - 1):
+            if self.__nz(idx, idx):
+                d[self.__row_index[idx]:self.__row_index[idx + 1]] = engine.to_host(self.__data[(idx, idx)].diagonal())
+        return d
+
+
+class NormalEquations:
+    """
+    System of normal equations (grates/lstsq.py:915-1059).
+
+    Parameters
+    ----------
+    normal_matrix : BlockMatrix
+        normal equation coefficient matrix
+    right_hand_side : ndarray(n, 1) or device tensor
+        normal equation right hand side
+    observation_square_sum : float
+        weighted square sum ob observations
+    observation_count : int
+        observation count
+    """
+
+    def __init__(self, normal_matrix, right_hand_side, observation_square_sum, observation_count):
+        self.matrix = normal_matrix
+        self.right_hand_side = right_hand_side
+        self.observation_square_sum = observation_square_sum
+        self.observation_count = observation_count
+        self.status = 'normal_matrix'
+
+    def __cholesky(self):
+        if self.status == 'cholesky_factor':
+            pass
+        elif self.status == 'normal_matrix':
+            self.matrix.cholesky()
+            self.status = 'cholesky_factor'
+        else:
+            raise ValueError('Cholesky factor can only be computed from the normal matrix')
+
+    def solve(self):
+        """
+        Solve the system; the coefficient matrix afterwards holds the upper triangular Cholesky factor.  As upstream, 100
+        Monte-Carlo vectors of random signs (numpy.random.randint, global state) are solved along with the right-hand side
+        and kept in `monte_carlo_vectors` (grates/lstsq.py:950-968).
+        """
+        self.__cholesky()
+        rhs = _dev(self.right_hand_side)
+        h = self.matrix.solve_triangular(rhs, transpose=True)
+        xi = np.random.randint(0, 2, size=(h.shape[0], 100))
+        xi[xi == 0] = -1
+        torch = engine.require_gpu()
+        x = self.matrix.solve_triangular(torch.cat((h, _dev(xi.astype(np.float64))), dim=1))
+        if _is_tensor(self.right_hand_side):
+            self.monte_carlo_vectors = x[:, 1:]
+            return x[:, 0:1]
+        x = engine.to_host(x)
+        self.monte_carlo_vectors = x[:, 1:]
+        return x[:, 0:1]
+
+    def redundancy(self, combined_normals, variance_factor):
+        """grates/lstsq.py:970-988"""
+        mc = _dev(combined_normals.monte_carlo_vectors)
+        Nm = self.matrix.multiply_symmetric(mc)
+        estimated_trace = _dot(mc, Nm) / mc.shape[1]
+        return np.asarray(self.observation_count - estimated_trace / variance_factor).squeeze()
+
+    def residual_square_sum(self, solution):
+        """grates/lstsq.py:990-1005"""
+        x = _dev(solution)
+        Nx = self.matrix.multiply_symmetric(x)
+        rhs = _dev(self.right_hand_side)
+        return np.asarray(self.observation_square_sum - 2 * _dot(rhs, x) + _dot(x, Nx)).squeeze()
+
+    def posterior_sigma(self, solution):
+        """grates/lstsq.py:1007-1024"""
+        x = _dev(solution)
+        Wx = self.matrix.multiply_triangular(x)
+        rhs = _dev(self.right_hand_side)
+        ePe = self.observation_square_sum - 2 * _dot(rhs, x) + _dot(Wx, Wx)
+        return np.sqrt(ePe / (self.observation_count - x.shape[0])).squeeze()
+
+    def compute_covariance(self, sparse=True):
+        """(sparse) inverse of the coefficient matrix (grates/lstsq.py:1026-1042)"""
+        self.__cholesky()
+        if sparse:
+            self.matrix.sparse_inverse()
+        else:
+            self.matrix.inverse()
+        self.status = 'covariance_matrix'
+
+    def to_array(self):
+        """grates/lstsq.py:1044-1059"""
+        rhs = engine.to_host(self.right_hand_side) if _is_tensor(self.right_hand_side) else self.right_hand_side
+        return self.matrix.to_array(), rhs, self.observation_square_sum, self.observation_count
+
+
+class TikhonovRegularization(NormalEquations):
+    """Normal equations of a Tikhonov regularization with a diagonal regularization matrix (grates/lstsq.py:1062-1088)."""
+
+    def __init__(self, regularization_vector, block_index, right_hand_side=None):
+        if right_hand_side is None:
+            right_hand_side = np.zeros((block_index[-1], 1))
+            lPl = 0
+        else:
+            lPl = np.sum(right_hand_side**2 * regularization_vector[:, np.newaxis])
+            right_hand_side = right_hand_side * regularization_vector[:, np.newaxis]
+        matrix = BlockMatrix(block_index, block_index)
+        for i in range(matrix.shape[0]):
+            matrix[i, i] = np.diag(regularization_vector[block_index[i]:block_index[i + 1]])
+        super(TikhonovRegularization, self).__init__(matrix, right_hand_side, lPl, right_hand_side.size)
+
+
+def accumulate_normals(normal_equations, variance_factors):
+    """Accumulate normal equations with given variance factors (grates/lstsq.py:1091-1119)."""
+    def host(v):
+        return engine.to_host(v) if _is_tensor(v) else v
+    output_matrix = normal_equations[0].matrix.copy()
+    output_matrix._scale(1 / variance_factors[0])
+    output_rhs = host(normal_equations[0].right_hand_side).copy() / variance_factors[0]
+    lPl = normal_equations[0].observation_square_sum / variance_factors[0]
+    obs_count = normal_equations[0].observation_count
+    for k in range(1, len(normal_equations)):
+        output_matrix._axpy(1 / variance_factors[k], normal_equations[k].matrix)
+        output_rhs += host(normal_equations[k].right_hand_side).copy() / variance_factors[k]
+        lPl += normal_equations[k].observation_square_sum / variance_factors[k]
+        obs_count += normal_equations[k].observation_count
+    return NormalEquations(output_matrix, output_rhs, lPl, obs_count)
+
+
+def compute_variance_factors(normal_equations, combined_normals, solution, variance_factors):
+    """Variance component estimates of the individual systems (grates/lstsq.py:1122-1149)."""
+    vc = []
+    for normals, sigma2 in zip(normal_equations, variance_factors):
+        ePe = normals.residual_square_sum(solution)
+        r = normals.redundancy(combined_normals, sigma2)
+        vc.append(ePe / r)
+    return np.array(vc)

@@ -1,0 +1,190 @@
+"""
+GPU parity of the block-banded normal-equation solver ("Kalman smoother", SURVEY.md 8f rank 1, BASELINE config 5):
+grates_amd.lstsq (host loops of the reference, block operations on fp64 MFMA through the C-ABI) against the golden
+vectors of the reference (tests/golden/g11_lstsq.npz) and, at larger sizes, against the NumPy oracle.
+
+Tolerances (fp64, stated per quantity): factors, solutions and products 1e-11 relative to the largest reference
+entry; inverses / covariances 1e-10 (triangular solves are GEMMs with explicit inverses of the diagonal factor
+blocks; the seeded systems have condition numbers of 1e2 ... 1e4).
+"""
+
+import numpy as np
+import pytest
+
+import grates_amd as ga
+import inputs
+from conftest import relerr
+from oracle import lstsq_oracle as lo
+
+pytestmark = pytest.mark.gpu
+ls = ga.lstsq
+TOL = 1e-11
+TOL_INV = 1e-10
+DIM, ORDER, EPOCHS = 6, 2, 7
+
+
+def observation_system(seed, epochs, dim):
+    per_epoch = inputs.observation_normals(seed, epochs, dim)
+    idx = np.arange(0, (epochs + 1) * dim, dim)
+    bm = ls.BlockMatrix(idx, idx)
+    for t, e in enumerate(per_epoch):
+        bm[t, t] = e[0]
+    return ls.NormalEquations(bm, np.vstack([e[1] for e in per_epoch]), sum(e[2] for e in per_epoch), sum(e[3] for e in per_epoch))
+
+
+def test_var_models_golden(golden):
+    g = golden('g11_lstsq')
+    cf = inputs.var_covariance_function(1, DIM, ORDER)
+    for k in range(ORDER + 1):
+        model = ls.AutoregressiveModel.from_covariance_function(cf[0:k + 1])
+        assert model.order == k and model.dimension == DIM
+        assert relerr(model.white_noise_covariance, g['var{0}_Q'.format(k)]) < TOL
+        if k:
+            assert relerr(np.array(model.coefficients), g['var{0}_coefficients'.format(k)]) < TOL
+        # relative to the largest block of the model: the process is VAR(1), so B_2 and the blocks built from it are
+        # rounding noise (1e-15 / 1e-30) in the reference as well
+        keys = [(r, c) for r in range(k + 1) for c in range(r, k + 1)]
+        scale = max(np.abs(g['var{0}_normals_{1}{2}'.format(k, r, c)]).max() for r, c in keys)
+        for r, c in keys:
+            assert np.abs(model.normal_equation_block(r, c) - g['var{0}_normals_{1}{2}'.format(k, r, c)]).max() < TOL * scale
+    seq = ls.AutoregressiveModelSequence.from_covariance_function(cf)
+    assert seq.maximum_order == ORDER and seq.dimension == DIM
+    constraint = seq.normal_equations(EPOCHS)
+    assert constraint.status == 'normal_matrix' and constraint.observation_count == EPOCHS * DIM
+    assert relerr(constraint.matrix.to_array(), g['constraint_matrix']) < TOL
+    back = np.array(seq.covariance_function(3))
+    assert relerr(back, g['covariance_function_back']) < TOL_INV
+    # order-one representation and transformed coefficients are pure re-arrangements
+    m2 = ls.AutoregressiveModel.from_covariance_function(cf)
+    one = m2.order_one_representation()
+    assert one.order == 2 * DIM and one.dimension == 2 * DIM       # as upstream: ndarray coefficients become a tuple of rows
+    tc = m2.to_transformed_coefficients()
+    W_inv = np.linalg.inv(np.linalg.cholesky(m2.white_noise_covariance).T)
+    ref = np.hstack([-W_inv @ B for B in m2.coefficients[::-1]] + [W_inv])
+    assert relerr(tc, ref) < TOL
+
+
+def test_smoother_golden(golden):
+    g = golden('g11_lstsq')
+    factors = [1.0, 0.5]
+    seq = ls.AutoregressiveModelSequence.from_covariance_function(inputs.var_covariance_function(1, DIM, ORDER))
+    parts = [observation_system(2, EPOCHS, DIM), seq.normal_equations(EPOCHS)]
+    combined = ls.accumulate_normals(parts, factors)
+    assert relerr(combined.matrix.to_array(), g['combined_matrix']) < TOL
+    assert relerr(combined.right_hand_side, g['combined_rhs']) < TOL
+    assert abs(combined.observation_square_sum - g['combined_lPl']) < TOL * abs(g['combined_lPl'])
+    assert combined.observation_count == int(g['combined_count'])
+    np.random.seed(123)                                   # the reference draws the Monte-Carlo signs from numpy's global state
+    x = combined.solve()
+    assert combined.status == 'cholesky_factor'
+    assert x.shape == (EPOCHS * DIM, 1) and isinstance(x, np.ndarray)
+    assert relerr(x, g['solution']) < TOL
+    assert relerr(combined.monte_carlo_vectors, g['monte_carlo_vectors']) < TOL
+    assert relerr(combined.matrix.to_array(), g['factor']) < TOL
+    assert abs(combined.posterior_sigma(x) - g['posterior_sigma']) < 1e-10 * abs(g['posterior_sigma'])
+    assert relerr(np.array([p.residual_square_sum(x) for p in parts]), g['residual_square_sums']) < TOL_INV
+    assert relerr(np.array([p.redundancy(combined, f) for p, f in zip(parts, factors)]), g['redundancies']) < TOL_INV
+    assert relerr(ls.compute_variance_factors(parts, combined, x, factors), g['variance_factors']) < 1e-9
+    combined.compute_covariance(sparse=True)
+    assert combined.status == 'covariance_matrix'
+    assert relerr(combined.matrix.to_array(), g['sparse_inverse']) < TOL_INV
+    with pytest.raises(ValueError):
+        combined.solve()                                  # 'Cholesky factor can only be computed from the normal matrix'
+    again = ls.accumulate_normals([observation_system(2, EPOCHS, DIM), seq.normal_equations(EPOCHS)], factors)
+    again.compute_covariance(sparse=False)
+    assert relerr(again.matrix.to_array(), g['full_inverse']) < TOL_INV
+    N, n, lPl, count = parts[0].to_array()
+    assert N.shape == (EPOCHS * DIM, EPOCHS * DIM) and n.shape == (EPOCHS * DIM, 1) and count == EPOCHS * (DIM + 5)
+
+
+def test_ragged_block_matrix_golden(golden):
+    g = golden('g11_lstsq')
+    rows, cols = ls.BlockMatrix.compute_block_index(g['ragged_input'].shape, 5)
+    np.testing.assert_array_equal(rows, g['ragged_index'])
+    bm = ls.BlockMatrix.from_array(np.triu(g['ragged_input']), rows, cols)
+    assert bm.shape == (4, 4)
+    assert bm[0, 3] is None and bm[1, 2] is None and bm[2, 1] is None and bm[0, 1].shape == (5, 5) and bm[2, 3].shape == (5, 2)
+    np.testing.assert_array_equal(bm.to_array(), np.triu(g['ragged_input']))
+    b = g['ragged_rhs']
+    assert relerr(bm.multiply_symmetric(b), g['ragged_multiply_symmetric']) < TOL
+    np.testing.assert_array_equal(bm.diag(), g['ragged_diag'])
+    assert relerr((bm @ bm).to_array(), g['ragged_matmul']) < TOL
+    bm.cholesky()
+    assert bm.is_nonzero(1, 2)                             # fill-in
+    assert relerr(bm.to_array(), g['ragged_factor']) < TOL
+    assert relerr(bm.solve_triangular(b, transpose=True), g['ragged_solve_T']) < TOL
+    assert relerr(bm.solve_triangular(b, transpose=False), g['ragged_solve_N']) < TOL
+    assert relerr(bm.multiply_triangular(b, transpose=False), g['ragged_multiply_N']) < TOL
+    assert relerr(bm.multiply_triangular(b, transpose=True), g['ragged_multiply_T']) < TOL
+    import torch
+    xt = bm.solve_triangular(torch.from_numpy(b).cuda(), transpose=True)       # device in -> device out
+    assert torch.is_tensor(xt) and relerr(xt.cpu().numpy(), g['ragged_solve_T']) < TOL
+    sp = bm.copy()
+    sp.sparse_inverse()
+    assert relerr(sp.to_array(), g['ragged_sparse_inverse']) < TOL_INV
+    bm.inverse()
+    assert relerr(bm.to_array(), g['ragged_inverse']) < TOL_INV
+
+
+def test_block_matrix_errors_and_factor_set_directly():
+    bm = ls.BlockMatrix([0, 3, 5], [0, 3, 5])
+    with pytest.raises(ValueError):
+        bm[0, 0] = [[1.0]]                                 # not an ndarray
+    with pytest.raises(ValueError):
+        bm[0, 0] = np.zeros(3)                             # not two-dimensional
+    with pytest.raises(ValueError):
+        bm[0, 1] = np.zeros((3, 3))                        # wrong shape
+    with pytest.raises(IndexError):
+        bm[5, 0] = np.zeros((3, 3))
+    with pytest.raises(ValueError):
+        ls.BlockMatrix.from_array([[1.0]], [0, 1], [0, 1])
+    with pytest.raises(ValueError):
+        ls.BlockMatrix.from_array(np.eye(4), [0, 3], [0, 4])
+    with pytest.raises(ValueError):
+        bm @ np.eye(5)
+    # a factor assigned block by block (no cholesky() call) is solved with on-demand inverses of its diagonal blocks
+    rng = np.random.default_rng(0)
+    U = np.triu(rng.standard_normal((5, 5))) + 3 * np.eye(5)
+    f = ls.BlockMatrix.from_array(U, [0, 3, 5], [0, 3, 5])
+    b = rng.standard_normal((5, 2))
+    assert relerr(f.solve_triangular(b), np.linalg.solve(U, b)) < TOL
+    assert relerr(f.solve_triangular(b, transpose=True), np.linalg.solve(U.T, b)) < TOL
+    not_pd = ls.BlockMatrix.from_array(-np.eye(5), [0, 3, 5], [0, 3, 5])
+    with pytest.raises(np.linalg.LinAlgError):
+        not_pd.cholesky()
+
+
+def test_tikhonov_golden(golden):
+    g = golden('g11_lstsq')
+    reg = np.random.default_rng(11).uniform(0.5, 2.0, 12)
+    bias = np.random.default_rng(12).standard_normal((12, 1))
+    tk = ls.TikhonovRegularization(reg, [0, 4, 8, 12], bias)
+    np.testing.assert_array_equal(tk.matrix.to_array(), g['tikhonov_matrix'])
+    np.testing.assert_array_equal(tk.right_hand_side, g['tikhonov_rhs'])
+    assert tk.observation_square_sum == g['tikhonov_lPl'] and tk.observation_count == int(g['tikhonov_count'])
+
+
+@pytest.mark.parametrize('dim,order,epochs', [(130, 1, 6), (257, 2, 5), (1681, 1, 3)])
+def test_smoother_against_oracle(dim, order, epochs):
+    """larger blocks (ragged against the 128 x 128 MFMA tiles, and the d/o-40 block size of config 5) against the oracle"""
+    cf = inputs.var_covariance_function(5, dim, order)
+    factors = [1.0, 2.0]
+    signs = np.random.default_rng(6).integers(0, 2, size=(epochs * dim, 4)) * 2.0 - 1.0
+    ref_parts = [lo.block_diagonal_normals(inputs.observation_normals(7, epochs, dim)), lo.var_sequence_normals(lo.var_sequence(cf), epochs)]
+    ref = lo.accumulate(ref_parts, factors)
+    xr, mcr = lo.solve(ref, signs)
+    factor_ref = lo.to_array(ref['matrix'])
+    lo.sparse_inverse(ref['matrix'])
+
+    seq = ls.AutoregressiveModelSequence.from_covariance_function(cf)
+    parts = [observation_system(7, epochs, dim), seq.normal_equations(epochs)]
+    combined = ls.accumulate_normals(parts, factors)
+    combined.matrix.cholesky()
+    combined.status = 'cholesky_factor'
+    assert relerr(combined.matrix.to_array(), factor_ref) < TOL
+    h = combined.matrix.solve_triangular(combined.right_hand_side, transpose=True)
+    x = combined.matrix.solve_triangular(np.hstack((h, signs)))
+    assert relerr(x[:, 0:1], xr) < TOL
+    assert relerr(x[:, 1:], mcr) < TOL
+    combined.compute_covariance(sparse=True)
+    assert relerr(combined.matrix.to_array(), lo.to_array(ref['matrix'])) < TOL_INV

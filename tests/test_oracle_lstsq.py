@@ -27,8 +27,9 @@ def test_var_models(golden):
         if k:
             assert relerr(np.array(coefficients), g['var{0}_coefficients'.format(k)]) < TOL
         blocks = lo.var_normal_blocks(coefficients, Q)
+        scale = max(np.abs(g['var{0}_normals_{1}{2}'.format(k, r, c)]).max() for r, c in blocks)    # B_2 of a VAR(1) process is rounding noise
         for (r, c), blk in blocks.items():
-            assert relerr(blk, g['var{0}_normals_{1}{2}'.format(k, r, c)]) < TOL
+            assert np.abs(blk - g['var{0}_normals_{1}{2}'.format(k, r, c)]).max() < TOL * scale
     constraint = lo.var_sequence_normals(lo.var_sequence(cf), EPOCHS)
     assert relerr(lo.to_array(constraint['matrix']), g['constraint_matrix']) < TOL
     # the constraint normals reproduce the covariance function they were built from (grates/lstsq.py:394-411)
