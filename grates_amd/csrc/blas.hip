@@ -32,6 +32,7 @@ struct GemmExParams {
     long long strideC;
     double alpha, beta;
     int upper_only;           // skip output tiles that lie entirely below the diagonal
+    int Ktotal;               // > 0: split-K launch, slice z covers k in [z K, min(Ktotal, (z + 1) K))
 };
 
 // TA: A is stored [K][M] (op(A) = A^T);  TB: B is stored [N][K] (op(B) = B^T).  Row-major everywhere.
@@ -48,6 +49,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, fk = lane >> 4;
+    // split-K launches (Ktotal > 0) give every z slice its own K range of at most P.K (= Kz here) entries
+    const int Kz = P.Ktotal > 0 ? min(P.K, P.Ktotal - (int)blockIdx.z * P.K) : P.K;
     const double* A = P.A + (size_t)blockIdx.z * P.strideA;
     const double* B = P.B + (size_t)blockIdx.z * P.strideB;
     double* C = P.C + (size_t)blockIdx.z * P.strideC;
@@ -109,26 +112,26 @@ __global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int ka = k0 + r_k, kb = ka + 1;                         // R-type: a thread's two k indices
-            const int ca = min(ka, P.K - 1) - r_k, cb = min(kb, P.K - 1) - r_k;
+            const int ca = min(ka, Kz - 1) - r_k, cb = min(kb, Kz - 1) - r_k;
             const int kk = k0 + k_k + 4 * h;                              // K-type: the k row of piece h
-            const size_t ok = (size_t)(min(kk, P.K - 1) - k_k);
+            const size_t ok = (size_t)(min(kk, Kz - 1) - k_k);
             if (!TA) {
                 const double v0 = ar[h][ca], v1 = ar[h][cb];
-                areg[2 * h] = ka < P.K ? v0 : 0.0;
-                areg[2 * h + 1] = kb < P.K ? v1 : 0.0;
+                areg[2 * h] = ka < Kz ? v0 : 0.0;
+                areg[2 * h + 1] = kb < Kz ? v1 : 0.0;
             } else {
                 const double v0 = ak0[ok * P.lda], v1 = ak1[ok * P.lda];
-                areg[2 * h] = kk < P.K ? v0 : 0.0;
-                areg[2 * h + 1] = kk < P.K ? v1 : 0.0;
+                areg[2 * h] = kk < Kz ? v0 : 0.0;
+                areg[2 * h + 1] = kk < Kz ? v1 : 0.0;
             }
             if (TB) {
                 const double v0 = br[h][ca], v1 = br[h][cb];
-                breg[2 * h] = ka < P.K ? v0 : 0.0;
-                breg[2 * h + 1] = kb < P.K ? v1 : 0.0;
+                breg[2 * h] = ka < Kz ? v0 : 0.0;
+                breg[2 * h + 1] = kb < Kz ? v1 : 0.0;
             } else {
                 const double v0 = bk0[ok * P.ldb], v1 = bk1[ok * P.ldb];
-                breg[2 * h] = kk < P.K ? v0 : 0.0;
-                breg[2 * h + 1] = kk < P.K ? v1 : 0.0;
+                breg[2 * h] = kk < Kz ? v0 : 0.0;
+                breg[2 * h + 1] = kk < Kz ? v1 : 0.0;
             }
         }
     };
@@ -177,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
         }
     };
 
-    const int nfull = P.K / XK;
-    const bool has_tail = (P.K % XK) != 0;
+    const int nfull = Kz / XK;
+    const bool has_tail = (Kz % XK) != 0;
     if (nfull > 0)
         fetch_full(0);
     else
@@ -224,6 +227,17 @@ __global__ void scale_kernel(int M, int N, double beta, double* __restrict__ C, 
     *p = beta == 0.0 ? 0.0 : beta * *p;
 }
 
+__global__ void splitk_reduce_kernel(int M, int N, int slices, double alpha, const double* __restrict__ partial, double beta,
+                                     double* __restrict__ C, int ldc) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const size_t e = (size_t)blockIdx.y * N + c;
+    double s = 0.0;
+    for (int z = 0; z < slices; ++z) s += partial[(size_t)z * M * N + e];
+    double* out = C + (size_t)blockIdx.y * ldc + c;
+    *out = beta == 0.0 ? alpha * s : fma(beta, *out, alpha * s);
+}
+
 int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
             long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, hipStream_t stream) {
     if (M <= 0 || N <= 0 || batch <= 0) return SHG_OK;
@@ -248,8 +262,36 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
         SHG_HIP(hipGetLastError());
         return SHG_OK;
     }
-    const dim3 grid(ceil_div(N, XN), ceil_div(M, XM), batch);
+    P.Ktotal = 0;
+    dim3 grid(ceil_div(N, XN), ceil_div(M, XM), batch);
     const size_t lds = (size_t)4 * XBUF * sizeof(double);          // 73.7 KB: two workgroups per CU
+    // Few output tiles and a long K (block times a handful of right-hand sides): split K over grid.z into a workspace of
+    // partial products that a second kernel sums in a fixed order (deterministic, unlike atomics).
+    const int tiles = (int)(grid.x * grid.y);
+    double* partial = nullptr;
+    int slices = 1;
+    if (batch == 1 && !upper_only && tiles <= 32 && K >= 512) {
+        slices = std::min(std::min(16, K / 128), std::max(1, 128 / tiles));
+        if (slices > 1) {
+            const int chunk = round_up(ceil_div(K, slices), XK);
+            slices = ceil_div(K, chunk);
+            if (slices > 1 && workspace_alloc((void**)&partial, (size_t)slices * M * N * sizeof(double), stream) == hipSuccess) {
+                P.K = chunk;
+                P.Ktotal = K;
+                P.strideA = ta ? (long long)chunk * lda : chunk;
+                P.strideB = tb ? chunk : (long long)chunk * ldb;
+                P.C = partial;
+                P.ldc = N;
+                P.strideC = (long long)M * N;
+                P.alpha = 1.0;
+                P.beta = 0.0;
+                grid.z = slices;
+            } else {
+                slices = 1;
+                partial = nullptr;
+            }
+        }
+    }
 #define SHG_GEMM_EX(TA_, TB_)                                                                                                     \
     do {                                                                                                                           \
         SHG_HIP(hipFuncSetAttribute((const void*)gemm_ex_kernel<TA_, TB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -261,6 +303,10 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
         if (tb) SHG_GEMM_EX(false, true); else SHG_GEMM_EX(false, false);
     }
 #undef SHG_GEMM_EX
+    if (partial) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(N, 256), M), dim3(256), 0, stream, M, N, slices, alpha, partial, beta, C, ldc);
+        (void)hipFreeAsync(partial, stream);
+    }
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
@@ -273,88 +319,162 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
 constexpr int LEAF = 128;
 constexpr int LLD = LEAF + 1;
 
-__global__ __launch_bounds__(256) void leaf_kernel(int n, double* __restrict__ A, int lda, long long strideA, double* __restrict__ X,
+// 1 / x from the hardware estimate and two Newton steps (the IEEE division is a ~40-instruction dependent chain that
+// sits on the critical path of every elimination step); relative error <= 2^-52
+__device__ __forceinline__ double fast_reciprocal(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// Thread (ty, tx) = (tid >> 4, tid & 15) of the 32 x 16 thread grid owns the 4 x 8 register tile
+//   u[ii][cc] = U[ty + 32 ii][tx + 16 cc]          (cyclic distribution: the work stays balanced as k advances)
+// Blocks smaller than 128 are padded with the identity.  Every elimination step broadcasts one row through a double
+// buffered LDS line (one barrier per step) and does its rank-1 update in registers; the steps are grouped by 32-row
+// groups (template parameter) so that all register indices are compile-time constants.  Two waves per SIMD.
+
+// the 32 elimination steps k = 32 KI .. 32 KI + 31 of the factorisation
+template <int KI>
+__device__ __forceinline__ void leaf_factor_group(double (&u)[4][8], double (*rowbuf)[LEAF], int* bad, int ty, int tx, int tid) {
+    for (int kr = 0; kr < 32; ++kr) {
+        const int k = KI * 32 + kr, buf = k & 1;
+        if (ty == kr) {
+#pragma unroll
+            for (int cc = 2 * KI; cc < 8; ++cc) rowbuf[buf][tx + 16 * cc] = u[KI][cc];
+        }
+        __syncthreads();
+        double piv = rowbuf[buf][k];
+        if (!(piv > 0.0)) {                      // not positive definite (also catches NaN); the same value in all threads
+            if (tid == 0 && *bad == 0) *bad = k + 1;
+            piv = 1.0;
+        }
+        const double inv = fast_reciprocal(piv);
+#pragma unroll
+        for (int ii = KI; ii < 4; ++ii) {
+            const int i = ty + 32 * ii;
+            if (ii > KI || ty > kr) {            // row i > k
+                const double f = rowbuf[buf][i] * inv;
+#pragma unroll
+                for (int cc = 2 * ii; cc < 8; ++cc)
+                    if (cc >= 2 * ii + 2 || tx + 16 * cc >= i) u[ii][cc] = fma(-f, rowbuf[buf][tx + 16 * cc], u[ii][cc]);
+            }
+        }
+    }
+}
+
+// the 32 back-substitution steps k = 32 KI + 31 .. 32 KI of the inversion (registers hold X, Ul the factor)
+template <int KI>
+__device__ __forceinline__ void leaf_invert_group(double (&x)[4][8], double (*rowbuf)[LEAF], const double* dg, const double* Ul, int ty, int tx) {
+    for (int kr = 31; kr >= 0; --kr) {
+        const int k = KI * 32 + kr, buf = k & 1;
+        if (ty == kr) {
+            const double r = dg[k];
+#pragma unroll
+            for (int cc = 2 * KI; cc < 8; ++cc) {
+                x[KI][cc] *= r;
+                rowbuf[buf][tx + 16 * cc] = x[KI][cc];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii <= KI; ++ii) {
+            if (ii < KI || ty < kr) {            // row i < k
+                const double m = Ul[(ty + 32 * ii) * LLD + k];
+#pragma unroll
+                for (int cc = 2 * KI; cc < 8; ++cc)
+                    if (cc >= 2 * KI + 2 || tx + 16 * cc >= k) x[ii][cc] = fma(-m, rowbuf[buf][tx + 16 * cc], x[ii][cc]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void leaf_kernel(int n, double* __restrict__ A, int lda, long long strideA, double* __restrict__ X,
                                                    int ldx, long long strideX, int mode, int* __restrict__ info, int info_base) {
-    extern __shared__ double U[];                       // [n][LLD]
+    extern __shared__ double Ul[];                      // [LEAF][LLD] factor, inversion phase only
+    __shared__ double rowbuf[2][LEAF];
+    __shared__ double dg[LEAF];
     __shared__ int bad;
     const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
     A += (size_t)blockIdx.x * strideA;
     if (X) X += (size_t)blockIdx.x * strideX;
     if (tid == 0) bad = 0;
-    for (int e = tid; e < n * n; e += 256) {
-        const int r = e / n, c = e % n;
-        U[r * LLD + c] = c >= r ? A[(size_t)r * lda + c] : 0.0;
-    }
-    __syncthreads();
+
+    double u[4][8];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int i = ty + 32 * ii, c = tx + 16 * cc;
+            u[ii][cc] = (i < n && c < n) ? (c >= i ? A[(size_t)i * lda + c] : 0.0) : (i == c ? 1.0 : 0.0);
+        }
+
     if (mode & 1) {
         // right-looking elimination with the row scaling deferred: step k uses the unscaled pivot row,
-        //   U[i][c] -= U[k][i] U[k][c] / U[k][k]   (k < i <= c),   one barrier per step
-        const int ty = tid >> 4, tx = tid & 15;
-        for (int k = 0; k < n; ++k) {
-            const double piv = U[k * LLD + k];
-            if (!(piv > 0.0)) {                          // not positive definite (also catches NaN); uniform: all threads read the same value
-                if (tid == 0) bad = k + 1;
-                break;
-            }
-            const double inv = 1.0 / piv;
-            for (int i = k + 1 + ty; i < n; i += 16) {
-                const double f = U[k * LLD + i] * inv;
-                for (int c = k + 1 + tx; c < n; c += 16)
-                    if (c >= i) U[i * LLD + c] = fma(-f, U[k * LLD + c], U[i * LLD + c]);
-            }
-            __syncthreads();
-        }
+        //   U[i][c] -= U[k][i] U[k][c] / U[k][k]   (k < i <= c)
+        leaf_factor_group<0>(u, rowbuf, &bad, ty, tx, tid);
+        leaf_factor_group<1>(u, rowbuf, &bad, ty, tx, tid);
+        leaf_factor_group<2>(u, rowbuf, &bad, ty, tx, tid);
+        leaf_factor_group<3>(u, rowbuf, &bad, ty, tx, tid);
+        // scale the rows: U[k][c] /= sqrt(d_k)
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+                if (ty + 32 * ii == tx + 16 * cc) dg[ty + 32 * ii] = u[ii][cc];
         __syncthreads();
         if (bad) {
             if (tid == 0 && info) atomicCAS(info, 0, info_base + (int)blockIdx.x * LEAF + bad);
             return;
         }
-        // scale the rows: U[k][c] /= sqrt(d_k)
-        for (int e = tid; e < n * n; e += 256) {
-            const int r = e / n, c = e % n;
-            if (c >= r) {
-                const double s = sqrt(U[r * LLD + r]);
-                // the diagonal entry is read by other threads of the same row: write it last, after a barrier
-                if (c > r) U[r * LLD + c] = U[r * LLD + c] / s;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const double s = sqrt(dg[ty + 32 * ii]);
+            const double rs = 1.0 / s;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                const int i = ty + 32 * ii, c = tx + 16 * cc;
+                if (c > i) u[ii][cc] *= rs;
+                if (c == i) u[ii][cc] = s;
+                if (i < n && c < n) A[(size_t)i * lda + c] = c >= i ? u[ii][cc] : 0.0;
             }
-        }
-        __syncthreads();
-        for (int r = tid; r < n; r += 256) U[r * LLD + r] = sqrt(U[r * LLD + r]);
-        __syncthreads();
-        for (int e = tid; e < n * n; e += 256) {
-            const int r = e / n, c = e % n;
-            A[(size_t)r * lda + c] = U[r * LLD + c];   // strictly lower part: zeros
         }
     }
     if (mode & 2) {
-        // in-place inversion of the upper triangular block, column by column (unblocked LAPACK trti2 scheme):
-        //   x_jj = 1 / u_jj;   x[0:j, j] = -x_jj * X[0:j, 0:j] u[0:j, j]   with the already inverted leading block
-        __syncthreads();
-        for (int j = 0; j < n; ++j) {
-            const double xjj = 1.0 / U[j * LLD + j];
-            double v = 0.0;
-            const int i = tid;                            // one thread per row (n <= 128 < 256)
-            if (i < j) {
-                for (int k = i; k < j; ++k) v = fma(U[i * LLD + k], U[k * LLD + j], v);     // X[i][k] (k >= i) times u[k][j]
-                v = -v * xjj;
+        // X = U^-1 by right-looking back substitution on the identity: for k = 127 .. 0
+        //   X[k][:] /= U[k][k];   X[i][c] -= U[i][k] X[k][c]   (i < k <= c)
+        __syncthreads();                                 // dg is rewritten below
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                const int i = ty + 32 * ii, c = tx + 16 * cc;
+                Ul[i * LLD + c] = u[ii][cc];
+                if (i == c) dg[i] = 1.0 / u[ii][cc];
+                u[ii][cc] = i == c ? 1.0 : 0.0;          // from here on the registers hold X
             }
-            __syncthreads();
-            if (i < j) U[i * LLD + j] = v;
-            if (i == j) U[j * LLD + j] = xjj;
-            __syncthreads();
-        }
-        for (int e = tid; e < n * n; e += 256) {
-            const int r = e / n, c = e % n;
-            X[(size_t)r * ldx + c] = U[r * LLD + c];   // strictly lower part: zeros
-        }
+        __syncthreads();
+        leaf_invert_group<3>(u, rowbuf, dg, Ul, ty, tx);
+        leaf_invert_group<2>(u, rowbuf, dg, Ul, ty, tx);
+        leaf_invert_group<1>(u, rowbuf, dg, Ul, ty, tx);
+        leaf_invert_group<0>(u, rowbuf, dg, Ul, ty, tx);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                const int i = ty + 32 * ii, c = tx + 16 * cc;
+                if (i < n && c < n) X[(size_t)i * ldx + c] = c >= i ? u[ii][cc] : 0.0;
+            }
     }
 }
 
 static int launch_leaf(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, int batch, int mode, int* info,
                        int info_base, hipStream_t stream) {
-    const size_t lds = (size_t)n * LLD * sizeof(double);
+    const size_t lds = (mode & 2) ? (size_t)LEAF * LLD * sizeof(double) : 0;
     SHG_HIP(hipFuncSetAttribute((const void*)leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LEAF * LLD * sizeof(double))));
-    hipLaunchKernelGGL(leaf_kernel, dim3(batch), dim3(256), lds, stream, n, A, lda, strideA, X, ldx, strideX, mode, info, info_base);
+    hipLaunchKernelGGL(leaf_kernel, dim3(batch), dim3(512), lds, stream, n, A, lda, strideA, X, ldx, strideX, mode, info, info_base);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
@@ -388,13 +508,23 @@ int trtri_upper(int n, const double* U, int ldu, double* X, int ldx, double* wor
     // recursive doubling: units of size s are complete; merge neighbours (a, a + s) into units of 2 s:
     //   X12 = -X11 (U12 X22)
     for (int s = LEAF; s < n; s *= 2) {
-        for (int a = 0; a + s < n; a += 2 * s) {
-            const int n2 = std::min(s, n - (a + s));             // right unit (may be ragged)
+        // pairs with a full right unit: one batched launch per product (uniform strides along the diagonal)
+        const int nfullpairs = n / (2 * s);
+        if (nfullpairs > 0) {
+            rc = gemm_ex(false, false, s, s, s, 1.0, U + s, ldu, (long long)2 * s * (ldu + 1), X + (size_t)s * (ldx + 1), ldx,
+                         (long long)2 * s * (ldx + 1), 0.0, work, s, (long long)s * s, nfullpairs, false, stream);
+            if (rc) return rc;
+            rc = gemm_ex(false, false, s, s, s, -1.0, X, ldx, (long long)2 * s * (ldx + 1), work, s, (long long)s * s, 0.0, X + s, ldx,
+                         (long long)2 * s * (ldx + 1), nfullpairs, false, stream);
+            if (rc) return rc;
+        }
+        const int a = nfullpairs * 2 * s;                       // a last pair with a ragged right unit
+        if (a + s < n) {
+            const int n2 = n - (a + s);
             const double* U12 = U + (size_t)a * ldu + (a + s);
             const double* X11 = X + (size_t)a * ldx + a;
             const double* X22 = X + (size_t)(a + s) * ldx + (a + s);
             double* X12 = X + (size_t)a * ldx + (a + s);
-            // T[s][n2] = U12 X22   (work, ld = n2)
             rc = gemm_ex(false, false, s, n2, n2, 1.0, U12, ldu, 0, X22, ldx, 0, 0.0, work, n2, 0, 1, false, stream);
             if (rc) return rc;
             rc = gemm_ex(false, false, s, n2, s, -1.0, X11, ldx, 0, work, n2, 0, 0.0, X12, ldx, 0, 1, false, stream);
@@ -480,7 +610,7 @@ extern "C" int shg_potrf(int n, double* A, int lda, int* info, void* stream_) {
     SHG_REQUIRE(A != nullptr && lda >= n, "shg_potrf: bad matrix");
     hipStream_t stream = (hipStream_t)stream_;
     double* work = nullptr;
-    if (hipMallocAsync((void**)&work, (size_t)LEAF * LEAF * sizeof(double), stream) != hipSuccess)
+    if (workspace_alloc((void**)&work, (size_t)LEAF * LEAF * sizeof(double), stream) != hipSuccess)
         return fail(SHG_ERR_NOMEM, "shg_potrf: workspace allocation failed");
     if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
     const int rc = potrf_upper(n, A, lda, work, info, stream);
@@ -495,7 +625,7 @@ extern "C" int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, vo
     SHG_REQUIRE(U != X, "shg_trtri: in-place inversion is not supported");
     hipStream_t stream = (hipStream_t)stream_;
     double* work = nullptr;
-    if (hipMallocAsync((void**)&work, (size_t)n * n / 2 * sizeof(double) + 1024, stream) != hipSuccess)
+    if (workspace_alloc((void**)&work, (size_t)n * n / 2 * sizeof(double) + 1024, stream) != hipSuccess)
         return fail(SHG_ERR_NOMEM, "shg_trtri: workspace allocation failed");
     const int rc = trtri_upper(n, U, ldu, X, ldx, work, stream);
     (void)hipFreeAsync(work, stream);

@@ -13,6 +13,7 @@
 namespace shg {
 
 int fail(int code, const char* fmt, ...);
+hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream);    // hipMallocAsync from a pool that keeps freed memory cached
 
 #define SHG_HIP(call)                                                                              \
     do {                                                                                           \

@@ -21,6 +21,23 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// Stream-ordered scratch memory.  The default memory pool of a device gives freed memory back to the driver at the next
+// synchronisation unless its release threshold is raised; with the threshold at its maximum hipMallocAsync / hipFreeAsync
+// of per-call workspaces cost microseconds instead of a driver allocation each.
+hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream) {
+    static thread_local int prepared_device = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev != prepared_device) {
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            uint64_t threshold = UINT64_MAX;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+        }
+        prepared_device = dev;
+    }
+    return hipMallocAsync(ptr, bytes, stream);
+}
+
 // a_nm / b_nm of  P_nm = (a_nm t) P_(n-1)m - b_nm P_(n-2)m   in packed order-major layout.
 //   n == m     : unused (seed), a = b = 0
 //   n == m + 1 : a = sqrt(2n + 1), b = 0                                    utilities.py:45-47

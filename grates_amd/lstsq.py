@@ -548,19 +548,25 @@ class NormalEquations:
         else:
             raise ValueError('Cholesky factor can only be computed from the normal matrix')
 
-    def solve(self):
+    def solve(self, signs=None):
         """
         Solve the system; the coefficient matrix afterwards holds the upper triangular Cholesky factor.  As upstream, 100
-        Monte-Carlo vectors of random signs (numpy.random.randint, global state) are solved along with the right-hand side
-        and kept in `monte_carlo_vectors` (grates/lstsq.py:950-968).
+        Monte-Carlo vectors of random signs (numpy.random.randint, global state, drawn on the host so that a seeded run
+        reproduces the reference) are solved along with the right-hand side and kept in `monte_carlo_vectors`
+        (grates/lstsq.py:950-968).
+
+        signs : ndarray or device tensor [n, k] of +-1, optional (extension)
+            Monte-Carlo vectors to use instead of the host draw (5e8 draws and a 5 GB upload for config 5).
         """
         self.__cholesky()
         rhs = _dev(self.right_hand_side)
         h = self.matrix.solve_triangular(rhs, transpose=True)
-        xi = np.random.randint(0, 2, size=(h.shape[0], 100))
-        xi[xi == 0] = -1
+        if signs is None:
+            xi = np.random.randint(0, 2, size=(h.shape[0], 100))
+            xi[xi == 0] = -1
+            signs = xi.astype(np.float64)
         torch = engine.require_gpu()
-        x = self.matrix.solve_triangular(torch.cat((h, _dev(xi.astype(np.float64))), dim=1))
+        x = self.matrix.solve_triangular(torch.cat((h, _dev(signs)), dim=1))
         if _is_tensor(self.right_hand_side):
             self.monte_carlo_vectors = x[:, 1:]
             return x[:, 0:1]

@@ -166,7 +166,10 @@ def test_tikhonov_golden(golden):
 
 @pytest.mark.parametrize('dim,order,epochs', [(130, 1, 6), (257, 2, 5), (1681, 1, 3)])
 def test_smoother_against_oracle(dim, order, epochs):
-    """larger blocks (ragged against the 128 x 128 MFMA tiles, and the d/o-40 block size of config 5) against the oracle"""
+    """larger blocks (ragged against the 128 x 128 MFMA tiles, and the d/o-40 block size of config 5) against the oracle.
+    The d = 1681 observation normals A^T A with A [d + 5, d] have condition numbers around 1e6, so two correct fp64
+    factorisations differ by ~ cond * eps = 1e-10 of the largest entry: tolerance 1e-9 there."""
+    tol, tol_inv = (1e-9, 1e-8) if dim > 1000 else (TOL, TOL_INV)
     cf = inputs.var_covariance_function(5, dim, order)
     factors = [1.0, 2.0]
     signs = np.random.default_rng(6).integers(0, 2, size=(epochs * dim, 4)) * 2.0 - 1.0
@@ -181,10 +184,10 @@ def test_smoother_against_oracle(dim, order, epochs):
     combined = ls.accumulate_normals(parts, factors)
     combined.matrix.cholesky()
     combined.status = 'cholesky_factor'
-    assert relerr(combined.matrix.to_array(), factor_ref) < TOL
+    assert relerr(combined.matrix.to_array(), factor_ref) < tol
     h = combined.matrix.solve_triangular(combined.right_hand_side, transpose=True)
     x = combined.matrix.solve_triangular(np.hstack((h, signs)))
-    assert relerr(x[:, 0:1], xr) < TOL
-    assert relerr(x[:, 1:], mcr) < TOL
+    assert relerr(x[:, 0:1], xr) < tol
+    assert relerr(x[:, 1:], mcr) < tol
     combined.compute_covariance(sparse=True)
-    assert relerr(combined.matrix.to_array(), lo.to_array(ref['matrix'])) < TOL_INV
+    assert relerr(combined.matrix.to_array(), lo.to_array(ref['matrix'])) < tol_inv
