@@ -270,8 +270,8 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
     const int tiles = (int)(grid.x * grid.y);
     double* partial = nullptr;
     int slices = 1;
-    if (batch == 1 && !upper_only && tiles <= 32 && K >= 512) {
-        slices = std::min(std::min(16, K / 128), std::max(1, 128 / tiles));
+    if (batch == 1 && !upper_only && tiles < 384 && K >= 512) {                 // fewer than 1.5 workgroups per CU
+        slices = std::min(std::min(16, K / 256), std::max(1, 512 / tiles));
         if (slices > 1) {
             const int chunk = round_up(ceil_div(K, slices), XK);
             slices = ceil_div(K, chunk);

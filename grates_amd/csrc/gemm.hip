@@ -374,6 +374,8 @@ int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, con
 }  // namespace shg
 
 namespace shg {
+int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
+            long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, hipStream_t stream);   // blas.hip
 int covprop_rows(shg_plan* p, const double* cov, int Pn, int p_off, int lat0, int lat1, double* partial, hipStream_t stream);
 }
 
@@ -390,6 +392,9 @@ extern "C" int shg_dgemm(int M, int N, int K, const double* A, int lda, const do
     }
     SHG_REQUIRE(A && B, "shg_dgemm: NULL pointer");
     SHG_REQUIRE(lda >= K && ldb >= N, "shg_dgemm: leading dimension too small");
+    // too few output tiles to fill the chip (e.g. the dense filter: 14637 x 240): the general kernel splits K
+    if (ceil_div(M, BM) * ceil_div(N, BN) < 384 && K >= 512)
+        return gemm_ex(false, false, M, N, K, 1.0, A, lda, 0, B, ldb, 0, 0.0, C, ldc, 0, 1, false, (hipStream_t)stream_);
     GemmParams P = {};
     P.M = M;
     P.N = N;
