@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, fk = lane >> 4;
+    // wave-uniform half of the K tile a thread generates in COVPROP mode: keeps the degree / rank bookkeeping on the scalar unit
+    const int khalf = __builtin_amdgcn_readfirstlane(tid >> 7);
     // PLAIN: column block fastest.  COVPROP: row block fastest -- the blocks resident at one time then walk the same
     // 33 MB column panel of Sigma together and it is fetched from HBM once instead of once per row block.
     const int m0 = (MODE == MODE_PLAIN ? blockIdx.y : blockIdx.x) * BM;
@@ -64,6 +66,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     // COVPROP A: element h of a thread: row = tid & 127 (fixed), k = (tid >> 7) + 2 h, generated from two small tables
     // B: 16 k-rows x 64 pieces of 2 doubles; piece h: k = (tid >> 6) + 4 h, col = (tid & 63) * 2
     double areg[8];
+    double creg[8];             // COVPROP: cos/sin factors; the product with areg is formed when the tile is staged, i.e.
+                                // after the MFMAs of the current tile, so that the loads stay in flight across them
     double2 breg[4];
     const int a_kk = (tid & 7) * 2;
     const double* a_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -103,14 +107,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
             // degree-wise index p = n^2 + r: the rank r inside the degree selects the cos/sin row (derived arithmetically)
             const int p0 = k0 + P.p_off;
             while ((cov_deg + 1) * (cov_deg + 1) <= p0) ++cov_deg;
-            int n = cov_deg, r = p0 + (tid >> 7) - cov_deg * cov_deg;
+            int n = cov_deg, r = p0 + khalf - cov_deg * cov_deg;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
                 while (r > 2 * n) {
                     r -= 2 * n + 1;
                     ++n;
                 }
-                areg[h] = cov_pk[k0 + 2 * h + (tid >> 7)] * cov_cs[(size_t)r * P.ldcs];
+                areg[h] = cov_pk[k0 + 2 * h + khalf];
+                creg[h] = cov_cs[(size_t)r * P.ldcs];
                 r += 2;
             }
         }
@@ -139,15 +144,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
             while ((cov_deg + 1) * (cov_deg + 1) <= p0) ++cov_deg;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                const int gk = k0 + 2 * h + (tid >> 7);
+                const int gk = k0 + 2 * h + khalf;
                 const int kc = min(gk, P.K - 1);
                 int n = cov_deg, r = kc + P.p_off - cov_deg * cov_deg;
                 while (r > 2 * n) {
                     r -= 2 * n + 1;
                     ++n;
                 }
-                const double v = cov_pk[kc] * cov_cs[(size_t)r * P.ldcs];
-                areg[h] = gk < P.K ? v : 0.0;
+                areg[h] = gk < P.K ? cov_pk[kc] : 0.0;
+                creg[h] = cov_cs[(size_t)r * P.ldcs];
             }
         }
 #pragma unroll
@@ -168,9 +173,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
                 As[buf][row * LDA + a_kk + 1] = areg[2 * h + 1];
             }
         } else {
-            const int row = tid & 127, kb = tid >> 7;
+            const int row = tid & 127, kb = khalf;
 #pragma unroll
-            for (int h = 0; h < 8; ++h) As[buf][row * LDA + 2 * h + kb] = areg[h];
+            for (int h = 0; h < 8; ++h) As[buf][row * LDA + 2 * h + kb] = areg[h] * creg[h];
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h) *reinterpret_cast<double2*>(&Bs[buf][(b_k + 4 * h) * LDB + b_col]) = breg[h];
