@@ -47,6 +47,7 @@ struct shg_plan {
     int N = 0, nlat = 0, nlon = 0;
     int ldlat = 0;          // nlat rounded up to 64: leading dimension of per-parallel tables / F
     bool sym4 = false;      // 4-fold longitude symmetry path
+    bool sym_ns = false;    // parallels (colatitude and kn rows) symmetric about the equator
     int ngroups = 1;        // 4 (sym4) or 1
     int goff[5] = {0, 0, 0, 0, 0};   // first K slot of each group (multiples of 4), goff[ngroups] = K
     int K = 0;              // total K slots of the longitude stage (multiple of 4)
@@ -79,13 +80,17 @@ struct shg_plan {
     double* pkf = nullptr;      // [nit][Qtot][64 lanes][2] the same table in MFMA-fragment order (fused kernel), built on first use
     int* qoff = nullptr;        // [N+2] first row-octet of every order in the fragment-ordered tables; qoff[N+1] = Qtot
     int Qtot = 0;
+    std::vector<int> ns_badmap; // per block of 8 northern parallels: -1, or rank among the blocks whose mirrored parallels get their own table
+    int ns_nbad = 0;
+    int* badmap_d = nullptr;
+    int pkf_variant = 0;        // 1 plain fragment order, 2 north-south symmetric fragment order
     double* cpk4 = nullptr;     // repacked coefficients of the whole batch: [ceil(B/4)][Qtot][32][2] (fused) or [ceil(B/8)][packed][2][8]
     size_t cpk4_size = 0;
     int cpk4_variant = 0;       // layout the workspace was last zero-initialised for
     size_t cpk4_zeroed = 0;
     double* panel = nullptr;    // two-kernel synthesis: [B/4][nit][K][64] Legendre-stage output in LDS-image order
     size_t panel_size = 0;
-    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel, 3 Legendre kernel + longitude kernel
+    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel, 3 Legendre kernel + longitude kernel, 4 fused kernel without the north-south symmetry
 
     // optional per-kernel event timing (shg_plan_profile)
     bool profiling = false;
@@ -98,6 +103,7 @@ namespace shg {
 int plan_alloc_workspace(shg_plan* p);
 int fused_chunk_for(const shg_plan* p);
 int build_pk_table(shg_plan* p, hipStream_t stream);
+int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream);
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 
 // RAII event pair around one kernel launch (no-op unless profiling is enabled on the plan)

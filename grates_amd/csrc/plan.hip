@@ -80,6 +80,35 @@ static bool has_fourfold_symmetry(int nlon, const double* lon) {
     return true;
 }
 
+// True when the parallels are symmetric about the equator: colat[nlat-1-i] = pi - colat[i] and equal degree factors, up to
+// the rounding of the caller's geometry (grates/gravityfield.py:353-356 evaluates both hemispheres independently; near the
+// poles colatitude = arccos(...) is ill conditioned and mirrored values differ by up to 1.5e-14 rad on a 0.25 degree grid).
+// Blocks of 8 northern parallels whose mirror images deviate by more than 1e-13 / (N + 1) rad or 5e-14 relative in kn are
+// flagged in `badmap`: the fused kernel evaluates their southern rows from a table of their own instead of (-1)^(n-m)
+// times the northern one, which keeps the deviation from an independent evaluation below ~1e-13 of the field maximum.
+static bool has_north_south_symmetry(int N, int nlat, const double* colat, const double* kn, std::vector<int>& badmap, int& nbad) {
+    badmap.clear();
+    nbad = 0;
+    if (nlat < 2 || nlat % 2 != 0) return false;
+    const double pi = 3.14159265358979323846;
+    const int nh = nlat / 2;
+    badmap.assign(ceil_div(nh, 8), -1);
+    for (int i = 0; i < nh; ++i) {
+        const int mi = nlat - 1 - i;
+        const double dtheta = std::fabs(colat[i] + colat[mi] - pi);
+        if (dtheta > 1e-11) return false;
+        bool bad = dtheta * (N + 1) > 1e-13;
+        for (int n = 0; n <= N; ++n) {
+            const double a = kn[(size_t)i * (N + 1) + n], b = kn[(size_t)mi * (N + 1) + n];
+            const double d = std::fabs(a - b), s = std::max(std::fabs(a), std::fabs(b));
+            if (d > 1e-10 * s) return false;
+            if (d > 5e-14 * s) bad = true;
+        }
+        if (bad && badmap[i >> 3] < 0) badmap[i >> 3] = nbad++;
+    }
+    return true;
+}
+
 int plan_alloc_workspace(shg_plan* p) {
     if (p->chunk_alloc == p->chunk && p->F) return SHG_OK;
     if (p->cpk) (void)hipFree(p->cpk);
@@ -166,6 +195,7 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
     p->nlon = nlon;
     p->ldlat = round_up(nlat, kLatTile);
     p->sym4 = has_fourfold_symmetry(nlon, lon_h);
+    p->sym_ns = has_north_south_symmetry(N, nlat, colat_h, kn_h, p->ns_badmap, p->ns_nbad);
 
     // ---- K slots of the longitude stage
     if (p->sym4) {
@@ -244,6 +274,7 @@ extern "C" int shg_plan_destroy(shg_plan* p) {
                       p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->pkf, p->cpk4, p->cov_partial, p->panel};
     if (p->rslot) (void)hipFree(p->rslot);
     if (p->qoff) (void)hipFree(p->qoff);
+    if (p->badmap_d) (void)hipFree(p->badmap_d);
     for (double* q : ptrs)
         if (q) (void)hipFree(q);
     for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
@@ -260,7 +291,7 @@ extern "C" int shg_plan_set_chunk(shg_plan* p, int epochs_per_pass) {
 
 extern "C" int shg_plan_set_path(shg_plan* p, int path) {
     SHG_REQUIRE(p != nullptr, "shg_plan_set_path: NULL plan");
-    SHG_REQUIRE(path >= 0 && path <= 3, "shg_plan_set_path: path %d not in {0, 1, 2, 3}", path);
+    SHG_REQUIRE(path >= 0 && path <= 4, "shg_plan_set_path: path %d not in {0, 1, 2, 3, 4}", path);
     SHG_REQUIRE(path < 2 || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
     p->path = path;
     return SHG_OK;
@@ -271,7 +302,7 @@ extern "C" int shg_plan_info(const shg_plan* p, int64_t which[8]) {
     which[0] = p->N;
     which[1] = p->nlat;
     which[2] = p->nlon;
-    which[3] = p->sym4 ? 1 : 0;
+    which[3] = (p->sym4 ? 1 : 0) | (p->sym_ns ? 2 : 0);
     which[4] = p->chunk;
     which[5] = p->K;
     which[6] = (p->path >= 2 || (p->path == 0 && fused_chunk_for(p) != 0)) ? 1 : 0;

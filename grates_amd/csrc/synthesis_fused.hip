@@ -95,15 +95,80 @@ __global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, i
     for (int bb = 0; bb < 4; ++bb) dst[bb * 2] = (bt * 4 + bb < B) ? anm[(size_t)(bt * 4 + bb) * E + e] : 0.0;
 }
 
+// North-south symmetric grids (colat[nlat-1-i] = pi - colat[i], equal kn rows): P_nm(pi - theta) = (-1)^(n-m) P_nm(theta), so
+// the Legendre stage only needs the northern parallels.  A block then covers 8 northern parallels and their 8 mirror
+// images; the sums over even and odd n - m are formed side by side in one MFMA tile,
+//   A rows 0-7 : coefficients of degrees m + 2 j      (4 epochs x cos/sin),   B columns 0-7 : PK[m + 2 j][8 parallels]
+//   A rows 8-15: coefficients of degrees m + 2 j + 1,                          B columns 8-15: PK[m + 2 j + 1][8 parallels]
+// (k-step = 4 degree pairs j; the off-diagonal 8 x 8 blocks of the product are discarded), and north / south panel
+// rows are E + O / E - O.  Half the MFMAs and half the PK bytes of the plain layout.  Order m owns ceil((N+1-m)/16)
+// octets (16 degrees = 2 k-steps); octet = 64 lanes x 2 doubles, lane = (pair & 3) * 16 + parity * 8 + parallel.
+__global__ __launch_bounds__(64) void pkf_ns_table_kernel(int N, int nlat, int ldlat, int nh, int nit, int Qtot, const int* __restrict__ qoff,
+                                                          const int* __restrict__ badmap, const double* __restrict__ ct,
+                                                          const double* __restrict__ pmm, const double* __restrict__ knT,
+                                                          const double* __restrict__ arec, const double* __restrict__ brec,
+                                                          double* __restrict__ pkf) {
+    const int i = blockIdx.x * 64 + threadIdx.x;                    // northern parallel
+    if (i >= nh) return;
+    // z = 0: northern parallels, tile i / 8.  z = 1: the mirrored parallels of the blocks flagged in badmap get their own
+    // tile (nit + rank) in the same lane slots
+    int row = i, tile = i >> 3;
+    if (blockIdx.z == 1) {
+        const int rank = badmap[i >> 3];
+        if (rank < 0) return;
+        row = nlat - 1 - i;
+        tile = nit + rank;
+    }
+    const int m = blockIdx.y;
+    const int off = order_offset(N, m);
+    const double t = ct[row];
+    double* dst = pkf + (((size_t)tile * Qtot + qoff[m]) * 64 + (i & 7)) * 2;
+    double p1 = pmm[(size_t)m * ldlat + row], p2 = 0.0;
+    dst[0] = p1 * knT[(size_t)m * ldlat + row];
+    for (int n = m + 1; n <= N; ++n) {
+        const int idx = off + n - m, nl = n - m;
+        const double p = (arec[idx] * t) * p1 - brec[idx] * p2;      // grates/utilities.py:52-54, no contraction
+        p2 = p1;
+        p1 = p;
+        const int j = nl >> 1, kstep = j >> 2;
+        dst[(size_t)(kstep >> 1) * 128 + ((j & 3) * 16 + (nl & 1) * 8) * 2 + (kstep & 1)] = p * knT[(size_t)n * ldlat + row];
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_coefficients4_ns_kernel(int N, int B, int Qtot, const int* __restrict__ qoff,
+                                                                     const double* __restrict__ anm, double* __restrict__ cpk4) {
+    const int E = (N + 1) * (N + 1);
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int bt = blockIdx.y;
+    const int r = e / (N + 1), c = e % (N + 1);
+    int m, nl, cs;
+    if (c <= r) {
+        m = c;
+        nl = r - c;
+        cs = 0;
+    } else {
+        m = r + 1;
+        nl = c - (r + 1);
+        cs = 1;
+    }
+    const int j = nl >> 1, kstep = j >> 2;
+    double* dst = cpk4 + (((size_t)bt * Qtot + qoff[m] + (kstep >> 1)) * 64 + (j & 3) * 16 + (nl & 1) * 8 + cs * 4) * 2 + (kstep & 1);
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) dst[bb * 2] = (bt * 4 + bb < B) ? anm[(size_t)(bt * 4 + bb) * E + e] : 0.0;
+}
+
 struct FusedParams {
     int N, nlat, nlon, ldlat, K, ncol, B, nit, Ppk, ncb;   // nit = 16-parallel tiles, ncb = column blocks (8 tiles each)
     int goff[5];              // first K slot of each (cos/sin, m even/odd) group; every group is a multiple of 16 slots
     int gcount[4];            // used slots per group (the rest up to goff[g+1] is zero padding)
+    int ns, nh;               // north-south symmetric variant: blocks of 8 northern parallels + mirrors; nh = nlat / 2
     int dbg;                  // experiment switches (SHG_DEBUG): 1 no stores, 2 no Legendre phase, 4 no longitude phase, 8 no longitude MFMAs
     int Qtot;                 // row octets of the fragment-ordered tables
     const int* qoff;          // [N+2]
     const double* cpk4;       // [nbt][Qtot][32][2]
     const double* pkf;        // [nit][Qtot][64][2]
+    const int* badmap;        // NS variant: [nit] -1, or rank of the block among those whose mirrored parallels need their own table
     const double* trig;       // [ncb * 8][K][16]
     const double* panel;      // two-kernel variant: [B/4][nit][K][64] panels written by legendre_mfma_kernel
     double* G;
@@ -118,13 +183,22 @@ __device__ inline double swap_neighbour(double x) {
     return __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned int)lo2);
 }
 
+// value of the lane 8 positions away inside the row of 16 lanes (DPP row_ror:8)
+__device__ inline double swap_half_row(double x) {
+    const long long bits = __builtin_bit_cast(long long, x);
+    const int lo = (int)bits, hi = (int)(bits >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned int)lo2);
+}
+
 // One work item of phase 1: two row octets (4 k-steps, 16 degrees) of order m starting at octet j0 of that order.
 struct LegendreItem {
     int m, j0;
     __device__ bool valid(int N) const { return m <= N; }
-    __device__ LegendreItem next(int N) const {
+    __device__ LegendreItem next(int N, int octet_degrees = 8) const {
         LegendreItem r = {m, j0 + 2};
-        if (r.j0 * 8 >= N + 1 - m) {
+        if (r.j0 * octet_degrees >= N + 1 - m) {
             r.m = m + 8;
             r.j0 = 0;
         }
@@ -132,7 +206,7 @@ struct LegendreItem {
     }
 };
 
-template <bool FROM_PANEL>
+template <bool FROM_PANEL, bool NS>
 __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     extern __shared__ double As[];                     // panel [K][kPanelStride]
 
@@ -142,7 +216,8 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     const int nbt = (P.B + 3) >> 2;
     const int bt = blockIdx.x % nbt;                   // epoch tile fastest: neighbouring blocks share the PK slab
     const int it = blockIdx.x / nbt;
-    const int i0 = it * 16;
+    const int i0 = it * 16;                             // plain layout: first parallel of the block
+    const int i0n = it * 8;                             // NS layout: first northern parallel of the block
     const int fr = lane & 15, fk = lane >> 4;
 
     // ---- zero the padding slots of the panel
@@ -170,38 +245,59 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     // ---- phase 1: Legendre stage.  Orders are distributed over the 8 waves; items of 4 k-steps are double
     //      buffered in two named register sets so that the fragments of item t+1 are in flight while item t runs.
     if (!FROM_PANEL && !(P.dbg & 2)) {
+        // plain layout: octet = 8 degrees, A rows 8-15 are zero (not stored);  NS layout: octet = 16 degrees, all 16 rows used
+        constexpr int OD = NS ? 16 : 8;                               // degrees per octet
+        constexpr int ASTRIDE = NS ? 128 : 64;                        // doubles per octet of the coefficient table
+        const int bad = NS ? P.badmap[it] : -1;                       // block-uniform
         const double* pkb = P.pkf + ((size_t)it * P.Qtot * 64 + lane) * 2;                       // + octet * 128
-        const double* cf = P.cpk4 + ((size_t)bt * P.Qtot * 32 + fk * 8 + (fr & 7)) * 2;          // + octet * 64
-        const bool arow = fr < 8;                                     // rows 8-15 of the A operand are zero
+        int mode = NS && bad >= 0 ? 1 : 0;
+        int prow = lane;                                              // panel row written by this lane
+        const double* cf = NS ? P.cpk4 + ((size_t)bt * P.Qtot * 64 + lane) * 2
+                              : P.cpk4 + ((size_t)bt * P.Qtot * 32 + fk * 8 + (fr & 7)) * 2;     // + octet * ASTRIDE
+        const bool arow = NS || fr < 8;
         double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 
-        // 16-byte fragment loads: A and B of two k-steps per load, 1 KB (B) / 512 B (A) contiguous per wave
+        // 16-byte fragment loads: A and B of two k-steps per load, 1 KB (B) / 512 B or 1 KB (A) contiguous per wave
 #define SHG_P1_ISSUE(item, ALO, AHI, BLO, BHI)                                               \
     do {                                                                                     \
-        const int q_ = (P.N + 8 - (item).m) >> 3;                                            \
+        const int q_ = (P.N + OD - (item).m) / OD;                                           \
         const int o0_ = P.qoff[(item).m] + (item).j0;                                        \
         const int o1_ = o0_ + ((item).j0 + 1 < q_ ? 1 : 0);                                  \
-        ALO = *reinterpret_cast<const double2*>(cf + (size_t)o0_ * 64);                      \
+        ALO = *reinterpret_cast<const double2*>(cf + (size_t)o0_ * ASTRIDE);                 \
         BLO = *reinterpret_cast<const double2*>(pkb + (size_t)o0_ * 128);                    \
-        AHI = *reinterpret_cast<const double2*>(cf + (size_t)o1_ * 64);                      \
+        AHI = *reinterpret_cast<const double2*>(cf + (size_t)o1_ * ASTRIDE);                 \
         BHI = *reinterpret_cast<const double2*>(pkb + (size_t)o1_ * 128);                    \
     } while (0)
 
-#define SHG_P1_CONSUME(item, nxt, ALO, AHI, BLO, BHI)                                                               \
+#define SHG_P1_CONSUME(item, nxt, ALO, AHI, BLO, BHI)                                                                   \
     do {                                                                                                            \
         const bool lo_ = arow && (item).m <= P.N;                                                                   \
-        const bool hi_ = lo_ && ((item).j0 + 1) * 8 < P.N + 1 - (item).m;                                           \
+        const bool hi_ = lo_ && ((item).j0 + 1) * OD < P.N + 1 - (item).m;                                          \
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.x : 0.0, BLO.x, acc0, 0, 0, 0);                       \
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.y : 0.0, BLO.y, acc1, 0, 0, 0);                       \
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.x : 0.0, BHI.x, acc0, 0, 0, 0);                       \
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.y : 0.0, BHI.y, acc1, 0, 0, 0);                       \
         if ((nxt).m != (item).m && (item).m <= P.N) {                                                               \
             /* C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15: reg 0 = cosine part of epoch (lane >> 4),  */ \
-            /* reg 1 = sine part; panel row = epoch * 16 + parallel = lane                                        */ \
+            /* reg 1 = sine part; panel row = epoch * 16 + parallel slot = lane.                                  */ \
+            /* NS: regs 0, 1 = even-degree sums E (valid in columns 0-7), regs 2, 3 = odd-degree sums O (valid in */ \
+            /* columns 8-15) of the same 8 parallels: lanes fr and fr + 8 exchange them; slots 0-7 get E + O      */ \
+            /* (northern parallels), slots 8-15 E - O (their mirror images)                                       */ \
             const int m_ = (item).m;                                                                                \
-            As[(P.goff[m_ & 1] + (m_ >> 1)) * kPanelStride + lane] = acc0[0] + acc1[0];                             \
-            if (m_ >= 1)                                                                                            \
-                As[(P.goff[2 + (m_ & 1)] + ((m_ & 1) ? (m_ >> 1) : (m_ >> 1) - 1)) * kPanelStride + lane] = acc0[1] + acc1[1]; \
+            /* mode 0: both hemispheres from the northern table; mode 1 / 2 (blocks near the poles): northern / mirrored */ \
+            /* parallels from their own tables, E + O each, written by the lanes fr < 8                            */ \
+            double vc_ = acc0[0] + acc1[0], vs_ = acc0[1] + acc1[1];                                                \
+            if (NS) {                                                                                               \
+                const double oc_ = acc0[2] + acc1[2], os_ = acc0[3] + acc1[3];                                      \
+                const double rc_ = swap_half_row(fr < 8 ? vc_ : oc_), rs_ = swap_half_row(fr < 8 ? vs_ : os_);      \
+                vc_ = (mode == 0 && fr >= 8) ? rc_ - oc_ : vc_ + rc_;                                               \
+                vs_ = (mode == 0 && fr >= 8) ? rs_ - os_ : vs_ + rs_;                                               \
+            }                                                                                                       \
+            if (!NS || mode == 0 || fr < 8) {                                                                       \
+                As[(P.goff[m_ & 1] + (m_ >> 1)) * kPanelStride + prow] = vc_;                                       \
+                if (m_ >= 1)                                                                                        \
+                    As[(P.goff[2 + (m_ & 1)] + ((m_ & 1) ? (m_ >> 1) : (m_ >> 1) - 1)) * kPanelStride + prow] = vs_; \
+            }                                                                                                       \
             acc0 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
             acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
         }                                                                                                           \
@@ -214,25 +310,36 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         // bookkeeping exact, so the fragments of item t+1 really are in flight while item t runs.  (Three items in
         // flight measured no faster: the stage is bound by L2 -> CU throughput, not by latency.)
         int nitems = 0;
-        for (int m = wave; m <= P.N; m += 8) nitems += (P.N + 1 - m + 15) >> 4;
-        LegendreItem cur = {wave, 0};
-        const LegendreItem first = cur;
-        if (nitems > 0) SHG_P1_ISSUE(cur, xal, xah, xbl, xbh);
-        for (int trip = 0; trip < (nitems + 1) / 2; ++trip) {
-            const LegendreItem nx = cur.next(P.N);
-            const LegendreItem ld1 = nx.valid(P.N) ? nx : first;
-            SHG_P1_ISSUE(ld1, yal, yah, ybl, ybh);
-            SHG_P1_CONSUME(cur, nx, xal, xah, xbl, xbh);
-            const LegendreItem nn = nx.next(P.N);
-            const LegendreItem ld2 = nn.valid(P.N) ? nn : first;
-            SHG_P1_ISSUE(ld2, xal, xah, xbl, xbh);
-            SHG_P1_CONSUME(nx, nn, yal, yah, ybl, ybh);
-            cur = nn;
+        for (int m = wave; m <= P.N; m += 8) nitems += (P.N + 1 - m + 2 * OD - 1) / (2 * OD);
+        for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
+            if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
+                mode = 2;
+                prow = lane + 8;
+                pkb = P.pkf + ((size_t)(P.nit + bad) * P.Qtot * 64 + lane) * 2;
+            }
+            LegendreItem cur = {wave, 0};
+            const LegendreItem first = cur;
+            if (nitems > 0) SHG_P1_ISSUE(cur, xal, xah, xbl, xbh);
+            for (int trip = 0; trip < (nitems + 1) / 2; ++trip) {
+                const LegendreItem nx = cur.next(P.N, OD);
+                const LegendreItem ld1 = nx.valid(P.N) ? nx : first;
+                SHG_P1_ISSUE(ld1, yal, yah, ybl, ybh);
+                SHG_P1_CONSUME(cur, nx, xal, xah, xbl, xbh);
+                const LegendreItem nn = nx.next(P.N, OD);
+                const LegendreItem ld2 = nn.valid(P.N) ? nn : first;
+                SHG_P1_ISSUE(ld2, xal, xah, xbl, xbh);
+                SHG_P1_CONSUME(nx, nn, yal, yah, ybl, ybh);
+                cur = nn;
+            }
         }
 #undef SHG_P1_ISSUE
 #undef SHG_P1_CONSUME
     }
     __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
+
+    // grid row of panel row slot s (0..15) of this block.  NS: slots 0-7 = northern parallels, 8-15 = their mirror images
+    auto grid_row = [&](int s) { return NS ? (s < 8 ? i0n + s : P.nlat - 1 - (i0n + s - 8)) : i0 + s; };
+    auto slot_valid = [&](int s) { return NS ? i0n + (s & 7) < P.nh : i0 + s < P.nlat; };
 
     // ---- phase 2: longitude stage
     const int nbody = P.K >> 4;                        // bodies of 4 k-steps; every group is a whole number of bodies
@@ -321,9 +428,11 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
                 // adjacent columns and stores 16 bytes
                 const int jc = jt + (fr & ~1);
                 const bool jok = jc < P.ncol;
-                const int ia = i0 + fk + (par ? 8 : 0), ib = ia + 4;
-                double* rowa = P.G + ((size_t)b * P.nlat + ia) * P.nlon;
-                double* rowb = P.G + ((size_t)b * P.nlat + ib) * P.nlon;
+                const int sa = fk + (par ? 8 : 0), sb = sa + 4;             // panel row slots of this lane
+                const int ia = grid_row(sa), ib = grid_row(sb);
+                const bool oka = slot_valid(sa), okb = slot_valid(sb);
+                double* rowa = P.G + ((size_t)b * P.nlat + (oka ? ia : 0)) * P.nlon;
+                double* rowb = P.G + ((size_t)b * P.nlat + (okb ? ib : 0)) * P.nlon;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const double r0 = swap_neighbour(par ? img[t][0] : img[t][2]);
@@ -338,16 +447,16 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
                     else { col = P.nlon / 2 + jc; ascending = true; }
                     const double2_t va = ascending ? (double2_t){a_lo, a_hi} : (double2_t){a_hi, a_lo};
                     const double2_t vb = ascending ? (double2_t){b_lo, b_hi} : (double2_t){b_hi, b_lo};
-                    if (jok && ia < P.nlat) *reinterpret_cast<double2_t*>(rowa + col) = va;
-                    if (jok && ib < P.nlat) *reinterpret_cast<double2_t*>(rowb + col) = vb;
+                    if (jok && oka) *reinterpret_cast<double2_t*>(rowa + col) = va;
+                    if (jok && okb) *reinterpret_cast<double2_t*>(rowb + col) = vb;
                 }
             } else {
                 const int j = jt + fr;
                 if (j >= P.ncol) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = i0 + fk + 4 * r;
-                    if (i >= P.nlat) continue;
+                    if (!slot_valid(fk + 4 * r)) continue;
+                    const int i = grid_row(fk + 4 * r);
                     double* row = P.G + ((size_t)b * P.nlat + i) * P.nlon;
                     row[j] = img[0][r];
                     row[P.nlon - 1 - j] = img[1][r];
@@ -443,25 +552,43 @@ int build_pk_table(shg_plan* p, hipStream_t stream) {
 }
 
 // fragment-ordered table of the fused kernel (and the octet offsets both fragment-ordered tables share)
-int build_pkf_table(shg_plan* p, hipStream_t stream) {
-    if (p->pkf) return SHG_OK;
-    const int N = p->N, nit = ceil_div(p->nlat, 16);
+int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream) {
+    const int variant = ns ? 2 : 1;
+    if (p->pkf && p->pkf_variant == variant) return SHG_OK;
+    if (p->pkf) {                                       // the other layout was built before (explicit path switch)
+        SHG_HIP(hipDeviceSynchronize());
+        (void)hipFree(p->pkf);
+        p->pkf = nullptr;
+    }
+    const int N = p->N;
+    const int od = ns ? 16 : 8;                         // degrees per octet
+    const int nit = ns ? ceil_div(p->nlat / 2, 8) : ceil_div(p->nlat, 16);
     std::vector<int> qoff(N + 2);
     int q = 0;
     for (int m = 0; m <= N; ++m) {
         qoff[m] = q;
-        q += (N + 1 - m + 7) / 8;
+        q += (N + 1 - m + od - 1) / od;
     }
     qoff[N + 1] = q;
     p->Qtot = q;
     if (!p->qoff && hipMalloc((void**)&p->qoff, qoff.size() * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "octet table allocation failed");
     SHG_HIP(hipMemcpy(p->qoff, qoff.data(), qoff.size() * sizeof(int), hipMemcpyHostToDevice));
-    const size_t n = (size_t)nit * q * 128;
+    const size_t n = (size_t)(nit + (ns ? p->ns_nbad : 0)) * q * 128;
     if (hipMalloc((void**)&p->pkf, n * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "PK table allocation failed (%zu doubles)", n);
     SHG_HIP(hipMemsetAsync(p->pkf, 0, n * sizeof(double), stream));
-    hipLaunchKernelGGL(pkf_table_kernel, dim3(p->ldlat / 64, N + 1), dim3(64), 0, stream, N, p->ldlat, nit, q, p->qoff, p->ct, p->pmm,
-                       p->knT, p->arec, p->brec, p->pkf);
+    if (ns) {
+        if (!p->badmap_d) {
+            if (hipMalloc((void**)&p->badmap_d, p->ns_badmap.size() * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "block map allocation failed");
+            SHG_HIP(hipMemcpy(p->badmap_d, p->ns_badmap.data(), p->ns_badmap.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL(pkf_ns_table_kernel, dim3(ceil_div(p->nlat / 2, 64), N + 1, 2), dim3(64), 0, stream, N, p->nlat, p->ldlat, p->nlat / 2, nit, q,
+                           p->qoff, p->badmap_d, p->ct, p->pmm, p->knT, p->arec, p->brec, p->pkf);
+    }
+    else
+        hipLaunchKernelGGL(pkf_table_kernel, dim3(p->ldlat / 64, N + 1), dim3(64), 0, stream, N, p->ldlat, nit, q, p->qoff, p->ct, p->pmm,
+                           p->knT, p->arec, p->brec, p->pkf);
     SHG_HIP(hipGetLastError());
+    p->pkf_variant = variant;
     return SHG_OK;
 }
 
@@ -469,14 +596,16 @@ int build_pkf_table(shg_plan* p, hipStream_t stream) {
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
     if (fused_chunk_for(p) == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
     const bool two_kernel = p->path == 3;
-    int rc = two_kernel ? build_pk_table(p, stream) : build_pkf_table(p, stream);
+    const bool ns = !two_kernel && p->sym_ns && p->path != 4;      // north-south symmetric variant (path 4 forces the plain one)
+    int rc = two_kernel ? build_pk_table(p, stream) : build_pkf_table(p, ns, stream);
     if (rc) return rc;
     const int nbt = ceil_div(B, 4);
     const int nbt8 = ceil_div(B, 8);
     const int Ppk = packed_count(p->N);
-    const int nit = ceil_div(p->nlat, 16);
-    // coefficient workspace: [nbt][Qtot][32][2] (fused) or [nbt8][Ppk][2][8] (two-kernel)
-    const size_t need = two_kernel ? (size_t)nbt8 * Ppk * 16 : (size_t)nbt * p->Qtot * 64;
+    const int nit = ns ? ceil_div(p->nlat / 2, 8) : ceil_div(p->nlat, 16);
+    const int variant = two_kernel ? 3 : (ns ? 4 : 2);
+    // coefficient workspace: [nbt][Qtot][32][2] (fused), [nbt][Qtot][64][2] (fused, NS) or [nbt8][Ppk][2][8] (two-kernel)
+    const size_t need = two_kernel ? (size_t)nbt8 * Ppk * 16 : (size_t)nbt * p->Qtot * (ns ? 128 : 64);
     if (need > p->cpk4_size) {
         if (p->cpk4) {
             SHG_HIP(hipStreamSynchronize(stream));
@@ -489,9 +618,9 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     }
     // sine slots of order 0 and the padding rows of the octets are never written by the pack kernels and must read as
     // zero (layouts differ per variant)
-    if (need > 0 && (p->cpk4_variant != (two_kernel ? 3 : 2) || p->cpk4_zeroed < need)) {
+    if (need > 0 && (p->cpk4_variant != variant || p->cpk4_zeroed < need)) {
         SHG_HIP(hipMemsetAsync(p->cpk4, 0, p->cpk4_size * sizeof(double), stream));
-        p->cpk4_variant = two_kernel ? 3 : 2;
+        p->cpk4_variant = variant;
         p->cpk4_zeroed = p->cpk4_size;
     }
     const int E = (p->N + 1) * (p->N + 1);
@@ -504,6 +633,8 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.ncol = p->ncol;
     P.B = B;
     P.nit = nit;
+    P.ns = ns ? 1 : 0;
+    P.nh = p->nlat / 2;
     P.Ppk = Ppk;
     P.ncb = ceil_div(p->ncoltiles, 8);
     for (int g = 0; g < 5; ++g) P.goff[g] = p->goff[g];
@@ -516,6 +647,7 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.qoff = p->qoff;
     P.cpk4 = p->cpk4;
     P.pkf = p->pkf;
+    P.badmap = p->badmap_d;
     P.trig = p->trig;
     P.panel = nullptr;
     P.G = grid;
@@ -544,16 +676,24 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
         }
         P.panel = p->panel;
         ProfileScope ps(p, 2, stream);
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(synthesis_fused_kernel<true>, grid_dim, dim3(512), lds, stream, P);
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((synthesis_fused_kernel<true, false>), grid_dim, dim3(512), lds, stream, P);
     } else {
         {
             ProfileScope ps(p, 0, stream);
-            hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, p->qoff, anm, p->cpk4);
+            if (ns)
+                hipLaunchKernelGGL(pack_coefficients4_ns_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, p->qoff, anm, p->cpk4);
+            else
+                hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, p->qoff, anm, p->cpk4);
         }
         ProfileScope ps(p, 2, stream);
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(synthesis_fused_kernel<false>, grid_dim, dim3(512), lds, stream, P);
+        if (ns) {
+            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((synthesis_fused_kernel<false, true>), grid_dim, dim3(512), lds, stream, P);
+        } else {
+            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((synthesis_fused_kernel<false, false>), grid_dim, dim3(512), lds, stream, P);
+        }
     }
     SHG_HIP(hipGetLastError());
     return SHG_OK;

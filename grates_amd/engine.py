@@ -89,12 +89,14 @@ class Plan:
     def info(self):
         arr = (ctypes.c_int64 * 8)()
         _lib.call('shg_plan_info', self._handle, arr)
-        return {'max_degree': arr[0], 'nlat': arr[1], 'nlon': arr[2], 'fourfold_symmetry': bool(arr[3]),
+        return {'max_degree': arr[0], 'nlat': arr[1], 'nlon': arr[2], 'fourfold_symmetry': bool(arr[3] & 1), 'north_south_symmetry': bool(arr[3] & 2),
                 'epochs_per_pass': arr[4], 'k_slots': arr[5], 'fused': bool(arr[6])}
 
     def set_path(self, path):
-        """'auto', 'staged' (three kernels, any grid), 'fused' (single kernel) or 'panel' (Legendre kernel + longitude kernel)."""
-        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'panel': 3}[path])
+        """'auto', 'staged' (three kernels, any grid), 'fused' (single kernel; uses the north-south symmetry of the
+        parallels when present), 'panel' (Legendre kernel + longitude kernel) or 'fused_plain' (single kernel without
+        the north-south symmetry)."""
+        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'panel': 3, 'fused_plain': 4}[path])
 
     def set_chunk(self, epochs_per_pass):
         _lib.call('shg_plan_set_chunk', self._handle, int(epochs_per_pass))

@@ -57,12 +57,13 @@ int shg_plan_destroy(shg_plan* plan);
 int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
 
 /* Synthesis path: 0 = automatic, 1 = three-kernel path (pack, Legendre stage, longitude stage; any grid, any degree),
- * 2 = single fused kernel, 3 = Legendre-stage kernel + longitude kernel exchanging LDS-image panels
- * (2 and 3: 4-fold symmetric meridians, degree <= 126). */
+ * 2 = single fused kernel (uses the north-south symmetry of the parallels when present), 3 = Legendre-stage kernel +
+ * longitude kernel exchanging LDS-image panels, 4 = single fused kernel without the north-south symmetry
+ * (2, 3 and 4: 4-fold symmetric meridians, degree <= 126). */
 int shg_plan_set_path(shg_plan* plan, int path);
 
-/* Introspection: which[0]=N, [1]=nlat, [2]=nlon, [3]=1 if the 4-fold longitude symmetry path is active,
- * [4]=epochs per pass, [5]=K slots of the longitude stage, [6]=1 if synthesis uses the fused kernel, [7]=0. */
+/* Introspection: which[0]=N, [1]=nlat, [2]=nlon, [3]=bit 0: 4-fold longitude symmetry, bit 1: parallels symmetric about the
+ * equator, [4]=epochs per pass, [5]=K slots of the longitude stage, [6]=1 if synthesis uses the fused kernel, [7]=path. */
 int shg_plan_info(const shg_plan* plan, int64_t which[8]);
 
 /* Per-kernel timing with HIP events recorded on the caller's stream around every kernel a plan launches.

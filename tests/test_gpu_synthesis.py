@@ -202,7 +202,8 @@ def test_fused_and_staged_paths(N, dlon, dlat):
     ref = np.stack([orc.synthesis_regular(batch[e], grid.meridians, grid.parallels, ker) for e in range(B)])
     plan = ga.engine.Plan(N, *_tables(grid, N, 'ewh'))
     assert plan.info()['fourfold_symmetry'] and plan.info()['fused']
-    for path in ('fused', 'panel', 'staged'):
+    assert plan.info()['north_south_symmetry'] == (grid.parallels.size % 2 == 0)
+    for path in ('fused', 'fused_plain', 'panel', 'staged'):
         plan.set_path(path)
         assert plan.info()['fused'] == (path != 'staged')
         for nb in (1, 3, 4, 5, 7):
