@@ -83,6 +83,12 @@ struct shg_plan {
     std::vector<int> ns_badmap; // per block of 8 northern parallels: -1, or rank among the blocks whose mirrored parallels get their own table
     int ns_nbad = 0;
     int* badmap_d = nullptr;
+    std::vector<char> ns_badrow;    // per northern parallel: mirror image deviates too much to share the northern table
+    // two-workgroup fused synthesis (synthesis_fused32.hip): blocks of 4 northern parallels
+    double* pkf32 = nullptr;
+    int* qoff32 = nullptr;
+    int* badmap32_d = nullptr;
+    int Qtot32 = 0, nbad32 = 0;
     int pkf_variant = 0;        // 1 plain fragment order, 2 north-south symmetric fragment order
     double* cpk4 = nullptr;     // repacked coefficients of the whole batch: [ceil(B/4)][Qtot][32][2] (fused) or [ceil(B/8)][packed][2][8]
     size_t cpk4_size = 0;
@@ -90,7 +96,7 @@ struct shg_plan {
     size_t cpk4_zeroed = 0;
     double* panel = nullptr;    // two-kernel synthesis: [B/4][nit][K][64] Legendre-stage output in LDS-image order
     size_t panel_size = 0;
-    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel, 3 Legendre kernel + longitude kernel, 4 fused kernel without the north-south symmetry
+    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel, 3 Legendre kernel + longitude kernel, 4 fused kernel without the north-south symmetry, 5 fused kernel with 32-row panels (two workgroups per CU)
 
     // optional per-kernel event timing (shg_plan_profile)
     bool profiling = false;
@@ -105,6 +111,8 @@ int fused_chunk_for(const shg_plan* p);
 int build_pk_table(shg_plan* p, hipStream_t stream);
 int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream);
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
+int fused32_applicable(const shg_plan* p);
+int synthesis_fused32(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 
 // RAII event pair around one kernel launch (no-op unless profiling is enabled on the plan)
 struct ProfileScope {

@@ -86,13 +86,16 @@ static bool has_fourfold_symmetry(int nlon, const double* lon) {
 // Blocks of 8 northern parallels whose mirror images deviate by more than 1e-13 / (N + 1) rad or 5e-14 relative in kn are
 // flagged in `badmap`: the fused kernel evaluates their southern rows from a table of their own instead of (-1)^(n-m)
 // times the northern one, which keeps the deviation from an independent evaluation below ~1e-13 of the field maximum.
-static bool has_north_south_symmetry(int N, int nlat, const double* colat, const double* kn, std::vector<int>& badmap, int& nbad) {
+static bool has_north_south_symmetry(int N, int nlat, const double* colat, const double* kn, std::vector<int>& badmap, int& nbad,
+                                     std::vector<char>& badrow) {
     badmap.clear();
+    badrow.clear();
     nbad = 0;
     if (nlat < 2 || nlat % 2 != 0) return false;
     const double pi = 3.14159265358979323846;
     const int nh = nlat / 2;
     badmap.assign(ceil_div(nh, 8), -1);
+    badrow.assign(nh, 0);
     for (int i = 0; i < nh; ++i) {
         const int mi = nlat - 1 - i;
         const double dtheta = std::fabs(colat[i] + colat[mi] - pi);
@@ -104,6 +107,7 @@ static bool has_north_south_symmetry(int N, int nlat, const double* colat, const
             if (d > 1e-10 * s) return false;
             if (d > 5e-14 * s) bad = true;
         }
+        badrow[i] = bad ? 1 : 0;
         if (bad && badmap[i >> 3] < 0) badmap[i >> 3] = nbad++;
     }
     return true;
@@ -195,7 +199,7 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
     p->nlon = nlon;
     p->ldlat = round_up(nlat, kLatTile);
     p->sym4 = has_fourfold_symmetry(nlon, lon_h);
-    p->sym_ns = has_north_south_symmetry(N, nlat, colat_h, kn_h, p->ns_badmap, p->ns_nbad);
+    p->sym_ns = has_north_south_symmetry(N, nlat, colat_h, kn_h, p->ns_badmap, p->ns_nbad, p->ns_badrow);
 
     // ---- K slots of the longitude stage
     if (p->sym4) {
@@ -271,10 +275,12 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
 extern "C" int shg_plan_destroy(shg_plan* p) {
     if (!p) return SHG_OK;
     double* ptrs[] = {p->ct, p->st, p->pmm, p->knT, p->arec, p->brec, p->trig, p->lon, p->colat,
-                      p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->pkf, p->cpk4, p->cov_partial, p->panel};
+                      p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->pkf, p->pkf32, p->cpk4, p->cov_partial, p->panel};
     if (p->rslot) (void)hipFree(p->rslot);
     if (p->qoff) (void)hipFree(p->qoff);
     if (p->badmap_d) (void)hipFree(p->badmap_d);
+    if (p->qoff32) (void)hipFree(p->qoff32);
+    if (p->badmap32_d) (void)hipFree(p->badmap32_d);
     for (double* q : ptrs)
         if (q) (void)hipFree(q);
     for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
@@ -291,7 +297,8 @@ extern "C" int shg_plan_set_chunk(shg_plan* p, int epochs_per_pass) {
 
 extern "C" int shg_plan_set_path(shg_plan* p, int path) {
     SHG_REQUIRE(p != nullptr, "shg_plan_set_path: NULL plan");
-    SHG_REQUIRE(path >= 0 && path <= 4, "shg_plan_set_path: path %d not in {0, 1, 2, 3, 4}", path);
+    SHG_REQUIRE(path >= 0 && path <= 5, "shg_plan_set_path: path %d not in {0, ..., 5}", path);
+    SHG_REQUIRE(path != 5 || fused32_applicable(p), "shg_plan_set_path: the two-workgroup fused kernel needs both grid symmetries and K <= 208 (K = %d)", p->K);
     SHG_REQUIRE(path < 2 || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
     p->path = path;
     return SHG_OK;

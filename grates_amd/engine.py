@@ -96,7 +96,7 @@ class Plan:
         """'auto', 'staged' (three kernels, any grid), 'fused' (single kernel; uses the north-south symmetry of the
         parallels when present), 'panel' (Legendre kernel + longitude kernel) or 'fused_plain' (single kernel without
         the north-south symmetry)."""
-        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'panel': 3, 'fused_plain': 4}[path])
+        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'panel': 3, 'fused_plain': 4, 'fused32': 5}[path])
 
     def set_chunk(self, epochs_per_pass):
         _lib.call('shg_plan_set_chunk', self._handle, int(epochs_per_pass))

@@ -203,7 +203,12 @@ def test_fused_and_staged_paths(N, dlon, dlat):
     plan = ga.engine.Plan(N, *_tables(grid, N, 'ewh'))
     assert plan.info()['fourfold_symmetry'] and plan.info()['fused']
     assert plan.info()['north_south_symmetry'] == (grid.parallels.size % 2 == 0)
-    for path in ('fused', 'fused_plain', 'panel', 'staged'):
+    fused32_ok = plan.info()['north_south_symmetry'] and 2 * plan.info()['k_slots'] * 48 * 8 <= 160 * 1024
+    for path in ('fused', 'fused_plain', 'fused32', 'panel', 'staged'):
+        if path == 'fused32' and not fused32_ok:
+            with pytest.raises(ga._lib.ShgError):
+                plan.set_path(path)
+            continue
         plan.set_path(path)
         assert plan.info()['fused'] == (path != 'staged')
         for nb in (1, 3, 4, 5, 7):
