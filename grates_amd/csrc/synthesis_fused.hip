@@ -304,35 +304,46 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         }                                                                                                           \
     } while (0)
 
-        double2 xal = {0, 0}, xah = {0, 0}, xbl = {0, 0}, xbh = {0, 0};     // register set X
-        double2 yal = {0, 0}, yah = {0, 0}, ybl = {0, 0}, ybh = {0, 0};     // register set Y
-        // Counted loop, two items per trip, loads issued unconditionally (an exhausted sequence re-reads a valid item and
-        // its MFMAs see a zero A operand): no branch around loads and a single loop exit keep the compiler's vmcnt
-        // bookkeeping exact, so the fragments of item t+1 really are in flight while item t runs.  (Three items in
-        // flight measured no faster: the stage is bound by L2 -> CU throughput, not by latency.)
+        double2 xal = {0, 0}, xah = {0, 0}, xbl = {0, 0}, xbh = {0, 0};     // register sets X, Y, Z, W
+        double2 yal = {0, 0}, yah = {0, 0}, ybl = {0, 0}, ybh = {0, 0};
+        double2 zal = {0, 0}, zah = {0, 0}, zbl = {0, 0}, zbh = {0, 0};
+        double2 wal = {0, 0}, wah = {0, 0}, wbl = {0, 0}, wbh = {0, 0};
+        // Counted loop, four items per trip, three items in flight (with 16-byte fragment loads and the north-south layout
+        // the stage is bound by the L2 latency of a wave's own item chain).  Loads are issued unconditionally (an
+        // exhausted sequence re-reads a valid item and its MFMAs see a zero A operand): no branch around loads and a single
+        // loop exit keep the compiler's vmcnt bookkeeping exact.
         int nitems = 0;
         for (int m = wave; m <= P.N; m += 8) nitems += (P.N + 1 - m + 2 * OD - 1) / (2 * OD);
+        const LegendreItem first = {wave, 0};
+#define SHG_LD(it_) ((it_).valid(P.N) ? (it_) : first)
         for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
             if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
                 mode = 2;
                 prow = lane + 8;
                 pkb = P.pkf + ((size_t)(P.nit + bad) * P.Qtot * 64 + lane) * 2;
             }
-            LegendreItem cur = {wave, 0};
-            const LegendreItem first = cur;
-            if (nitems > 0) SHG_P1_ISSUE(cur, xal, xah, xbl, xbh);
-            for (int trip = 0; trip < (nitems + 1) / 2; ++trip) {
-                const LegendreItem nx = cur.next(P.N, OD);
-                const LegendreItem ld1 = nx.valid(P.N) ? nx : first;
-                SHG_P1_ISSUE(ld1, yal, yah, ybl, ybh);
-                SHG_P1_CONSUME(cur, nx, xal, xah, xbl, xbh);
-                const LegendreItem nn = nx.next(P.N, OD);
-                const LegendreItem ld2 = nn.valid(P.N) ? nn : first;
-                SHG_P1_ISSUE(ld2, xal, xah, xbl, xbh);
-                SHG_P1_CONSUME(nx, nn, yal, yah, ybl, ybh);
-                cur = nn;
+            LegendreItem i0_ = first, i1_ = i0_.next(P.N, OD), i2_ = i1_.next(P.N, OD);
+            if (nitems > 0) {
+                SHG_P1_ISSUE(i0_, xal, xah, xbl, xbh);
+                SHG_P1_ISSUE(SHG_LD(i1_), yal, yah, ybl, ybh);
+                SHG_P1_ISSUE(SHG_LD(i2_), zal, zah, zbl, zbh);
+            }
+            for (int trip = 0; trip < (nitems + 3) / 4; ++trip) {
+                const LegendreItem i3_ = i2_.next(P.N, OD), i4_ = i3_.next(P.N, OD), i5_ = i4_.next(P.N, OD), i6_ = i5_.next(P.N, OD);
+                SHG_P1_ISSUE(SHG_LD(i3_), wal, wah, wbl, wbh);
+                SHG_P1_CONSUME(i0_, i1_, xal, xah, xbl, xbh);
+                SHG_P1_ISSUE(SHG_LD(i4_), xal, xah, xbl, xbh);
+                SHG_P1_CONSUME(i1_, i2_, yal, yah, ybl, ybh);
+                SHG_P1_ISSUE(SHG_LD(i5_), yal, yah, ybl, ybh);
+                SHG_P1_CONSUME(i2_, i3_, zal, zah, zbl, zbh);
+                SHG_P1_ISSUE(SHG_LD(i6_), zal, zah, zbl, zbh);
+                SHG_P1_CONSUME(i3_, i4_, wal, wah, wbl, wbh);
+                i0_ = i4_;
+                i1_ = i5_;
+                i2_ = i6_;
             }
         }
+#undef SHG_LD
 #undef SHG_P1_ISSUE
 #undef SHG_P1_CONSUME
     }
