@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libshg.so')
+LIB_PATH = os.environ.get('SHG_LIBRARY', os.path.join(_HERE, 'lib', 'libshg.so'))      # override: A/B timing of two builds
 
 c_double_p = ctypes.c_void_p     # device or host pointer passed as integer address
 c_plan_p = ctypes.c_void_p

@@ -83,6 +83,8 @@ struct shg_plan {
     std::vector<int> ns_badmap; // per block of 8 northern parallels: -1, or rank among the blocks whose mirrored parallels get their own table
     int ns_nbad = 0;
     int* badmap_d = nullptr;
+    int* blockmap_d = nullptr;  // XCD-aware (epoch tile, parallel tile) order of the fused kernel's workgroups
+    int blockmap_nbt = 0, blockmap_nit = 0;
     std::vector<char> ns_badrow;    // per northern parallel: mirror image deviates too much to share the northern table
     // two-workgroup fused synthesis (synthesis_fused32.hip): blocks of 4 northern parallels
     double* pkf32 = nullptr;

@@ -13,7 +13,9 @@
 //     (cos/sin table) straight from L2 through a register ring that runs one body (16 MFMAs) ahead; there is
 //     no barrier after the panel is complete.  The four longitude images of every quarter-column are formed
 //     in registers and stored with 16-byte stores.
+#include <algorithm>
 #include <cstdlib>
+#include <utility>
 
 #include "common.h"
 
@@ -169,6 +171,7 @@ struct FusedParams {
     const int* qoff;          // [N+2]
     const double* cpk4;       // [nbt][Qtot][32][2]
     const double* pkf;        // [nit][Qtot][64][2]
+    const int* blockmap;      // [blocks][2] (epoch tile, parallel tile) of every workgroup, or NULL for the plain order
     const int* badmap;        // NS variant: [nit] -1, or rank of the block among those whose mirrored parallels need their own table
     const double* trig;       // [ncb * 8][K][16]
     const double* panel;      // two-kernel variant: [B/4][nit][K][64] panels written by legendre_mfma_kernel
@@ -215,8 +218,11 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: keeps the order loops on the scalar unit
     const int nbt = (P.B + 3) >> 2;
-    const int bt = blockIdx.x % nbt;                   // epoch tile fastest: neighbouring blocks share the PK slab
-    const int it = blockIdx.x / nbt;
+    // XCD-aware block order (blockmap, built on the host): workgroup b runs on XCD b % 8; every XCD gets a contiguous
+    // range of epoch tiles (their coefficient slabs, ~2.6 MB, then stay in its 4 MB L2) and walks it parallel-tile major,
+    // so that the PK slab of a parallel tile is fetched once per XCD and reused by its epoch tiles back to back
+    const int bt = P.blockmap ? P.blockmap[2 * blockIdx.x] : (int)(blockIdx.x % nbt);
+    const int it = P.blockmap ? P.blockmap[2 * blockIdx.x + 1] : (int)(blockIdx.x / nbt);
     const int i0 = it * 16;                             // plain layout: first parallel of the block
     const int i0n = it * 8;                             // NS layout: first northern parallel of the block
     const int fr = lane & 15, fk = lane >> 4;
@@ -613,6 +619,45 @@ int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream) {
     return SHG_OK;
 }
 
+// (epoch tile, parallel tile) of every workgroup in XCD-aware order, cached in the plan per (epoch tiles, parallel tiles)
+static int build_blockmap(shg_plan* p, int nbt, int nit, hipStream_t stream) {
+    if (p->blockmap_d && p->blockmap_nbt == nbt && p->blockmap_nit == nit) return SHG_OK;
+    constexpr int XCDS = 8;
+    const int total = nbt * nit;
+    std::vector<int> map((size_t)total * 2);
+    // XCD k owns the linear range [k total / 8, (k + 1) total / 8) of s = bt * nit + it and serves it parallel-tile major
+    std::vector<std::vector<int>> per_xcd(XCDS);
+    for (int k = 0; k < XCDS; ++k) {
+        const long long s0 = (long long)k * total / XCDS, s1 = (long long)(k + 1) * total / XCDS;
+        std::vector<std::pair<int, int>> items;            // (it, bt)
+        for (long long s_ = s0; s_ < s1; ++s_) items.emplace_back((int)(s_ % nit), (int)(s_ / nit));
+        std::sort(items.begin(), items.end());
+        for (auto& e : items) {
+            per_xcd[k].push_back(e.second);
+            per_xcd[k].push_back(e.first);
+        }
+    }
+    // workgroup b -> XCD b % 8, its (b / 8)-th item; XCDs with fewer items than others take the leftovers in order
+    std::vector<size_t> next(XCDS, 0);
+    for (int b = 0; b < total; ++b) {
+        int k = b % XCDS;
+        for (int tries = 0; tries < XCDS && next[k] >= per_xcd[k].size(); ++tries) k = (k + 1) % XCDS;
+        map[2 * (size_t)b] = per_xcd[k][next[k]];
+        map[2 * (size_t)b + 1] = per_xcd[k][next[k] + 1];
+        next[k] += 2;
+    }
+    if (p->blockmap_d) {
+        SHG_HIP(hipStreamSynchronize(stream));
+        (void)hipFree(p->blockmap_d);
+        p->blockmap_d = nullptr;
+    }
+    if (hipMalloc((void**)&p->blockmap_d, map.size() * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "block map allocation failed");
+    SHG_HIP(hipMemcpy(p->blockmap_d, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    p->blockmap_nbt = nbt;
+    p->blockmap_nit = nit;
+    return SHG_OK;
+}
+
 // variant 2: single fused kernel; variant 3: Legendre stage as its own kernel + longitude kernel reading the panels
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
     if (fused_chunk_for(p) == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
@@ -669,6 +714,12 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.cpk4 = p->cpk4;
     P.pkf = p->pkf;
     P.badmap = p->badmap_d;
+    P.blockmap = nullptr;
+    if (!(P.dbg & 2048)) {                             // SHG_DEBUG bit 11: plain block order (experiment switch)
+        rc = build_blockmap(p, nbt, nit, stream);
+        if (rc) return rc;
+        P.blockmap = p->blockmap_d;
+    }
     P.trig = p->trig;
     P.panel = nullptr;
     P.G = grid;
