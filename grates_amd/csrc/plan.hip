@@ -280,6 +280,7 @@ extern "C" int shg_plan_destroy(shg_plan* p) {
     if (p->qoff) (void)hipFree(p->qoff);
     if (p->badmap_d) (void)hipFree(p->badmap_d);
     if (p->blockmap_d) (void)hipFree(p->blockmap_d);
+    if (p->itemtab_d) (void)hipFree(p->itemtab_d);
     if (p->qoff32) (void)hipFree(p->qoff32);
     if (p->badmap32_d) (void)hipFree(p->badmap32_d);
     for (double* q : ptrs)

@@ -171,6 +171,8 @@ struct FusedParams {
     const int* qoff;          // [N+2]
     const double* cpk4;       // [nbt][Qtot][32][2]
     const double* pkf;        // [nit][Qtot][64][2]
+    const int4* itemtab;      // [8 waves][nrec] work items of the Legendre stage (see build_item_table)
+    int nrec, ntrip;
     const int* blockmap;      // [blocks][2] (epoch tile, parallel tile) of every workgroup, or NULL for the plain order
     const int* badmap;        // NS variant: [nit] -1, or rank of the block among those whose mirrored parallels need their own table
     const double* trig;       // [ncb * 8][K][16]
@@ -253,7 +255,6 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     //      buffered in two named register sets so that the fragments of item t+1 are in flight while item t runs.
     if (!FROM_PANEL && !(P.dbg & 2)) {
         // plain layout: octet = 8 degrees, A rows 8-15 are zero (not stored);  NS layout: octet = 16 degrees, all 16 rows used
-        constexpr int OD = NS ? 16 : 8;                               // degrees per octet
         constexpr int ASTRIDE = NS ? 128 : 64;                        // doubles per octet of the coefficient table
         const int bad = NS ? P.badmap[it] : -1;                       // block-uniform
         const double* pkb = P.pkf + ((size_t)it * P.Qtot * 64 + lane) * 2;                       // + octet * 128
@@ -265,32 +266,28 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 
         // 16-byte fragment loads: A and B of two k-steps per load, 1 KB (B) / 512 B or 1 KB (A) contiguous per wave
-#define SHG_P1_ISSUE(item, ALO, AHI, BLO, BHI)                                               \
+#define SHG_P1_ISSUE(rec, ALO, AHI, BLO, BHI)                                                \
     do {                                                                                     \
-        const int q_ = (P.N + OD - (item).m) / OD;                                           \
-        const int o0_ = P.qoff[(item).m] + (item).j0;                                        \
-        const int o1_ = o0_ + ((item).j0 + 1 < q_ ? 1 : 0);                                  \
-        ALO = *reinterpret_cast<const double2*>(cf + (size_t)o0_ * ASTRIDE);                 \
-        BLO = *reinterpret_cast<const double2*>(pkb + (size_t)o0_ * 128);                    \
-        AHI = *reinterpret_cast<const double2*>(cf + (size_t)o1_ * ASTRIDE);                 \
-        BHI = *reinterpret_cast<const double2*>(pkb + (size_t)o1_ * 128);                    \
+        ALO = *reinterpret_cast<const double2*>(cf + (size_t)(rec).x * ASTRIDE);             \
+        BLO = *reinterpret_cast<const double2*>(pkb + (size_t)(rec).x * 128);                \
+        AHI = *reinterpret_cast<const double2*>(cf + (size_t)(rec).y * ASTRIDE);             \
+        BHI = *reinterpret_cast<const double2*>(pkb + (size_t)(rec).y * 128);                \
     } while (0)
 
-#define SHG_P1_CONSUME(item, nxt, ALO, AHI, BLO, BHI)                                                                   \
+#define SHG_P1_CONSUME(rec, ALO, AHI, BLO, BHI)                                                                     \
     do {                                                                                                            \
-        const bool lo_ = arow && (item).m <= P.N;                                                                   \
-        const bool hi_ = lo_ && ((item).j0 + 1) * OD < P.N + 1 - (item).m;                                          \
+        const bool lo_ = arow && ((rec).w & 1);                                                                     \
+        const bool hi_ = arow && ((rec).w & 2);                                                                     \
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.x : 0.0, BLO.x, acc0, 0, 0, 0);                       \
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.y : 0.0, BLO.y, acc1, 0, 0, 0);                       \
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.x : 0.0, BHI.x, acc0, 0, 0, 0);                       \
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.y : 0.0, BHI.y, acc1, 0, 0, 0);                       \
-        if ((nxt).m != (item).m && (item).m <= P.N) {                                                               \
+        if ((rec).w & 4) {                                  /* last item of an order */                             \
             /* C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15: reg 0 = cosine part of epoch (lane >> 4),  */ \
             /* reg 1 = sine part; panel row = epoch * 16 + parallel slot = lane.                                  */ \
             /* NS: regs 0, 1 = even-degree sums E (valid in columns 0-7), regs 2, 3 = odd-degree sums O (valid in */ \
             /* columns 8-15) of the same 8 parallels: lanes fr and fr + 8 exchange them; slots 0-7 get E + O      */ \
             /* (northern parallels), slots 8-15 E - O (their mirror images)                                       */ \
-            const int m_ = (item).m;                                                                                \
             /* mode 0: both hemispheres from the northern table; mode 1 / 2 (blocks near the poles): northern / mirrored */ \
             /* parallels from their own tables, E + O each, written by the lanes fr < 8                            */ \
             double vc_ = acc0[0] + acc1[0], vs_ = acc0[1] + acc1[1];                                                \
@@ -301,9 +298,8 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
                 vs_ = (mode == 0 && fr >= 8) ? rs_ - os_ : vs_ + rs_;                                               \
             }                                                                                                       \
             if (!NS || mode == 0 || fr < 8) {                                                                       \
-                As[(P.goff[m_ & 1] + (m_ >> 1)) * kPanelStride + prow] = vc_;                                       \
-                if (m_ >= 1)                                                                                        \
-                    As[(P.goff[2 + (m_ & 1)] + ((m_ & 1) ? (m_ >> 1) : (m_ >> 1) - 1)) * kPanelStride + prow] = vs_; \
+                As[((rec).z & 0xFFFF) * kPanelStride + prow] = vc_;                   /* cosine slot */            \
+                if ((rec).z >> 16) As[(((rec).z >> 16) - 1) * kPanelStride + prow] = vs_;   /* sine slot (m >= 1) */ \
             }                                                                                                       \
             acc0 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
             acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
@@ -318,38 +314,43 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         // the stage is bound by the L2 latency of a wave's own item chain).  Loads are issued unconditionally (an
         // exhausted sequence re-reads a valid item and its MFMAs see a zero A operand): no branch around loads and a single
         // loop exit keep the compiler's vmcnt bookkeeping exact.
-        int nitems = 0;
-        for (int m = wave; m <= P.N; m += 8) nitems += (P.N + 1 - m + 2 * OD - 1) / (2 * OD);
-        const LegendreItem first = {wave, 0};
-#define SHG_LD(it_) ((it_).valid(P.N) ? (it_) : first)
+        // The work items of a wave (orders wave, wave + 8, ...; two octets each) are the same for every workgroup: they come
+        // as records {first octet, second octet, panel slots, flags} from a table built with the plan, fetched four records
+        // per trip with scalar loads one trip ahead.  Counted loop, four items per trip, three items in flight; exhausted
+        // sequences are padded with records that re-read a valid octet with all flags clear (zero A operand): no branch
+        // around loads and a single loop exit keep the compiler's vmcnt bookkeeping exact.
+        const int4* recs = P.itemtab + (size_t)wave * P.nrec;
         for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
             if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
                 mode = 2;
                 prow = lane + 8;
                 pkb = P.pkf + ((size_t)(P.nit + bad) * P.Qtot * 64 + lane) * 2;
             }
-            LegendreItem i0_ = first, i1_ = i0_.next(P.N, OD), i2_ = i1_.next(P.N, OD);
-            if (nitems > 0) {
-                SHG_P1_ISSUE(i0_, xal, xah, xbl, xbh);
-                SHG_P1_ISSUE(SHG_LD(i1_), yal, yah, ybl, ybh);
-                SHG_P1_ISSUE(SHG_LD(i2_), zal, zah, zbl, zbh);
-            }
-            for (int trip = 0; trip < (nitems + 3) / 4; ++trip) {
-                const LegendreItem i3_ = i2_.next(P.N, OD), i4_ = i3_.next(P.N, OD), i5_ = i4_.next(P.N, OD), i6_ = i5_.next(P.N, OD);
-                SHG_P1_ISSUE(SHG_LD(i3_), wal, wah, wbl, wbh);
-                SHG_P1_CONSUME(i0_, i1_, xal, xah, xbl, xbh);
-                SHG_P1_ISSUE(SHG_LD(i4_), xal, xah, xbl, xbh);
-                SHG_P1_CONSUME(i1_, i2_, yal, yah, ybl, ybh);
-                SHG_P1_ISSUE(SHG_LD(i5_), yal, yah, ybl, ybh);
-                SHG_P1_CONSUME(i2_, i3_, zal, zah, zbl, zbh);
-                SHG_P1_ISSUE(SHG_LD(i6_), zal, zah, zbl, zbh);
-                SHG_P1_CONSUME(i3_, i4_, wal, wah, wbl, wbh);
-                i0_ = i4_;
-                i1_ = i5_;
-                i2_ = i6_;
+            int4 c0 = recs[0], c1 = recs[1], c2 = recs[2];
+            int4 n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
+            SHG_P1_ISSUE(c0, xal, xah, xbl, xbh);
+            SHG_P1_ISSUE(c1, yal, yah, ybl, ybh);
+            SHG_P1_ISSUE(c2, zal, zah, zbl, zbh);
+            for (int trip = 0; trip < P.ntrip; ++trip) {
+                const int4 a3 = n0, a4 = n1, a5 = n2, a6 = n3;
+                const int4* nr = recs + 4 * trip + 7;
+                n0 = nr[0];
+                n1 = nr[1];
+                n2 = nr[2];
+                n3 = nr[3];
+                SHG_P1_ISSUE(a3, wal, wah, wbl, wbh);
+                SHG_P1_CONSUME(c0, xal, xah, xbl, xbh);
+                SHG_P1_ISSUE(a4, xal, xah, xbl, xbh);
+                SHG_P1_CONSUME(c1, yal, yah, ybl, ybh);
+                SHG_P1_ISSUE(a5, yal, yah, ybl, ybh);
+                SHG_P1_CONSUME(c2, zal, zah, zbl, zbh);
+                SHG_P1_ISSUE(a6, zal, zah, zbl, zbh);
+                SHG_P1_CONSUME(a3, wal, wah, wbl, wbh);
+                c0 = a4;
+                c1 = a5;
+                c2 = a6;
             }
         }
-#undef SHG_LD
 #undef SHG_P1_ISSUE
 #undef SHG_P1_CONSUME
     }
@@ -579,6 +580,8 @@ int build_pk_table(shg_plan* p, hipStream_t stream) {
 }
 
 // fragment-ordered table of the fused kernel (and the octet offsets both fragment-ordered tables share)
+static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, hipStream_t stream);
+
 int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream) {
     const int variant = ns ? 2 : 1;
     if (p->pkf && p->pkf_variant == variant) return SHG_OK;
@@ -615,7 +618,54 @@ int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream) {
         hipLaunchKernelGGL(pkf_table_kernel, dim3(p->ldlat / 64, N + 1), dim3(64), 0, stream, N, p->ldlat, nit, q, p->qoff, p->ct, p->pmm,
                            p->knT, p->arec, p->brec, p->pkf);
     SHG_HIP(hipGetLastError());
+    const int rc_items = build_item_table(p, od, qoff, stream);
+    if (rc_items) return rc_items;
     p->pkf_variant = variant;
+    return SHG_OK;
+}
+
+// Work items of the Legendre stage per wave (8 waves; wave w serves the orders w, w + 8, ...): records
+//   x, y = first / second octet of the item in the fragment-ordered tables (y = x when the order has no second octet left)
+//   z    = panel slot of the cosine part | (panel slot of the sine part + 1) << 16   (0 in the upper half: order 0)
+//   w    = bit 0 item valid, bit 1 second octet valid, bit 2 last item of its order
+// padded per wave to 4 * ntrip + 8 records (the kernel runs ntrip trips of four items and prefetches one trip ahead).
+static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, hipStream_t stream) {
+    const int N = p->N;
+    std::vector<std::vector<int>> rec(8);
+    size_t longest = 0;
+    for (int w = 0; w < 8; ++w) {
+        for (int m = w; m <= N; m += 8) {
+            const int cnt = N + 1 - m, q = (cnt + od - 1) / od;
+            const int slot_c = p->goff[m & 1] + (m >> 1);
+            const int slot_s = m >= 1 ? p->goff[2 + (m & 1)] + ((m & 1) ? (m >> 1) : (m >> 1) - 1) + 1 : 0;
+            for (int j0 = 0; j0 < q; j0 += 2) {
+                const int o0 = qoff[m] + j0, o1 = o0 + (j0 + 1 < q ? 1 : 0);
+                const int flags = 1 | ((j0 + 1) * od < cnt ? 2 : 0) | (j0 + 2 >= q ? 4 : 0);
+                rec[w].insert(rec[w].end(), {o0, o1, slot_c | (slot_s << 16), flags});
+            }
+        }
+        longest = std::max(longest, rec[w].size() / 4);
+    }
+    const int ntrip = (int)((longest + 3) / 4), nrec = 4 * ntrip + 8;
+    std::vector<int> table((size_t)8 * nrec * 4, 0);
+    for (int w = 0; w < 8; ++w) {
+        const int pad = rec[w].empty() ? 0 : rec[w][0];              // a valid octet for the padding records
+        for (int t = 0; t < nrec; ++t)
+            for (int c = 0; c < 4; ++c) {
+                const size_t src = (size_t)t * 4 + c;
+                table[((size_t)w * nrec + t) * 4 + c] = src < rec[w].size() ? rec[w][src] : (c < 2 ? pad : 0);
+            }
+    }
+    if (p->itemtab_d) {
+        SHG_HIP(hipDeviceSynchronize());
+        (void)hipFree(p->itemtab_d);
+        p->itemtab_d = nullptr;
+    }
+    if (hipMalloc((void**)&p->itemtab_d, table.size() * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "work item table allocation failed");
+    SHG_HIP(hipMemcpyAsync(p->itemtab_d, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    SHG_HIP(hipStreamSynchronize(stream));                             // the host vector goes out of scope
+    p->itemtab_nrec = nrec;
+    p->itemtab_ntrip = ntrip;
     return SHG_OK;
 }
 
@@ -714,6 +764,9 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.cpk4 = p->cpk4;
     P.pkf = p->pkf;
     P.badmap = p->badmap_d;
+    P.itemtab = reinterpret_cast<const int4*>(p->itemtab_d);
+    P.nrec = p->itemtab_nrec;
+    P.ntrip = p->itemtab_ntrip;
     P.blockmap = nullptr;
     if (!(P.dbg & 2048)) {                             // SHG_DEBUG bit 11: plain block order (experiment switch)
         rc = build_blockmap(p, nbt, nit, stream);
