@@ -69,7 +69,7 @@ def main():
     out = torch.empty((240, 720, 1440), dtype=torch.float64, device='cuda')
     for path in ('fused', 'panel', 'staged'):
         plan.set_path(path)
-        ms = device_ms(lambda: plan.synthesis(batch, out=out))
+        ms = device_ms(lambda: plan.synthesis(batch, out=out), reps=40, warmup=10)
         emit('synthesis d/o 96 -> 0.25 deg, 240 epochs, path=' + path, ms, solutions_per_s=round(240 / ms * 1e3), GBs_algorithmic=round(240 * 8369672 / ms / 1e6, 1))
     plan.set_path('auto')
     one = batch[0:1].contiguous()
