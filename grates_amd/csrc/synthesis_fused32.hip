@@ -335,10 +335,12 @@ __global__ __launch_bounds__(256) void pack_coefficients4_ns_kernel(int N, int B
 
 static size_t fused32_lds_bytes(int K) { return (size_t)K * kPanelStride32 * sizeof(double); }
 
-// non-zero when this variant applies: both symmetries and two panels in the 160 KiB LDS
+// non-zero when this variant applies: both symmetries and the panel in the 160 KiB LDS (degrees up to ~210; two workgroups
+// per CU up to degree 96)
 int fused32_applicable(const shg_plan* p) {
     if (!p->sym4 || !p->sym_ns || (p->K & 15)) return 0;
-    return 2 * fused32_lds_bytes(p->K) <= 160 * 1024 ? 1 : 0;
+    if ((long long)p->nlat * p->nlon * 8 >= (1LL << 31)) return 0;
+    return fused32_lds_bytes(p->K) <= 160 * 1024 ? 1 : 0;
 }
 
 static int build_pkf32_table(shg_plan* p, hipStream_t stream) {

@@ -59,7 +59,8 @@ int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
 /* Synthesis path: 0 = automatic, 1 = three-kernel path (pack, Legendre stage, longitude stage; any grid, any degree),
  * 2 = single fused kernel (uses the north-south symmetry of the parallels when present), 3 = Legendre-stage kernel +
  * longitude kernel exchanging LDS-image panels, 4 = single fused kernel without the north-south symmetry
- * (2, 3 and 4: 4-fold symmetric meridians, degree <= 126). */
+ * (2, 3 and 4: 4-fold symmetric meridians, degree <= 126), 5 = fused kernel with 32-row panels (both symmetries, degree
+ * <= ~210; chosen automatically above degree 126). */
 int shg_plan_set_path(shg_plan* plan, int path);
 
 /* Introspection: which[0]=N, [1]=nlat, [2]=nlon, [3]=bit 0: 4-fold longitude symmetry, bit 1: parallels symmetric about the

@@ -203,7 +203,7 @@ def test_fused_and_staged_paths(N, dlon, dlat):
     plan = ga.engine.Plan(N, *_tables(grid, N, 'ewh'))
     assert plan.info()['fourfold_symmetry'] and plan.info()['fused']
     assert plan.info()['north_south_symmetry'] == (grid.parallels.size % 2 == 0)
-    fused32_ok = plan.info()['north_south_symmetry'] and 2 * plan.info()['k_slots'] * 48 * 8 <= 160 * 1024
+    fused32_ok = plan.info()['north_south_symmetry'] and plan.info()['k_slots'] * 48 * 8 <= 160 * 1024
     for path in ('fused', 'fused_plain', 'fused32', 'panel', 'staged'):
         if path == 'fused32' and not fused32_ok:
             with pytest.raises(ga._lib.ShgError):
@@ -219,9 +219,22 @@ def test_fused_and_staged_paths(N, dlon, dlat):
 def test_fused_path_limits():
     grid = ga.grid.GeographicGrid(2, 2)
     plan = ga.engine.Plan(140, *_tables(grid, 140, 'potential'))
-    assert not plan.info()['fused']            # K = 4 * 80 = 320 > 256: falls back to the staged kernels
+    assert plan.info()['fused']                # K = 4 * 80 = 320: too large for the 64-row panel, the 32-row fused kernel takes over
     with pytest.raises(ga._lib.ShgError):
         plan.set_path('fused')
+    ker = orc.KernelTable('potential', love())
+    batch = np.stack([inputs.coefficients(700 + e, 140) for e in range(5)])
+    ref = np.stack([orc.synthesis_regular(batch[e], grid.meridians, grid.parallels, ker) for e in range(5)])
+    for path in ('auto', 'fused32', 'staged'):
+        plan.set_path(path)
+        assert relerr(ga.engine.to_host(plan.synthesis(batch)), ref) < TOL, path
+    big = ga.engine.Plan(220, *_tables(grid, 220, 'potential'))
+    assert not big.info()['fused']             # K = 448: staged kernels
+    with pytest.raises(ga._lib.ShgError):
+        big.set_path('fused32')
+    odd = ga.grid.GeographicGrid(2, 20)        # 9 parallels: no north-south pairing
+    plan = ga.engine.Plan(140, *_tables(odd, 140, 'potential'))
+    assert not plan.info()['fused'] and not plan.info()['north_south_symmetry']
     g7 = ga.grid.RegularGrid(np.array([-3.0, -2.2, -0.4, 0.1, 0.9, 2.5, 3.1]), np.array([1.3, 1.0, 0.2, -0.5]))
     plan = ga.engine.Plan(10, *_tables(g7, 10, 'potential'))
     assert not plan.info()['fused'] and not plan.info()['fourfold_symmetry']
