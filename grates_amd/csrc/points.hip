@@ -9,7 +9,7 @@ namespace shg {
 
 void recursion_tables(int N, std::vector<double>& a, std::vector<double>& b);   // plan.hip
 
-constexpr int kPtEpochs = 4;
+constexpr int kPtEpochs = 8;
 
 __device__ inline double rec_a_pt(int ni, int mi) {
     const double n = ni, m = mi;

@@ -84,7 +84,7 @@ class Plan:
                 _lib.load().shg_plan_destroy(handle)
             except Exception:
                 pass
-            self._handle = ctypes.c_void_p()
+            self._handle = None             # (module globals may already be gone at interpreter shutdown)
 
     def info(self):
         arr = (ctypes.c_int64 * 8)()
