@@ -187,21 +187,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
+    // fragments of k-step ks + 1 are read from LDS while the 16 MFMAs of k-step ks run (two named fragment sets)
     auto compute = [&](int buf) {
         const double* Ab = As[buf] + (wr * 64 + fr) * LDA + fk;
         const double* Bb = Bs[buf] + fk * LDB + wc * 64 + fr;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) af[a] = Ab[a * 16 * LDA + ks * 4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) bf[b] = Bb[ks * 4 * LDB + b * 16];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
+        double af0[4], bf0[4], af1[4], bf1[4];
+#define SHG_FRAGS(af, bf, ks)                                                              \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) af[a] = Ab[a * 16 * LDA + (ks) * 4];     \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) bf[b] = Bb[(ks) * 4 * LDB + b * 16]
+#define SHG_MFMA16(af, bf)                                                                 \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                         \
+        _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0)
+        SHG_FRAGS(af0, bf0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        SHG_FRAGS(af1, bf1, 1);
+        SHG_MFMA16(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        SHG_FRAGS(af0, bf0, 2);
+        SHG_MFMA16(af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        SHG_FRAGS(af1, bf1, 3);
+        SHG_MFMA16(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        SHG_MFMA16(af1, bf1);
+#undef SHG_FRAGS
+#undef SHG_MFMA16
     };
 
     const int nfull = P.K / BK;
