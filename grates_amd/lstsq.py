@@ -49,24 +49,14 @@ def _like_input(result, template):
 
 
 class AutoregressiveModel:
-    """
-    Vector-autoregressive (VAR) model (grates/lstsq.py:12-247).
-
-    Parameters
-    ----------
-    coefficients : list, tuple, ndarray
-        VAR model coefficients
-    covariance_matrix : ndarray
-        covariance matrix of the white noise sequence
-    """
+    """VAR(p) model x_t = sum_k B_k x_(t-k) + w_t given by its coefficient matrices B_1 .. B_p and the covariance matrix of
+    the white noise w (grates/lstsq.py:12-247)."""
 
     def __init__(self, coefficients, covariance_matrix):
-        if isinstance(coefficients, np.ndarray):
-            self.__coefficients = tuple(coefficients)
-        else:
-            self.__coefficients = coefficients
+        # an ndarray of stacked matrices is split along its first axis (upstream behaviour); lists / tuples are kept as given
+        self.__coefficients = tuple(coefficients) if isinstance(coefficients, np.ndarray) else coefficients
         self.__covariance_matrix = covariance_matrix
-        self.__normal_equation = None
+        self.__normal_equation = None           # BlockMatrix of the pseudo-observation normals, built on first use
 
     @property
     def dimension(self):
@@ -98,23 +88,20 @@ class AutoregressiveModel:
     @staticmethod
     def from_covariance_function(covariance_function):
         """Yule-Walker equations solved with the block Cholesky factorisation on the device (grates/lstsq.py:127-167)."""
-        if isinstance(covariance_function, np.ndarray):
-            covariance_function = tuple(covariance_function)
-        model_order = len(covariance_function) - 1
-        if model_order == 0:
-            return AutoregressiveModel((), covariance_function[0])
-
-        dimension = covariance_function[0].shape[0]
-        block_index = [0]
-        while block_index[-1] < model_order * dimension:
-            block_index.append(block_index[-1] + dimension)
-
-        coefficient_matrix = BlockMatrix(block_index, block_index)
-        right_hand_side = np.empty((dimension * model_order, dimension))
-        for row in range(coefficient_matrix.shape[0]):
-            right_hand_side[row * dimension:(row + 1) * dimension, :] = covariance_function[row + 1]
-            for column in range(row, coefficient_matrix.shape[1]):
-                coefficient_matrix[row, column] = np.ascontiguousarray(covariance_function[column - row].T)
+        lags = tuple(covariance_function)                      # Sigma_0 .. Sigma_p (an ndarray is split along its first axis)
+        p = len(lags) - 1
+        if p == 0:
+            return AutoregressiveModel((), lags[0])
+        d = lags[0].shape[0]
+        bounds = list(range(0, (p + 1) * d, d))               # p blocks of size d
+        # block Toeplitz system of the Yule-Walker equations, upper blocks only: T[r, c] = Sigma_(c - r)^T, rhs rows = Sigma_(r + 1)
+        coefficient_matrix = BlockMatrix(bounds, bounds)
+        for r in range(p):
+            for c in range(r, p):
+                coefficient_matrix[r, c] = np.ascontiguousarray(lags[c - r].T)
+        right_hand_side = np.vstack([lags[r + 1] for r in range(p)])
+        covariance_function = lags
+        model_order = p
 
         coefficient_matrix.cholesky()
         rhs = _dev(right_hand_side)
@@ -142,13 +129,12 @@ class AutoregressiveModel:
         engine.axpby(-1.0, Winv.t().contiguous(), 0.0, minus)
         observation_equations.append(minus)
 
-        block_index = [0]
-        while block_index[-1] < (self.order + 1) * self.dimension:
-            block_index.append(block_index[-1] + self.dimension)
-        self.__normal_equation = BlockMatrix(block_index, block_index)
-        for row in range(self.__normal_equation.shape[0]):
-            for column in range(row, self.__normal_equation.shape[1]):
-                self.__normal_equation._set_device(row, column, engine.gemm(observation_equations[row], observation_equations[column], transa=True))
+        count = self.order + 1
+        bounds = list(range(0, (count + 1) * self.dimension, self.dimension))
+        self.__normal_equation = BlockMatrix(bounds, bounds)
+        for r, left in enumerate(observation_equations):
+            for c in range(r, count):
+                self.__normal_equation._set_device(r, c, engine.gemm(left, observation_equations[c], transa=True))
 
     def normal_equation_block(self, row, column):
         """normal-equation block (row, column) as ndarray (grates/lstsq.py:211-230)"""
@@ -224,9 +210,10 @@ class AutoregressiveModelSequence:
 
     def covariance_function(self, maximum_lag):
         """grates/lstsq.py:394-411"""
-        normals = self.normal_equations(max(maximum_lag + 1, self.maximum_order + 1))
-        normals.compute_covariance(sparse=False)
-        return [normals.matrix[0, k] for k in range(maximum_lag + 1)]
+        epochs = max(maximum_lag, self.maximum_order) + 1
+        system = self.normal_equations(epochs)
+        system.compute_covariance(sparse=False)                # full inverse: block (0, k) is the covariance of lag k
+        return [system.matrix[0, lag] for lag in range(maximum_lag + 1)]
 
 
 class BlockMatrix:
@@ -253,25 +240,19 @@ class BlockMatrix:
     @staticmethod
     def compute_block_index(array_shape, block_size):
         """grates/lstsq.py:437-463"""
-        row_index = [0]
-        while row_index[-1] < array_shape[0]:
-            row_index.append(min(array_shape[0], row_index[-1] + block_size))
-        column_index = [0]
-        while column_index[-1] < array_shape[1]:
-            column_index.append(min(array_shape[1], column_index[-1] + block_size))
-        return np.array(row_index), np.array(column_index)
+        def bounds(extent):
+            # 0, block_size, 2 block_size, ..., extent (the last block may be smaller)
+            return np.append(np.arange(0, extent, block_size), extent).astype(int) if extent > 0 else np.array([0])
+        return bounds(array_shape[0]), bounds(array_shape[1])
 
     @staticmethod
     def from_array(array, row_index, column_index):
         """Block matrix from a 2D ndarray; blocks without a non-zero entry stay empty (grates/lstsq.py:466-497)."""
-        if not isinstance(array, np.ndarray):
-            raise ValueError('array must be of type ' + str(np.ndarray))
-        if array.ndim != 2:
-            raise ValueError('array must be a two-dimensional ' + str(np.ndarray))
-        if row_index[-1] != array.shape[0]:
-            raise ValueError("mismatch in array shape in dimension 0 and row block index")
-        if column_index[-1] != array.shape[1]:
-            raise ValueError("mismatch in array shape in dimension 1 and column block index")
+        if not isinstance(array, np.ndarray) or array.ndim != 2:
+            raise ValueError('from_array expects a two-dimensional numpy.ndarray')
+        for axis, index in enumerate((row_index, column_index)):
+            if index[-1] != array.shape[axis]:
+                raise ValueError('block index of axis {0} ends at {1}, the array has {2} entries there'.format(axis, index[-1], array.shape[axis]))
         block_matrix = BlockMatrix(row_index, column_index)
         for row in range(len(row_index) - 1):
             for column in range(len(column_index) - 1):
@@ -345,14 +326,14 @@ class BlockMatrix:
     def __matmul__(self, other):
         """C = A B over the non-zero blocks (grates/lstsq.py:651-681)"""
         if not isinstance(other, BlockMatrix):
-            raise ValueError("Matrix multiplication not implemented for type {0}".format(type(other)))
-        result = BlockMatrix(self.__row_index, other.__column_index)
-        for i in range(result.shape[0]):
-            for j in range(result.shape[1]):
-                for k in range(self.shape[1]):
-                    if self.__nz(i, k) and other.__nz(k, j):
-                        engine.gemm(self.__data[(i, k)], other.__data[(k, j)], beta=1.0, out=result.__set_block(i, j))
-        return result
+            raise ValueError('BlockMatrix @ {0} is not defined'.format(type(other).__name__))
+        product = BlockMatrix(self.__row_index, other.__column_index)
+        inner = range(self.shape[1])
+        for i in range(product.shape[0]):
+            for j in range(product.shape[1]):
+                for k in (k for k in inner if self.__nz(i, k) and other.__nz(k, j)):       # ascending k: upstream summation order
+                    engine.gemm(self.__data[(i, k)], other.__data[(k, j)], beta=1.0, out=product.__set_block(i, j))
+        return product
 
     def __set_block(self, i, j):
         """zero block on first use (grates/lstsq.py:683-696)"""
@@ -517,36 +498,22 @@ class BlockMatrix:
 
 
 class NormalEquations:
-    """
-    System of normal equations (grates/lstsq.py:915-1059).
-
-    Parameters
-    ----------
-    normal_matrix : BlockMatrix
-        normal equation coefficient matrix
-    right_hand_side : ndarray(n, 1) or device tensor
-        normal equation right hand side
-    observation_square_sum : float
-        weighted square sum ob observations
-    observation_count : int
-        observation count
-    """
+    """Normal equations N x = n of a least-squares problem: block matrix N (upper blocks), right-hand side n [n, 1] (ndarray or
+    device tensor), l^T P l and the number of observations (grates/lstsq.py:915-1059).  `status` tracks what `matrix` currently
+    holds: 'normal_matrix', 'cholesky_factor' or 'covariance_matrix'."""
 
     def __init__(self, normal_matrix, right_hand_side, observation_square_sum, observation_count):
-        self.matrix = normal_matrix
-        self.right_hand_side = right_hand_side
-        self.observation_square_sum = observation_square_sum
-        self.observation_count = observation_count
+        self.matrix, self.right_hand_side = normal_matrix, right_hand_side
+        self.observation_square_sum, self.observation_count = observation_square_sum, observation_count
         self.status = 'normal_matrix'
 
     def __cholesky(self):
-        if self.status == 'cholesky_factor':
-            pass
-        elif self.status == 'normal_matrix':
+        """factor the matrix once; a matrix that already holds covariances cannot be factored again (ValueError, as upstream)"""
+        if self.status == 'covariance_matrix' or self.status not in ('normal_matrix', 'cholesky_factor'):
+            raise ValueError('the matrix holds {0}: only a normal matrix can be factored'.format(self.status))
+        if self.status == 'normal_matrix':
             self.matrix.cholesky()
             self.status = 'cholesky_factor'
-        else:
-            raise ValueError('Cholesky factor can only be computed from the normal matrix')
 
     def solve(self, signs=None):
         """
@@ -599,10 +566,7 @@ class NormalEquations:
     def compute_covariance(self, sparse=True):
         """(sparse) inverse of the coefficient matrix (grates/lstsq.py:1026-1042)"""
         self.__cholesky()
-        if sparse:
-            self.matrix.sparse_inverse()
-        else:
-            self.matrix.inverse()
+        (self.matrix.sparse_inverse if sparse else self.matrix.inverse)()
         self.status = 'covariance_matrix'
 
     def to_array(self):
@@ -615,16 +579,16 @@ class TikhonovRegularization(NormalEquations):
     """Normal equations of a Tikhonov regularization with a diagonal regularization matrix (grates/lstsq.py:1062-1088)."""
 
     def __init__(self, regularization_vector, block_index, right_hand_side=None):
-        if right_hand_side is None:
-            right_hand_side = np.zeros((block_index[-1], 1))
-            lPl = 0
-        else:
-            lPl = np.sum(right_hand_side**2 * regularization_vector[:, np.newaxis])
-            right_hand_side = right_hand_side * regularization_vector[:, np.newaxis]
-        matrix = BlockMatrix(block_index, block_index)
-        for i in range(matrix.shape[0]):
-            matrix[i, i] = np.diag(regularization_vector[block_index[i]:block_index[i + 1]])
-        super(TikhonovRegularization, self).__init__(matrix, right_hand_side, lPl, right_hand_side.size)
+        weights = np.asarray(regularization_vector)
+        if right_hand_side is None:                            # zero bias: zero right-hand side, l^T P l = 0
+            bias, weighted_square_sum = np.zeros((block_index[-1], 1)), 0
+        else:                                                  # bias b with weights w: n = w * b, l^T P l = sum(w b^2)
+            weighted_square_sum = np.sum(right_hand_side**2 * weights[:, np.newaxis])
+            bias = right_hand_side * weights[:, np.newaxis]
+        diagonal = BlockMatrix(block_index, block_index)
+        for k, (lo, hi) in enumerate(zip(block_index[:-1], block_index[1:])):
+            diagonal[k, k] = np.diag(weights[lo:hi])
+        super().__init__(diagonal, bias, weighted_square_sum, bias.size)
 
 
 def accumulate_normals(normal_equations, variance_factors):
@@ -646,9 +610,5 @@ def accumulate_normals(normal_equations, variance_factors):
 
 def compute_variance_factors(normal_equations, combined_normals, solution, variance_factors):
     """Variance component estimates of the individual systems (grates/lstsq.py:1122-1149)."""
-    vc = []
-    for normals, sigma2 in zip(normal_equations, variance_factors):
-        ePe = normals.residual_square_sum(solution)
-        r = normals.redundancy(combined_normals, sigma2)
-        vc.append(ePe / r)
-    return np.array(vc)
+    return np.array([part.residual_square_sum(solution) / part.redundancy(combined_normals, factor)
+                     for part, factor in zip(normal_equations, variance_factors)])
