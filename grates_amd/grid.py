@@ -23,42 +23,12 @@ _R = 6.3781363000e+06
 class Grid(metaclass=abc.ABCMeta):
     """Base interface for point collections."""
 
-    @abc.abstractmethod
-    def copy(self):
-        pass
-
-    @property
-    @abc.abstractmethod
-    def semimajor_axis(self):
-        pass
-
-    @property
-    @abc.abstractmethod
-    def flattening(self):
-        pass
-
-    @property
-    @abc.abstractmethod
-    def longitude(self):
-        pass
-
-    @property
-    @abc.abstractmethod
-    def latitude(self):
-        pass
-
-    @property
-    @abc.abstractmethod
-    def area(self):
-        pass
-
-    @abc.abstractmethod
-    def values(self):
-        pass
-
-    @abc.abstractmethod
-    def point_count(self):
-        pass
+    # interface every grid type provides: copy(), the ellipsoid (semimajor_axis, flattening), per-point longitude / latitude /
+    # area, values (None or one value per point) and point_count
+    copy = abc.abstractmethod(lambda self: None)
+    semimajor_axis, flattening, longitude, latitude, area = (property(abc.abstractmethod(lambda self: None)) for _ in range(5))
+    values = abc.abstractmethod(lambda self: None)
+    point_count = abc.abstractmethod(lambda self: None)
 
     @property
     def size(self):
@@ -179,51 +149,37 @@ class RegularGrid(Grid):
         return grid
 
     def to_regular(self, threshold=1e-6):
-        if threshold <= 0:
+        """A regular grid is its own regular representation (a copy); the threshold is only validated."""
+        if not threshold > 0:
             raise ValueError('threshold should be positive (got {0:e})'.format(threshold))
         return self.copy()
 
-    @property
-    def semimajor_axis(self):
-        return self.__a
+    # ellipsoid and per-point views (points are enumerated parallel by parallel, north to south)
+    semimajor_axis = property(lambda self: self.__a)
+    flattening = property(lambda self: self.__f)
+    point_count = property(lambda self: self.parallels.size * self.meridians.size)
+    longitude = property(lambda self: np.tile(self.meridians, self.parallels.size))
+    latitude = property(lambda self: np.repeat(self.parallels, self.meridians.size))
+    area = property(lambda self: self.__areas.ravel())
 
-    @property
-    def flattening(self):
-        return self.__f
+    def __get_values(self):
+        return None if self.value_array is None else self.value_array.ravel()
 
-    @property
-    def point_count(self):
-        return self.parallels.size * self.meridians.size
-
-    @property
-    def longitude(self):
-        return np.tile(self.meridians, self.parallels.size)
-
-    @property
-    def latitude(self):
-        return np.repeat(self.parallels, self.meridians.size)
-
-    @property
-    def area(self):
-        return self.__areas.ravel()
-
-    @property
-    def values(self):
-        if self.value_array is not None:
-            return self.value_array.ravel()
-
-    @values.setter
-    def values(self, val):
+    def __set_values(self, val):
+        """None clears the grid; a 1-d ndarray with one value per point is reshaped to (parallels, meridians); anything else
+        is a ValueError (grates/grid.py:614-625)"""
         if val is None:
             self.value_array = None
-        elif isinstance(val, np.ndarray):
-            if val.ndim > 1:
-                raise ValueError("unable to assign values of dimension {0:d} to grid".format(val.ndim))
-            if val.size != self.point_count:
-                raise ValueError("unable to assign values of size {0:d} to grid with {1:d} points".format(val.size, self.point_count))
-            self.value_array = np.reshape(val, (self.parallels.size, self.meridians.size))
-        else:
+            return
+        if not isinstance(val, np.ndarray):
             raise ValueError("grid values must be either None or " + str(np.ndarray))
+        if val.ndim > 1:
+            raise ValueError("unable to assign values of dimension {0:d} to grid".format(val.ndim))
+        if val.size != self.point_count:
+            raise ValueError("unable to assign values of size {0:d} to grid with {1:d} points".format(val.size, self.point_count))
+        self.value_array = np.reshape(val, (self.parallels.size, self.meridians.size))
+
+    values = property(__get_values, __set_values)
 
     # ---- tables ----------------------------------------------------------------------------------------------------
     def _parallel_tables(self, kernel, max_degree, GM, R):
@@ -297,61 +253,38 @@ class IrregularGrid(Grid):
     """Arbitrary point list given by longitude / latitude pairs [rad]."""
 
     def __init__(self, longitude, latitude, area_element=None, a=6378137.0, f=298.2572221010**-1):
-        self.__lons = longitude
-        self.__lats = latitude
-        self.__areas = np.full(self.__lons.size, 4 * np.pi / self.__lons.size) if area_element is None else area_element
-        self.__a = a
-        self.__f = f
+        count = longitude.size
+        # points: (longitude, latitude, area); without area elements every point gets an equal share of the unit sphere
+        self.__points = (longitude, latitude, np.full(count, 4 * np.pi / count) if area_element is None else area_element)
+        self.__ellipsoid = (a, f)
         self.__values = None
         self.epoch = None
 
     def copy(self):
-        grid = IrregularGrid(self.__lons.copy(), self.__lats.copy(), self.__areas.copy(), self.semimajor_axis, self.flattening)
-        if self.__values is not None:
-            grid.values = self.values.copy()
-        grid.epoch = self.epoch
-        return grid
+        other = IrregularGrid(*(part.copy() for part in self.__points), *self.__ellipsoid)
+        other.values = None if self.__values is None else self.__values.copy()
+        other.epoch = self.epoch
+        return other
 
-    @property
-    def semimajor_axis(self):
-        return self.__a
+    semimajor_axis = property(lambda self: self.__ellipsoid[0])
+    flattening = property(lambda self: self.__ellipsoid[1])
+    longitude = property(lambda self: self.__points[0])
+    latitude = property(lambda self: self.__points[1])
+    area = property(lambda self: self.__points[2])
+    point_count = property(lambda self: self.__points[0].size)
 
-    @property
-    def flattening(self):
-        return self.__f
-
-    @property
-    def longitude(self):
-        return self.__lons
-
-    @property
-    def latitude(self):
-        return self.__lats
-
-    @property
-    def area(self):
-        return self.__areas
-
-    @property
-    def values(self):
-        return self.__values
-
-    @values.setter
-    def values(self, val):
-        if val is None:
-            self.__values = None
-        elif isinstance(val, np.ndarray):
+    def __set_values(self, val):
+        """None, or a 1-d ndarray with one value per point (ValueError otherwise, grates/grid.py:936-947)"""
+        if val is not None:
+            if not isinstance(val, np.ndarray):
+                raise ValueError("grid values must be either None or " + str(np.ndarray))
             if val.ndim > 1:
                 raise ValueError("unable to assign values of dimension {0:d} to grid".format(val.ndim))
             if val.size != self.point_count:
                 raise ValueError("unable to assign values of size {0:d} to grid with {1:d} points".format(val.size, self.point_count))
-            self.__values = val
-        else:
-            raise ValueError("grid values must be either None or " + str(np.ndarray))
+        self.__values = val
 
-    @property
-    def point_count(self):
-        return self.__lons.size
+    values = property(lambda self: self.__values, __set_values)
 
     def to_regular(self, threshold=1e-6):
         """Coerce into a RegularGrid if the points form meridians x parallels (grates/grid.py:886-914)."""
