@@ -25,12 +25,11 @@ def degree_indices(n, max_order=None):
 def order_indices(max_degree, m):
     """Row / column indices of all coefficients of order m (cosines by increasing degree, then sines)
     (grates/gravityfield.py:43-73)."""
-    rows = np.arange(m, max_degree + 1, dtype=int)
-    columns = np.full(rows.size, m)
-    if m > 0:
-        rows = np.concatenate((rows, np.full(max_degree + 1 - m, m - 1)))
-        columns = np.concatenate((columns, np.arange(m, max_degree + 1, dtype=int)))
-    return rows, columns
+    degrees = np.arange(m, max_degree + 1, dtype=int)
+    if m == 0:                                                 # zonal: cosine terms only, C_n0 at [n, 0]
+        return degrees, np.zeros(degrees.size, dtype=int)
+    # C_nm at [n, m] followed by S_nm at [m - 1, n]
+    return np.concatenate((degrees, np.full(degrees.size, m - 1))), np.concatenate((np.full(degrees.size, m), degrees))
 
 
 def _degree_array(max_degree):
@@ -123,16 +122,18 @@ class PotentialCoefficients:
     def __add__(self, other):
         if not isinstance(other, PotentialCoefficients):
             raise TypeError("unsupported operand type(s) for +: '" + str(type(self)) + "' and '" + str(type(other)) + "'")
-        factor = (other.R / self.R) ** _degree_array(other.max_degree) * (other.GM / self.GM)
-        if self.max_degree >= other.max_degree:
-            result = self.copy()
-            result.anm[0:other.anm.shape[0], 0:other.anm.shape[1]] += (other.anm * factor)
-        else:
-            result = PotentialCoefficients(self.GM, self.R)
-            result.anm = other.anm * factor
-            result.anm[0:self.anm.shape[0], 0:self.anm.shape[1]] += self.anm
-            result.epoch = self.epoch
-        return result
+        # the other set is brought to this set's GM and R first; the sum takes the larger of the two degrees (and, as
+        # upstream, the left operand's epoch and constants)
+        rescaled = other.anm * ((other.R / self.R) ** _degree_array(other.max_degree) * (other.GM / self.GM))
+        if other.max_degree <= self.max_degree:
+            total = self.copy()
+            total.anm[:rescaled.shape[0], :rescaled.shape[1]] += rescaled
+            return total
+        total = PotentialCoefficients(self.GM, self.R)
+        total.anm = rescaled
+        total.anm[:self.anm.shape[0], :self.anm.shape[1]] += self.anm
+        total.epoch = self.epoch
+        return total
 
     def __sub__(self, other):
         if not isinstance(other, PotentialCoefficients):
@@ -375,13 +376,14 @@ class TimeSeries:
         t = np.array([d.epoch for d in self.__data])
         if t.size < 2:
             raise ValueError("at least two data points are required for interpolation")
-        if epoch < t[0] or epoch > t[-1]:
-            raise ValueError("extrapolation is not supported (trying to extrapolate to " + str(epoch) + " from the interval " + str(t[0]) + ", " + str(t[-1]) + ")")
-        idx = np.searchsorted(t, epoch)
-        weight = (epoch - t[idx - 1]).total_seconds() / (t[idx] - t[idx - 1]).total_seconds()
-        output = self.__data[idx - 1] * (1 - weight) + self.__data[idx] * weight
-        output.epoch = epoch
-        return output
+        if not (t[0] <= epoch <= t[-1]):
+            raise ValueError('{0} lies outside the series ({1} .. {2}): no extrapolation'.format(epoch, t[0], t[-1]))
+        right = np.searchsorted(t, epoch)                     # first element at or after the epoch (as upstream: side='left')
+        before, after = self.__data[right - 1], self.__data[right]
+        w = (epoch - before.epoch).total_seconds() / (after.epoch - before.epoch).total_seconds()
+        blend = before * (1 - w) + after * w
+        blend.epoch = epoch
+        return blend
 
     def evaluate_at(self, epoch):
         return self.interpolate_to(epoch)
