@@ -63,86 +63,127 @@ __global__ __launch_bounds__(256) void weight_squares_kernel(int S, int nlat, in
     }
 }
 
-struct SolveParams {
-    int N, nmin, nlat, ldlat, nb, b0, B;
-    const double* pk;      // [(m, n)][ldlat]
-    const double* w2;      // [S][nlat]
-    const double* gt;      // [S][nb * nlat]
-    double* wsN;           // [S][(N+1)^2] normal matrices / Cholesky factors
-    double* wsR;           // [S][(N+1) * nb] right-hand sides / solutions
-    int factor;            // 1: build and factor the normal matrix (first epoch chunk), 0: reuse
-    double* anm;           // [B][N+1][N+1]
-};
+// blas.hip
+int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
+            long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, hipStream_t stream);
+int factor_invert_batched(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, int batch, int* info,
+                          hipStream_t stream);
+int potrf_upper(int n, double* A, int lda, double* work, int* info, hipStream_t stream);
+int trtri_upper(int n, const double* U, int ldu, double* X, int ldx, double* work, hipStream_t stream);
 
-__global__ __launch_bounds__(256) void analysis_solve_kernel(SolveParams P) {
-    const int s = blockIdx.x;
+// Per slot s = (m, cos | sin) the least-squares solution is x_s = H_s g_s with the operator
+//   H_s = (PK_m W2_s PK_m^T)^-1 PK_m      [d_s][nlat],   d_s = N + 1 - max(m, nmin) degrees,
+// which depends on the plan, the area weights and nmin only.  It is built once (batched over the 2N+1 slots: MFMA GEMMs for
+// the normal matrices, one workgroup per slot for the Cholesky factor U_s and its inverse, N_s^-1 PK_m = U^-1 (U^-T PK_m) as
+// two more GEMMs), cached in the plan under a checksum of the weights, and every call is then the longitude transform plus
+// ONE batched GEMM.  Slots are padded to N + 1 rows (zero rows of PK, unit diagonal in the normal matrix).
+
+// PKs[s][a][i] = PK[(m, n0 + a)][i] (a < d_s, else 0);  PKw = PKs * w2[s][i]
+__global__ void analysis_gather_kernel(int N, int nmin, int nlat, int ldlat, const double* __restrict__ pk, const double* __restrict__ w2,
+                                       double* __restrict__ pks, double* __restrict__ pkw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.y, s = blockIdx.z;
+    if (i >= nlat) return;
+    const int m = (s + 1) >> 1;
+    const int n0 = max(m, nmin);
+    const int d = N + 1 - n0;
+    const size_t o = ((size_t)s * (N + 1) + a) * nlat + i;
+    const double v = a < d ? pk[(size_t)(order_offset(N, m) + n0 - m + a) * ldlat + i] : 0.0;
+    pks[o] = v;
+    pkw[o] = v * w2[(size_t)s * nlat + i];
+}
+
+__global__ void analysis_pad_kernel(int N, int nmin, double* __restrict__ nmat) {
+    const int s = blockIdx.x, a = threadIdx.x;
+    const int m = (s + 1) >> 1;
+    const int d = N + 1 - max(m, nmin);
+    if (a <= N && a >= d) nmat[((size_t)s * (N + 1) + a) * (N + 1) + a] = 1.0;
+}
+
+// anm[b][n][m] / anm[b][m-1][n] <- X[s][a][b]
+__global__ void analysis_scatter_kernel(int N, int nmin, int nb, int b0, const double* __restrict__ X, double* __restrict__ anm) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.y, s = blockIdx.z;
+    if (b >= nb) return;
     const int m = (s + 1) >> 1;
     const bool sine = s > 0 && (s & 1) == 0;
-    const int n0 = max(m, P.nmin);
-    const int d = P.N + 1 - n0;
-    if (d <= 0) return;
-    const int tid = threadIdx.x;
-    const double* pk = P.pk + (size_t)(order_offset(P.N, m) + n0 - m) * P.ldlat;       // row a <-> degree n0 + a
-    const double* w2 = P.w2 + (size_t)s * P.nlat;
-    double* L = P.wsN + (size_t)s * (P.N + 1) * (P.N + 1);                             // [d][d], lower triangle used
-    double* R = P.wsR + (size_t)s * (P.N + 1) * P.nb;                                  // [d][nb]
+    const int n0 = max(m, nmin);
+    if (a >= N + 1 - n0) return;
+    const int n = n0 + a;
+    double* out = anm + (size_t)(b0 + b) * (N + 1) * (N + 1);
+    out[sine ? (size_t)(m - 1) * (N + 1) + n : (size_t)n * (N + 1) + m] = X[((size_t)s * (N + 1) + a) * nb + b];
+}
 
-    if (P.factor) {
-        // ---- normal matrix, lower triangle:  L[a][c] = sum_i pk[a][i] w2[i] pk[c][i]
-        for (int e = tid; e < d * d; e += 256) {
-            const int a = e / d, c = e % d;
-            if (c > a) continue;
-            const double* pa = pk + (size_t)a * P.ldlat;
-            const double* pc = pk + (size_t)c * P.ldlat;
-            double acc = 0.0;
-            for (int i = 0; i < P.nlat; ++i) acc = fma(pa[i] * w2[i], pc[i], acc);
-            L[a * d + c] = acc;
+// two checksums of the S x nlat weight table (plain sum and index-weighted sum): key of the operator cache
+__global__ __launch_bounds__(256) void analysis_checksum_kernel(long long n, const double* __restrict__ w2, double* __restrict__ out) {
+    __shared__ double r0[256], r1[256];
+    double s0 = 0.0, s1 = 0.0;
+    for (long long e = threadIdx.x; e < n; e += 256) {
+        s0 += w2[e];
+        s1 += w2[e] * (double)(1 + (e % 1021));
+    }
+    r0[threadIdx.x] = s0;
+    r1[threadIdx.x] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            r0[threadIdx.x] += r0[threadIdx.x + w];
+            r1[threadIdx.x] += r1[threadIdx.x + w];
         }
         __syncthreads();
-        // ---- Cholesky factorisation in place (right-looking)
-        for (int k = 0; k < d; ++k) {
-            if (tid == 0) L[k * d + k] = sqrt(L[k * d + k]);
-            __syncthreads();
-            const double piv = L[k * d + k];
-            for (int r = k + 1 + tid; r < d; r += 256) L[r * d + k] /= piv;
-            __syncthreads();
-            const int t = d - k - 1;
-            for (int e = tid; e < t * t; e += 256) {
-                const int r = k + 1 + e / t, c = k + 1 + e % t;
-                if (c <= r) L[r * d + c] = fma(-L[r * d + k], L[c * d + k], L[r * d + c]);
+    }
+    if (threadIdx.x == 0) {
+        out[0] = r0[0];
+        out[1] = r1[0];
+    }
+}
+
+// builds p->ana_H for the weights w2 (device, [S][nlat]); returns SHG_ERR_INVALID if a normal matrix is not positive definite
+static int build_analysis_operator(shg_plan* p, const double* w2, int nmin, hipStream_t stream) {
+    const int N = p->N, S = 2 * N + 1, nlat = p->nlat, R = N + 1;
+    const size_t slab = (size_t)S * R * nlat;
+    if (!p->ana_H && hipMalloc((void**)&p->ana_H, slab * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "analysis operator allocation failed");
+    double *pks = nullptr, *pkw = nullptr, *nmat = nullptr, *uinv = nullptr, *work = nullptr;
+    int* info = nullptr;
+    if (workspace_alloc((void**)&pks, slab * sizeof(double), stream) != hipSuccess || workspace_alloc((void**)&pkw, slab * sizeof(double), stream) != hipSuccess ||
+        workspace_alloc((void**)&nmat, (size_t)S * R * R * sizeof(double), stream) != hipSuccess ||
+        workspace_alloc((void**)&uinv, (size_t)S * R * R * sizeof(double), stream) != hipSuccess ||
+        workspace_alloc((void**)&work, ((size_t)R * R + 128 * 128) * sizeof(double), stream) != hipSuccess ||
+        workspace_alloc((void**)&info, sizeof(int), stream) != hipSuccess)
+        return fail(SHG_ERR_NOMEM, "analysis operator workspace allocation failed");
+    SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(analysis_gather_kernel, dim3(ceil_div(nlat, 128), R, S), dim3(128), 0, stream, N, nmin, nlat, p->ldlat, p->pk, w2, pks, pkw);
+    // normal matrices N_s = PKw_s PKs_s^T
+    int rc = gemm_ex(false, true, R, R, nlat, 1.0, pkw, nlat, (long long)R * nlat, pks, nlat, (long long)R * nlat, 0.0, nmat, R, (long long)R * R, S,
+                     false, stream);
+    if (!rc) {
+        hipLaunchKernelGGL(analysis_pad_kernel, dim3(S), dim3(std::max(64, round_up(R, 64))), 0, stream, N, nmin, nmat);
+        if (R <= 128) {
+            rc = factor_invert_batched(R, nmat, R, (long long)R * R, uinv, R, (long long)R * R, S, info, stream);
+        } else {
+            for (int s = 0; s < S && !rc; ++s) {
+                rc = potrf_upper(R, nmat + (size_t)s * R * R, R, work + (size_t)R * R, info, stream);
+                if (!rc) rc = trtri_upper(R, nmat + (size_t)s * R * R, R, uinv + (size_t)s * R * R, R, work, stream);
             }
-            __syncthreads();
         }
     }
-    // ---- right-hand sides of all epochs of the chunk:  R[a][b] = sum_i pk[a][i] gt[s][b][i]
-    const double* gt = P.gt + (size_t)s * P.nb * P.nlat;
-    for (int e = tid; e < d * P.nb; e += 256) {
-        const int a = e / P.nb, b = e % P.nb;
-        const double* pa = pk + (size_t)a * P.ldlat;
-        const double* g = gt + (size_t)b * P.nlat;
-        double acc = 0.0;
-        for (int i = 0; i < P.nlat; ++i) acc = fma(pa[i], g[i], acc);
-        R[a * P.nb + b] = acc;
+    // H_s = U_s^-1 (U_s^-T PKs_s)
+    if (!rc) rc = gemm_ex(true, false, R, nlat, R, 1.0, uinv, R, (long long)R * R, pks, nlat, (long long)R * nlat, 0.0, pkw, nlat, (long long)R * nlat, S, false, stream);
+    if (!rc) rc = gemm_ex(false, false, R, nlat, R, 1.0, uinv, R, (long long)R * R, pkw, nlat, (long long)R * nlat, 0.0, p->ana_H, nlat, (long long)R * nlat, S, false, stream);
+    int bad = 0;
+    if (!rc) {
+        SHG_HIP(hipMemcpyAsync(&bad, info, sizeof(int), hipMemcpyDeviceToHost, stream));
+        SHG_HIP(hipStreamSynchronize(stream));
     }
-    __syncthreads();
-    // ---- L y = r, L^T x = y: one thread per epoch
-    for (int b = tid; b < P.nb; b += 256) {
-        for (int k = 0; k < d; ++k) {
-            double acc = R[k * P.nb + b];
-            for (int j = 0; j < k; ++j) acc = fma(-L[k * d + j], R[j * P.nb + b], acc);
-            R[k * P.nb + b] = acc / L[k * d + k];
-        }
-        for (int k = d - 1; k >= 0; --k) {
-            double acc = R[k * P.nb + b];
-            for (int j = k + 1; j < d; ++j) acc = fma(-L[j * d + k], R[j * P.nb + b], acc);
-            R[k * P.nb + b] = acc / L[k * d + k];
-        }
-        double* out = P.anm + (size_t)(P.b0 + b) * (P.N + 1) * (P.N + 1);
-        for (int a = 0; a < d; ++a) {
-            const int n = n0 + a;
-            out[sine ? (size_t)(m - 1) * (P.N + 1) + n : (size_t)n * (P.N + 1) + m] = R[a * P.nb + b];
-        }
-    }
+    (void)hipFreeAsync(pks, stream);
+    (void)hipFreeAsync(pkw, stream);
+    (void)hipFreeAsync(nmat, stream);
+    (void)hipFreeAsync(uinv, stream);
+    (void)hipFreeAsync(work, stream);
+    (void)hipFreeAsync(info, stream);
+    if (rc) return rc;
+    if (bad) return fail(SHG_ERR_INVALID, "shg_analysis: a normal matrix is not positive definite (grid does not resolve the requested degrees)");
+    return SHG_OK;
 }
 
 }  // namespace shg
@@ -163,14 +204,29 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     SHG_HIP(hipMemsetAsync(anm, 0, (size_t)B * (N + 1) * (N + 1) * sizeof(double), stream));
 
     const int chunk = std::min(B, kAnaEpochChunk);
-    double *wvt = nullptr, *gt = nullptr, *w2 = nullptr, *wsN = nullptr, *wsR = nullptr;
-    if (hipMallocAsync((void**)&wvt, (size_t)nlon * chunk * nlat * sizeof(double), stream) != hipSuccess ||
-        hipMallocAsync((void**)&gt, (size_t)S * chunk * nlat * sizeof(double), stream) != hipSuccess ||
-        hipMallocAsync((void**)&w2, (size_t)S * nlat * sizeof(double), stream) != hipSuccess ||
-        hipMallocAsync((void**)&wsN, (size_t)S * (N + 1) * (N + 1) * sizeof(double), stream) != hipSuccess ||
-        hipMallocAsync((void**)&wsR, (size_t)S * (N + 1) * chunk * sizeof(double), stream) != hipSuccess)
+    const int R = N + 1;
+    double *wvt = nullptr, *gt = nullptr, *w2 = nullptr, *X = nullptr, *key_d = nullptr;
+    if (workspace_alloc((void**)&wvt, (size_t)nlon * chunk * nlat * sizeof(double), stream) != hipSuccess ||
+        workspace_alloc((void**)&gt, (size_t)S * chunk * nlat * sizeof(double), stream) != hipSuccess ||
+        workspace_alloc((void**)&w2, (size_t)S * nlat * sizeof(double), stream) != hipSuccess ||
+        workspace_alloc((void**)&X, (size_t)S * R * chunk * sizeof(double), stream) != hipSuccess ||
+        workspace_alloc((void**)&key_d, 2 * sizeof(double), stream) != hipSuccess)
         return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
     hipLaunchKernelGGL(weight_squares_kernel, dim3(nlat), dim3(256), 0, stream, S, nlat, nlon, area, p->cs_slot, w2);
+    // operator cache: rebuilt when the weights (or nmin) differ from those it was built for
+    hipLaunchKernelGGL(analysis_checksum_kernel, dim3(1), dim3(256), 0, stream, (long long)S * nlat, w2, key_d);
+    double key[2] = {0.0, 0.0};
+    SHG_HIP(hipMemcpyAsync(key, key_d, sizeof(key), hipMemcpyDeviceToHost, stream));
+    SHG_HIP(hipStreamSynchronize(stream));
+    if (!p->ana_H || p->ana_nmin != nmin || p->ana_key[0] != key[0] || p->ana_key[1] != key[1]) {
+        p->ana_nmin = -1;
+        rc = build_analysis_operator(p, w2, nmin, stream);
+        if (rc == SHG_OK) {
+            p->ana_nmin = nmin;
+            p->ana_key[0] = key[0];
+            p->ana_key[1] = key[1];
+        }
+    }
 
     for (int b0 = 0; b0 < B && rc == SHG_OK; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);
@@ -182,29 +238,17 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
             rc = shg_dgemm(S, (int)rows, nlon, p->cs_slot, nlon, wvt, (int)rows, gt, (int)rows, stream);
         }
         if (rc) break;
-        SolveParams Q;
-        Q.N = N;
-        Q.nmin = nmin;
-        Q.nlat = nlat;
-        Q.ldlat = p->ldlat;
-        Q.nb = nb;
-        Q.b0 = b0;
-        Q.B = B;
-        Q.pk = p->pk;
-        Q.w2 = w2;
-        Q.gt = gt;
-        Q.wsN = wsN;
-        Q.wsR = wsR;
-        Q.factor = b0 == 0 ? 1 : 0;
-        Q.anm = anm;
         ProfileScope ps(p, 5, stream);
-        hipLaunchKernelGGL(analysis_solve_kernel, dim3(S), dim3(256), 0, stream, Q);
+        // X_s [R][nb] = H_s [R][nlat] gt_s^T   (gt_s is [nb][nlat])
+        rc = gemm_ex(false, true, R, nb, nlat, 1.0, p->ana_H, nlat, (long long)R * nlat, gt, nlat, rows, 0.0, X, nb, (long long)R * nb, S, false, stream);
+        if (rc) break;
+        hipLaunchKernelGGL(analysis_scatter_kernel, dim3(ceil_div(nb, 64), R, S), dim3(64), 0, stream, N, nmin, nb, b0, X, anm);
     }
     (void)hipFreeAsync(wvt, stream);
     (void)hipFreeAsync(gt, stream);
     (void)hipFreeAsync(w2, stream);
-    (void)hipFreeAsync(wsN, stream);
-    (void)hipFreeAsync(wsR, stream);
+    (void)hipFreeAsync(X, stream);
+    (void)hipFreeAsync(key_d, stream);
     if (rc) return rc;
     SHG_HIP(hipGetLastError());
     return SHG_OK;

@@ -490,6 +490,13 @@ static int launch_leaf(int n, double* A, int lda, long long strideA, double* X, 
     return SHG_OK;
 }
 
+// batch of n x n blocks (n <= 128): A_b = U_b^T U_b in place and X_b = U_b^-1, one workgroup per block (analysis.hip)
+int factor_invert_batched(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, int batch, int* info,
+                          hipStream_t stream) {
+    if (n > LEAF) return fail(SHG_ERR_INVALID, "factor_invert_batched: block size %d exceeds %d", n, LEAF);
+    return launch_leaf(n, A, lda, strideA, X, ldx, strideX, batch, 3, info, 0, stream);
+}
+
 __global__ void zero_lower_kernel(int n, double* __restrict__ A, int lda) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long long)n * n) return;

@@ -100,6 +100,10 @@ struct shg_plan {
     size_t cpk4_zeroed = 0;
     double* panel = nullptr;    // two-kernel synthesis: [B/4][nit][K][64] Legendre-stage output in LDS-image order
     size_t panel_size = 0;
+    // analysis operator cache (analysis.hip): H[S][N+1][nlat] for the weights with checksum ana_key and min degree ana_nmin
+    double* ana_H = nullptr;
+    double ana_key[2] = {0.0, 0.0};
+    int ana_nmin = -1;
     int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel, 3 Legendre kernel + longitude kernel, 4 fused kernel without the north-south symmetry, 5 fused kernel with 32-row panels (two workgroups per CU)
 
     // optional per-kernel event timing (shg_plan_profile)
