@@ -83,6 +83,7 @@ struct shg_plan {
     std::vector<int> ns_badmap; // per block of 8 northern parallels: -1, or rank among the blocks whose mirrored parallels get their own table
     int ns_nbad = 0;
     int* badmap_d = nullptr;
+    int* octinfo_d = nullptr;   // [Qtot] order | octet-in-order << 8 of every octet of the fragment-ordered tables
     int* itemtab_d = nullptr;   // work items of the fused kernel's Legendre stage, [8 waves][nrec][4]
     int itemtab_nrec = 0, itemtab_ntrip = 0;
     int* blockmap_d = nullptr;  // XCD-aware (epoch tile, parallel tile) order of the fused kernel's workgroups

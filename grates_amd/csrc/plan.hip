@@ -281,6 +281,7 @@ extern "C" int shg_plan_destroy(shg_plan* p) {
     if (p->badmap_d) (void)hipFree(p->badmap_d);
     if (p->blockmap_d) (void)hipFree(p->blockmap_d);
     if (p->itemtab_d) (void)hipFree(p->itemtab_d);
+    if (p->octinfo_d) (void)hipFree(p->octinfo_d);
     if (p->qoff32) (void)hipFree(p->qoff32);
     if (p->badmap32_d) (void)hipFree(p->badmap32_d);
     for (double* q : ptrs)

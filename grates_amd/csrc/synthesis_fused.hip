@@ -161,6 +161,32 @@ __global__ __launch_bounds__(256) void pack_coefficients4_ns_kernel(int N, int B
     for (int bb = 0; bb < 4; ++bb) dst[bb * 2] = (bt * 4 + bb < B) ? anm[(size_t)(bt * 4 + bb) * E + e] : 0.0;
 }
 
+// Gather form of the NS repack: one thread per 16-byte element of the fragment-ordered table (fully coalesced writes, every
+// element written, padding included: no zero-fill of the workspace); the two degrees of an element are read from the epoch's
+// coefficient triangle, which stays in L2.  octinfo[octet] = order | (octet index inside the order) << 8.
+__global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N, int B, int Qtot, const int* __restrict__ octinfo,
+                                                                            const double* __restrict__ anm, double* __restrict__ cpk4) {
+    const int t = blockIdx.x * 256 + threadIdx.x;                  // (octet, lane)
+    if (t >= Qtot * 64) return;
+    const int bt = blockIdx.y;
+    const int oct = t >> 6, lane = t & 63;
+    const int info = octinfo[oct];
+    const int m = info & 255, ol = info >> 8;
+    const int fk = lane >> 4, row = lane & 15;
+    const int par = row >> 3, cs = (row >> 2) & 1, b = bt * 4 + (row & 3);
+    const size_t E = (size_t)(N + 1) * (N + 1);
+    double v[2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+        const int nl = 2 * ((2 * ol + s_) * 4 + fk) + par;         // degree offset n - m
+        const int n = m + nl;
+        const bool ok = n <= N && b < B && !(cs == 1 && m == 0);
+        const size_t e = cs == 0 ? (size_t)n * (N + 1) + m : (size_t)(m - 1) * (N + 1) + n;
+        v[s_] = ok ? anm[(size_t)b * E + e] : 0.0;
+    }
+    *reinterpret_cast<double2*>(cpk4 + ((size_t)bt * Qtot * 64 + t) * 2) = make_double2(v[0], v[1]);
+}
+
 struct FusedParams {
     int N, nlat, nlon, ldlat, K, ncol, B, nit, Ppk, ncb;   // nit = 16-parallel tiles, ncb = column blocks (8 tiles each)
     int goff[5];              // first K slot of each (cos/sin, m even/odd) group; every group is a multiple of 16 slots
@@ -646,6 +672,17 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, h
         }
         longest = std::max(longest, rec[w].size() / 4);
     }
+    // octet -> (order, octet inside the order) for the gather repack
+    std::vector<int> octinfo((size_t)qoff[N + 1], 0);
+    for (int m = 0; m <= N; ++m)
+        for (int o = qoff[m]; o < qoff[m + 1]; ++o) octinfo[o] = m | ((o - qoff[m]) << 8);
+    if (p->octinfo_d) {
+        SHG_HIP(hipDeviceSynchronize());
+        (void)hipFree(p->octinfo_d);
+        p->octinfo_d = nullptr;
+    }
+    if (hipMalloc((void**)&p->octinfo_d, std::max<size_t>(octinfo.size(), 1) * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "octet table allocation failed");
+    SHG_HIP(hipMemcpy(p->octinfo_d, octinfo.data(), octinfo.size() * sizeof(int), hipMemcpyHostToDevice));
     const int ntrip = (int)((longest + 3) / 4), nrec = 4 * ntrip + 8;
     std::vector<int> table((size_t)8 * nrec * 4, 0);
     for (int w = 0; w < 8; ++w) {
@@ -807,7 +844,8 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
         {
             ProfileScope ps(p, 0, stream);
             if (ns)
-                hipLaunchKernelGGL(pack_coefficients4_ns_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, p->qoff, anm, p->cpk4);
+                hipLaunchKernelGGL(pack_coefficients4_ns_gather_kernel, dim3(ceil_div(p->Qtot * 64, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot,
+                                   p->octinfo_d, anm, p->cpk4);
             else
                 hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, p->qoff, anm, p->cpk4);
         }
