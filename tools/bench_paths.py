@@ -82,7 +82,7 @@ def main():
     b180 = torch.from_numpy(rng.standard_normal((64, 181, 181)) * 1e-10).cuda()
     p180 = plan_for(g05, 180, 'ewh')
     ms = device_ms(lambda: p180.synthesis(b180))
-    emit('synthesis d/o 180 -> 0.5 deg, 64 epochs (staged path)', ms, solutions_per_s=round(64 / ms * 1e3))
+    emit('synthesis d/o 180 -> 0.5 deg, 64 epochs (32-row fused kernel)', ms, solutions_per_s=round(64 / ms * 1e3))
 
     # point-list synthesis
     lon, lat = inputs.scattered_points(1, 100000)
