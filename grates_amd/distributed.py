@@ -109,3 +109,155 @@ def synthesize_sharded(time_series_batch, grid, kernel='ewh', GM=3.9860044150e+1
     start, stop = shard_range(total, rank, world)
     local = np.ascontiguousarray(time_series_batch[start:stop]) if isinstance(time_series_batch, np.ndarray) else time_series_batch[start:stop]
     return start, stop, gravityfield.synthesize(local, grid, kernel, GM, R)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Block-tridiagonal normal equations partitioned over epochs (BASELINE config 5: smoother sharded over the GPUs of a node)
+# ---------------------------------------------------------------------------------------------------------------------
+def _gather_blocks(tensors, group=None):
+    """all_gather of a list of equally shaped device tensors: returns per-rank lists.  RCCL gathers device buffers; under gloo
+    (tests, rehearsals on one GPU) the payload is staged through the host."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    flat = torch.cat([t.reshape(-1) for t in tensors]) if tensors else torch.zeros(0, dtype=torch.float64)
+    on_host = dist.get_backend(group) == 'gloo'
+    send = flat.cpu() if on_host else flat
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    out = []
+    for part in parts:
+        part = part.to(flat.device) if on_host else part
+        blocks, pos = [], 0
+        for t in tensors:
+            blocks.append(part[pos:pos + t.numel()].reshape(t.shape))
+            pos += t.numel()
+        out.append(blocks)
+    return out
+
+
+def solve_block_tridiagonal_partitioned(diag, upper, rhs, group=None):
+    """
+    Solve the symmetric positive definite block-tridiagonal system N x = b whose block rows (epochs) are distributed over the
+    ranks in contiguous ranges: the fixed-interval smoother of grates.lstsq (NormalEquations.solve on a VAR(1)-constrained
+    system; wider bands are the same after grouping `order` epochs into one block row).
+
+    Every rank passes the blocks of ITS epochs t0 .. t1-1 as device tensors:
+        diag[k]   N[t0+k, t0+k]      (upper triangle significant, like BlockMatrix)
+        upper[k]  N[t0+k, t0+k+1]    (upper[-1] couples to the next rank's first epoch; ignored on the last rank)
+        rhs       [sum of block sizes, columns]
+    and receives x for its epochs.  Every rank but the last needs at least two epochs.
+
+    Scheme (nested dissection with the last epoch of every rank but the last as separator): each rank factors its interior
+    chain with the block Cholesky of grates_amd.lstsq.BlockMatrix (sequential in epochs, all ranks concurrently) and solves it
+    for the right-hand side and for its two coupling blocks; ONE all_gather (RCCL) collects the separator blocks and the Schur
+    complement pieces (5 d x d blocks and a few vectors per rank), every rank solves the small separator system redundantly and
+    back-substitutes.  A second small all_gather beforehand hands every rank the coupling block to its left separator.
+    """
+    import torch
+    import torch.distributed as dist
+    from . import engine
+    from .lstsq import BlockMatrix
+    torch_cat = torch.cat
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n_loc = len(diag)
+    last = rank == world - 1
+    if n_loc < (1 if last else 2):
+        raise ValueError('every rank but the last needs at least two epochs (got {0})'.format(n_loc))
+    sizes = [int(b.shape[0]) for b in diag]
+    bounds = np.concatenate(([0], np.cumsum(sizes)))
+    k = rhs.shape[1]
+
+    def chain(blocks_d, blocks_u):
+        index = np.concatenate(([0], np.cumsum([int(b.shape[0]) for b in blocks_d])))
+        bm = BlockMatrix(index, index)
+        for i, b in enumerate(blocks_d):
+            bm._set_device(i, i, b.clone())
+        for i, b in enumerate(blocks_u):
+            bm._set_device(i, i + 1, b.clone())
+        return bm
+
+    if world == 1:
+        bm = chain(diag, upper[:n_loc - 1])
+        bm.cholesky()
+        return bm.solve_triangular(bm.solve_triangular(rhs, transpose=True))
+
+    # coupling to the left separator: N[s_(g-1), t0] lives on the previous rank
+    d_sep = sizes[-1]
+    boundary = upper[n_loc - 1] if not last else torch.zeros((d_sep, d_sep), dtype=torch.float64, device=rhs.device)
+    if not last and boundary.shape[1] != boundary.shape[0]:
+        raise ValueError('partitioned solve expects equal block sizes at the rank boundaries')
+    boundaries = _gather_blocks([boundary.contiguous()], group)           # collective: every rank takes part
+    left = boundaries[rank - 1][0] if rank > 0 else None                  # [d_sep_left, d_first]
+
+    ni = n_loc if last else n_loc - 1                                   # interior epochs
+    interior = chain(diag[:ni], upper[:ni - 1])
+    interior.cholesky()
+    n_int = int(bounds[ni])
+    columns = [rhs[:n_int]]
+    if left is not None:                                                # C_left = left^T in the first interior block rows
+        cl = torch.zeros((n_int, left.shape[0]), dtype=torch.float64, device=rhs.device)
+        cl[:sizes[0]] = left.t()
+        columns.append(cl)
+    if not last:                                                        # C_right = N[t1-2, t1-1] in the last interior block rows
+        cr = torch.zeros((n_int, d_sep), dtype=torch.float64, device=rhs.device)
+        cr[int(bounds[ni - 1]):n_int] = upper[ni - 1]
+        columns.append(cr)
+    W = torch_cat(columns, dim=1).contiguous()
+    Z = interior.solve_triangular(interior.solve_triangular(W, transpose=True))
+    zb = Z[:, :k]
+    pos = k
+    ZL = ZR = None
+    if left is not None:
+        ZL = Z[:, pos:pos + left.shape[0]]
+        pos += left.shape[0]
+    if not last:
+        ZR = Z[:, pos:pos + d_sep]
+
+    def zeros(r, c):
+        return torch.zeros((r, c), dtype=torch.float64, device=rhs.device)
+
+    first = slice(0, sizes[0])
+    tail = slice(int(bounds[ni - 1]), n_int)
+    # Schur complement pieces of this rank's interior chain (d = separator block size; equal sizes at the boundaries)
+    d = d_sep if not last else left.shape[0]
+    S_ll = engine.gemm(left, ZL[first].contiguous()) if left is not None else zeros(d, d)
+    b_l = engine.gemm(left, zb[first].contiguous()) if left is not None else zeros(d, k)
+    S_lr = engine.gemm(left, ZR[first].contiguous()) if (left is not None and not last) else zeros(d, d)
+    S_rr = engine.gemm(upper[ni - 1], ZR[tail].contiguous(), transa=True) if not last else zeros(d, d)
+    b_r = engine.gemm(upper[ni - 1], zb[tail].contiguous(), transa=True) if not last else zeros(d, k)
+    sep_d = diag[n_loc - 1] if not last else zeros(d, d)
+    sep_b = rhs[n_int:] if not last else zeros(d, k)
+    gathered = _gather_blocks([sep_d.contiguous(), S_ll, S_lr, S_rr, sep_b.contiguous(), b_l, b_r], group)
+
+    # separator system (world - 1 block rows), solved redundantly on every rank
+    nsep = world - 1
+    index = np.arange(0, (nsep + 1) * d, d)
+    reduced = BlockMatrix(index, index)
+    red_rhs = zeros(nsep * d, k)
+    for i in range(nsep):
+        own, nxt = gathered[i], gathered[i + 1]
+        block = own[0].clone()
+        engine.axpby(-1.0, own[3], 1.0, block)                           # - S_rr of the chain on its left
+        engine.axpby(-1.0, nxt[1], 1.0, block)                           # - S_ll of the chain on its right
+        reduced._set_device(i, i, block)
+        if i + 1 < nsep:
+            coupling = zeros(d, d)
+            engine.axpby(-1.0, nxt[2], 0.0, coupling)                    # - S_lr of the chain between separators i and i + 1
+            reduced._set_device(i, i + 1, coupling)
+        r = red_rhs[i * d:(i + 1) * d]
+        engine.axpby(1.0, own[4], 0.0, r)
+        engine.axpby(-1.0, own[6], 1.0, r)
+        engine.axpby(-1.0, nxt[5], 1.0, r)
+    reduced.cholesky()
+    x_sep = reduced.solve_triangular(reduced.solve_triangular(red_rhs, transpose=True))
+
+    # back substitution of the interior chain
+    x_int = zb.clone()
+    if left is not None:
+        engine.gemm(ZL.contiguous(), x_sep[(rank - 1) * d:rank * d], alpha=-1.0, beta=1.0, out=x_int)
+    if not last:
+        engine.gemm(ZR.contiguous(), x_sep[rank * d:(rank + 1) * d], alpha=-1.0, beta=1.0, out=x_int)
+        return torch_cat((x_int, x_sep[rank * d:(rank + 1) * d]), dim=0)
+    return x_int

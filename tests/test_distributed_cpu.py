@@ -50,6 +50,13 @@ def _worker(rank, world, port, nlat, nlon, result_dir):
     counts = torch.zeros(17, dtype=torch.int64)
     counts[start:stop] = 1
     dist.all_reduce(counts)
+    # block gather of the partitioned smoother: every rank contributes a list of blocks, everybody receives all lists
+    mine = [torch.full((2, 3), float(rank), dtype=torch.float64), torch.arange(4, dtype=torch.float64).reshape(4, 1) + 10 * rank]
+    everyone = gd._gather_blocks(mine)
+    assert len(everyone) == world
+    for r, blocks in enumerate(everyone):
+        assert torch.equal(blocks[0], torch.full((2, 3), float(r), dtype=torch.float64))
+        assert torch.equal(blocks[1], torch.arange(4, dtype=torch.float64).reshape(4, 1) + 10 * r)
     np.save(os.path.join(result_dir, 'full_{0}.npy'.format(rank)), full.numpy())
     np.save(os.path.join(result_dir, 'counts_{0}.npy'.format(rank)), counts.numpy())
     dist.barrier()
