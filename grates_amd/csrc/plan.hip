@@ -302,7 +302,7 @@ extern "C" int shg_plan_set_path(shg_plan* p, int path) {
     SHG_REQUIRE(p != nullptr, "shg_plan_set_path: NULL plan");
     SHG_REQUIRE(path >= 0 && path <= 5, "shg_plan_set_path: path %d not in {0, ..., 5}", path);
     SHG_REQUIRE(path != 5 || fused32_applicable(p), "shg_plan_set_path: the two-workgroup fused kernel needs both grid symmetries and K <= 416 (K = %d)", p->K);
-    SHG_REQUIRE(path < 2 || path == 5 || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
+    SHG_REQUIRE(path < 2 || path >= 5 || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
     p->path = path;
     return SHG_OK;
 }

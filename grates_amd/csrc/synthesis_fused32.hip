@@ -343,7 +343,7 @@ int fused32_applicable(const shg_plan* p) {
     return fused32_lds_bytes(p->K) <= 160 * 1024 ? 1 : 0;
 }
 
-static int build_pkf32_table(shg_plan* p, hipStream_t stream) {
+int build_pkf32_table(shg_plan* p, hipStream_t stream) {
     if (p->pkf32) return SHG_OK;
     const int N = p->N, nh = p->nlat / 2, nit = ceil_div(nh, 4);
     // octet offsets (16 degrees per octet) and the polar-block map at 4-parallel granularity
