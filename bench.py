@@ -117,6 +117,16 @@ def covariance_leg(args, rank, world, barrier, reduce_device='cuda'):
                      'avg_launch_ms': k_ms / max(k_n, 1)},
         'sigma_checksum': float(sigma.sum().item()),
     }
+    if world == 1:
+        # extension, reported beside the headline and not part of `value`: the same band with the upper-triangle shortcut for a
+        # symmetric Sigma (half the MFMA work; GFLOP/s still counted with the algorithmic 2 M P^2 + 2 M P of the general product)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sigma_sym = plan.covariance_propagation(cov, 0, lat0, lat1, symmetric=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out['symmetric_shortcut'] = {'seconds': dt, 'algorithmic_GFLOPs': flops / dt / 1e9,
+                                     'max_rel_diff_vs_general': float(((sigma_sym - sigma).abs().max() / sigma.abs().max()).item())}
     if world == 1 and args.cov_cpu_parallels > 0:
         from oracle import shg_oracle as orc
         ker = orc.KernelTable(KERNEL, ga.data.load_love_numbers()[0])

@@ -39,7 +39,12 @@ struct GemmParams {
     double* partial;        // [gridDim.x][M] per-column-block partial row sums
 };
 
-template <int MODE, bool VEC>
+// SYM (covariance mode only): Sigma is symmetric and only its upper triangle is used,
+//   sigma2[r] = sum_c [ sum_{p<c} 2 A[r][p] Sigma[p][c] + A[r][c] Sigma[c][c] ] A[r][c]:
+// column block n0 runs its K loop over p < n0 + 128 only (half the MFMAs on average); the accumulators are doubled once when
+// the loop reaches the diagonal block, inside which the Sigma tile is weighted 2 / 1 / 0 (p < c / p = c / p > c) while it is
+// staged.  Column blocks are taken from the last (longest) to the first.
+template <int MODE, bool VEC, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      // 2 waves per SIMD: two blocks per CU
     extern __shared__ double gemm_lds[];
     double (*As)[BM * LDA] = reinterpret_cast<double (*)[BM * LDA]>(gemm_lds);                       // [2][BM * LDA]
@@ -55,8 +60,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     // PLAIN: column block fastest.  COVPROP: row block fastest -- the blocks resident at one time then walk the same
     // 33 MB column panel of Sigma together and it is fetched from HBM once instead of once per row block.
     const int m0 = (MODE == MODE_PLAIN ? blockIdx.y : blockIdx.x) * BM;
-    const int n0 = (MODE == MODE_PLAIN ? blockIdx.x : blockIdx.y) * BN;
-    const int colblock = MODE == MODE_PLAIN ? blockIdx.x : blockIdx.y;
+    const int colblock = MODE == MODE_PLAIN ? (int)blockIdx.x : (SYM ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y);
+    const int n0 = colblock * BN;
+    const int Keff = SYM ? min(P.K, n0 + BN) : P.K;                // SYM: rows of Sigma up to the end of the diagonal block
 
     // ---- operand fetch.  Full K tiles are fetched without any bounds test: row / column indices beyond the matrix are
     //      clamped to valid addresses (the garbage only reaches rows / columns that are never stored), so the main loop
@@ -180,6 +186,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
 #pragma unroll
         for (int h = 0; h < 4; ++h) *reinterpret_cast<double2*>(&Bs[buf][(b_k + 4 * h) * LDB + b_col]) = breg[h];
     };
+    // SYM: weights of the Sigma tile rows k0 + b_k + 4 h inside the diagonal block (applied to breg before staging)
+    auto weight_diagonal = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int p = k0 + b_k + 4 * h, c = n0 + b_col;
+            breg[h].x *= p < c ? 2.0 : (p == c ? 1.0 : 0.0);
+            breg[h].y *= p < c + 1 ? 2.0 : (p == c + 1 ? 1.0 : 0.0);
+        }
+    };
 
     double4_t acc[4][4];
 #pragma unroll
@@ -214,27 +229,53 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
 #undef SHG_MFMA16
     };
 
-    const int nfull = P.K / BK;
-    const bool has_tail = (P.K % BK) != 0;
+    const int nfull = Keff / BK;
+    const bool has_tail = (Keff % BK) != 0;
+    const int tdiag = n0 / BK;                         // SYM: first K tile of the diagonal block
     if (nfull > 0)
         fetch_full(0);
     else
         fetch_tail(0);
+    if (SYM && tdiag == 0) weight_diagonal(0);
     stage(0);
     __syncthreads();
     for (int t = 0; t + 1 < nfull; ++t) {             // branch-free steady state
         fetch_full((t + 1) * BK);
+        if (SYM && t == tdiag && t > 0) {              // all rows above the diagonal block are accumulated: they count twice
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] *= 2.0;
+        }
         compute(t & 1);
+        if (SYM && t + 1 >= tdiag) weight_diagonal((t + 1) * BK);
         stage((t + 1) & 1);
         __syncthreads();
     }
     if (nfull > 0) {
         if (has_tail) fetch_tail(nfull * BK);
+        if (SYM && nfull - 1 == tdiag && tdiag > 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] *= 2.0;
+        }
         compute((nfull - 1) & 1);
-        if (has_tail) stage(nfull & 1);
+        if (has_tail) {
+            if (SYM) weight_diagonal(nfull * BK);
+            stage(nfull & 1);
+        }
         __syncthreads();
     }
-    if (has_tail) compute(nfull & 1);
+    if (has_tail) {
+        if (SYM && nfull == tdiag && tdiag > 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] *= 2.0;
+        }
+        compute(nfull & 1);
+    }
     __syncthreads();
 
     // ---- epilogue.  C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
@@ -335,7 +376,7 @@ int covprop_build_cs_table(shg_plan* p, hipStream_t stream) {
     return SHG_OK;
 }
 
-static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream) {
+static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream, bool symmetric = false) {
     const dim3 grid = mode == MODE_PLAIN ? dim3(ceil_div(P.N, BN), ceil_div(P.M, BM)) : dim3(ceil_div(P.M, BM), ceil_div(P.N, BN));
     const size_t lds = (size_t)(2 * BM * LDA + 2 * BK * LDB) * sizeof(double);      // 71.7 KB: two blocks per CU
     // 16-byte operand loads need even leading dimensions / sizes and 16-byte aligned bases
@@ -349,7 +390,14 @@ static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream) {
     if (mode == MODE_PLAIN) {
         if (vec) SHG_GEMM_LAUNCH(MODE_PLAIN, true); else SHG_GEMM_LAUNCH(MODE_PLAIN, false);
     } else {
-        if (vec) SHG_GEMM_LAUNCH(MODE_COVPROP, true); else SHG_GEMM_LAUNCH(MODE_COVPROP, false);
+        if (symmetric) {
+            SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_COVPROP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((gemm_f64_kernel<MODE_COVPROP, false, true>), grid, dim3(256), lds, stream, P);
+        } else if (vec) {
+            SHG_GEMM_LAUNCH(MODE_COVPROP, true);
+        } else {
+            SHG_GEMM_LAUNCH(MODE_COVPROP, false);
+        }
     }
 #undef SHG_GEMM_LAUNCH
     SHG_HIP(hipGetLastError());
@@ -359,7 +407,7 @@ static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream) {
 // sigma[r] = sqrt(a_r^T Sigma a_r) for M rows whose A entries are products of two table entries
 int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
                     long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
-                    hipStream_t stream) {
+                    hipStream_t stream, bool symmetric) {
     GemmParams G = {};
     G.M = M;
     G.N = Pn;
@@ -378,7 +426,7 @@ int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, con
     G.partial = partial;
     {
         ProfileScope ps(prof, 3, stream);
-        int rc = launch_gemm(MODE_COVPROP, G, stream);
+        int rc = launch_gemm(MODE_COVPROP, G, stream, symmetric);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(covprop_reduce_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, stream, M, ceil_div(Pn, BN), partial, sigma);
@@ -428,7 +476,59 @@ extern "C" int shg_dense_filter(const double* W, int Pn, const double* X, int T,
     return shg_dgemm(Pn, T, Pn, W, Pn, X, T, Y, T, stream_);
 }
 
+static int covprop_diag_impl(shg_plan* p, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream_, bool symmetric);
+
 extern "C" int shg_covprop_diag(shg_plan* p, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream_) {
+    return covprop_diag_impl(p, cov, nmin, lat0, lat1, sigma, stream_, false);
+}
+
+extern "C" int shg_covprop_diag_symmetric(shg_plan* p, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream_) {
+    return covprop_diag_impl(p, cov, nmin, lat0, lat1, sigma, stream_, true);
+}
+
+namespace shg {
+// max |S[p][c] - S[c][p]| over 32 x 32 tile pairs (upper tiles compared with their mirror images through LDS)
+__global__ __launch_bounds__(256) void symmetry_defect_kernel(int n, const double* __restrict__ S, int ld, double* __restrict__ out) {
+    __shared__ double tile[32][33];
+    __shared__ double red[256];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    double worst = 0.0;
+    if (bj >= bi) {
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int k = ty; k < 32; k += 8) {
+            const int r = bj * 32 + k, c = bi * 32 + tx;                 // mirror tile (bj, bi), row r, column c
+            tile[k][tx] = (r < n && c < n) ? S[(size_t)r * ld + c] : 0.0;
+        }
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8) {
+            const int r = bi * 32 + k, c = bj * 32 + tx;
+            if (r < n && c < n) worst = fmax(worst, fabs(S[(size_t)r * ld + c] - tile[tx][k]));
+        }
+    }
+    red[threadIdx.x] = worst;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0] > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(red[0]));
+}
+}  // namespace shg
+
+extern "C" int shg_symmetry_defect(const double* S, int n, int ld, double* defect, void* stream_) {
+    SHG_REQUIRE(n >= 0 && ld >= n, "shg_symmetry_defect: bad size");
+    SHG_REQUIRE(defect != nullptr, "shg_symmetry_defect: NULL output");
+    hipStream_t stream = (hipStream_t)stream_;
+    SHG_HIP(hipMemsetAsync(defect, 0, sizeof(double), stream));
+    if (n == 0) return SHG_OK;
+    SHG_REQUIRE(S != nullptr, "shg_symmetry_defect: NULL matrix");
+    const int nt = ceil_div(n, 32);
+    hipLaunchKernelGGL(shg::symmetry_defect_kernel, dim3(nt, nt), dim3(256), 0, stream, n, S, ld, defect);     // non-negative doubles order like their bit patterns
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+static int covprop_diag_impl(shg_plan* p, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream_, bool symmetric) {
     SHG_REQUIRE(p != nullptr, "shg_covprop_diag: NULL plan");
     SHG_REQUIRE(nmin >= 0 && nmin <= p->N + 1, "shg_covprop_diag: min_degree %d out of range", nmin);
     SHG_REQUIRE(lat0 >= 0 && lat1 <= p->nlat && lat0 <= lat1, "shg_covprop_diag: bad band [%d, %d)", lat0, lat1);
@@ -471,7 +571,7 @@ extern "C" int shg_covprop_diag(shg_plan* p, const double* cov, int nmin, int la
     // Two kernels: covprop_rows (covprop.hip) keeps row tiles inside one parallel (operand tiles are plain table rows) but
     // pads every parallel to a multiple of 128 meridians; the general kernel generates A element-wise and wastes nothing.
     const int padded = round_up(p->nlon, 128);
-    if ((padded - p->nlon) * 25 <= p->nlon) {                 // padding waste <= 4 %
+    if (!symmetric && (padded - p->nlon) * 25 <= p->nlon) {   // padding waste <= 4 %
         rc = covprop_rows(p, cov, Pn, nmin * nmin, lat0, lat1, p->cov_partial, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(covprop_reduce_kernel, dim3(ceil_div((int)M, 256)), dim3(256), 0, stream, (int)M, ncolblocks, p->cov_partial, sigma);
@@ -479,5 +579,5 @@ extern "C" int shg_covprop_diag(shg_plan* p, const double* cov, int nmin, int la
         return SHG_OK;
     }
     return covprop_generic(p->pk_deg, Pfull, p->cs_slot, p->nlon, p->rslot, p->nlon, p->nlon, (long long)lat0 * p->nlon, (int)M, cov, Pn,
-                           nmin * nmin, p->cov_partial, sigma, p, stream);
+                           nmin * nmin, p->cov_partial, sigma, p, stream, symmetric);
 }

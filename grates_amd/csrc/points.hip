@@ -122,7 +122,7 @@ __global__ void covprop_point_tables_kernel(int N, int npts, const double* __res
 
 int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
                     long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
-                    hipStream_t stream);
+                    hipStream_t stream, bool symmetric);
 
 }  // namespace shg
 
@@ -170,7 +170,7 @@ extern "C" int shg_covprop_points(int N, const double* colat, const double* lon,
         hipMallocAsync((void**)&partial, (size_t)ncolblocks * npts * sizeof(double), stream) != hipSuccess)
         return fail(SHG_ERR_NOMEM, "shg_covprop_points: workspace allocation failed");
     hipLaunchKernelGGL(covprop_point_tables_kernel, dim3(ceil_div(npts, 64)), dim3(64), 0, stream, N, npts, colat, lon, kn, pkd, csr, rslot);
-    int rc = covprop_generic(pkd, Pfull, csr, npts, rslot, 1, (long long)1 << 40, 0, npts, cov, Pn, nmin * nmin, partial, sigma, nullptr, stream);
+    int rc = covprop_generic(pkd, Pfull, csr, npts, rslot, 1, (long long)1 << 40, 0, npts, cov, Pn, nmin * nmin, partial, sigma, nullptr, stream, false);
     (void)hipFreeAsync(pkd, stream);
     (void)hipFreeAsync(csr, stream);
     (void)hipFreeAsync(rslot, stream);

@@ -133,8 +133,12 @@ class Plan:
             _lib.call('shg_synthesis', self._handle, _ptr(x), B, _ptr(out), _stream())
         return out[0] if single else out
 
-    def covariance_propagation(self, cov, min_degree, lat0=0, lat1=None):
-        """cov [P, P] degree-wise -> sigma [(lat1-lat0)*nlon] for the band of parallels [lat0, lat1)."""
+    def covariance_propagation(self, cov, min_degree, lat0=0, lat1=None, symmetric=False):
+        """cov [P, P] degree-wise -> sigma [(lat1-lat0)*nlon] for the band of parallels [lat0, lat1).
+
+        symmetric: False (default) multiplies with the full matrix like the reference; True reads only the upper triangle
+        of a symmetric matrix (half the MFMA work); None checks the matrix on the device and takes the shortcut when it is
+        exactly symmetric (the result then differs from the general path by summation order only)."""
         torch = _torch()
         lat1 = self.nlat if lat1 is None else lat1
         c = to_device(cov, self.device)
@@ -143,7 +147,12 @@ class Plan:
             raise ValueError('covariance matrix must have shape ({0}, {0}), got {1}'.format(P, tuple(c.shape)))
         out = torch.empty(((lat1 - lat0) * self.nlon,), dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.call('shg_covprop_diag', self._handle, _ptr(c), int(min_degree), int(lat0), int(lat1), _ptr(out), _stream())
+            if symmetric is None:
+                defect = torch.zeros(1, dtype=torch.float64, device=self.device)
+                _lib.call('shg_symmetry_defect', _ptr(c), P, P, _ptr(defect), _stream())
+                symmetric = float(defect.item()) == 0.0
+            _lib.call('shg_covprop_diag_symmetric' if symmetric else 'shg_covprop_diag', self._handle, _ptr(c), int(min_degree), int(lat0), int(lat1),
+                      _ptr(out), _stream())
         return out
 
     def analysis(self, grid, area, min_degree):

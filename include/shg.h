@@ -118,6 +118,12 @@ int shg_unravel(const double* vec, int B, int nmin, int nmax, double* arr /* [B]
  *   The A rows are generated on the fly (never materialised); A*Sigma runs on v_mfma_f64_16x16x4_f64.
  * ------------------------------------------------------------------------------------------------ */
 int shg_covprop_diag(shg_plan* plan, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream);
+/* The same for a symmetric Sigma of which only the upper triangle is read: half of the MFMA work
+ *   sigma2 = sum_c [ sum_{p<c} 2 a_p Sigma_pc + a_c Sigma_cc ] a_c
+ * (an extension; the reference multiplies with the full matrix, grates/grid.py:833).  shg_symmetry_defect writes
+ * max |S[p][c] - S[c][p]| to *defect (device double): 0 means the shortcut reproduces the general result up to summation order. */
+int shg_covprop_diag_symmetric(shg_plan* plan, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream);
+int shg_symmetry_defect(const double* S, int n, int ld, double* defect, void* stream);
 
 /* Point-list variant  (grates/grid.py:1096-1120): colat, lon [npts]; kn [npts][N+1]; sigma [npts] */
 int shg_covprop_points(int N, const double* colat, const double* lon, const double* kn, int npts,

@@ -107,3 +107,28 @@ def test_row_tiled_kernel_on_128_multiple_grid():
     ref = orc.covariance_propagation_regular(cov, nmin, N, mer, par, orc.KernelTable('potential'))
     s = grid.covariance_propagation(cov, nmin, N, kernel='potential')
     assert relerr(s, ref) < TOL_SIGMA
+
+
+@pytest.mark.parametrize('N,step,nmin', [(20, 5.0, 0), (40, 2.0, 2), (60, 3.0, 0)])
+def test_symmetric_shortcut_matches_general_path(N, step, nmin):
+    """the upper-triangle variant (half the MFMA work) against the general kernel and, for an exactly symmetric
+    matrix, the automatic choice; a non-symmetric matrix keeps the general path under symmetric=None"""
+    import torch
+    grid = ga.grid.GeographicGrid(step, step)
+    P = (N + 1) ** 2 - nmin ** 2
+    cov = inputs.spd_covariance(21, P)
+    cov = 0.5 * (cov + cov.T)
+    full = grid.covariance_propagation(cov, nmin, N, kernel='ewh')
+    sym = grid.covariance_propagation(cov, nmin, N, kernel='ewh', symmetric=True)
+    auto = grid.covariance_propagation(cov, nmin, N, kernel='ewh', symmetric=None)
+    assert relerr(sym, full) < 1e-13
+    np.testing.assert_array_equal(auto, sym)
+    # only the upper triangle is read
+    junk = np.triu(cov) + np.tril(np.full_like(cov, 1e30), -1)
+    assert relerr(grid.covariance_propagation(junk, nmin, N, kernel='ewh', symmetric=True), full) < 1e-13
+    skew = cov.copy()
+    skew[0, 1] *= 1.0 + 1e-9
+    np.testing.assert_array_equal(grid.covariance_propagation(skew, nmin, N, kernel='ewh', symmetric=None),
+                                  grid.covariance_propagation(skew, nmin, N, kernel='ewh'))
+    band = grid.covariance_propagation(cov, nmin, N, kernel='ewh', parallel_range=(3, 11), symmetric=True)
+    assert relerr(band, full.reshape(grid.parallels.size, -1)[3:11].ravel()) < 1e-13
