@@ -19,6 +19,11 @@
 
 #include "common.h"
 
+#ifndef SHG_STORE_AUX
+#define SHG_STORE_AUX 2          // cache policy bits of the grid stores: 2 = nt (streaming data, not re-read: 3 % faster than 0;
+                                // 1 = sc0 and 16 = sc1 measured slower)
+#endif
+
 namespace shg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -500,8 +505,8 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
                     const bool ascending = t == 0 || t == 3;
                     const double2_t va = ascending ? (double2_t){a_lo, a_hi} : (double2_t){a_hi, a_lo};
                     const double2_t vb = ascending ? (double2_t){b_lo, b_hi} : (double2_t){b_hi, b_lo};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, va), rsrc, pair_off_a + pair_col[t], 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, vb), rsrc, pair_off_b + pair_col[t], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, va), rsrc, pair_off_a + pair_col[t], 0, SHG_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, vb), rsrc, pair_off_b + pair_col[t], 0, SHG_STORE_AUX);
                 }
             } else {
                 const int j = jt + fr;
