@@ -306,9 +306,9 @@ __global__ __launch_bounds__(256, 2) void synthesis_fused32_kernel(Fused32Params
                         else { col = P.nlon / 2 + jc; ascending = true; }
                         const double2_t vn = ascending ? (double2_t){n_lo, n_hi} : (double2_t){n_hi, n_lo};
                         const double2_t vs = ascending ? (double2_t){s_lo, s_hi} : (double2_t){s_hi, s_lo};
-                        if (ok) {
-                            *reinterpret_cast<double2_t*>(rown + col) = vn;
-                            *reinterpret_cast<double2_t*>(rows + col) = vs;
+                        if (ok) {                                         // streaming data: non-temporal stores
+                            __builtin_nontemporal_store(vn, reinterpret_cast<double2_t*>(rown + col));
+                            __builtin_nontemporal_store(vs, reinterpret_cast<double2_t*>(rows + col));
                         }
                     }
                 } else {
