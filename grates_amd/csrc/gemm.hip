@@ -71,67 +71,105 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     // PLAIN A: 128 rows x 8 pieces of 2 doubles; piece h of a thread: row = (tid >> 3) + 32 h, k = (tid & 7) * 2
     // COVPROP A: element h of a thread: row = tid & 127 (fixed), k = (tid >> 7) + 2 h, generated from two small tables
     // B: 16 k-rows x 64 pieces of 2 doubles; piece h: k = (tid >> 6) + 4 h, col = (tid & 63) * 2
+    // Addressing: fp64 MFMAs and the VALU instructions of all waves of a SIMD share one issue pipe (tools/mfma64_issue.hip),
+    // so the K loop keeps address arithmetic on the scalar unit: every load is "uniform 64-bit base (advanced per K tile by
+    // scalar instructions) + per-lane 32-bit byte offset (fixed for the whole kernel)".
     double areg[8];
     double creg[8];             // COVPROP: cos/sin factors; the product with areg is formed when the tile is staged, i.e.
                                 // after the MFMAs of the current tile, so that the loads stay in flight across them
     double2 breg[4];
     const int a_kk = (tid & 7) * 2;
-    const double* a_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    const int b_k = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform first k row of the B pieces
+    const int b_col = (tid & 63) * 2;
+    // (the empty asm pins the uniform base in scalar registers -- without it the compiler folds base + lane offset into one
+    //  loop-invariant 64-bit vector address and adds the scalar part with a VALU instruction per load; the address goes
+    //  through an integer, so the pointer is rebuilt in the global address space explicitly.  The 32 -> 64 bit extension of
+    //  the lane offset has to stay in the basic block of the load for the scalar-base form to be selected: `pin` below.)
+    auto pin = [](unsigned v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    typedef const double __attribute__((address_space(1))) gdouble_t;
+    typedef const char __attribute__((address_space(1))) gbyte_t;
+    typedef int __attribute__((address_space(4))) crank_t;
+    typedef double gdouble2_v __attribute__((ext_vector_type(2)));
+    typedef const gdouble2_v __attribute__((address_space(1))) gdouble2_t;
+    auto at = [](const double* base, unsigned byte_off) {
+        unsigned long long b = reinterpret_cast<unsigned long long>(base);
+        asm volatile("" : "+s"(b));
+        return *reinterpret_cast<gdouble_t*>(reinterpret_cast<gbyte_t*>(b) + byte_off);
+    };
+    auto at2 = [](const double* base, unsigned byte_off) {
+        unsigned long long b = reinterpret_cast<unsigned long long>(base);
+        asm volatile("" : "+s"(b));
+        const gdouble2_v v = *reinterpret_cast<gdouble2_t*>(reinterpret_cast<gbyte_t*>(b) + byte_off);
+        return make_double2(v.x, v.y);
+    };
+    // PLAIN A: per-lane offsets of the four row pieces relative to row m0 (clamped rows stay inside the matrix)
+    unsigned a_voff[4] = {0, 0, 0, 0};
+    const double* a_base = nullptr;                                  // uniform: &A[m0][0]
     if (MODE == MODE_PLAIN) {
+        a_base = P.A + (size_t)m0 * P.lda;
 #pragma unroll
-        for (int h = 0; h < 4; ++h) a_ptr[h] = P.A + (size_t)min(m0 + (tid >> 3) + 32 * h, P.M - 1) * P.lda + a_kk;
+        for (int h = 0; h < 4; ++h) a_voff[h] = (unsigned)(((size_t)(min(m0 + (tid >> 3) + 32 * h, P.M - 1) - m0) * P.lda + a_kk) * 8);
     }
-    const double* cov_pk = nullptr;
-    const double* cov_cs = nullptr;
-    int cov_deg = 0;     // degree of the first degree-wise index of the K tile being fetched (tracked incrementally)
+    // COVPROP A: per-lane offsets into the two tables
+    unsigned pk_voff = 0, cs_voff = 0;
+    const double* pk_base = nullptr;                                 // uniform: table row of the block's first grid row
     if (MODE == MODE_COVPROP) {
         const long long R = P.row0 + min(m0 + (tid & 127), P.M - 1);
-        cov_pk = P.pkd + (R / P.idiv) * P.ldp + P.p_off;
-        cov_cs = P.csr + (R % P.jmod);
+        // (64-bit division runs on the vector unit even for uniform operands: readfirstlane brings the quotient back)
+        const int gi0 = __builtin_amdgcn_readfirstlane((int)((P.row0 + m0) / P.idiv));
+        pk_base = P.pkd + (size_t)gi0 * P.ldp + P.p_off;
+        pk_voff = (unsigned)((R / P.idiv - gi0) * P.ldp * 8);        // at most 127 table rows
+        cs_voff = (unsigned)((R % P.jmod) * 8);
     }
-    const int b_k = tid >> 6;
-    const int b_col = (tid & 63) * 2;
-    const int b_c0 = VEC ? min(n0 + b_col, P.N - 2) : min(n0 + b_col, P.N - 1);
-    const int b_c1 = min(n0 + b_col + 1, P.N - 1);
-    const double* b_ptr0 = P.B + b_c0;
-    const double* b_ptr1 = P.B + b_c1;
+    const unsigned b_voff0 = (unsigned)((VEC ? min(n0 + b_col, P.N - 2) : min(n0 + b_col, P.N - 1)) * 8);
+    const unsigned b_voff1 = (unsigned)(min(n0 + b_col + 1, P.N - 1) * 8);
 
+    // COVPROP: ranks (inside their degree) of the eight degree-wise indices a thread generates in the next K tile, read from
+    // the rank table with scalar loads (constant address space: uniform loads from it are scalar loads)
+    int rank[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_ranks = [&](int k0) {
+        const crank_t* rs = reinterpret_cast<const crank_t*>(reinterpret_cast<unsigned long long>(P.rslot));
+#pragma unroll
+        for (int h = 0; h < 8; ++h) rank[h] = rs[min(k0 + P.p_off + khalf + 2 * h, P.ldp - 1)];
+    };
+    if (MODE == MODE_COVPROP) load_ranks(0);
     auto fetch_full = [&](int k0) {
         if (MODE == MODE_PLAIN) {
+            const double* ak = a_base + k0;                           // uniform
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
+                const unsigned off = pin(a_voff[h]);
                 if (VEC) {
-                    const double2 t = *reinterpret_cast<const double2*>(a_ptr[h] + k0);
+                    const double2 t = at2(ak, off);
                     areg[2 * h] = t.x;
                     areg[2 * h + 1] = t.y;
                 } else {
-                    areg[2 * h] = a_ptr[h][k0];
-                    areg[2 * h + 1] = a_ptr[h][k0 + 1];
+                    areg[2 * h] = at(ak, off);
+                    areg[2 * h + 1] = at(ak + 1, off);
                 }
             }
         } else {
-            // degree-wise index p = n^2 + r: the rank r inside the degree selects the cos/sin row (derived arithmetically)
-            const int p0 = k0 + P.p_off;
-            while ((cov_deg + 1) * (cov_deg + 1) <= p0) ++cov_deg;
-            int n = cov_deg, r = p0 + khalf - cov_deg * cov_deg;
+            // degree-wise index p = n^2 + r: the rank r inside the degree selects the cos/sin row (table lookup on the scalar unit)
+            const double* pk = pk_base + k0 + khalf;                  // uniform
+            const unsigned poff = pin(pk_voff), coff = pin(cs_voff);
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                while (r > 2 * n) {
-                    r -= 2 * n + 1;
-                    ++n;
-                }
-                areg[h] = cov_pk[k0 + 2 * h + khalf];
-                creg[h] = cov_cs[(size_t)r * P.ldcs];
-                r += 2;
+                areg[h] = at(pk + 2 * h, poff);
+                creg[h] = at(P.csr + (size_t)rank[h] * P.ldcs, coff);
             }
+            load_ranks(k0 + BK);                                      // for the next K tile: a whole tile ahead of their use
         }
+        const unsigned boff0 = pin(b_voff0), boff1 = pin(b_voff1);
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const size_t row = (size_t)(k0 + b_k + 4 * h) * P.ldb;
+            const double* brow = P.B + (size_t)(k0 + b_k + 4 * h) * P.ldb;      // uniform
             if (VEC)
-                breg[h] = *reinterpret_cast<const double2*>(b_ptr0 + row);
+                breg[h] = at2(brow, boff0);
             else
-                breg[h] = make_double2(b_ptr0[row], b_ptr1[row]);
+                breg[h] = make_double2(at(brow, boff0), at(brow, boff1));
         }
     };
     // last partial K tile: same addresses with k clamped, entries beyond K zeroed
@@ -139,34 +177,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
         if (MODE == MODE_PLAIN) {
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const int k1 = k0 + a_kk;                               // a_ptr already points at column a_kk
-                const double v0 = a_ptr[h][min(k1, P.K - 1) - a_kk];
-                const double v1 = a_ptr[h][min(k1 + 1, P.K - 1) - a_kk];
+                const int k1 = k0 + a_kk;                               // a_voff already points at column a_kk
+                const double* arow = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a_base) + a_voff[h]) - a_kk;     // per lane
+                const double v0 = arow[min(k1, P.K - 1)];
+                const double v1 = arow[min(k1 + 1, P.K - 1)];
                 areg[2 * h] = k1 < P.K ? v0 : 0.0;
                 areg[2 * h + 1] = k1 + 1 < P.K ? v1 : 0.0;
             }
         } else {
-            const int p0 = k0 + P.p_off;
-            while ((cov_deg + 1) * (cov_deg + 1) <= p0) ++cov_deg;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
                 const int gk = k0 + 2 * h + khalf;
                 const int kc = min(gk, P.K - 1);
-                int n = cov_deg, r = kc + P.p_off - cov_deg * cov_deg;
-                while (r > 2 * n) {
-                    r -= 2 * n + 1;
-                    ++n;
-                }
-                areg[h] = gk < P.K ? cov_pk[kc] : 0.0;
-                creg[h] = cov_cs[(size_t)r * P.ldcs];
+                areg[h] = gk < P.K ? at(pk_base + kc, pk_voff) : 0.0;
+                creg[h] = at(P.csr + (size_t)reinterpret_cast<const crank_t*>(reinterpret_cast<unsigned long long>(P.rslot))[kc + P.p_off] * P.ldcs, cs_voff);
             }
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int gk = k0 + b_k + 4 * h;
-            const size_t row = (size_t)min(gk, P.K - 1) * P.ldb;
-            const double x = b_ptr0[row];
-            const double y = VEC ? b_ptr0[row + 1] : b_ptr1[row];
+            const double* brow = P.B + (size_t)min(gk, P.K - 1) * P.ldb;
+            const double x = at(brow, b_voff0);
+            const double y = VEC ? at(brow + 1, b_voff0) : at(brow, b_voff1);
             breg[h] = gk < P.K ? make_double2(x, y) : make_double2(0.0, 0.0);
         }
     };
@@ -239,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     if (SYM && tdiag == 0) weight_diagonal(0);
     stage(0);
     __syncthreads();
-    for (int t = 0; t + 1 < nfull; ++t) {             // branch-free steady state
+    // branch-free steady state, two K tiles per trip so that the LDS buffer of every access is a literal
+    auto step = [&](int t, int buf) {
         fetch_full((t + 1) * BK);
         if (SYM && t == tdiag && t > 0) {              // all rows above the diagonal block are accumulated: they count twice
 #pragma unroll
@@ -247,11 +280,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] *= 2.0;
         }
-        compute(t & 1);
+        compute(buf);
         if (SYM && t + 1 >= tdiag) weight_diagonal((t + 1) * BK);
-        stage((t + 1) & 1);
+        stage(buf ^ 1);
         __syncthreads();
+    };
+    int t = 0;
+    for (; t + 2 < nfull; t += 2) {
+        step(t, 0);
+        step(t + 1, 1);
     }
+    if (t + 1 < nfull) step(t, 0);                     // t is even here
     if (nfull > 0) {
         if (has_tail) fetch_tail(nfull * BK);
         if (SYM && nfull - 1 == tdiag && tdiag > 0) {
