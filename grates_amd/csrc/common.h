@@ -36,6 +36,33 @@ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __host__ __device__ inline int order_offset(int N, int m) { return m * (N + 1) - (m * (m - 1)) / 2; }
 __host__ __device__ inline int packed_count(int N) { return (N + 1) * (N + 2) / 2; }
 
+// Exchange between the lanes 2q and 2q+1 that turns "4 rows x 1 column per lane" into "2 rows x 2 adjacent columns per lane":
+//   even lanes: lo = x (own),                  hi = x of the odd neighbour
+//   odd lanes:  lo = y of the even neighbour,  hi = y (own)
+// One v_cndmask_b32 with a DPP source (quad_perm [1, 0, 3, 2]) per 32-bit half: the select of the value to send, the DPP move
+// and the select of the received value collapse into one instruction.  fp64 MFMAs and VALU instructions of all waves
+// of a SIMD share one issue pipe (tools/mfma64_issue.hip), so every VALU instruction saved here is MFMA time.
+// `odd` = lane mask of the odd lanes.  All lanes must be active.
+__device__ inline void pair_exchange(double x, double y, unsigned long long odd, double& lo, double& hi) {
+    const long long xb = __builtin_bit_cast(long long, x), yb = __builtin_bit_cast(long long, y);
+    const int x0 = (int)xb, x1 = (int)(xb >> 32), y0 = (int)yb, y1 = (int)(yb >> 32);
+    int l0, l1, h0, h1;
+    asm volatile(
+        "s_nop 1\n\t"                                                   // VALU write -> DPP read of the same VGPR: 2 wait states
+        "s_mov_b64 vcc, %[odd]\n\t"
+        "v_cndmask_b32_dpp %[h0], %[x0], %[y0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // odd ? y : x of the neighbour
+        "v_cndmask_b32_dpp %[h1], %[x1], %[y1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %[l0], %[y0], %[x0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"     // even ? x : y of the neighbour
+        "v_cndmask_b32_dpp %[l1], %[y1], %[x1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : [l0] "=&v"(l0), [l1] "=&v"(l1), [h0] "=&v"(h0), [h1] "=&v"(h1)
+        : [x0] "v"(x0), [x1] "v"(x1), [y0] "v"(y0), [y1] "v"(y1), [odd] "s"(odd)
+        : "vcc", "scc");
+    lo = __builtin_bit_cast(double, ((long long)l1 << 32) | (unsigned int)l0);
+    hi = __builtin_bit_cast(double, ((long long)h1 << 32) | (unsigned int)h0);
+}
+
+
 constexpr int kEpochTile = 8;    // epochs handled together by one wave of the Legendre stage
 constexpr int kLatTile = 64;     // parallels per wave of the Legendre stage (lane <-> parallel)
 

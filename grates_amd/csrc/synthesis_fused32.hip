@@ -67,13 +67,6 @@ struct Fused32Params {
     double* G;
 };
 
-__device__ inline double swap_lane1(double x) {                     // lane ^ 1 (DPP quad_perm [1, 0, 3, 2])
-    const long long bits = __builtin_bit_cast(long long, x);
-    const int lo = (int)bits, hi = (int)(bits >> 32);
-    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
-    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned int)lo2);
-}
 __device__ inline double swap_lane8(double x) {                     // lane +- 8 inside the row of 16 (DPP row_ror:8)
     const long long bits = __builtin_bit_cast(long long, x);
     const int lo = (int)bits, hi = (int)(bits >> 32);
@@ -294,10 +287,9 @@ __global__ __launch_bounds__(256, 2) void synthesis_fused32_kernel(Fused32Params
                     double* rows = P.G + ((size_t)(ok ? b : 0) * P.nlat + (ok ? isouth : 0)) * P.nlon;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const double r0 = swap_lane1(par ? img[t][0] : img[t][2]);
-                        const double r1 = swap_lane1(par ? img[t][1] : img[t][3]);
-                        const double n_lo = par ? r0 : img[t][0], n_hi = par ? img[t][2] : r0;
-                        const double s_lo = par ? r1 : img[t][1], s_hi = par ? img[t][3] : r1;
+                        double n_lo, n_hi, s_lo, s_hi;
+                        pair_exchange(img[t][0], img[t][2], 0xAAAAAAAAAAAAAAAAull, n_lo, n_hi);
+                        pair_exchange(img[t][1], img[t][3], 0xAAAAAAAAAAAAAAAAull, s_lo, s_hi);
                         int col;
                         bool ascending;
                         if (t == 0) { col = jc; ascending = true; }
