@@ -90,6 +90,12 @@ struct shg_plan {
     double* arec = nullptr;     // [packed] recursion factor a_nm
     double* brec = nullptr;     // [packed] recursion factor b_nm
     double* trig = nullptr;     // [ncoltiles][K][16] cos/sin table, column-tile major
+    // 64-row fused kernel: order 0 (constant along a parallel) leaves the K loop and becomes the start value of the cosine /
+    // even-order accumulators, when that saves a body of 16 slots (d/o 96: 13 -> 12 bodies).  Slot K_f of the panel holds it.
+    bool fold0 = false;
+    int goff_f[5] = {0, 0, 0, 0, 0};
+    int K_f = 0;
+    double* trig_f = nullptr;   // [ncoltiles][K_f][16]
     double* lon = nullptr;      // [nlon]
     double* colat = nullptr;    // [nlat]
     // covariance-propagation tables (built lazily)

@@ -259,8 +259,34 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
         }
     }
 
+    // the same table without order 0 (see fold0 in common.h)
+    std::vector<double> trig_f;
+    if (p->sym4) {
+        const int cnt_f[4] = {N / 2, (N + 1) / 2, N / 2, (N + 1) / 2};
+        p->goff_f[0] = 0;
+        for (int g = 0; g < 4; ++g) p->goff_f[g + 1] = p->goff_f[g] + round_up(cnt_f[g], 16);
+        p->K_f = p->goff_f[4];
+        p->fold0 = p->K_f < p->K;
+        if (p->fold0) {
+            trig_f.assign(((size_t)round_up(p->ncoltiles, 8) * p->K_f + 16) * 16, 0.0);
+            for (int m = 1; m <= N; ++m)
+                for (int sine = 0; sine < 2; ++sine) {
+                    int slot;
+                    if (!sine) {
+                        if (m & 1) slot = p->goff_f[1] + m / 2; else slot = p->goff_f[0] + m / 2 - 1;
+                    } else {
+                        if (m & 1) slot = p->goff_f[3] + m / 2; else slot = p->goff_f[2] + m / 2 - 1;
+                    }
+                    for (int j = 0; j < p->ncol; ++j) {
+                        const double arg = (double)m * lon_h[j];
+                        trig_f[((size_t)(j / 16) * p->K_f + slot) * 16 + (j % 16)] = sine ? std::sin(arg) : std::cos(arg);
+                    }
+                }
+        }
+    }
+
     int rc = SHG_OK;
-    if ((rc = upload(&p->ct, ct)) || (rc = upload(&p->st, st)) || (rc = upload(&p->pmm, pmm)) ||
+    if ((p->fold0 && (rc = upload(&p->trig_f, trig_f))) || (rc = upload(&p->ct, ct)) || (rc = upload(&p->st, st)) || (rc = upload(&p->pmm, pmm)) ||
         (rc = upload(&p->knT, knT)) || (rc = upload(&p->arec, a)) || (rc = upload(&p->brec, b)) ||
         (rc = upload(&p->trig, trig)) ||
         (rc = upload(&p->lon, std::vector<double>(lon_h, lon_h + nlon))) ||
@@ -274,7 +300,7 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
 
 extern "C" int shg_plan_destroy(shg_plan* p) {
     if (!p) return SHG_OK;
-    double* ptrs[] = {p->ct, p->st, p->pmm, p->knT, p->arec, p->brec, p->trig, p->lon, p->colat,
+    double* ptrs[] = {p->ct, p->st, p->pmm, p->knT, p->arec, p->brec, p->trig, p->trig_f, p->lon, p->colat,
                       p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->pkf, p->pkf32, p->cpk4, p->cov_partial, p->panel, p->ana_H};
     if (p->rslot) (void)hipFree(p->rslot);
     if (p->qoff) (void)hipFree(p->qoff);

@@ -197,6 +197,7 @@ struct FusedParams {
     int goff[5];              // first K slot of each (cos/sin, m even/odd) group; every group is a multiple of 16 slots
     int gcount[4];            // used slots per group (the rest up to goff[g+1] is zero padding)
     int ns, nh;               // north-south symmetric variant: blocks of 8 northern parallels + mirrors; nh = nlat / 2
+    int slot0;                // panel slot of order 0 when it is folded out of the K loop (start value of the accumulators), or -1
     int dbg;                  // experiment switches (SHG_DEBUG): 1 no stores, 2 no Legendre phase, 4 no longitude phase, 8 no longitude MFMAs
     int Qtot;                 // row octets of the fragment-ordered tables
     const int* qoff;          // [N+2]
@@ -420,6 +421,15 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) acc[gg][rt] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if (P.slot0 >= 0) {
+            // order 0 does not depend on the longitude: its panel entry is the start value of the cosine / even-order sums
+            // (C/D layout: row = fk + 4 reg of row tile rt, the same value in all 16 columns)
+            const double* z = As + (size_t)P.slot0 * kPanelStride + fk;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[0][rt][r] = z[rt * 16 + 4 * r];
+        }
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
             for (int body = P.goff[gg] >> 4; body < (P.goff[gg + 1] >> 4) && !(P.dbg & 8); ++body) {
@@ -677,8 +687,11 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, h
     for (int w = 0; w < 8; ++w) {
         for (int m = w; m <= N; m += 8) {
             const int cnt = N + 1 - m, q = (cnt + od - 1) / od;
-            const int slot_c = p->goff[m & 1] + (m >> 1);
-            const int slot_s = m >= 1 ? p->goff[2 + (m & 1)] + ((m & 1) ? (m >> 1) : (m >> 1) - 1) + 1 : 0;
+            // panel slots (+1 for the sine part, 0 = none).  With order 0 folded out of the K loop (fold0) it sits behind the groups.
+            const int* go = p->fold0 ? p->goff_f : p->goff;
+            const int even_shift = p->fold0 ? 1 : 0;
+            const int slot_c = m == 0 && p->fold0 ? p->K_f : go[m & 1] + (m >> 1) - ((m & 1) ? 0 : even_shift);
+            const int slot_s = m >= 1 ? go[2 + (m & 1)] + ((m & 1) ? (m >> 1) : (m >> 1) - 1) + 1 : 0;
             for (int j0 = 0; j0 < q; j0 += 2) {
                 const int o0 = qoff[m] + j0, o1 = o0 + (j0 + 1 < q ? 1 : 0);
                 const int flags = 1 | ((j0 + 1) * od < cnt ? 2 : 0) | (j0 + 2 >= q ? 4 : 0);
@@ -797,7 +810,9 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.nlat = p->nlat;
     P.nlon = p->nlon;
     P.ldlat = p->ldlat;
-    P.K = p->K;
+    const bool fold = p->fold0 && !two_kernel;        // the panel kernel of the two-kernel variant writes the unfolded layout
+    P.K = fold ? p->K_f : p->K;
+    P.slot0 = fold ? p->K_f : -1;
     P.ncol = p->ncol;
     P.B = B;
     P.nit = nit;
@@ -805,9 +820,9 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.nh = p->nlat / 2;
     P.Ppk = Ppk;
     P.ncb = ceil_div(p->ncoltiles, 8);
-    for (int g = 0; g < 5; ++g) P.goff[g] = p->goff[g];
+    for (int g = 0; g < 5; ++g) P.goff[g] = fold ? p->goff_f[g] : p->goff[g];
     const int N = p->N;
-    const int cnt[4] = {N / 2 + 1, (N + 1) / 2, N / 2, (N + 1) / 2};
+    const int cnt[4] = {N / 2 + (fold ? 0 : 1), (N + 1) / 2, N / 2, (N + 1) / 2};
     for (int g = 0; g < 4; ++g) P.gcount[g] = cnt[g];
     const char* dbg_env = getenv("SHG_DEBUG");
     P.dbg = dbg_env ? atoi(dbg_env) : 0;
@@ -825,13 +840,13 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
         if (rc) return rc;
         P.blockmap = p->blockmap_d;
     }
-    P.trig = p->trig;
+    P.trig = fold ? p->trig_f : p->trig;
     P.panel = nullptr;
     P.G = grid;
 #ifdef SHG_TIMELINE
     P.tl = getenv("SHG_TIMELINE_PTR") ? (unsigned long long*)strtoull(getenv("SHG_TIMELINE_PTR"), nullptr, 0) : nullptr;
 #endif
-    const size_t lds = fused_lds_bytes(p->K);
+    const size_t lds = fused_lds_bytes(fold ? p->K_f + 1 : p->K);
     const dim3 grid_dim((unsigned)(nbt * P.nit));
     if (two_kernel) {
         const size_t pneed = (size_t)2 * nbt8 * nit * p->K * 64;
