@@ -318,8 +318,10 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         const bool hi_ = arow && ((rec).w & 2);                                                                     \
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.x : 0.0, BLO.x, acc0, 0, 0, 0);                       \
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.y : 0.0, BLO.y, acc1, 0, 0, 0);                       \
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.x : 0.0, BHI.x, acc0, 0, 0, 0);                       \
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.y : 0.0, BHI.y, acc1, 0, 0, 0);                       \
+        if ((rec).w & 2) {                                  /* second octet present (uniform) */                    \
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.x : 0.0, BHI.x, acc0, 0, 0, 0);                   \
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.y : 0.0, BHI.y, acc1, 0, 0, 0);                   \
+        }                                                                                                           \
         if ((rec).w & 4) {                                  /* last item of an order */                             \
             /* C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15: reg 0 = cosine part of epoch (lane >> 4),  */ \
             /* reg 1 = sine part; panel row = epoch * 16 + parallel slot = lane.                                  */ \
@@ -675,7 +677,8 @@ int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream) {
     return SHG_OK;
 }
 
-// Work items of the Legendre stage per wave (8 waves; wave w serves the orders w, w + 8, ...): records
+// Work items of the Legendre stage per wave (8 waves; the orders are dealt to the waves longest first, each to the wave
+// with the fewest items so far): records
 //   x, y = first / second octet of the item in the fragment-ordered tables (y = x when the order has no second octet left)
 //   z    = panel slot of the cosine part | (panel slot of the sine part + 1) << 16   (0 in the upper half: order 0)
 //   w    = bit 0 item valid, bit 1 second octet valid, bit 2 last item of its order
@@ -684,8 +687,11 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, h
     const int N = p->N;
     std::vector<std::vector<int>> rec(8);
     size_t longest = 0;
-    for (int w = 0; w < 8; ++w) {
-        for (int m = w; m <= N; m += 8) {
+    for (int m = 0; m <= N; ++m) {                       // orders by decreasing length, each to the wave with the fewest items so far
+        {
+            int w = 0;
+            for (int v = 1; v < 8; ++v)
+                if (rec[v].size() < rec[w].size()) w = v;
             const int cnt = N + 1 - m, q = (cnt + od - 1) / od;
             // panel slots (+1 for the sine part, 0 = none).  With order 0 folded out of the K loop (fold0) it sits behind the groups.
             const int* go = p->fold0 ? p->goff_f : p->goff;
@@ -698,8 +704,8 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, h
                 rec[w].insert(rec[w].end(), {o0, o1, slot_c | (slot_s << 16), flags});
             }
         }
-        longest = std::max(longest, rec[w].size() / 4);
     }
+    for (int w = 0; w < 8; ++w) longest = std::max(longest, rec[w].size() / 4);
     // octet -> (order, octet inside the order) for the gather repack
     std::vector<int> octinfo((size_t)qoff[N + 1], 0);
     for (int m = 0; m <= N; ++m)
