@@ -289,6 +289,11 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
             }
         }
     }
+    // cos/sin fragments (B operand of the longitude stage) of the first body: fetched ahead of the Legendre stage, so that the
+    // longitude stage starts without an exposed L2 round trip
+    const double* tbase = P.trig + ((size_t)wave * P.K + fk) * 16 + fr;      // + cb * cb_stride + body * 256 + u * 64
+    double ring0 = tbase[0], ring1 = tbase[64], ring2 = tbase[128], ring3 = tbase[192];      // B fragments of the current body
+
     // ---- phase 1: Legendre stage.  Orders are distributed over the 8 waves; items of 4 k-steps are double
     //      buffered in two named register sets so that the fragments of item t+1 are in flight while item t runs.
     if (!FROM_PANEL && !(P.dbg & 2)) {
@@ -407,16 +412,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     const bool pair_stores = (P.ncol & 1) == 0;
     const int grid_bytes = P.nlat * P.nlon * 8;        // one epoch's grid; < 2^31 (checked on the host)
     const int par = fr & 1;
-    const double* tbase = P.trig + ((size_t)wave * P.K + fk) * 16 + fr;      // + cb * cb_stride + body * 256 + u * 64
     const size_t cb_stride = (size_t)8 * P.K * 16;
-    double ring0, ring1, ring2, ring3;                 // B fragments of the current body
-    {
-        const double* t0 = tbase;
-        ring0 = t0[0];
-        ring1 = t0[64];
-        ring2 = t0[128];
-        ring3 = t0[192];
-    }
     for (int ccb = 0; ccb < P.ncb && !(P.dbg & 4); ++ccb) {
         double4_t acc[4][4];
 #pragma unroll
