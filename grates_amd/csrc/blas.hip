@@ -61,75 +61,98 @@ __global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
     // Indices beyond the matrix are clamped to valid addresses (the values only reach rows / columns that are never
     // stored); only the last partial K tile zero-fills.
     const int r_row = tid >> 3, r_k = (tid & 7) * 2;
-    const int k_k = tid >> 6, k_row = (tid & 63) * 2;
+    const int k_k = __builtin_amdgcn_readfirstlane(tid >> 6), k_row = (tid & 63) * 2;      // k_k is wave-uniform
     double areg[8], breg[8];
-    // base pointers of the steady state (k = 0): R-type operand: 4 row pointers; K-type operand: 2 column pointers
-    const double* ar[4];
-    const double* br[4];
+    // Addressing of the steady state: fp64 MFMAs and the VALU instructions of all waves of a SIMD share one issue pipe
+    // (tools/mfma64_issue.hip), so every load is "uniform 64-bit base, advanced per K tile by scalar instructions, + 32-bit
+    // lane offset fixed for the whole kernel" (see gemm.hip for the idiom: the base is pinned in scalar registers, the lane
+    // offset is pinned next to its use so that the scalar-base form of the load is selected).
+    typedef const double __attribute__((address_space(1))) gdouble_t;
+    typedef const char __attribute__((address_space(1))) gbyte_t;
+    auto pin = [](unsigned v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    auto at = [](const double* base, unsigned byte_off) {
+        unsigned long long b = reinterpret_cast<unsigned long long>(base);
+        asm volatile("" : "+s"(b));
+        return *reinterpret_cast<gdouble_t*>(reinterpret_cast<gbyte_t*>(b) + byte_off);
+    };
+    // R-type operand ([row][k]): offsets of the four row pieces relative to the block's first row;
+    // K-type operand ([k][row]): offsets of the two columns relative to the block's first column
+    unsigned ar_off[4], br_off[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        ar[h] = TA ? nullptr : A + (size_t)min(m0 + r_row + 32 * h, P.M - 1) * P.lda + r_k;
-        br[h] = TB ? B + (size_t)min(n0 + r_row + 32 * h, P.N - 1) * P.ldb + r_k : nullptr;
+        ar_off[h] = (unsigned)(((size_t)(min(m0 + r_row + 32 * h, P.M - 1) - m0) * P.lda + r_k) * 8);
+        br_off[h] = (unsigned)(((size_t)(min(n0 + r_row + 32 * h, P.N - 1) - n0) * P.ldb + r_k) * 8);
     }
-    const double* ak0 = A + (size_t)k_k * P.lda + min(m0 + k_row, P.M - 1);
-    const double* ak1 = A + (size_t)k_k * P.lda + min(m0 + k_row + 1, P.M - 1);
-    const double* bk0 = B + (size_t)k_k * P.ldb + min(n0 + k_row, P.N - 1);
-    const double* bk1 = B + (size_t)k_k * P.ldb + min(n0 + k_row + 1, P.N - 1);
-    const size_t lda4 = (size_t)4 * P.lda, ldb4 = (size_t)4 * P.ldb;
+    const unsigned ak_off0 = (unsigned)((min(m0 + k_row, P.M - 1) - m0) * 8), ak_off1 = (unsigned)((min(m0 + k_row + 1, P.M - 1) - m0) * 8);
+    const unsigned bk_off0 = (unsigned)((min(n0 + k_row, P.N - 1) - n0) * 8), bk_off1 = (unsigned)((min(n0 + k_row + 1, P.N - 1) - n0) * 8);
+    const double* a_base = TA ? A + m0 : A + (size_t)m0 * P.lda;           // uniform
+    const double* b_base = TB ? B + (size_t)n0 * P.ldb : B + n0;           // uniform
 
     auto fetch_full = [&](int k0) {
         if (!TA) {
+            const double* ak = a_base + k0;
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                areg[2 * h] = ar[h][k0];
-                areg[2 * h + 1] = ar[h][k0 + 1];
+                const unsigned off = pin(ar_off[h]);
+                areg[2 * h] = at(ak, off);
+                areg[2 * h + 1] = at(ak + 1, off);
             }
         } else {
-            const size_t o = (size_t)k0 * P.lda;
+            const unsigned o0 = pin(ak_off0), o1 = pin(ak_off1);
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                areg[2 * h] = ak0[o + h * lda4];
-                areg[2 * h + 1] = ak1[o + h * lda4];
+                const double* ak = a_base + (size_t)(k0 + k_k + 4 * h) * P.lda;
+                areg[2 * h] = at(ak, o0);
+                areg[2 * h + 1] = at(ak, o1);
             }
         }
         if (TB) {
+            const double* bk = b_base + k0;
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                breg[2 * h] = br[h][k0];
-                breg[2 * h + 1] = br[h][k0 + 1];
+                const unsigned off = pin(br_off[h]);
+                breg[2 * h] = at(bk, off);
+                breg[2 * h + 1] = at(bk + 1, off);
             }
         } else {
-            const size_t o = (size_t)k0 * P.ldb;
+            const unsigned o0 = pin(bk_off0), o1 = pin(bk_off1);
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                breg[2 * h] = bk0[o + h * ldb4];
-                breg[2 * h + 1] = bk1[o + h * ldb4];
+                const double* bk = b_base + (size_t)(k0 + k_k + 4 * h) * P.ldb;
+                breg[2 * h] = at(bk, o0);
+                breg[2 * h + 1] = at(bk, o1);
             }
         }
     };
-    // last partial K tile: same addresses with k clamped, entries beyond K zeroed
+    // last partial K tile (runs once, plain per-lane addresses): k clamped, entries beyond K zeroed
     auto fetch_tail = [&](int k0) {
+        auto lane_ptr = [](const double* base, unsigned byte_off) { return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off); };
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int ka = k0 + r_k, kb = ka + 1;                         // R-type: a thread's two k indices
             const int ca = min(ka, Kz - 1) - r_k, cb = min(kb, Kz - 1) - r_k;
             const int kk = k0 + k_k + 4 * h;                              // K-type: the k row of piece h
-            const size_t ok = (size_t)(min(kk, Kz - 1) - k_k);
+            const size_t kc = (size_t)min(kk, Kz - 1);
             if (!TA) {
-                const double v0 = ar[h][ca], v1 = ar[h][cb];
+                const double* ar = lane_ptr(a_base, ar_off[h]);
+                const double v0 = ar[ca], v1 = ar[cb];
                 areg[2 * h] = ka < Kz ? v0 : 0.0;
                 areg[2 * h + 1] = kb < Kz ? v1 : 0.0;
             } else {
-                const double v0 = ak0[ok * P.lda], v1 = ak1[ok * P.lda];
+                const double v0 = *lane_ptr(a_base + kc * P.lda, ak_off0), v1 = *lane_ptr(a_base + kc * P.lda, ak_off1);
                 areg[2 * h] = kk < Kz ? v0 : 0.0;
                 areg[2 * h + 1] = kk < Kz ? v1 : 0.0;
             }
             if (TB) {
-                const double v0 = br[h][ca], v1 = br[h][cb];
+                const double* br = lane_ptr(b_base, br_off[h]);
+                const double v0 = br[ca], v1 = br[cb];
                 breg[2 * h] = ka < Kz ? v0 : 0.0;
                 breg[2 * h + 1] = kb < Kz ? v1 : 0.0;
             } else {
-                const double v0 = bk0[ok * P.ldb], v1 = bk1[ok * P.ldb];
+                const double v0 = *lane_ptr(b_base + kc * P.ldb, bk_off0), v1 = *lane_ptr(b_base + kc * P.ldb, bk_off1);
                 breg[2 * h] = kk < Kz ? v0 : 0.0;
                 breg[2 * h + 1] = kk < Kz ? v1 : 0.0;
             }
@@ -199,12 +222,19 @@ __global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
         fetch_tail(0);
     stage(0);
     __syncthreads();
-    for (int t = 0; t + 1 < nfull; ++t) {             // branch-free steady state
+    // branch-free steady state, two K tiles per trip so that the LDS buffer of every access is a literal
+    auto step = [&](int t, int buf) {
         fetch_full((t + 1) * XK);
-        compute(t & 1);
-        stage((t + 1) & 1);
+        compute(buf);
+        stage(buf ^ 1);
         __syncthreads();
+    };
+    int t = 0;
+    for (; t + 2 < nfull; t += 2) {
+        step(t, 0);
+        step(t + 1, 1);
     }
+    if (t + 1 < nfull) step(t, 0);                     // t is even here
     if (nfull > 0) {
         if (has_tail) fetch_tail(nfull * XK);
         compute((nfull - 1) & 1);
