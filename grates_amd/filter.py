@@ -1,8 +1,7 @@
 """
 Spatial filters with the interface of ``grates.filter``: ``Gaussian`` (grates/filter.py:31-95),
 ``Butterworth`` (:98-130), ``OrderWiseFilter`` (:133-222), ``DDKGeneric`` / ``DDK`` (:225-349),
-``BlockedNormalsVDK`` (:352-427) and ``GeneralMatrix`` (:430-509).  ``VDK`` (one-off dense solve whose upstream
-``filter`` is broken) and ``FilterKernel`` are out of scope.
+``BlockedNormalsVDK`` (:352-427), ``GeneralMatrix`` (:430-509), ``VDK`` (:512-546) and ``FilterKernel`` (:575-598).
 
 ``filter(gravityfield)`` keeps the reference semantics (new object, input untouched); every filter also
 offers ``filter_batch(anm_batch)`` which filters a whole [T, N+1, N+1] stack of epochs in one GPU call --
@@ -259,3 +258,42 @@ class GeneralMatrix(SpatialFilter):
         idx_source, idx_target = _gravityfield.CoefficientSequence.reorder_indices(source, target)
         W[np.ix_(idx_target, idx_target)] = self.__W[np.ix_(idx_source, idx_source)].copy()
         return W
+
+
+class VDK(GeneralMatrix):
+    """
+    Decorrelation filter from a full normal equation matrix N (degree-wise order, degrees min_degree..max_degree)
+    regularised with Kaula weights: W = (N + diag(kaula_scale n^kaula_power))^-1 N (grates/filter.py:536-546), formed
+    on the device by a Cholesky solve.  `filter` is the dense matrix filter of GeneralMatrix (the reference's own
+    VDK.filter cannot run: it reads name-mangled attributes of its base class).
+    """
+
+    def __init__(self, normal_equation_matrix, min_degree, max_degree, kaula_scale, kaula_power):
+        normals = np.asarray(normal_equation_matrix, dtype=float)
+        count = (max_degree + 1) ** 2 - min_degree ** 2
+        if normals.ndim != 2 or normals.shape != (count, count):
+            raise ValueError('normal equation matrix does not match degrees {0:d} to {1:d} (got {2})'.format(min_degree, max_degree, str(normals.shape)))
+        weights = np.concatenate([np.full(2 * n + 1, kaula_scale * float(n) ** kaula_power) for n in range(min_degree, max_degree + 1)]) \
+            if count else np.zeros(0)
+        regularised = normals.copy()
+        regularised.flat[::count + 1] += weights
+        W = engine.to_host(engine.spd_solve(regularised, normals))
+        super(VDK, self).__init__(W, min_degree, max_degree)
+
+
+class FilterKernel(_kernel.AnisotropicKernel):
+    """
+    Space-domain kernel of a (possibly anisotropic) spatial filter (grates/filter.py:588-598): the filter matrix of
+    degrees min_degree..max_degree -- from a SpatialFilter or given directly -- as an AnisotropicKernel.
+
+    As executed by the reference the factors k_n and 1/k_n of `input_kernel` both scale the COLUMNS of the filter matrix
+    (its kernel coefficient arrays carry a leading axis of length one), so they cancel wherever k_n is non-zero and
+    zero the columns where it vanishes; this class reproduces that result.
+    """
+
+    def __init__(self, spatial_filter, min_degree, max_degree, input_kernel='potential'):
+        K = spatial_filter.matrix(min_degree, max_degree) if isinstance(spatial_filter, SpatialFilter) else np.asarray(spatial_filter, dtype=float)
+        generator = _kernel.get_kernel(input_kernel)
+        kn = utilities.ravel_coefficients(generator.coefficient_array(min_degree, max_degree)[0], min_degree, max_degree)
+        kn_inverse = utilities.ravel_coefficients(generator.inverse_coefficient_array(min_degree, max_degree)[0], min_degree, max_degree)
+        super(FilterKernel, self).__init__(K * (kn * kn_inverse)[np.newaxis, :], min_degree, max_degree)

@@ -1,16 +1,17 @@
 """
-Isotropic harmonic kernels with the interface of ``grates.kernel`` (grates/kernel.py:17-574).
+Harmonic kernels with the interface of ``grates.kernel`` (grates/kernel.py:17-654).
 
-Kernels only produce the small per-parallel degree-factor table kn[nlat, N+1] that is uploaded into a
-device plan; they are evaluated on the host.  ``AnisotropicKernel``, ``modulation_transfer`` and
-``spatial_resolution`` (diagnostics driven by scipy.optimize) are out of scope, see DESIGN.md.
+Isotropic kernels only produce the small per-parallel degree-factor table kn[nlat, N+1] that is uploaded into a
+device plan; they are evaluated on the host.  ``AnisotropicKernel`` evaluates y(source)^T K y(point) on the GPU
+(dense product + synthesis).  ``modulation_transfer`` and ``spatial_resolution`` (diagnostics driven by
+scipy.optimize) are out of scope, see DESIGN.md.
 """
 
 import abc
 
 import numpy as np
 
-from . import data, utilities
+from . import data, engine, utilities
 
 _GRAVITATIONAL_CONSTANT = 6.673e-11       # value used by the reference, grates/kernel.py:405
 
@@ -258,3 +259,55 @@ _REGISTRY = (
     (('deformation', 'vertical_derformation'), VerticalDeformation),
     (('uplift',), Uplift),
 )
+
+
+class AnisotropicKernel:
+    """
+    Possibly anisotropic kernel in the space domain, given by its spherical harmonic mapping K (degree-wise order,
+    degrees min_degree..max_degree): kernel(source, point) = y(source)^T K y(point) with the spherical harmonics y
+    (grates/kernel.py:589-654).  The row vector y(source)^T K is one dense product on the fp64 MFMA GEMM; the
+    evaluation is a spherical harmonic synthesis of that vector (point list or regular grid) with unit degree factors.
+    """
+
+    def __init__(self, K, min_degree, max_degree):
+        K = np.asarray(K, dtype=float)
+        count = (max_degree + 1) ** 2 - min_degree ** 2
+        if K.ndim != 2 or K.shape != (count, count):
+            raise ValueError('kernel matrix must be square with one row per coefficient of degrees {0:d} to {1:d} (got {2})'.format(min_degree, max_degree, str(K.shape)))
+        self.__matrix = K.copy()
+        self.__min_degree = min_degree
+        self.__max_degree = max_degree
+        self.__device_matrix = None
+
+    @property
+    def matrix(self):
+        return self.__matrix.copy()
+
+    def _source_coefficients(self, source_longitude, source_latitude):
+        """y(source)^T K as a coefficient array [1, nmax+1, nmax+1] on the device."""
+        N = self.__max_degree
+        if self.__device_matrix is None:
+            self.__device_matrix = engine.to_device(self.__matrix)
+        Y = engine.legendre_functions(N, np.atleast_1d(0.5 * np.pi - np.asarray(source_latitude, dtype=float)).ravel()[0:1])
+        Y = Y * engine.trigonometric_functions(N, np.atleast_1d(np.asarray(source_longitude, dtype=float)).ravel()[0:1])
+        row = engine.gemm(engine.ravel(Y, self.__min_degree, N), self.__device_matrix)
+        return engine.unravel(row, self.__min_degree, N)
+
+    def evaluate(self, source_longitude, source_latitude, eval_longitude, eval_latitude):
+        """Kernel centred at the source point, at a list of evaluation points [rad] (grates/kernel.py:615-620)."""
+        lon = np.atleast_1d(np.asarray(eval_longitude, dtype=float)).ravel()
+        lat = np.atleast_1d(np.asarray(eval_latitude, dtype=float)).ravel()
+        if lon.size != lat.size:
+            raise ValueError('evaluation longitudes and latitudes differ in size ({0:d} vs {1:d})'.format(lon.size, lat.size))
+        anm = self._source_coefficients(source_longitude, source_latitude)
+        ones = np.ones((lon.size, self.__max_degree + 1))
+        return engine.to_host(engine.synthesis_points(self.__max_degree, 0.5 * np.pi - lat, lon, ones, anm))[0]
+
+    def evaluate_grid(self, source_longitude, source_latitude, eval_longitude, eval_latitude):
+        """Kernel centred at the source point on meridians x parallels [rad]; returns (parallels, meridians) like the
+        reference (grates/kernel.py:642-654).  One batched synthesis on the regular-grid path."""
+        lon = np.atleast_1d(np.asarray(eval_longitude, dtype=float)).ravel()
+        lat = np.atleast_1d(np.asarray(eval_latitude, dtype=float)).ravel()
+        anm = self._source_coefficients(source_longitude, source_latitude)
+        plan = engine.Plan(self.__max_degree, 0.5 * np.pi - lat, np.ones((lat.size, self.__max_degree + 1)), lon)
+        return engine.to_host(plan.synthesis(anm))[0]

@@ -506,3 +506,54 @@ def general_matrix_filter(anm, W, min_degree, max_degree):
     out = unravel_coefficients(W @ x, min_degree, nmax_out)
     out[0:min_degree, 0:min_degree] = anm[0:min_degree, 0:min_degree]
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# dense decorrelation filter from a full normal matrix, filter kernels in the space domain
+#                                                      grates/filter.py:536-546, 588-598; grates/kernel.py:589-654
+# ----------------------------------------------------------------------------------------------
+
+
+def vdk_matrix(normals, min_degree, max_degree, kaula_scale, kaula_power):
+    """W = (N + diag(w))^-1 N with Kaula weights w = kaula_scale n^kaula_power of every degree-wise index.
+    grates/filter.py:538-546"""
+    weights = np.concatenate([np.full(2 * n + 1, kaula_scale * float(n) ** kaula_power) for n in range(min_degree, max_degree + 1)])
+    return np.linalg.solve(normals + np.diag(weights), normals)
+
+
+def filter_kernel_matrix(K, min_degree, max_degree, kernel):
+    """Matrix of grates.filter.FilterKernel AS THE REFERENCE EXECUTES IT (grates/filter.py:590-596): the kernel coefficient
+    arrays carry a leading axis of length one, so both factors of
+        K2 = (K * kn[np.newaxis, :]) * kn_inverse[:, np.newaxis]
+    broadcast along the COLUMNS: K2[i][j] = K[i][j] k_n(j) / k_n(j) -- K itself wherever the kernel coefficient of
+    column j is non-zero, zero where it vanishes -- whatever `input_kernel` is (the fixture holds identical values
+    for 'potential' and 'ewh').  Kernel coefficients at r = 6378136.3 m."""
+    kn = kernel.coefficients(min_degree, max_degree, 6378136.3, 0)[0]
+    kinv = kernel.inverse_coefficients(min_degree, max_degree, 6378136.3, 0)[0]
+    per_index = lambda t: np.concatenate([np.full(2 * n + 1, t[n - min_degree]) for n in range(min_degree, max_degree + 1)])
+    return K * per_index(kn)[np.newaxis, :] * per_index(kinv)[np.newaxis, :]
+
+
+def anisotropic_kernel_points(K, min_degree, max_degree, source_longitude, source_latitude, longitude, latitude):
+    """y(source)^T K y(point) for a list of points.  grates/kernel.py:615-620"""
+    ys = ravel_coefficients(spherical_harmonics(max_degree, np.atleast_1d(0.5 * np.pi - source_latitude), np.atleast_1d(source_longitude))[0],
+                            min_degree, max_degree)
+    v = ys @ K
+    out = np.empty(np.size(longitude))
+    for k, (lon, lat) in enumerate(zip(np.atleast_1d(longitude), np.atleast_1d(latitude))):
+        ye = ravel_coefficients(spherical_harmonics(max_degree, np.atleast_1d(0.5 * np.pi - lat), np.atleast_1d(lon))[0], min_degree, max_degree)
+        out[k] = v @ ye
+    return out
+
+
+def anisotropic_kernel_grid(K, min_degree, max_degree, source_longitude, source_latitude, meridians, parallels):
+    """The same on meridians x parallels, parallel by parallel.  grates/kernel.py:642-654"""
+    ys = ravel_coefficients(spherical_harmonics(max_degree, np.atleast_1d(0.5 * np.pi - source_latitude), np.atleast_1d(source_longitude))[0],
+                            min_degree, max_degree)
+    v = ys @ K
+    pnm = legendre_functions(max_degree, 0.5 * np.pi - np.asarray(parallels, dtype=float))
+    cs = trigonometric_functions(max_degree, np.asarray(meridians, dtype=float))
+    grid = np.empty((np.size(parallels), np.size(meridians)))
+    for k in range(grid.shape[0]):
+        grid[k, :] = np.stack([ravel_coefficients(cs[j] * pnm[k], min_degree, max_degree) for j in range(cs.shape[0])]) @ v
+    return grid

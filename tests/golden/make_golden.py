@@ -288,6 +288,39 @@ def g10():
     save('g10_filter', **out)
 
 
+# ---- G12: dense decorrelation filter from a full normal matrix (VDK) and filter kernels in the space domain ----------------
+def g12():
+    out = {}
+    nmin, nmax = 2, 12
+    P = (nmax + 1) ** 2 - nmin ** 2
+    N = inputs.spd_covariance(70, P, scale=1e20)                    # synthetic SPD normal equation matrix, degree-wise
+    vdk = grates.filter.VDK(N, nmin, nmax, 1e18, 2.0)
+    out['vdk_matrix'] = vdk.matrix(nmin, nmax)
+    # (VDK.filter is unusable upstream: it reads name-mangled attributes of its base class; the matrix is the contract)
+    W = vdk.matrix(nmin, nmax)
+    gm = grates.filter.GeneralMatrix(W, nmin, nmax)
+    out['vdk_filtered_n12'] = gm.filter(potential_coefficients(inputs.coefficients(71, 12))).anm
+    # space-domain kernel of an anisotropic filter
+    src_lon, src_lat = np.deg2rad(13.0), np.deg2rad(47.5)
+    ev_lon = np.deg2rad(np.linspace(-20.0, 50.0, 9))
+    ev_lat = np.deg2rad(np.linspace(30.0, 65.0, 6))
+    for name, kernel in (('potential', 'potential'), ('ewh', 'ewh')):
+        fk = grates.filter.FilterKernel(gm, nmin, nmax, input_kernel=kernel)
+        pts_lon, pts_lat = np.meshgrid(ev_lon, ev_lat)
+        out['filterkernel_{0}_points'.format(name)] = fk.evaluate(src_lon, src_lat, pts_lon.ravel(), pts_lat.ravel())
+        # (upstream FilterKernel.evaluate_grid raises: its matrix carries a leading axis of length 1; evaluate() on the mesh
+        #  defines the grid values)
+    K = np.random.default_rng(72).standard_normal((P, P)) / nmax
+    ak = grates.kernel.AnisotropicKernel(K, nmin, nmax)
+    out['anisotropic_grid'] = ak.evaluate_grid(src_lon, src_lat, ev_lon, ev_lat)
+    out['anisotropic_points'] = ak.evaluate(src_lon, src_lat, ev_lon, ev_lat[0:1].repeat(ev_lon.size))
+    ord_blocks = inputs.orderwise_random_blocks(73, nmax)
+    fo = grates.filter.FilterKernel(grates.filter.OrderWiseFilter(ord_blocks), nmin, nmax)
+    pts_lon, pts_lat = np.meshgrid(ev_lon, ev_lat)
+    out['filterkernel_orderwise_points'] = fo.evaluate(src_lon, src_lat, pts_lon.ravel(), pts_lat.ravel())
+    save('g12_filter_kernel', **out)
+
+
 # ---- G11: block-banded normal equations ("Kalman smoother", lstsq.py) ----------------------------------------------------
 def g11():
     from grates import lstsq
@@ -384,6 +417,6 @@ def g11():
 
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
         if not only or fn.__name__ in only:
             fn()

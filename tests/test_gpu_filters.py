@@ -97,3 +97,64 @@ def test_config3_ddk5_time_series_d120():
     dense = ga.filter.GeneralMatrix(flt.matrix(2, nmax), 2, nmax)             # 14637 x 14637 full normal-type matrix
     out_dense = ga.engine.to_host(dense.filter_batch(batch))
     assert relerr(out_dense, out_blocks) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8(f) rank 2
+def test_vdk_and_filter_kernels_golden(golden):
+    """VDK (dense decorrelation filter from a full normal matrix), AnisotropicKernel and FilterKernel against the
+    reference's outputs (tests/golden/g12_filter_kernel.npz) and the oracle."""
+    g = golden('g12_filter_kernel')
+    nmin, nmax = 2, 12
+    P = (nmax + 1) ** 2 - nmin ** 2
+    normals = inputs.spd_covariance(70, P, scale=1e20)
+    vdk = ga.filter.VDK(normals, nmin, nmax, 1e18, 2.0)
+    assert relerr(vdk.matrix(nmin, nmax), g['vdk_matrix']) < 1e-11
+    gf = ga.gravityfield.PotentialCoefficients()
+    gf.anm = inputs.coefficients(71, 12)
+    assert relerr(vdk.filter(gf).anm, g['vdk_filtered_n12']) < 1e-11
+    with pytest.raises(ValueError):
+        ga.filter.VDK(normals[0:5, 0:5], nmin, nmax, 1e18, 2.0)
+
+    src_lon, src_lat = np.deg2rad(13.0), np.deg2rad(47.5)
+    ev_lon = np.deg2rad(np.linspace(-20.0, 50.0, 9))
+    ev_lat = np.deg2rad(np.linspace(30.0, 65.0, 6))
+    pts_lon, pts_lat = np.meshgrid(ev_lon, ev_lat)
+    gm = ga.filter.GeneralMatrix(g['vdk_matrix'], nmin, nmax)
+    for name in ('potential', 'ewh'):
+        fk = ga.filter.FilterKernel(gm, nmin, nmax, input_kernel=name)
+        ref = g['filterkernel_{0}_points'.format(name)]
+        assert relerr(fk.evaluate(src_lon, src_lat, pts_lon.ravel(), pts_lat.ravel()), ref) < 1e-12
+        grid = fk.evaluate_grid(src_lon, src_lat, ev_lon, ev_lat)
+        assert grid.shape == (ev_lat.size, ev_lon.size)
+        assert relerr(grid.ravel(), ref) < 1e-12
+    K = np.random.default_rng(72).standard_normal((P, P)) / nmax
+    ak = ga.kernel.AnisotropicKernel(K, nmin, nmax)
+    assert relerr(ak.evaluate_grid(src_lon, src_lat, ev_lon, ev_lat), g['anisotropic_grid']) < 1e-12
+    assert relerr(ak.evaluate(src_lon, src_lat, ev_lon, ev_lat[0:1].repeat(ev_lon.size)), g['anisotropic_points']) < 1e-12
+    fo = ga.filter.FilterKernel(ga.filter.OrderWiseFilter(inputs.orderwise_random_blocks(73, nmax)), nmin, nmax)
+    assert relerr(fo.evaluate(src_lon, src_lat, pts_lon.ravel(), pts_lat.ravel()), g['filterkernel_orderwise_points']) < 1e-12
+    with pytest.raises(ValueError):
+        ga.kernel.AnisotropicKernel(K[0:4], nmin, nmax)
+    with pytest.raises(ValueError):
+        ak.evaluate(src_lon, src_lat, ev_lon, ev_lat)
+
+
+def test_anisotropic_kernel_d60_against_oracle():
+    """The same evaluation at d/o 60 (P = 3717, beyond the fixture size) against the oracle: Gaussian-filter kernel
+    (isotropic, so the kernel only depends on the spherical distance) and a dense random mapping."""
+    nmin, nmax = 2, 60
+    P = (nmax + 1) ** 2 - nmin ** 2
+    src_lon, src_lat = 0.3, -0.4
+    lon = np.linspace(-np.pi, np.pi, 24, endpoint=False) + 0.01
+    lat = np.linspace(-1.4, 1.4, 15)
+    K = np.random.default_rng(5).standard_normal((P, P)) / nmax
+    ak = ga.kernel.AnisotropicKernel(K, nmin, nmax)
+    ref = orc.anisotropic_kernel_grid(K, nmin, nmax, src_lon, src_lat, lon, lat)
+    assert relerr(ak.evaluate_grid(src_lon, src_lat, lon, lat), ref) < 1e-12
+    fk = ga.filter.FilterKernel(ga.filter.Gaussian(400), nmin, nmax)
+    vals = fk.evaluate_grid(src_lon, src_lat, lon, lat)
+    ref = orc.anisotropic_kernel_grid(orc.gaussian_matrix(400, nmin, nmax), nmin, nmax, src_lon, src_lat, lon, lat)
+    assert relerr(vals, ref) < 1e-12
+    # isotropy: equal spherical distance -> equal kernel value
+    mirror = fk.evaluate(src_lon, src_lat, np.array([src_lon + 0.2, src_lon - 0.2]), np.array([src_lat, src_lat]))
+    assert abs(mirror[0] - mirror[1]) < 1e-10 * np.abs(vals).max()

@@ -222,3 +222,30 @@ def test_filters(golden):
     out14 = orc.general_matrix_filter(inputs.coefficients(47, 14), W, 2, 20)
     assert out14.shape == g['general_2_20_n14'].shape
     assert relerr(out14, g['general_2_20_n14']) < 1e-14
+
+
+# ---------------------------------------------------------------- G12
+def test_vdk_and_filter_kernels(golden):
+    g = golden('g12_filter_kernel')
+    nmin, nmax = 2, 12
+    P = (nmax + 1) ** 2 - nmin ** 2
+    normals = inputs.spd_covariance(70, P, scale=1e20)
+    W = orc.vdk_matrix(normals, nmin, nmax, 1e18, 2.0)
+    assert relerr(W, g['vdk_matrix']) < 1e-12
+    assert relerr(orc.general_matrix_filter(inputs.coefficients(71, 12), W, nmin, nmax), g['vdk_filtered_n12']) < 1e-12
+    src_lon, src_lat = np.deg2rad(13.0), np.deg2rad(47.5)
+    ev_lon = np.deg2rad(np.linspace(-20.0, 50.0, 9))
+    ev_lat = np.deg2rad(np.linspace(30.0, 65.0, 6))
+    pts_lon, pts_lat = np.meshgrid(ev_lon, ev_lat)
+    for name in ('potential', 'ewh'):
+        K2 = orc.filter_kernel_matrix(g['vdk_matrix'], nmin, nmax, orc.KernelTable(name, love(golden)))
+        pts = orc.anisotropic_kernel_points(K2, nmin, nmax, src_lon, src_lat, pts_lon.ravel(), pts_lat.ravel())
+        assert relerr(pts, g['filterkernel_{0}_points'.format(name)]) < 1e-13
+        grid = orc.anisotropic_kernel_grid(K2, nmin, nmax, src_lon, src_lat, ev_lon, ev_lat)
+        assert relerr(grid.ravel(), g['filterkernel_{0}_points'.format(name)]) < 1e-13
+    K = np.random.default_rng(72).standard_normal((P, P)) / nmax
+    assert relerr(orc.anisotropic_kernel_grid(K, nmin, nmax, src_lon, src_lat, ev_lon, ev_lat), g['anisotropic_grid']) < 1e-13
+    assert relerr(orc.anisotropic_kernel_points(K, nmin, nmax, src_lon, src_lat, ev_lon, ev_lat[0:1].repeat(ev_lon.size)), g['anisotropic_points']) < 1e-13
+    blocks = inputs.orderwise_random_blocks(73, nmax)
+    Ko = orc.filter_kernel_matrix(orc.orderwise_matrix(blocks, nmin, nmax), nmin, nmax, orc.KernelTable('potential'))
+    assert relerr(orc.anisotropic_kernel_points(Ko, nmin, nmax, src_lon, src_lat, pts_lon.ravel(), pts_lat.ravel()), g['filterkernel_orderwise_points']) < 1e-13
