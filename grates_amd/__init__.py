@@ -13,6 +13,7 @@ from . import gravityfield
 from . import grid
 from . import filter
 from . import lstsq
+from . import io
 
 __all__ = ['data', 'engine', 'filter', 'gravityfield', 'grid', 'kernel', 'utilities']
 __version__ = '0.1.0'

@@ -80,3 +80,52 @@ def observation_normals(seed, epoch_count, dim, scale=1.0):
         l = rng.standard_normal((dim + 5, 1))
         out.append((A.T @ A * scale, A.T @ l * scale, float(np.sum(l * l) * scale), dim + 5))
     return out
+
+
+def gfc_file_text(seed, max_degree, with_header=True):
+    """Synthetic ICGEM GFC file (bytes): header keys, comment lines, `gfc n m C S [sigmas]` records in degree order."""
+    rng = np.random.default_rng(seed)
+    lines = ['product_type gravity_field', 'modelname synthetic_{0}'.format(seed)]
+    if with_header:
+        lines += ['earth_gravity_constant 3.986004418000E+14', 'radius 6.378136460000E+06']
+    lines += ['max_degree {0}'.format(max_degree), 'norm fully_normalized', 'tide_system zero_tide', 'errors formal',
+              'key    L    M        C                  S              sigma C       sigma S', 'end_of_head ====']
+    for n in range(max_degree + 1):
+        for m in range(n + 1):
+            c, s = rng.standard_normal(2) * 1e-6 / max(n, 1) ** 2
+            if m == 0:
+                s = 0.0
+            lines.append('gfc {0:4d} {1:4d} {2: .12E} {3: .12E} {4:.4E} {5:.4E}'.format(n, m, c, s, abs(c) * 1e-3, abs(s) * 1e-3))
+    return ('\n'.join(lines) + '\n').encode('ascii')
+
+
+def gsm_file_text(seed, max_degree, start='2010-03-01T00:00:00.00', end='2010-03-31T23:59:59.99'):
+    """Synthetic GRACE SDS level-2 file (bytes): YAML header with the keys the loaders read, `GRCOF2` records."""
+    rng = np.random.default_rng(seed)
+    header = '''header:
+  dimensions:
+    degree: {0}
+    order: {0}
+  global_attributes:
+    title: synthetic GSM product
+    time_coverage_start: {1}
+    time_coverage_end: {2}
+  non-standard_attributes:
+    earth_gravity_param:
+      long_name: gravitational constant times mass of Earth
+      units: m3/s2
+      value: 3.9860044150E+14
+    mean_equator_radius:
+      long_name: mean equator radius
+      units: meters
+      value: 6.3781363000E+06
+# End of YAML header
+'''.format(max_degree, start, end)
+    lines = []
+    for n in range(max_degree + 1):
+        for m in range(n + 1):
+            c, s = rng.standard_normal(2) * 1e-6 / max(n, 1) ** 2
+            if m == 0:
+                s = 0.0
+            lines.append('GRCOF2 {0:4d} {1:4d} {2: .12E} {3: .12E} {4:.4E} {5:.4E} 20100301.0000 20100401.0000 nnnn'.format(n, m, c, s, abs(c) * 1e-3, abs(s) * 1e-3))
+    return (header + '\n'.join(lines) + '\n').encode('ascii')

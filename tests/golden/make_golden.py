@@ -415,8 +415,31 @@ def g11():
     save('g11_lstsq', **out)
 
 
+# ---- G13: file feeders (synthetic GFC / GSM files written by inputs.py, parsed by the reference) ---------------------------
+def g13():
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, seed, nmax, header in (('a', 80, 12, True), ('b', 81, 7, False)):
+            path = os.path.join(tmp, 'model_{0}.gfc'.format(tag))
+            with open(path, 'wb') as f:
+                f.write(inputs.gfc_file_text(seed, nmax, header))
+            gf = grates.io.loadgfc(path)
+            out['gfc_{0}_anm'.format(tag)] = gf.anm
+            out['gfc_{0}_GM_R'.format(tag)] = np.array([gf.GM, gf.R])
+        out['gfc_a_truncated_anm'] = grates.io.loadgfc(os.path.join(tmp, 'model_a.gfc'), max_degree=5).anm
+        path = os.path.join(tmp, 'GSM-2_2010060-2010090.txt')
+        with open(path, 'wb') as f:
+            f.write(inputs.gsm_file_text(82, 10))
+        gf = grates.io.loadgsm(path)
+        out['gsm_anm'] = gf.anm
+        out['gsm_GM_R'] = np.array([gf.GM, gf.R])
+        out['gsm_epoch'] = np.array([gf.epoch.year, gf.epoch.month, gf.epoch.day, gf.epoch.hour, gf.epoch.minute, gf.epoch.second])
+    save('g13_io', **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
         if not only or fn.__name__ in only:
             fn()

@@ -259,3 +259,21 @@ def test_point_list_path(golden):
     a = make_pc(batch[0]).to_grid(reg, 'ewh').values
     b = make_pc(batch[0]).to_grid(irr, 'ewh').values
     assert relerr(a, b) < TOL
+
+
+def test_monthly_files_to_grids(tmp_path):
+    """monthly SDS files -> TimeSeries -> one batched synthesis; every epoch equals the oracle's synthesis
+    of the coefficients the file holds."""
+    names = []
+    for month in range(1, 7):
+        name = tmp_path / 'GSM-2_2012{0:02d}.txt'.format(month)
+        name.write_bytes(inputs.gsm_file_text(200 + month, 30, start='2012-{0:02d}-01T00:00:00.00'.format(month)))
+        names.append(str(name))
+    series = ga.io.load_time_series(names[::-1])
+    grid = ga.grid.GeographicGrid(2.0, 2.0)
+    grids = series.to_grid(grid, kernel='ewh')
+    assert [g.epoch.month for g in grids] == [1, 2, 3, 4, 5, 6]
+    kernel = orc.KernelTable('ewh', love())
+    for k in (0, 3, 5):
+        ref = orc.synthesis_regular(ga.io.loadgsm(names[k]).anm, grid.meridians, grid.parallels, kernel)
+        assert relerr(grids[k].value_array, ref) < 1e-12

@@ -295,3 +295,51 @@ def test_filter_matrices_and_errors(golden):
         ga.filter.DDKGeneric._blocked_normals = staticmethod(lambda: ga.data.ddk_normal_blocks())
     with pytest.raises(FileNotFoundError):
         ga.filter.DDK(5)
+
+
+def test_file_feeders(golden, tmp_path):
+    """GFC / GSM loaders against what the reference parsed from the same synthetic files
+    (tests/golden/g13_io.npz; the files are regenerated from their seeds).  Text -> float is bit-exact."""
+    import gzip
+    import io as _io
+    g = golden('g13_io')
+    for tag, seed, nmax, header in (('a', 80, 12, True), ('b', 81, 7, False)):
+        path = tmp_path / 'model_{0}.gfc'.format(tag)
+        path.write_bytes(inputs.gfc_file_text(seed, nmax, header))
+        gf = ga.io.loadgfc(str(path))
+        np.testing.assert_array_equal(gf.anm, g['gfc_{0}_anm'.format(tag)])
+        np.testing.assert_array_equal(np.array([gf.GM, gf.R]), g['gfc_{0}_GM_R'.format(tag)])
+        assert gf.epoch is None
+    np.testing.assert_array_equal(ga.io.loadgfc(tmp_path / 'model_a.gfc', max_degree=5).anm, g['gfc_a_truncated_anm'])
+    # compressed file, open binary stream, open text stream
+    with gzip.open(tmp_path / 'model_a.gfc.gz', 'wb') as f:
+        f.write(inputs.gfc_file_text(80, 12))
+    np.testing.assert_array_equal(ga.io.loadgfc(str(tmp_path / 'model_a.gfc.gz')).anm, g['gfc_a_anm'])
+    np.testing.assert_array_equal(ga.io.loadgfc(_io.BytesIO(inputs.gfc_file_text(80, 12))).anm, g['gfc_a_anm'])
+    np.testing.assert_array_equal(ga.io.loadgfc(_io.StringIO(inputs.gfc_file_text(80, 12).decode())).anm, g['gfc_a_anm'])
+    with pytest.raises(ValueError):
+        ga.io.loadgfc(42)
+
+    path = tmp_path / 'GSM-2_2010060-2010090.txt'
+    path.write_bytes(inputs.gsm_file_text(82, 10))
+    gf = ga.io.loadgsm(str(path))
+    np.testing.assert_array_equal(gf.anm, g['gsm_anm'])
+    np.testing.assert_array_equal(np.array([gf.GM, gf.R]), g['gsm_GM_R'])
+    e = gf.epoch
+    np.testing.assert_array_equal(np.array([e.year, e.month, e.day, e.hour, e.minute, e.second]), g['gsm_epoch'])
+
+    # a list of monthly files -> TimeSeries sorted by epoch
+    names = []
+    for month in (5, 3, 4):
+        name = tmp_path / 'GSM-2_2010{0:02d}.txt'.format(month)
+        name.write_bytes(inputs.gsm_file_text(90 + month, 10, start='2010-{0:02d}-01T00:00:00.00'.format(month)))
+        names.append(str(name))
+    ts = ga.io.load_time_series(names, max_degree=8)
+    assert [t.month for t in ts.epochs()] == [3, 4, 5]
+    assert ts.to_array().shape == (3, 81)
+    np.testing.assert_array_equal(ts[0].anm, ga.io.loadgsm(names[1]).anm[0:9, 0:9])
+    series = ga.io.load_time_series([str(tmp_path / 'model_a.gfc'), str(tmp_path / 'model_b.gfc')], loader=ga.io.loadgfc,
+                                    epochs=[datetime.datetime(2011, 2, 1), datetime.datetime(2011, 1, 1)])
+    assert series[0].max_degree == 7 and series[1].max_degree == 12
+    with pytest.raises(ValueError):
+        ga.io.load_time_series([str(tmp_path / 'model_a.gfc')], loader=ga.io.loadgfc)
