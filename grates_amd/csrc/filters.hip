@@ -7,8 +7,12 @@
 
 namespace shg {
 
-constexpr int kFiltEpochs = 32;     // epochs per thread block (x dimension of the 8 x 32 thread tile)
+constexpr int kFiltEpochs = 64;     // epochs per workgroup = lanes of a wave
 
+// One workgroup = one order block x 64 epochs, 4 waves.  The coefficient vectors of the 64 epochs are gathered into LDS
+// (xs[k][epoch]); every wave then takes groups of four block rows: the row index is wave-uniform, so the block entries come
+// through scalar loads and feed the FMAs as scalar operands, and one LDS read of xs[c][epoch] serves four FMAs.
+// HBM/L2 bound: bytes = 8 (sum of block sizes x epoch groups + 2 P B).
 __global__ __launch_bounds__(256) void orderwise_filter_kernel(int Nb, int N, int B, const double* __restrict__ blocks,
                                                                const long long* __restrict__ block_off,
                                                                const double* __restrict__ in, double* __restrict__ out) {
@@ -18,22 +22,61 @@ __global__ __launch_bounds__(256) void orderwise_filter_kernel(int Nb, int N, in
     const bool sine = kb > 0 && (kb & 1) == 0;
     const int n = N + 1 - m;                       // coefficients of this order in the field
     const int ld = Nb + 1 - m;                     // leading dimension of the stored block
-    const int e = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int e = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y * kFiltEpochs + e;
     const size_t E = (size_t)(N + 1) * (N + 1);
     const double* W = blocks + block_off[kb];
 
     // element k (degree m + k) of this order: cos at [m+k][m], sin at [m-1][m+k]
     auto pos = [&](int k) -> size_t { return sine ? (size_t)(m - 1) * (N + 1) + (m + k) : (size_t)(m + k) * (N + 1) + m; };
-    for (int k = ty; k < n; k += 8) xs[k * kFiltEpochs + e] = (b < B) ? in[(size_t)b * E + pos(k)] : 0.0;
+    // gather: 16 elements per thread in flight at a time (the addresses are a whole coefficient array apart from lane to lane,
+    // so every element is its own memory transaction: a loop that waits for each one is bound by their latency)
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        double v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + wave + 4 * j;
+            v[j] = (k < n && b < B) ? in[(size_t)b * E + pos(k)] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + wave + 4 * j;
+            if (k < n) xs[k * kFiltEpochs + e] = v[j];
+        }
+    }
     __syncthreads();
-    for (int r = ty; r < n; r += 8) {
-        const double* wrow = W + (size_t)r * ld;
-        double s = 0.0;
-        for (int c = 0; c < n; ++c) s = fma(wrow[c], xs[c * kFiltEpochs + e], s);
+    for (int r0 = 4 * wave; r0 < n; r0 += 16) {       // rows r0 .. r0 + 3 (clamped: a duplicate row is computed, not stored)
+        const double* w0 = W + (size_t)r0 * ld;
+        const double* w1 = W + (size_t)min(r0 + 1, n - 1) * ld;
+        const double* w2 = W + (size_t)min(r0 + 2, n - 1) * ld;
+        const double* w3 = W + (size_t)min(r0 + 3, n - 1) * ld;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = 0;
+        for (; c + 4 <= n; c += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double x = xs[(c + u) * kFiltEpochs + e];
+                s0 = fma(w0[c + u], x, s0);
+                s1 = fma(w1[c + u], x, s1);
+                s2 = fma(w2[c + u], x, s2);
+                s3 = fma(w3[c + u], x, s3);
+            }
+        }
+        for (; c < n; ++c) {
+            const double x = xs[c * kFiltEpochs + e];
+            s0 = fma(w0[c], x, s0);
+            s1 = fma(w1[c], x, s1);
+            s2 = fma(w2[c], x, s2);
+            s3 = fma(w3[c], x, s3);
+        }
         if (b < B) {
-            const int degree = m + r;
-            out[(size_t)b * E + pos(r)] = (degree <= 1) ? xs[r * kFiltEpochs + e] : s;    // filter.py:189
+            const double s[4] = {s0, s1, s2, s3};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + i;
+                if (r < n) out[(size_t)b * E + pos(r)] = (m + r <= 1) ? xs[r * kFiltEpochs + e] : s[i];    // filter.py:189
+            }
         }
     }
 }
