@@ -9,11 +9,12 @@ namespace shg {
 
 constexpr int kFiltEpochs = 64;     // epochs per workgroup = lanes of a wave
 
-// One workgroup = one order block x 64 epochs, 4 waves.  The coefficient vectors of the 64 epochs are gathered into LDS
+// One workgroup = one order block x 64 epochs, 16 waves (the work per block is small and made of dependent scalar-load /
+// LDS round trips: many waves per SIMD hide them).  The coefficient vectors of the 64 epochs are gathered into LDS
 // (xs[k][epoch]); every wave then takes groups of four block rows: the row index is wave-uniform, so the block entries come
 // through scalar loads and feed the FMAs as scalar operands, and one LDS read of xs[c][epoch] serves four FMAs.
 // HBM/L2 bound: bytes = 8 (sum of block sizes x epoch groups + 2 P B).
-__global__ __launch_bounds__(256) void orderwise_filter_kernel(int Nb, int N, int B, const double* __restrict__ blocks,
+__global__ __launch_bounds__(1024) void orderwise_filter_kernel(int Nb, int N, int B, const double* __restrict__ blocks,
                                                                const long long* __restrict__ block_off,
                                                                const double* __restrict__ in, double* __restrict__ out) {
     extern __shared__ double xs[];                 // [n][kFiltEpochs]
@@ -30,23 +31,23 @@ __global__ __launch_bounds__(256) void orderwise_filter_kernel(int Nb, int N, in
 
     // element k (degree m + k) of this order: cos at [m+k][m], sin at [m-1][m+k]
     auto pos = [&](int k) -> size_t { return sine ? (size_t)(m - 1) * (N + 1) + (m + k) : (size_t)(m + k) * (N + 1) + m; };
-    // gather: 16 elements per thread in flight at a time (the addresses are a whole coefficient array apart from lane to lane,
+    // gather: 8 elements per thread in flight at a time (the addresses are a whole coefficient array apart from lane to lane,
     // so every element is its own memory transaction: a loop that waits for each one is bound by their latency)
-    for (int k0 = 0; k0 < n; k0 += 64) {
-        double v[16];
+    for (int k0 = 0; k0 < n; k0 += 128) {
+        double v[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int k = k0 + wave + 4 * j;
-            v[j] = (k < n && b < B) ? in[(size_t)b * E + pos(k)] : 0.0;
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + wave + 16 * j;                     // indices clamped, not tested: no branch around the loads
+            v[j] = in[(size_t)min(b, B - 1) * E + pos(min(k, n - 1))];
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int k = k0 + wave + 4 * j;
-            if (k < n) xs[k * kFiltEpochs + e] = v[j];
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + wave + 16 * j;
+            if (k < n) xs[k * kFiltEpochs + e] = b < B ? v[j] : 0.0;
         }
     }
     __syncthreads();
-    for (int r0 = 4 * wave; r0 < n; r0 += 16) {       // rows r0 .. r0 + 3 (clamped: a duplicate row is computed, not stored)
+    for (int r0 = 4 * wave; r0 < n; r0 += 64) {       // rows r0 .. r0 + 3 (clamped: a duplicate row is computed, not stored)
         const double* w0 = W + (size_t)r0 * ld;
         const double* w1 = W + (size_t)min(r0 + 1, n - 1) * ld;
         const double* w2 = W + (size_t)min(r0 + 2, n - 1) * ld;
@@ -93,7 +94,7 @@ extern "C" int shg_orderwise_filter(const double* blocks_packed, const int64_t* 
     SHG_REQUIRE(blocks_packed && block_off && anm_in && anm_out, "shg_orderwise_filter: NULL pointer");
     SHG_REQUIRE(anm_in != anm_out, "shg_orderwise_filter: in-place operation is not supported");
     const size_t lds = (size_t)(N + 1) * kFiltEpochs * sizeof(double);
-    hipLaunchKernelGGL(orderwise_filter_kernel, dim3(2 * N + 1, ceil_div(B, kFiltEpochs)), dim3(256), lds, (hipStream_t)stream_, Nb, N, B,
+    hipLaunchKernelGGL(orderwise_filter_kernel, dim3(2 * N + 1, ceil_div(B, kFiltEpochs)), dim3(1024), lds, (hipStream_t)stream_, Nb, N, B,
                        blocks_packed, (const long long*)block_off, anm_in, anm_out);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
