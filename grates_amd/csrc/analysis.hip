@@ -115,26 +115,30 @@ __global__ void analysis_scatter_kernel(int N, int nmin, int nb, int b0, const d
 }
 
 // two checksums of the S x nlat weight table (plain sum and index-weighted sum): key of the operator cache
-__global__ __launch_bounds__(256) void analysis_checksum_kernel(long long n, const double* __restrict__ w2, double* __restrict__ out) {
+constexpr int kChecksumBlocks = 64;
+// two position-weighted sums of the area weights, per workgroup (fixed order; the host adds the 64 partial pairs): the key of
+// the cached analysis operator
+__global__ __launch_bounds__(256) void analysis_checksum_kernel(long long n, const double* __restrict__ w, double* __restrict__ out) {
     __shared__ double r0[256], r1[256];
     double s0 = 0.0, s1 = 0.0;
-    for (long long e = threadIdx.x; e < n; e += 256) {
-        s0 += w2[e];
-        s1 += w2[e] * (double)(1 + (e % 1021));
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)kChecksumBlocks * 256) {
+        const double x = w[e];
+        s0 += x;
+        s1 += x * (double)(1 + (e % 1021));
     }
     r0[threadIdx.x] = s0;
     r1[threadIdx.x] = s1;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            r0[threadIdx.x] += r0[threadIdx.x + w];
-            r1[threadIdx.x] += r1[threadIdx.x + w];
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            r0[threadIdx.x] += r0[threadIdx.x + k];
+            r1[threadIdx.x] += r1[threadIdx.x + k];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out[0] = r0[0];
-        out[1] = r1[0];
+        out[2 * blockIdx.x] = r0[0];
+        out[2 * blockIdx.x + 1] = r1[0];
     }
 }
 
@@ -208,19 +212,27 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     double *wvt = nullptr, *gt = nullptr, *w2 = nullptr, *X = nullptr, *key_d = nullptr;
     if (workspace_alloc((void**)&wvt, (size_t)nlon * chunk * nlat * sizeof(double), stream) != hipSuccess ||
         workspace_alloc((void**)&gt, (size_t)S * chunk * nlat * sizeof(double), stream) != hipSuccess ||
-        workspace_alloc((void**)&w2, (size_t)S * nlat * sizeof(double), stream) != hipSuccess ||
         workspace_alloc((void**)&X, (size_t)S * R * chunk * sizeof(double), stream) != hipSuccess ||
-        workspace_alloc((void**)&key_d, 2 * sizeof(double), stream) != hipSuccess)
+        workspace_alloc((void**)&key_d, 2 * kChecksumBlocks * sizeof(double), stream) != hipSuccess)
         return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
-    hipLaunchKernelGGL(weight_squares_kernel, dim3(nlat), dim3(256), 0, stream, S, nlat, nlon, area, p->cs_slot, w2);
-    // operator cache: rebuilt when the weights (or nmin) differ from those it was built for
-    hipLaunchKernelGGL(analysis_checksum_kernel, dim3(1), dim3(256), 0, stream, (long long)S * nlat, w2, key_d);
-    double key[2] = {0.0, 0.0};
-    SHG_HIP(hipMemcpyAsync(key, key_d, sizeof(key), hipMemcpyDeviceToHost, stream));
+    // operator cache: rebuilt when the area weights (or nmin) differ from those it was built for
+    hipLaunchKernelGGL(analysis_checksum_kernel, dim3(kChecksumBlocks), dim3(256), 0, stream, (long long)nlat * nlon, area, key_d);
+    double part[2 * kChecksumBlocks];
+    SHG_HIP(hipMemcpyAsync(part, key_d, sizeof(part), hipMemcpyDeviceToHost, stream));
     SHG_HIP(hipStreamSynchronize(stream));
+    double key[2] = {0.0, 0.0};
+    for (int k = 0; k < kChecksumBlocks; ++k) {
+        key[0] += part[2 * k];
+        key[1] += part[2 * k + 1];
+    }
     if (!p->ana_H || p->ana_nmin != nmin || p->ana_key[0] != key[0] || p->ana_key[1] != key[1]) {
         p->ana_nmin = -1;
+        if (workspace_alloc((void**)&w2, (size_t)S * nlat * sizeof(double), stream) != hipSuccess)
+            return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
+        hipLaunchKernelGGL(weight_squares_kernel, dim3(nlat), dim3(256), 0, stream, S, nlat, nlon, area, p->cs_slot, w2);
         rc = build_analysis_operator(p, w2, nmin, stream);
+        (void)hipFreeAsync(w2, stream);
+        w2 = nullptr;
         if (rc == SHG_OK) {
             p->ana_nmin = nmin;
             p->ana_key[0] = key[0];
@@ -246,7 +258,6 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     }
     (void)hipFreeAsync(wvt, stream);
     (void)hipFreeAsync(gt, stream);
-    (void)hipFreeAsync(w2, stream);
     (void)hipFreeAsync(X, stream);
     (void)hipFreeAsync(key_d, stream);
     if (rc) return rc;
