@@ -266,8 +266,7 @@ def main():
             'config': {'workload': 'batch of {0} monthly solutions d/o {1} -> {2} deg GeographicGrid ({3}x{4}), kernel {5}, per GPU'.format(
                 B, MAX_DEGREE, GRID_STEP, nlat, nlon, KERNEL),
                 'max_degree': MAX_DEGREE, 'epochs_per_gpu': B, 'grid': [nlat, nlon], 'parallelism': 'epochs sharded over {0} GPU(s), no collective'.format(world),
-                'fused_kernel': info['fused'], 'fourfold_symmetry': info['fourfold_symmetry']},
-                'untimed_ramp_launches': args.ramp,
+                'fused_kernel': info['fused'], 'fourfold_symmetry': info['fourfold_symmetry'], 'untimed_ramp_launches': args.ramp},
             'roofline': {
                 'kernel': main_kernel, 'bound': 'hbm',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
