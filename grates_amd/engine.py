@@ -133,12 +133,15 @@ class Plan:
             _lib.call('shg_synthesis', self._handle, _ptr(x), B, _ptr(out), _stream())
         return out[0] if single else out
 
-    def covariance_propagation(self, cov, min_degree, lat0=0, lat1=None, symmetric=False):
+    def covariance_propagation(self, cov, min_degree, lat0=0, lat1=None, symmetric=False, method='direct'):
         """cov [P, P] degree-wise -> sigma [(lat1-lat0)*nlon] for the band of parallels [lat0, lat1).
 
         symmetric: False (default) multiplies with the full matrix like the reference; True reads only the upper triangle
         of a symmetric matrix (half the MFMA work); None checks the matrix on the device and takes the shortcut when it is
-        exactly symmetric (the result then differs from the general path by summation order only)."""
+        exactly symmetric (the result then differs from the general path by summation order only).
+        method: 'direct' forms A Sigma like the reference (2 M P^2 flops on the MFMA units); 'separable' uses the
+        factorisation of the synthesis matrix into a latitude and a longitude part (about nlon times fewer flops,
+        P^2 + 32 P nlat doubles of workspace), same result up to summation order."""
         torch = _torch()
         lat1 = self.nlat if lat1 is None else lat1
         c = to_device(cov, self.device)
@@ -146,7 +149,12 @@ class Plan:
         if c.dim() != 2 or c.shape[0] != P or c.shape[1] != P:
             raise ValueError('covariance matrix must have shape ({0}, {0}), got {1}'.format(P, tuple(c.shape)))
         out = torch.empty(((lat1 - lat0) * self.nlon,), dtype=torch.float64, device=self.device)
+        if method not in ('direct', 'separable'):
+            raise ValueError("method must be 'direct' or 'separable'")
         with torch.cuda.device(self.device):
+            if method == 'separable':
+                _lib.call('shg_covprop_diag_separable', self._handle, _ptr(c), int(min_degree), int(lat0), int(lat1), _ptr(out), _stream())
+                return out
             if symmetric is None:
                 defect = torch.zeros(1, dtype=torch.float64, device=self.device)
                 _lib.call('shg_symmetry_defect', _ptr(c), P, P, _ptr(defect), _stream())

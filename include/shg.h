@@ -124,6 +124,11 @@ int shg_covprop_diag(shg_plan* plan, const double* cov, int nmin, int lat0, int 
  * max |S[p][c] - S[c][p]| to *defect (device double): 0 means the shortcut reproduces the general result up to summation order. */
 int shg_covprop_diag_symmetric(shg_plan* plan, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream);
 int shg_symmetry_defect(const double* S, int n, int ld, double* defect, void* stream);
+/* The same result through the separable structure of the synthesis matrix (an extension, see csrc/covsep.hip):
+ *   sigma^2(i, j) = t(j)^T B_i t(j),  B_i[s][s'] = sum_{n,n'} PK_n,s(i) Sigma[(n,s)][(n',s')] PK_n',s'(i)
+ * 2 nlat P^2 flops instead of 2 nlat nlon P^2 (d/o 180, 0.5 deg: 8e11 instead of 5.6e14); differs from shg_covprop_diag by
+ * summation order only.  Workspace: about P^2 + 32 P nlat doubles (17 GB at d/o 180 for the full grid). */
+int shg_covprop_diag_separable(shg_plan* plan, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream);
 
 /* Point-list variant  (grates/grid.py:1096-1120): colat, lon [npts]; kn [npts][N+1]; sigma [npts] */
 int shg_covprop_points(int N, const double* colat, const double* lon, const double* kn, int npts,

@@ -132,3 +132,39 @@ def test_symmetric_shortcut_matches_general_path(N, step, nmin):
                                   grid.covariance_propagation(skew, nmin, N, kernel='ewh'))
     band = grid.covariance_propagation(cov, nmin, N, kernel='ewh', parallel_range=(3, 11), symmetric=True)
     assert relerr(band, full.reshape(grid.parallels.size, -1)[3:11].ravel()) < 1e-13
+
+
+@pytest.mark.parametrize('N,step,nmin', [(20, 5.0, 0), (40, 2.0, 2), (60, 3.0, 0), (33, 4.0, 5)])
+def test_separable_variant_matches_direct_path_and_oracle(golden, N, step, nmin):
+    """method='separable' (latitude / longitude factorisation of the synthesis matrix) against the reference-formulation
+    kernel, the oracle and -- for a non-symmetric matrix -- the direct kernel again: nothing in it assumes symmetry."""
+    grid = ga.grid.GeographicGrid(step, step)
+    P = (N + 1) ** 2 - nmin ** 2
+    cov = inputs.spd_covariance(31, P)
+    direct = grid.covariance_propagation(cov, nmin, N, kernel='ewh')
+    sep = grid.covariance_propagation(cov, nmin, N, kernel='ewh', method='separable')
+    assert relerr(sep, direct) < 1e-12
+    if N <= 40:
+        ref = orc.covariance_propagation_regular(cov, nmin, N, grid.meridians, grid.parallels, orc.KernelTable('ewh', love()))
+        assert relerr(sep, ref) < TOL_SIGMA
+    band = grid.covariance_propagation(cov, nmin, N, kernel='ewh', parallel_range=(2, 9), method='separable')
+    assert relerr(band, direct.reshape(grid.parallels.size, -1)[2:9].ravel()) < 1e-12
+    skew = cov + np.triu(np.random.default_rng(3).standard_normal(cov.shape) * np.abs(cov).max() * 1e-3, 1)
+    a = grid.covariance_propagation(skew, nmin, N, kernel='potential')
+    b = grid.covariance_propagation(skew, nmin, N, kernel='potential', method='separable')
+    ok = np.isfinite(a)
+    np.testing.assert_array_equal(np.isfinite(b), ok)
+    assert relerr(b[ok], a[ok]) < 1e-11
+    with pytest.raises(ValueError):
+        grid.covariance_propagation(cov, nmin, N, kernel='ewh', method='fast')
+
+
+def test_separable_variant_golden(golden):
+    """the reference's own outputs (g9) through the separable variant"""
+    g = golden('g9_covariance')
+    grid = ga.grid.GeographicGrid(2.0, 2.0)
+    s = grid.covariance_propagation(inputs.spd_covariance(31, 41 * 41), 0, 40, kernel='ewh', method='separable')
+    assert relerr(s, g['n40_2deg_ewh']) < TOL_SIGMA
+    grid = ga.grid.GeographicGrid(5.0, 5.0)
+    s = grid.covariance_propagation(inputs.spd_covariance(32, 21 * 21 - 4), 2, 20, kernel='potential', method='separable')
+    assert relerr(s, g['n20_5deg_min2_potential']) < TOL_SIGMA
