@@ -127,6 +127,21 @@ def covariance_leg(args, rank, world, barrier, reduce_device='cuda'):
         dt = time.perf_counter() - t0
         out['symmetric_shortcut'] = {'seconds': dt, 'algorithmic_GFLOPs': flops / dt / 1e9,
                                      'max_rel_diff_vs_general': float(((sigma_sym - sigma).abs().max() / sigma.abs().max()).item())}
+    if world == 1:
+        # second extension, also outside `value`: the WHOLE grid through the latitude / longitude factorisation of the synthesis
+        # matrix (csrc/covsep.hip: 2 nlat P^2 flops instead of 2 nlat nlon P^2); the band above is compared with its rows
+        plan.covariance_propagation(cov, 0, lat0, lat0 + 1, method='separable')
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sigma_sep = plan.covariance_propagation(cov, 0, method='separable')
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rows = sigma_sep.reshape(nlat, nlon)[lat0:lat1].reshape(-1)
+        out['separable_variant'] = {'full_grid_seconds': dt, 'full_grid_points': nlat * nlon,
+                                    'equivalent_reference_formulation_GFLOPs': 2.0 * nlat * nlon * P * (P + 1.0) / dt / 1e9,
+                                    'executed_GFLOP': (2.0 * nlat * P * P + 2.0 * nlat * nlon * (2 * N + 1) ** 2) / 1e9,
+                                    'max_rel_diff_vs_general': float(((rows - sigma).abs().max() / sigma.abs().max()).item())}
+        del sigma_sep
     if world == 1 and args.cov_cpu_parallels > 0:
         from oracle import shg_oracle as orc
         ker = orc.KernelTable(KERNEL, ga.data.load_love_numbers()[0])
