@@ -133,15 +133,17 @@ extern "C" int shg_covprop_diag_separable(shg_plan* p, const double* cov, int nm
         ProfileScope ps(p, 3, stream);
         for (int sc0 = 0; sc0 < S && rc == SHG_OK; sc0 += kSepSlotChunk) {
             const int nsc = std::min(kSepSlotChunk, S - sc0);
-            for (int c = 0; c < nsc && rc == SHG_OK; ++c) {
+            for (int c = 0; c < nsc && rc == SHG_OK;) {
                 const int s = sc0 + c, m = (s + 1) >> 1, n0 = std::max(m, nmin), ns = N - n0 + 1;
+                // the cosine and the sine slot of an order have the same coefficients count and the same PK rows: one batched launch
+                const int pair = (s >= 1 && (s & 1) == 1 && c + 1 < nsc) ? 2 : 1;
                 double* Gc = G + (size_t)c * Pn * nb;
-                if (ns <= 0) {
-                    SHG_HIP(hipMemsetAsync(Gc, 0, (size_t)Pn * nb * sizeof(double), stream));
-                    continue;
-                }
-                rc = gemm_ex(false, false, Pn, nb, ns, 1.0, Sp + soff[s], Pn, 0, p->pk + (size_t)(order_offset(N, m) + n0 - m) * p->ldlat + lat0,
-                             p->ldlat, 0, 0.0, Gc, nb, 0, 1, false, stream);
+                if (ns <= 0)
+                    SHG_HIP(hipMemsetAsync(Gc, 0, (size_t)pair * Pn * nb * sizeof(double), stream));
+                else
+                    rc = gemm_ex(false, false, Pn, nb, ns, 1.0, Sp + soff[s], Pn, ns, p->pk + (size_t)(order_offset(N, m) + n0 - m) * p->ldlat + lat0,
+                                 p->ldlat, 0, 0.0, Gc, nb, (long long)Pn * nb, pair, false, stream);
+                c += pair;
             }
             if (rc) break;
             hipLaunchKernelGGL(covsep_contract_kernel, dim3(ceil_div(nb, 32), S, ceil_div(nsc, 32)), dim3(256), 0, stream, N, nmin, Pn, nb, p->ldlat,
