@@ -74,7 +74,7 @@ def all_gather_bands(local, band_sizes, group=None):
 
 
 def covariance_propagation_sharded(grid, covariance_matrix, min_degree, max_degree, kernel='potential',
-                                   GM=3.9860044150e+14, R=6.3781363000e+06, gather=True, group=None, symmetric=False):
+                                   GM=3.9860044150e+14, R=6.3781363000e+06, gather=True, group=None, symmetric=False, method='direct'):
     """
     Latitude-band sharded RegularGrid.covariance_propagation: this rank propagates its band of parallels on its
     GPU; with gather=True every rank receives the full sigma vector (one RCCL all_gather), otherwise the local band.
@@ -87,7 +87,7 @@ def covariance_propagation_sharded(grid, covariance_matrix, min_degree, max_degr
     bands = latitude_bands(grid.parallels.size, world)
     lat0, lat1 = bands[rank]
     plan = grid._plan(kernel, max_degree, GM, R)
-    local = plan.covariance_propagation(covariance_matrix, min_degree, lat0, lat1, symmetric=symmetric)
+    local = plan.covariance_propagation(covariance_matrix, min_degree, lat0, lat1, symmetric=symmetric, method=method)
     if not gather:
         return local
     sizes = [(b1 - b0) * grid.meridians.size for b0, b1 in bands]
