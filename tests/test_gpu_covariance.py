@@ -168,3 +168,37 @@ def test_separable_variant_golden(golden):
     grid = ga.grid.GeographicGrid(5.0, 5.0)
     s = grid.covariance_propagation(inputs.spd_covariance(32, 21 * 21 - 4), 2, 20, kernel='potential', method='separable')
     assert relerr(s, g['n20_5deg_min2_potential']) < TOL_SIGMA
+
+
+def test_full_size_properties_config4():
+    """BASELINE config 4 at full size (d/o 180, P = 32761, Sigma 8.6 GB, 0.5 degree grid): size-independent properties.
+    Sigma = c I gives sigma^2(i, j) = c sum_n (2n + 1) kn[i, n]^2 for every meridian (addition theorem of the 4 pi normalised
+    harmonics); sigma scales with the square root of Sigma; the direct kernel (a band) and the separable variant (whole grid)
+    agree on a dense random Sigma."""
+    import torch
+    N = 180
+    grid = ga.grid.GeographicGrid(0.5, 0.5)
+    P = (N + 1) ** 2
+    colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel('ewh'), N, grid.parallels, 3.9860044150e+14, 6.3781363000e+06,
+                                                   grid.semimajor_axis, grid.flattening)
+    plan = ga.engine.Plan(N, colat, kn, grid.meridians)
+    c = 3.0e-20
+    cov = torch.zeros((P, P), dtype=torch.float64, device='cuda')
+    cov.diagonal().fill_(c)
+    closed = np.sqrt(c * (kn ** 2 * (2 * np.arange(N + 1) + 1)[None, :]).sum(axis=1))          # [nlat]
+    sep = ga.engine.to_host(plan.covariance_propagation(cov, 0, method='separable')).reshape(360, 720)
+    assert relerr(sep, np.repeat(closed[:, None], 720, axis=1)) < 1e-12
+    band = ga.engine.to_host(plan.covariance_propagation(cov, 0, 100, 103)).reshape(3, 720)
+    assert relerr(band, np.repeat(closed[100:103, None], 720, axis=1)) < 1e-12
+    # dense random (non-symmetric) matrix with a dominant diagonal: both paths, and the scaling law
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(11)
+    cov = torch.rand((P, P), dtype=torch.float64, device='cuda', generator=gen)
+    cov.mul_(1e-22 / P)
+    cov.diagonal().add_(2e-22)
+    direct = plan.covariance_propagation(cov, 0, 178, 181)
+    sep = plan.covariance_propagation(cov, 0, method='separable')
+    assert float(((sep.reshape(360, 720)[178:181].reshape(-1) - direct).abs().max() / direct.abs().max()).item()) < 1e-12
+    cov.mul_(9.0)
+    sep9 = plan.covariance_propagation(cov, 0, method='separable')
+    assert float(((sep9 - 3.0 * sep).abs().max() / sep9.abs().max()).item()) < 1e-13
