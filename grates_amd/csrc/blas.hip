@@ -14,10 +14,15 @@ namespace shg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int XM = 128, XN = 128, XK = 16;
+constexpr int XK = 16;
 constexpr int XLR = 17;      // [row][k] staging: 17-double rows (operand contiguous along k in memory)
-constexpr int XLK = 144;     // [k][row] staging: 128 + 16 pad (operand contiguous along its row / column index)
-constexpr int XBUF = 2304;   // doubles per operand buffer: max(128 * 17, 16 * 144)
+// Output tile T x T with T = 128 (wave tile 64 x 64) or, for products with fewer than one 128-tile per CU, T = 64 (wave tile
+// 32 x 32: four times as many workgroups).  [k][row] staging: T + 16 doubles per k row.
+template <int T> struct GemmExTile {
+    static constexpr int LK = T + 16;
+    static constexpr int BUF = (T * XLR > XK * (T + 16)) ? T * XLR : XK * (T + 16);      // doubles per operand buffer
+    static constexpr int F = T / 32;          // 16 x 16 fragments per wave and dimension = pieces of a thread per operand
+};
 
 struct GemmExParams {
     int M, N, K;
@@ -36,8 +41,9 @@ struct GemmExParams {
 };
 
 // TA: A is stored [K][M] (op(A) = A^T);  TB: B is stored [N][K] (op(B) = B^T).  Row-major everywhere.
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
+template <bool TA, bool TB, int T>
+__global__ __launch_bounds__(256, T == 128 ? 2 : 3) void gemm_ex_kernel(GemmExParams P) {
+    constexpr int XM = T, XN = T, XLK = GemmExTile<T>::LK, XBUF = GemmExTile<T>::BUF, F = GemmExTile<T>::F, HALF = T / 2;
     extern __shared__ double gemm_ex_lds[];
     double* As0 = gemm_ex_lds;                  // [2][XBUF]
     double* Bs0 = gemm_ex_lds + 2 * XBUF;       // [2][XBUF]
@@ -58,10 +64,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
     // staging roles of a thread
     //   k-contiguous operand  ([row][k] in memory):  piece h: row = (tid >> 3) + 32 h, k = (tid & 7) * 2, 2 elements
     //   row-contiguous operand ([k][row] in memory): piece h: k = (tid >> 6) + 4 h, row = (tid & 63) * 2, 2 elements
+    //                                                 (T = 64: row = tid & 63, one element)
     // Indices beyond the matrix are clamped to valid addresses (the values only reach rows / columns that are never
     // stored); only the last partial K tile zero-fills.
     const int r_row = tid >> 3, r_k = (tid & 7) * 2;
-    const int k_k = __builtin_amdgcn_readfirstlane(tid >> 6), k_row = (tid & 63) * 2;      // k_k is wave-uniform
+    const int k_k = __builtin_amdgcn_readfirstlane(tid >> 6), k_row = T == 128 ? (tid & 63) * 2 : (tid & 63);      // k_k is wave-uniform
     double areg[8], breg[8];
     // Addressing of the steady state: fp64 MFMAs and the VALU instructions of all waves of a SIMD share one issue pipe
     // (tools/mfma64_issue.hip), so every load is "uniform 64-bit base, advanced per K tile by scalar instructions, + 32-bit
@@ -78,11 +85,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
         asm volatile("" : "+s"(b));
         return *reinterpret_cast<gdouble_t*>(reinterpret_cast<gbyte_t*>(b) + byte_off);
     };
-    // R-type operand ([row][k]): offsets of the four row pieces relative to the block's first row;
-    // K-type operand ([k][row]): offsets of the two columns relative to the block's first column
-    unsigned ar_off[4], br_off[4];
+    // R-type operand ([row][k]): offsets of the F row pieces (two elements each) relative to the block's first row;
+    // K-type operand ([k][row]): offsets of the column pair (T = 128) or the single column (T = 64) relative to the block's first column
+    unsigned ar_off[F], br_off[F];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    for (int h = 0; h < F; ++h) {
         ar_off[h] = (unsigned)(((size_t)(min(m0 + r_row + 32 * h, P.M - 1) - m0) * P.lda + r_k) * 8);
         br_off[h] = (unsigned)(((size_t)(min(n0 + r_row + 32 * h, P.N - 1) - n0) * P.ldb + r_k) * 8);
     }
@@ -91,113 +98,107 @@ __global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
     const double* a_base = TA ? A + m0 : A + (size_t)m0 * P.lda;           // uniform
     const double* b_base = TB ? B + (size_t)n0 * P.ldb : B + n0;           // uniform
 
-    auto fetch_full = [&](int k0) {
-        if (!TA) {
-            const double* ak = a_base + k0;
+    // register layout of the staged elements: R-type piece h -> [2 h], [2 h + 1];  K-type piece h (k = k_k + 4 h) -> [2 h], [2 h + 1]
+    // for T = 128 and [h] for T = 64
+    auto fetch_r = [&](double* reg, const double* base, const unsigned* off, int k0) {
+        const double* bk = base + k0;
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const unsigned off = pin(ar_off[h]);
-                areg[2 * h] = at(ak, off);
-                areg[2 * h + 1] = at(ak + 1, off);
-            }
-        } else {
-            const unsigned o0 = pin(ak_off0), o1 = pin(ak_off1);
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const double* ak = a_base + (size_t)(k0 + k_k + 4 * h) * P.lda;
-                areg[2 * h] = at(ak, o0);
-                areg[2 * h + 1] = at(ak, o1);
-            }
+        for (int h = 0; h < F; ++h) {
+            const unsigned o = pin(off[h]);
+            reg[2 * h] = at(bk, o);
+            reg[2 * h + 1] = at(bk + 1, o);
         }
-        if (TB) {
-            const double* bk = b_base + k0;
+    };
+    auto fetch_k = [&](double* reg, const double* base, int ld, unsigned off0, unsigned off1, int k0) {
+        const unsigned o0 = pin(off0), o1 = pin(off1);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const unsigned off = pin(br_off[h]);
-                breg[2 * h] = at(bk, off);
-                breg[2 * h + 1] = at(bk + 1, off);
-            }
-        } else {
-            const unsigned o0 = pin(bk_off0), o1 = pin(bk_off1);
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const double* bk = b_base + (size_t)(k0 + k_k + 4 * h) * P.ldb;
-                breg[2 * h] = at(bk, o0);
-                breg[2 * h + 1] = at(bk, o1);
+        for (int h = 0; h < 4; ++h) {
+            const double* bk = base + (size_t)(k0 + k_k + 4 * h) * ld;
+            if (T == 128) {
+                reg[2 * h] = at(bk, o0);
+                reg[2 * h + 1] = at(bk, o1);
+            } else {
+                reg[h] = at(bk, o0);
             }
         }
     };
+    auto fetch_full = [&](int k0) {
+        if (!TA) fetch_r(areg, a_base, ar_off, k0); else fetch_k(areg, a_base, P.lda, ak_off0, ak_off1, k0);
+        if (TB) fetch_r(breg, b_base, br_off, k0); else fetch_k(breg, b_base, P.ldb, bk_off0, bk_off1, k0);
+    };
     // last partial K tile (runs once, plain per-lane addresses): k clamped, entries beyond K zeroed
-    auto fetch_tail = [&](int k0) {
-        auto lane_ptr = [](const double* base, unsigned byte_off) { return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off); };
+    auto lane_ptr = [](const double* base, unsigned byte_off) { return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off); };
+    auto tail_r = [&](double* reg, const double* base, const unsigned* off, int k0) {
+        const int ka = k0 + r_k, kb = ka + 1;                             // a thread's two k indices
+        const int ca = min(ka, Kz - 1) - r_k, cb = min(kb, Kz - 1) - r_k;
+#pragma unroll
+        for (int h = 0; h < F; ++h) {
+            const double* row = lane_ptr(base, off[h]);
+            const double v0 = row[ca], v1 = row[cb];
+            reg[2 * h] = ka < Kz ? v0 : 0.0;
+            reg[2 * h + 1] = kb < Kz ? v1 : 0.0;
+        }
+    };
+    auto tail_k = [&](double* reg, const double* base, int ld, unsigned off0, unsigned off1, int k0) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int ka = k0 + r_k, kb = ka + 1;                         // R-type: a thread's two k indices
-            const int ca = min(ka, Kz - 1) - r_k, cb = min(kb, Kz - 1) - r_k;
-            const int kk = k0 + k_k + 4 * h;                              // K-type: the k row of piece h
-            const size_t kc = (size_t)min(kk, Kz - 1);
-            if (!TA) {
-                const double* ar = lane_ptr(a_base, ar_off[h]);
-                const double v0 = ar[ca], v1 = ar[cb];
-                areg[2 * h] = ka < Kz ? v0 : 0.0;
-                areg[2 * h + 1] = kb < Kz ? v1 : 0.0;
+            const int kk = k0 + k_k + 4 * h;                              // the k row of piece h
+            const double* row = base + (size_t)min(kk, Kz - 1) * ld;
+            if (T == 128) {
+                const double v0 = *lane_ptr(row, off0), v1 = *lane_ptr(row, off1);
+                reg[2 * h] = kk < Kz ? v0 : 0.0;
+                reg[2 * h + 1] = kk < Kz ? v1 : 0.0;
             } else {
-                const double v0 = *lane_ptr(a_base + kc * P.lda, ak_off0), v1 = *lane_ptr(a_base + kc * P.lda, ak_off1);
-                areg[2 * h] = kk < Kz ? v0 : 0.0;
-                areg[2 * h + 1] = kk < Kz ? v1 : 0.0;
+                const double v0 = *lane_ptr(row, off0);
+                reg[h] = kk < Kz ? v0 : 0.0;
             }
-            if (TB) {
-                const double* br = lane_ptr(b_base, br_off[h]);
-                const double v0 = br[ca], v1 = br[cb];
-                breg[2 * h] = ka < Kz ? v0 : 0.0;
-                breg[2 * h + 1] = kb < Kz ? v1 : 0.0;
-            } else {
-                const double v0 = *lane_ptr(b_base + kc * P.ldb, bk_off0), v1 = *lane_ptr(b_base + kc * P.ldb, bk_off1);
-                breg[2 * h] = kk < Kz ? v0 : 0.0;
-                breg[2 * h + 1] = kk < Kz ? v1 : 0.0;
-            }
+        }
+    };
+    auto fetch_tail = [&](int k0) {
+        if (!TA) tail_r(areg, a_base, ar_off, k0); else tail_k(areg, a_base, P.lda, ak_off0, ak_off1, k0);
+        if (TB) tail_r(breg, b_base, br_off, k0); else tail_k(breg, b_base, P.ldb, bk_off0, bk_off1, k0);
+    };
+    auto stage_r = [&](double* Xs, const double* reg) {
+#pragma unroll
+        for (int h = 0; h < F; ++h) {
+            Xs[(r_row + 32 * h) * XLR + r_k] = reg[2 * h];
+            Xs[(r_row + 32 * h) * XLR + r_k + 1] = reg[2 * h + 1];
+        }
+    };
+    auto stage_k = [&](double* Xs, const double* reg) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (T == 128)
+                *reinterpret_cast<double2*>(&Xs[(k_k + 4 * h) * XLK + k_row]) = make_double2(reg[2 * h], reg[2 * h + 1]);
+            else
+                Xs[(k_k + 4 * h) * XLK + k_row] = reg[h];
         }
     };
     auto stage = [&](int buf) {
-        double* As = As0 + buf * XBUF;
-        double* Bs = Bs0 + buf * XBUF;
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            if (!TA) {
-                As[(r_row + 32 * h) * XLR + r_k] = areg[2 * h];
-                As[(r_row + 32 * h) * XLR + r_k + 1] = areg[2 * h + 1];
-            } else {
-                *reinterpret_cast<double2*>(&As[(k_k + 4 * h) * XLK + k_row]) = make_double2(areg[2 * h], areg[2 * h + 1]);
-            }
-            if (TB) {
-                Bs[(r_row + 32 * h) * XLR + r_k] = breg[2 * h];
-                Bs[(r_row + 32 * h) * XLR + r_k + 1] = breg[2 * h + 1];
-            } else {
-                *reinterpret_cast<double2*>(&Bs[(k_k + 4 * h) * XLK + k_row]) = make_double2(breg[2 * h], breg[2 * h + 1]);
-            }
-        }
+        if (!TA) stage_r(As0 + buf * XBUF, areg); else stage_k(As0 + buf * XBUF, areg);
+        if (TB) stage_r(Bs0 + buf * XBUF, breg); else stage_k(Bs0 + buf * XBUF, breg);
     };
 
-    double4_t acc[4][4];
+    double4_t acc[F][F];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < F; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < F; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     // fragments of k-step ks + 1 are read from LDS while the 16 MFMAs of k-step ks run (two named fragment sets; the
     // sched_barriers keep hipcc from regrouping the reads in front of the MFMAs that hide them)
     auto compute = [&](int buf) {
         const double* As = As0 + buf * XBUF;
         const double* Bs = Bs0 + buf * XBUF;
-        double af0[4], bf0[4], af1[4], bf1[4];
+        double af0[F], bf0[F], af1[F], bf1[F];
 #define SHG_FRAGS(af, bf, ks)                                                                                                  \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                             \
-        af[a] = TA ? As[((ks) * 4 + fk) * XLK + wr * 64 + a * 16 + fr] : As[(wr * 64 + a * 16 + fr) * XLR + (ks) * 4 + fk];    \
-    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                                             \
-        bf[b] = TB ? Bs[(wc * 64 + b * 16 + fr) * XLR + (ks) * 4 + fk] : Bs[((ks) * 4 + fk) * XLK + wc * 64 + b * 16 + fr]
+    _Pragma("unroll") for (int a = 0; a < F; ++a)                                                                             \
+        af[a] = TA ? As[((ks) * 4 + fk) * XLK + wr * HALF + a * 16 + fr] : As[(wr * HALF + a * 16 + fr) * XLR + (ks) * 4 + fk];  \
+    _Pragma("unroll") for (int b = 0; b < F; ++b)                                                                             \
+        bf[b] = TB ? Bs[(wc * HALF + b * 16 + fr) * XLR + (ks) * 4 + fk] : Bs[((ks) * 4 + fk) * XLK + wc * HALF + b * 16 + fr]
 #define SHG_MFMA16(af, bf)                                                                                                     \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                             \
-        _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0)
+    _Pragma("unroll") for (int a = 0; a < F; ++a)                                                                             \
+        _Pragma("unroll") for (int b = 0; b < F; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0)
         SHG_FRAGS(af0, bf0, 0);
         __builtin_amdgcn_sched_barrier(0);
         SHG_FRAGS(af1, bf1, 1);
@@ -245,14 +246,14 @@ __global__ __launch_bounds__(256, 2) void gemm_ex_kernel(GemmExParams P) {
 
     // epilogue.  C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < F; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int gr = m0 + wr * 64 + a * 16 + fk + 4 * r;
+            const int gr = m0 + wr * HALF + a * 16 + fk + 4 * r;
             if (gr >= P.M) continue;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int gc = n0 + wc * 64 + b * 16 + fr;
+            for (int b = 0; b < F; ++b) {
+                const int gc = n0 + wc * HALF + b * 16 + fr;
                 if (gc >= P.N) continue;
                 double* c = C + (size_t)gr * P.ldc + gc;
                 const double v = P.alpha * acc[a][b][r];
@@ -304,8 +305,16 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
         return SHG_OK;
     }
     P.Ktotal = 0;
-    dim3 grid(ceil_div(N, XN), ceil_div(M, XM), batch);
-    const size_t lds = (size_t)4 * XBUF * sizeof(double);          // 73.7 KB: two workgroups per CU
+    // 128 x 128 output tiles; products that would leave most CUs without a tile (the K = 128 panel updates of the blocked
+    // factorisation, small batches) take 64 x 64 tiles: four times as many workgroups
+    long long work_tiles = (long long)ceil_div(N, 128) * ceil_div(M, 128) * batch;
+    if (upper_only) work_tiles = (work_tiles + ceil_div(N, 128)) / 2;
+    // (long K: split below instead; an output that overwrites an operand -- the in-place row panel U12 = U11^-T A12 of the
+    //  factorisation -- relies on one workgroup owning a whole column tile of that operand: 128-row tiles only)
+    const bool small_tiles = work_tiles < 200 && !(batch == 1 && !upper_only && K >= 512) && (const double*)C != A && (const double*)C != B;
+    const int XT = small_tiles ? 64 : 128;
+    dim3 grid(ceil_div(N, XT), ceil_div(M, XT), batch);
+    const size_t lds = (size_t)4 * (small_tiles ? GemmExTile<64>::BUF : GemmExTile<128>::BUF) * sizeof(double);   // 73.7 KB (two workgroups per CU) / 41 KB
     // Few output tiles and a long K (block times a handful of right-hand sides): split K over grid.z into a workspace of
     // partial products that a second kernel sums in a fixed order (deterministic, unlike atomics).
     const int tiles = (int)(grid.x * grid.y);
@@ -333,10 +342,15 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
             }
         }
     }
-#define SHG_GEMM_EX(TA_, TB_)                                                                                                     \
-    do {                                                                                                                           \
-        SHG_HIP(hipFuncSetAttribute((const void*)gemm_ex_kernel<TA_, TB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((gemm_ex_kernel<TA_, TB_>), grid, dim3(256), lds, stream, P);                                           \
+#define SHG_GEMM_EX(TA_, TB_)                                                                                                          \
+    do {                                                                                                                                \
+        if (small_tiles) {                                                                                                              \
+            SHG_HIP(hipFuncSetAttribute((const void*)gemm_ex_kernel<TA_, TB_, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+            hipLaunchKernelGGL((gemm_ex_kernel<TA_, TB_, 64>), grid, dim3(256), lds, stream, P);                                        \
+        } else {                                                                                                                        \
+            SHG_HIP(hipFuncSetAttribute((const void*)gemm_ex_kernel<TA_, TB_, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((gemm_ex_kernel<TA_, TB_, 128>), grid, dim3(256), lds, stream, P);                                       \
+        }                                                                                                                               \
     } while (0)
     if (ta) {
         if (tb) SHG_GEMM_EX(true, true); else SHG_GEMM_EX(true, false);

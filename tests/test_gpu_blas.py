@@ -78,6 +78,17 @@ def test_potrf_and_trtri(n):
     assert relerr(X @ ref, np.eye(n)) < 1e-12
 
 
+@pytest.mark.parametrize('n', [257, 400, 900, 1300])
+def test_potrf_reproducible_bitwise(n):
+    """The row panel U12 = U11^-T A12 is formed in place (the output overwrites an operand): repeated factorisations must
+    agree bit for bit, whatever the order in which the workgroups of a launch run."""
+    A = dev(spd(n + 1, n))
+    first = eng.potrf(A.clone())
+    for _ in range(4):
+        assert bool((eng.potrf(A.clone()) == first).all())
+    assert relerr(first.cpu().numpy(), la.cholesky(spd(n + 1, n), lower=False)) < 1e-12
+
+
 def test_potrf_only_upper_triangle_referenced_and_strided():
     n = 200
     A = spd(3, n)
