@@ -309,9 +309,12 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
     // factorisation, small batches) take 64 x 64 tiles: four times as many workgroups
     long long work_tiles = (long long)ceil_div(N, 128) * ceil_div(M, 128) * batch;
     if (upper_only) work_tiles = (work_tiles + ceil_div(N, 128)) / 2;
-    // (long K: split below instead; an output that overwrites an operand -- the in-place row panel U12 = U11^-T A12 of the
-    //  factorisation -- relies on one workgroup owning a whole column tile of that operand: 128-row tiles only)
-    const bool small_tiles = work_tiles < 200 && !(batch == 1 && !upper_only && K >= 512) && (const double*)C != A && (const double*)C != B;
+    // (a long K with too few 64-tiles to fill the chip is split below instead; an output that overwrites an operand -- the
+    //  in-place row panel U12 = U11^-T A12 of the factorisation -- relies on one workgroup owning a whole column tile of that
+    //  operand: 128-row tiles only)
+    const long long tiles64 = (long long)ceil_div(N, 64) * ceil_div(M, 64) * batch;
+    const bool split_candidate = batch == 1 && !upper_only && K >= 512 && tiles64 < 256;
+    const bool small_tiles = work_tiles < 200 && !split_candidate && (const double*)C != A && (const double*)C != B;
     const int XT = small_tiles ? 64 : 128;
     dim3 grid(ceil_div(N, XT), ceil_div(M, XT), batch);
     const size_t lds = (size_t)4 * (small_tiles ? GemmExTile<64>::BUF : GemmExTile<128>::BUF) * sizeof(double);   // 73.7 KB (two workgroups per CU) / 41 KB
@@ -320,7 +323,7 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
     const int tiles = (int)(grid.x * grid.y);
     double* partial = nullptr;
     int slices = 1;
-    if (batch == 1 && !upper_only && tiles < 384 && K >= 512) {                 // fewer than 1.5 workgroups per CU
+    if (!small_tiles && batch == 1 && !upper_only && tiles < 384 && K >= 512) {                 // fewer than 1.5 workgroups per CU
         slices = std::min(std::min(16, K / 256), std::max(1, 512 / tiles));
         if (slices > 1) {
             const int chunk = round_up(ceil_div(K, slices), XK);
