@@ -392,56 +392,109 @@ __device__ __forceinline__ double fast_reciprocal(double x) {
 // buffered LDS line (one barrier per step) and does its rank-1 update in registers; the steps are grouped by 32-row
 // groups (template parameter) so that all register indices are compile-time constants.  Two waves per SIMD.
 
-// the 32 elimination steps k = 32 KI .. 32 KI + 31 of the factorisation
+// the 32 elimination steps k = 32 KI .. 32 KI + 31 of the factorisation, two per barrier: the owners of the rows k and k + 1
+// publish them as they are (row k + 1 not yet updated by step k); every thread forms the updated row k + 1 for the columns
+// it needs itself, with exactly the operations its owner would have used, so the result is bit-identical to one step per
+// barrier while the serial chain has half as many barrier / LDS round trips
 template <int KI>
-__device__ __forceinline__ void leaf_factor_group(double (&u)[4][8], double (*rowbuf)[LEAF], int* bad, int ty, int tx, int tid) {
-    for (int kr = 0; kr < 32; ++kr) {
-        const int k = KI * 32 + kr, buf = k & 1;
-        if (ty == kr) {
+__device__ __forceinline__ void leaf_factor_group(double (&u)[4][8], double (*rowbuf)[2][LEAF], int* bad, int ty, int tx, int tid) {
+    for (int kr = 0; kr < 32; kr += 2) {
+        const int k = KI * 32 + kr, buf = (kr >> 1) & 1;
+        if (ty == kr || ty == kr + 1) {
+            double* dst = rowbuf[buf][ty - kr];
 #pragma unroll
-            for (int cc = 2 * KI; cc < 8; ++cc) rowbuf[buf][tx + 16 * cc] = u[KI][cc];
+            for (int cc = 2 * KI; cc < 8; ++cc) dst[tx + 16 * cc] = u[KI][cc];
         }
         __syncthreads();
-        double piv = rowbuf[buf][k];
-        if (!(piv > 0.0)) {                      // not positive definite (also catches NaN); the same value in all threads
+        const double* r0 = rowbuf[buf][0];
+        const double* r1raw = rowbuf[buf][1];
+        double piv0 = r0[k];
+        if (!(piv0 > 0.0)) {                     // not positive definite (also catches NaN); the same value in all threads
             if (tid == 0 && *bad == 0) *bad = k + 1;
-            piv = 1.0;
+            piv0 = 1.0;
         }
-        const double inv = fast_reciprocal(piv);
+        const double inv0 = fast_reciprocal(piv0);
+        const double f01 = r0[k + 1] * inv0;                             // multiplier of row k + 1 in step k
+        double piv1 = fma(-f01, r0[k + 1], r1raw[k + 1]);
+        if (!(piv1 > 0.0)) {
+            if (tid == 0 && *bad == 0) *bad = k + 2;
+            piv1 = 1.0;
+        }
+        const double inv1 = fast_reciprocal(piv1);
+        double c0[8], c1[8];                                             // rows k and k + 1 (after step k) at this thread's columns
+#pragma unroll
+        for (int cc = 2 * KI; cc < 8; ++cc) {
+            c0[cc] = r0[tx + 16 * cc];
+            c1[cc] = fma(-f01, c0[cc], r1raw[tx + 16 * cc]);
+        }
 #pragma unroll
         for (int ii = KI; ii < 4; ++ii) {
             const int i = ty + 32 * ii;
             if (ii > KI || ty > kr) {            // row i > k
-                const double f = rowbuf[buf][i] * inv;
+                const double f0 = r0[i] * inv0;
+                const bool both = ii > KI || ty > kr + 1;                // row i > k + 1: step k + 1 as well
+                const double f1 = both ? fma(-f01, r0[i], r1raw[i]) * inv1 : 0.0;
 #pragma unroll
                 for (int cc = 2 * ii; cc < 8; ++cc)
-                    if (cc >= 2 * ii + 2 || tx + 16 * cc >= i) u[ii][cc] = fma(-f, rowbuf[buf][tx + 16 * cc], u[ii][cc]);
+                    if (cc >= 2 * ii + 2 || tx + 16 * cc >= i) {
+                        double v = fma(-f0, c0[cc], u[ii][cc]);
+                        if (both) v = fma(-f1, c1[cc], v);
+                        u[ii][cc] = v;
+                    }
             }
         }
     }
 }
 
-// the 32 back-substitution steps k = 32 KI + 31 .. 32 KI of the inversion (registers hold X, Ul the factor)
+// the 32 back-substitution steps k = 32 KI + 31 .. 32 KI of the inversion (registers hold X, Ul the factor), two per barrier
+// like the factorisation: the owner of row k publishes it scaled, the owner of row k - 1 as it is; every thread forms the
+// final row k - 1 for its columns with the operations its owner would have used (bit-identical results)
 template <int KI>
-__device__ __forceinline__ void leaf_invert_group(double (&x)[4][8], double (*rowbuf)[LEAF], const double* dg, const double* Ul, int ty, int tx) {
-    for (int kr = 31; kr >= 0; --kr) {
-        const int k = KI * 32 + kr, buf = k & 1;
+__device__ __forceinline__ void leaf_invert_group(double (&x)[4][8], double (*rowbuf)[2][LEAF], const double* dg, const double* Ul, int ty, int tx) {
+    for (int kr = 31; kr >= 1; kr -= 2) {
+        const int k = KI * 32 + kr, buf = ((31 - kr) >> 1) & 1;
         if (ty == kr) {
             const double r = dg[k];
 #pragma unroll
             for (int cc = 2 * KI; cc < 8; ++cc) {
                 x[KI][cc] *= r;
-                rowbuf[buf][tx + 16 * cc] = x[KI][cc];
+                rowbuf[buf][0][tx + 16 * cc] = x[KI][cc];
             }
         }
+        if (ty == kr - 1) {
+#pragma unroll
+            for (int cc = 2 * KI; cc < 8; ++cc) rowbuf[buf][1][tx + 16 * cc] = x[KI][cc];
+        }
         __syncthreads();
+        const double* xk = rowbuf[buf][0];
+        const double* raw = rowbuf[buf][1];
+        const double m01 = Ul[(k - 1) * LLD + k];                        // U[k-1][k]
+        const double r1 = dg[k - 1];
+        double c0[8], c1[8];                                             // rows k and k - 1 of X (final) at this thread's columns
+#pragma unroll
+        for (int cc = 2 * KI; cc < 8; ++cc) {
+            const int c = tx + 16 * cc;
+            c0[cc] = xk[c];
+            const double t = (cc >= 2 * KI + 2 || c >= k) ? fma(-m01, c0[cc], raw[c]) : raw[c];
+            c1[cc] = t * r1;
+        }
+        if (ty == kr - 1) {
+#pragma unroll
+            for (int cc = 2 * KI; cc < 8; ++cc) x[KI][cc] = c1[cc];
+        }
 #pragma unroll
         for (int ii = 0; ii <= KI; ++ii) {
-            if (ii < KI || ty < kr) {            // row i < k
-                const double m = Ul[(ty + 32 * ii) * LLD + k];
+            if (ii < KI || ty < kr - 1) {        // row i < k - 1
+                const double m0 = Ul[(ty + 32 * ii) * LLD + k];
+                const double m1 = Ul[(ty + 32 * ii) * LLD + k - 1];
 #pragma unroll
-                for (int cc = 2 * KI; cc < 8; ++cc)
-                    if (cc >= 2 * KI + 2 || tx + 16 * cc >= k) x[ii][cc] = fma(-m, rowbuf[buf][tx + 16 * cc], x[ii][cc]);
+                for (int cc = 2 * KI; cc < 8; ++cc) {
+                    const int c = tx + 16 * cc;
+                    double v = x[ii][cc];
+                    if (cc >= 2 * KI + 2 || c >= k) v = fma(-m0, c0[cc], v);
+                    if (cc >= 2 * KI + 2 || c >= k - 1) v = fma(-m1, c1[cc], v);
+                    x[ii][cc] = v;
+                }
             }
         }
     }
@@ -450,7 +503,7 @@ __device__ __forceinline__ void leaf_invert_group(double (&x)[4][8], double (*ro
 __global__ __launch_bounds__(512) void leaf_kernel(int n, double* __restrict__ A, int lda, long long strideA, double* __restrict__ X,
                                                    int ldx, long long strideX, int mode, int* __restrict__ info, int info_base) {
     extern __shared__ double Ul[];                      // [LEAF][LLD] factor, inversion phase only
-    __shared__ double rowbuf[2][LEAF];
+    __shared__ double rowpair[2][2][LEAF];             // two published rows per barrier, double buffered
     __shared__ double dg[LEAF];
     __shared__ int bad;
     const int tid = threadIdx.x;
@@ -471,10 +524,10 @@ __global__ __launch_bounds__(512) void leaf_kernel(int n, double* __restrict__ A
     if (mode & 1) {
         // right-looking elimination with the row scaling deferred: step k uses the unscaled pivot row,
         //   U[i][c] -= U[k][i] U[k][c] / U[k][k]   (k < i <= c)
-        leaf_factor_group<0>(u, rowbuf, &bad, ty, tx, tid);
-        leaf_factor_group<1>(u, rowbuf, &bad, ty, tx, tid);
-        leaf_factor_group<2>(u, rowbuf, &bad, ty, tx, tid);
-        leaf_factor_group<3>(u, rowbuf, &bad, ty, tx, tid);
+        leaf_factor_group<0>(u, rowpair, &bad, ty, tx, tid);
+        leaf_factor_group<1>(u, rowpair, &bad, ty, tx, tid);
+        leaf_factor_group<2>(u, rowpair, &bad, ty, tx, tid);
+        leaf_factor_group<3>(u, rowpair, &bad, ty, tx, tid);
         // scale the rows: U[k][c] /= sqrt(d_k)
         __syncthreads();
 #pragma unroll
@@ -514,10 +567,10 @@ __global__ __launch_bounds__(512) void leaf_kernel(int n, double* __restrict__ A
                 u[ii][cc] = i == c ? 1.0 : 0.0;          // from here on the registers hold X
             }
         __syncthreads();
-        leaf_invert_group<3>(u, rowbuf, dg, Ul, ty, tx);
-        leaf_invert_group<2>(u, rowbuf, dg, Ul, ty, tx);
-        leaf_invert_group<1>(u, rowbuf, dg, Ul, ty, tx);
-        leaf_invert_group<0>(u, rowbuf, dg, Ul, ty, tx);
+        leaf_invert_group<3>(u, rowpair, dg, Ul, ty, tx);
+        leaf_invert_group<2>(u, rowpair, dg, Ul, ty, tx);
+        leaf_invert_group<1>(u, rowpair, dg, Ul, ty, tx);
+        leaf_invert_group<0>(u, rowpair, dg, Ul, ty, tx);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
