@@ -389,7 +389,7 @@ __device__ __forceinline__ double fast_reciprocal(double x) {
 // Thread (ty, tx) = (tid >> 4, tid & 15) of the 32 x 16 thread grid owns the 4 x 8 register tile
 //   u[ii][cc] = U[ty + 32 ii][tx + 16 cc]          (cyclic distribution: the work stays balanced as k advances)
 // Blocks smaller than 128 are padded with the identity.  Every elimination step broadcasts one row through a double
-// buffered LDS line (one barrier per step) and does its rank-1 update in registers; the steps are grouped by 32-row
+// buffered LDS line pair (one barrier per two steps) and does its rank-1 updates in registers; the steps are grouped by 32-row
 // groups (template parameter) so that all register indices are compile-time constants.  Two waves per SIMD.
 
 // the 32 elimination steps k = 32 KI .. 32 KI + 31 of the factorisation, two per barrier: the owners of the rows k and k + 1
