@@ -33,6 +33,28 @@ def test_gemm_transposes(ta, tb, M, N, K):
     assert relerr(out, ref) < 1e-13
 
 
+def test_gemm_seeded_random_shapes():
+    """60 seeded shapes across the tile variants of the kernel (128 x 128, 64 x 64, split K), all four transposes, with
+    alpha / beta and an output row stride: the paths are chosen from the shape, so the sweep covers their borders."""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        M, N = int(rng.integers(1, 1800)), int(rng.integers(1, 1800))
+        K = int(rng.choice([1, 3, 16, 17, 100, 128, 300, 511, 512, 900, 2100]))
+        if case % 3 == 0:
+            M = int(rng.integers(1, 200))
+        ta, tb = bool(case & 1), bool(case & 2)
+        A = rng.standard_normal((K, M) if ta else (M, K))
+        B = rng.standard_normal((N, K) if tb else (K, N))
+        C0 = rng.standard_normal((M, N + 3))
+        alpha, beta = (1.0, 0.0) if case % 4 else (-0.5, 1.5)
+        ref = alpha * ((A.T if ta else A) @ (B.T if tb else B)) + beta * C0[:, 0:N]
+        buf = dev(C0)
+        eng.gemm(dev(A), dev(B), transa=ta, transb=tb, alpha=alpha, beta=beta, out=buf[:, 0:N])
+        got = buf.cpu().numpy()
+        assert relerr(got[:, 0:N], ref) < 1e-13, (case, M, N, K, ta, tb)
+        np.testing.assert_array_equal(got[:, N:], C0[:, N:])            # the padding columns are untouched
+
+
 def test_gemm_alpha_beta_and_views():
     rng = np.random.default_rng(5)
     A, B, C = rng.standard_normal((150, 90)), rng.standard_normal((90, 70)), rng.standard_normal((150, 70))
