@@ -28,6 +28,20 @@ def test_dgemm_against_numpy(M, N, K):
     assert relerr(C, A @ B) < 1e-14
 
 
+@pytest.mark.parametrize('M,N,K', [(2570, 2700, 515), (2560, 2688, 528), (3001, 2049, 1000)])
+def test_dgemm_large_tile_counts(M, N, K):
+    """Shapes with more than 384 output tiles stay on the plain MFMA kernel (odd sizes: 8-byte operand loads and a partial
+    last K tile; even sizes: 16-byte loads); checked against torch on the device."""
+    import torch
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(M + N + K)
+    A = torch.randn((M, K), dtype=torch.float64, device='cuda', generator=gen)
+    B = torch.randn((K, N), dtype=torch.float64, device='cuda', generator=gen)
+    C = ga.engine.dgemm(A, B)
+    ref = A @ B
+    assert float(((C - ref).abs().max() / ref.abs().max()).item()) < 1e-13
+
+
 def test_dgemm_layout_with_asymmetric_operand():
     # A = I with an asymmetric B catches transposed fragment layouts
     n = 48
