@@ -1,15 +1,32 @@
 // Point-list paths (irregular grids): every point carries its own colatitude, longitude and kn row.
 //   shg_synthesis_points   replaces grates/gravityfield.py:370-388 (blocks of 512 points, spherical_harmonics + dgemv)
 //   shg_covprop_points     replaces grates/grid.py:1096-1120       (blocks of 256 points, F Sigma F^T diagonal)
-// Synthesis: lane <-> point, column recursion of P_nm in registers, coefficients fetched with wave-uniform
-// scalar loads, 4 epochs per pass.  Covariance: per-point tables feed the same fp64 MFMA kernel as the regular grid.
+// Synthesis: lane <-> point, column recursion of P_nm in registers, coefficients of an order staged in LDS,
+// 16 epochs per pass.  Covariance: per-point tables feed the same fp64 MFMA kernel as the regular grid.
 #include "common.h"
 
 namespace shg {
 
 void recursion_tables(int N, std::vector<double>& a, std::vector<double>& b);   // plan.hip
 
-constexpr int kPtEpochs = 8;
+constexpr int kPtEpochs = 16;
+
+// knT[n][pt] = kn[pt][n]: inside the kernel consecutive lanes are consecutive points, so the degree factors are read
+// along the points (with the point-major layout of the interface every lane would touch its own cache line, N + 1 times over)
+__global__ __launch_bounds__(256) void transpose_kn_kernel(int N, int npts, const double* __restrict__ kn, double* __restrict__ knT) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const int p0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    for (int k = ty; k < 32; k += 8) {
+        const int pt = p0 + k, n = n0 + tx;
+        tile[k][tx] = (pt < npts && n <= N) ? kn[(size_t)pt * (N + 1) + n] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int n = n0 + k, pt = p0 + tx;
+        if (n <= N && pt < npts) knT[(size_t)n * npts + pt] = tile[tx][k];
+    }
+}
 
 __device__ inline double rec_a_pt(int ni, int mi) {
     const double n = ni, m = mi;
@@ -22,23 +39,41 @@ __device__ inline double rec_b_pt(int ni, int mi) {
     return sqrt((2.0 * n + 1.0) / (2.0 * n - 3.0) * (n - m - 1.0) / (n - m) * (n + m - 1.0) / (n + m));
 }
 
+// One wave = 64 points x up to 16 epochs.  For every order m the coefficients C_nm, S_nm (n = m..N) of the 16 epochs are first
+// gathered into LDS with ordinary vector loads (many in flight; fetched through wave-uniform scalar loads instead, 32 dependent
+// cache misses per (n, m) made the kernel 80 times slower), then the degree loop reads them as LDS broadcasts.
 __global__ __launch_bounds__(64) void synthesis_points_kernel(int N, int npts, int B, const double* __restrict__ colat,
-                                                              const double* __restrict__ lon, const double* __restrict__ kn,
+                                                              const double* __restrict__ lon, const double* __restrict__ knT,
                                                               const double* __restrict__ arec, const double* __restrict__ brec,
                                                               const double* __restrict__ anm, double* __restrict__ values) {
-    const int pt = blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ double slab[];                 // [N + 1 - m][2][kPtEpochs]
+    const int lane = threadIdx.x;
+    const int pt = blockIdx.x * 64 + lane;
     const int b0 = blockIdx.y * kPtEpochs;
     const bool ok = pt < npts;
     const int q = ok ? pt : 0;
     const double th = colat[q], lam = lon[q];
     const double t = cos(th), st = sin(th);
-    const double* knp = kn + (size_t)q * (N + 1);
+    const double* knp = knT + q;                                 // + n * npts
     const size_t E = (size_t)(N + 1) * (N + 1);
     double acc[kPtEpochs];
 #pragma unroll
     for (int bb = 0; bb < kPtEpochs; ++bb) acc[bb] = 0.0;
     double pmm = 1.0;
     for (int m = 0; m <= N; ++m) {
+        const int cnt = N + 1 - m;
+        __syncthreads();                                         // the previous order's slab has been consumed
+        for (int idx = lane; idx < cnt * 2 * kPtEpochs; idx += 64) {
+            const int e = idx % kPtEpochs, cs = (idx / kPtEpochs) & 1, k = idx / (2 * kPtEpochs);
+            const double* a = anm + (size_t)min(b0 + e, B - 1) * E;
+            double v = 0.0;
+            if (cs == 0)
+                v = a[(size_t)(m + k) * (N + 1) + m];
+            else if (m >= 1)
+                v = a[(size_t)(m - 1) * (N + 1) + m + k];
+            slab[idx] = v;
+        }
+        __syncthreads();
         if (m == 1)
             pmm = sqrt(3.0) * st;
         else if (m >= 2)
@@ -53,14 +88,13 @@ __global__ __launch_bounds__(64) void synthesis_points_kernel(int N, int npts, i
                 p2 = p1;
                 p1 = p;
             }
-            const double pk = p1 * knp[n];
+            const double pk = p1 * knp[(size_t)n * npts];
             const double yc = pk * cm, ys = pk * sm;
+            const double* c = slab + (size_t)(n - m) * 2 * kPtEpochs;
 #pragma unroll
             for (int bb = 0; bb < kPtEpochs; ++bb) {
-                const int b = min(b0 + bb, B - 1);
-                const double* a = anm + (size_t)b * E;                 // wave-uniform addresses: scalar loads
-                acc[bb] = fma(yc, a[(size_t)n * (N + 1) + m], acc[bb]);
-                if (m >= 1) acc[bb] = fma(ys, a[(size_t)(m - 1) * (N + 1) + n], acc[bb]);
+                acc[bb] = fma(yc, c[bb], acc[bb]);
+                acc[bb] = fma(ys, c[kPtEpochs + bb], acc[bb]);
             }
         }
     }
@@ -141,8 +175,15 @@ extern "C" int shg_synthesis_points(int N, const double* colat, const double* lo
     SHG_HIP(hipMemcpyAsync(tab, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     SHG_HIP(hipMemcpyAsync(tab + a.size(), b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     SHG_HIP(hipStreamSynchronize(stream));           // the host vectors go out of scope
-    hipLaunchKernelGGL(synthesis_points_kernel, dim3(ceil_div(npts, 64), ceil_div(B, kPtEpochs)), dim3(64), 0, stream, N, npts, B, colat, lon,
-                       kn, tab, tab + a.size(), anm, values);
+    double* knT = nullptr;
+    if (hipMallocAsync((void**)&knT, (size_t)(N + 1) * npts * sizeof(double), stream) != hipSuccess) {
+        (void)hipFreeAsync(tab, stream);
+        return fail(SHG_ERR_NOMEM, "shg_synthesis_points: table allocation failed");
+    }
+    hipLaunchKernelGGL(transpose_kn_kernel, dim3(ceil_div(npts, 32), ceil_div(N + 1, 32)), dim3(256), 0, stream, N, npts, kn, knT);
+    hipLaunchKernelGGL(synthesis_points_kernel, dim3(ceil_div(npts, 64), ceil_div(B, kPtEpochs)), dim3(64), (size_t)(N + 1) * 2 * kPtEpochs * sizeof(double), stream, N, npts, B, colat, lon,
+                       knT, tab, tab + a.size(), anm, values);
+    (void)hipFreeAsync(knT, stream);
     (void)hipFreeAsync(tab, stream);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
