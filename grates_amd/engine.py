@@ -198,8 +198,30 @@ def cached_plan(max_degree, colat, kn, meridians):
     return plan
 
 
+_table_cache = {}
+
+
+def cached_point_tables(max_degree, latitude, longitude, tag, build):
+    """Device copies of the per-point tables (colatitude, longitude, degree factors) of a point list, cached by content like
+    the plans: `build()` -> (colat, lon, kn) host arrays is only called for a new (points, kernel / constants tag, degree)."""
+    torch = require_gpu()
+    h = hashlib.blake2b(digest_size=16)
+    h.update(repr((int(max_degree), int(torch.cuda.current_device()), tag)).encode())
+    for a in (latitude, longitude):
+        h.update(np.ascontiguousarray(a).tobytes())
+    key = h.hexdigest()
+    entry = _table_cache.get(key)
+    if entry is None:
+        if len(_table_cache) >= _PLAN_CACHE_LIMIT:
+            _table_cache.pop(next(iter(_table_cache)))
+        entry = tuple(to_device(a) for a in build())
+        _table_cache[key] = entry
+    return entry
+
+
 def clear_plan_cache():
     _plan_cache.clear()
+    _table_cache.clear()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -300,8 +300,12 @@ def synthesize(anm_batch, grid, kernel='ewh', GM=3.9860044150e+14, R=6.378136300
     try:
         parallels, meridians = grid.parallels, grid.meridians
     except AttributeError:
-        colat, _, kn = surface_factors(ker, max_degree, grid.latitude, GM, R, grid.semimajor_axis, grid.flattening)
-        return engine.synthesis_points(max_degree, colat, grid.longitude, kn, anm_batch)
+        def build():
+            colat, _, kn = surface_factors(ker, max_degree, grid.latitude, GM, R, grid.semimajor_axis, grid.flattening)
+            return colat, grid.longitude, kn
+        colat, lon, kn = engine.cached_point_tables(max_degree, grid.latitude, grid.longitude,
+                                                    (str(kernel), float(GM), float(R), float(grid.semimajor_axis), float(grid.flattening)), build)
+        return engine.synthesis_points(max_degree, colat, lon, kn, anm_batch)
     colat, _, kn = surface_factors(ker, max_degree, parallels, GM, R, grid.semimajor_axis, grid.flattening)
     plan = engine.cached_plan(max_degree, colat, kn, meridians)
     return plan.synthesis(anm_batch)
