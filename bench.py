@@ -130,7 +130,7 @@ def covariance_leg(args, rank, world, barrier, reduce_device='cuda'):
     if world == 1:
         # second extension, also outside `value`: the WHOLE grid through the latitude / longitude factorisation of the synthesis
         # matrix (csrc/covsep.hip: 2 nlat P^2 flops instead of 2 nlat nlon P^2); the band above is compared with its rows
-        plan.covariance_propagation(cov, 0, lat0, lat0 + 1, method='separable')
+        plan.covariance_propagation(cov, 0, method='separable')      # warm-up with the same workspace sizes (the pool grows by 12 GB)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sigma_sep = plan.covariance_propagation(cov, 0, method='separable')
