@@ -4,6 +4,7 @@
 //                 with the rows of A = synthesis matrix generated on the fly:
 //                 A[(i, j)][p] = PK[i][p] * CS[slot(p)][j]         (grates/grid.py:825-834: F = cs * Pnm[k])
 //                 A (68 GB at d/o 180 / 0.5 deg) is never materialised, only M doubles leave the kernel.
+//   MODE_SYNTH    C[M][N] = A[M][K] X[K][N] with the same generated A     point-list synthesis of many epochs (points.hip)
 //
 // Block tile 128 x 128, BK = 16, 4 waves as 2 x 2, wave tile 64 x 64 (16 accumulators).  Global -> register
 // prefetch of the next K tile overlaps the 64 MFMAs of the current one; one barrier per K tile.
@@ -17,7 +18,7 @@ constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDA = 17;     // As[row][k], 17-double rows: the 16 rows x 4 k of one fragment read hit distinct banks
 constexpr int LDB = 144;    // Bs[k][col], 128 + 16 pad
 
-enum { MODE_PLAIN = 0, MODE_COVPROP = 1 };
+enum { MODE_PLAIN = 0, MODE_COVPROP = 1, MODE_SYNTH = 2 };      // SYNTH: A generated like COVPROP, C stored like PLAIN
 
 struct GemmParams {
     int M, N, K;
@@ -44,7 +45,9 @@ struct GemmParams {
 // column block n0 runs its K loop over p < n0 + 128 only (half the MFMAs on average); the accumulators are doubled once when
 // the loop reaches the diagonal block, inside which the Sigma tile is weighted 2 / 1 / 0 (p < c / p = c / p > c) while it is
 // staged.  Column blocks are taken from the last (longest) to the first.
-template <int MODE, bool VEC, bool SYM = false>
+// PKT (generated A only): the Legendre table is stored transposed, pkd[p][row] with ldp = number of rows -- the layout of
+// point lists, where every row of A has its own table row and consecutive lanes (rows) then read consecutive addresses.
+template <int MODE, bool VEC, bool SYM = false, bool PKT = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      // 2 waves per SIMD: two blocks per CU
     extern __shared__ double gemm_lds[];
     double (*As)[BM * LDA] = reinterpret_cast<double (*)[BM * LDA]>(gemm_lds);                       // [2][BM * LDA]
@@ -116,12 +119,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     // COVPROP A: per-lane offsets into the two tables
     unsigned pk_voff = 0, cs_voff = 0;
     const double* pk_base = nullptr;                                 // uniform: table row of the block's first grid row
-    if (MODE == MODE_COVPROP) {
+    if (MODE != MODE_PLAIN) {
         const long long R = P.row0 + min(m0 + (tid & 127), P.M - 1);
         // (64-bit division runs on the vector unit even for uniform operands: readfirstlane brings the quotient back)
         const int gi0 = __builtin_amdgcn_readfirstlane((int)((P.row0 + m0) / P.idiv));
-        pk_base = P.pkd + (size_t)gi0 * P.ldp + P.p_off;
-        pk_voff = (unsigned)((R / P.idiv - gi0) * P.ldp * 8);        // at most 127 table rows
+        if (PKT) {
+            pk_base = P.pkd + (size_t)P.p_off * P.ldp + (P.row0 + m0);       // + k * ldp
+            pk_voff = (unsigned)((R - (P.row0 + m0)) * 8);
+        } else {
+            pk_base = P.pkd + (size_t)gi0 * P.ldp + P.p_off;
+            pk_voff = (unsigned)((R / P.idiv - gi0) * P.ldp * 8);    // at most 127 table rows
+        }
         cs_voff = (unsigned)((R % P.jmod) * 8);
     }
     const unsigned b_voff0 = (unsigned)((VEC ? min(n0 + b_col, P.N - 2) : min(n0 + b_col, P.N - 1)) * 8);
@@ -133,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     auto load_ranks = [&](int k0) {
         const crank_t* rs = reinterpret_cast<const crank_t*>(reinterpret_cast<unsigned long long>(P.rslot));
 #pragma unroll
-        for (int h = 0; h < 8; ++h) rank[h] = rs[min(k0 + P.p_off + khalf + 2 * h, P.ldp - 1)];
+        for (int h = 0; h < 8; ++h) rank[h] = rs[min(k0 + khalf + 2 * h, P.K - 1) + P.p_off];      // (the table ends at p_off + K)
     };
-    if (MODE == MODE_COVPROP) load_ranks(0);
+    if (MODE != MODE_PLAIN) load_ranks(0);
     auto fetch_full = [&](int k0) {
         if (MODE == MODE_PLAIN) {
             const double* ak = a_base + k0;                           // uniform
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
             const unsigned poff = pin(pk_voff), coff = pin(cs_voff);
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                areg[h] = at(pk + 2 * h, poff);
+                areg[h] = PKT ? at(pk_base + (size_t)(k0 + khalf + 2 * h) * P.ldp, poff) : at(pk + 2 * h, poff);
                 creg[h] = at(P.csr + (size_t)rank[h] * P.ldcs, coff);
             }
             load_ranks(k0 + BK);                                      // for the next K tile: a whole tile ahead of their use
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
             for (int h = 0; h < 8; ++h) {
                 const int gk = k0 + 2 * h + khalf;
                 const int kc = min(gk, P.K - 1);
-                areg[h] = gk < P.K ? at(pk_base + kc, pk_voff) : 0.0;
+                areg[h] = gk < P.K ? (PKT ? at(pk_base + (size_t)kc * P.ldp, pk_voff) : at(pk_base + kc, pk_voff)) : 0.0;
                 creg[h] = at(P.csr + (size_t)reinterpret_cast<const crank_t*>(reinterpret_cast<unsigned long long>(P.rslot))[kc + P.p_off] * P.ldcs, cs_voff);
             }
         }
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     __syncthreads();
 
     // ---- epilogue.  C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
-    if (MODE == MODE_PLAIN) {
+    if (MODE != MODE_COVPROP) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -428,6 +436,15 @@ static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream, bool s
     } while (0)
     if (mode == MODE_PLAIN) {
         if (vec) SHG_GEMM_LAUNCH(MODE_PLAIN, true); else SHG_GEMM_LAUNCH(MODE_PLAIN, false);
+    } else if (mode == MODE_SYNTH) {
+        // (point lists: transposed Legendre table)
+        if (vec) {
+            SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_SYNTH, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((gemm_f64_kernel<MODE_SYNTH, true, false, true>), grid, dim3(256), lds, stream, P);
+        } else {
+            SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_SYNTH, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((gemm_f64_kernel<MODE_SYNTH, false, false, true>), grid, dim3(256), lds, stream, P);
+        }
     } else {
         if (symmetric) {
             SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_COVPROP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -441,6 +458,30 @@ static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream, bool s
 #undef SHG_GEMM_LAUNCH
     SHG_HIP(hipGetLastError());
     return SHG_OK;
+}
+
+// C[M][N] = A X for M rows whose A entries are products of two table entries; point lists: pkdT [P][M] (transposed Legendre
+// table, ldp = M), csr [2N+1][M]
+int synth_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod, int M,
+                  const double* X, int K, int N, double* C, hipStream_t stream) {
+    GemmParams G = {};
+    G.M = M;
+    G.N = N;
+    G.K = K;
+    G.B = X;
+    G.ldb = N;
+    G.C = C;
+    G.ldc = N;
+    G.pkd = pkd;
+    G.ldp = ldp;
+    G.csr = csr;
+    G.ldcs = ldcs;
+    G.rslot = rslot;
+    G.idiv = idiv;
+    G.jmod = jmod;
+    G.p_off = 0;
+    G.row0 = 0;
+    return launch_gemm(MODE_SYNTH, G, stream);
 }
 
 // sigma[r] = sqrt(a_r^T Sigma a_r) for M rows whose A entries are products of two table entries

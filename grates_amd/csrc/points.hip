@@ -11,20 +11,23 @@ void recursion_tables(int N, std::vector<double>& a, std::vector<double>& b);   
 
 constexpr int kPtEpochs = 16;
 
-// knT[n][pt] = kn[pt][n]: inside the kernel consecutive lanes are consecutive points, so the degree factors are read
-// along the points (with the point-major layout of the interface every lane would touch its own cache line, N + 1 times over)
-__global__ __launch_bounds__(256) void transpose_kn_kernel(int N, int npts, const double* __restrict__ kn, double* __restrict__ knT) {
+// dst[c][r] = src[r][c] through 32 x 32 LDS tiles (coalesced on both sides).  Used for knT[n][pt] = kn[pt][n] -- inside the
+// recursion kernel consecutive lanes are consecutive points, so the degree factors are read along the points (with the
+// point-major layout of the interface every lane would touch its own cache line, N + 1 times over) -- and for the operand /
+// result layouts of the GEMM path.
+__global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const double* __restrict__ src, size_t ld_src,
+                                                        double* __restrict__ dst, size_t ld_dst) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
-    const int p0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     for (int k = ty; k < 32; k += 8) {
-        const int pt = p0 + k, n = n0 + tx;
-        tile[k][tx] = (pt < npts && n <= N) ? kn[(size_t)pt * (N + 1) + n] : 0.0;
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : 0.0;
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
-        const int n = n0 + k, pt = p0 + tx;
-        if (n <= N && pt < npts) knT[(size_t)n * npts + pt] = tile[tx][k];
+        const int c = c0 + k, r = r0 + tx;
+        if (c < cols && r < rows) dst[(size_t)c * ld_dst + r] = tile[tx][k];
     }
 }
 
@@ -154,6 +157,60 @@ __global__ void covprop_point_tables_kernel(int N, int npts, const double* __res
     }
 }
 
+// tables of the GEMM path of the point-list synthesis: pkT[p][pt] (degree-wise index p, min_degree 0; lanes = points, so
+// every store runs along the points), csr[r][pt], rslot[p]
+__global__ void synth_point_tables_kernel(int N, int npts, const double* __restrict__ colat, const double* __restrict__ lon,
+                                          const double* __restrict__ knT, size_t ld_kn, const double* __restrict__ arec,
+                                          const double* __restrict__ brec, double* __restrict__ pkT, double* __restrict__ csr,
+                                          int* __restrict__ rslot) {
+    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= npts) return;
+    const double th = colat[pt], lam = lon[pt];
+    const double t = cos(th), st = sin(th);
+    double pmm = 1.0;
+    for (int m = 0; m <= N; ++m) {
+        if (m == 1)
+            pmm = sqrt(3.0) * st;
+        else if (m >= 2)
+            pmm = sqrt((2.0 * m + 1.0) / (2.0 * m)) * st * pmm;
+        const double arg = (double)m * lam;
+        if (m == 0) {
+            csr[pt] = 1.0;
+        } else {
+            csr[(size_t)(2 * m - 1) * npts + pt] = cos(arg);
+            csr[(size_t)(2 * m) * npts + pt] = sin(arg);
+        }
+        double p1 = pmm, p2 = 0.0;
+        const int off = order_offset(N, m);
+        for (int n = m; n <= N; ++n) {
+            if (n > m) {
+                const double p = (arec[off + n - m] * t) * p1 - brec[off + n - m] * p2;     // host-built factors, as everywhere
+                p2 = p1;
+                p1 = p;
+            }
+            const double pk = p1 * knT[(size_t)n * ld_kn + pt];
+            const int base = n * n;
+            if (m == 0) {
+                pkT[(size_t)base * npts + pt] = pk;
+            } else {
+                pkT[(size_t)(base + 2 * m - 1) * npts + pt] = pk;
+                pkT[(size_t)(base + 2 * m) * npts + pt] = pk;
+            }
+            if (pt == 0) {
+                if (m == 0) {
+                    rslot[base] = 0;
+                } else {
+                    rslot[base + 2 * m - 1] = 2 * m - 1;
+                    rslot[base + 2 * m] = 2 * m;
+                }
+            }
+        }
+    }
+}
+
+int synth_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod, int M,
+                  const double* X, int K, int N, double* C, hipStream_t stream);      // gemm.hip
+
 int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
                     long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
                     hipStream_t stream, bool symmetric);
@@ -180,7 +237,41 @@ extern "C" int shg_synthesis_points(int N, const double* colat, const double* lo
         (void)hipFreeAsync(tab, stream);
         return fail(SHG_ERR_NOMEM, "shg_synthesis_points: table allocation failed");
     }
-    hipLaunchKernelGGL(transpose_kn_kernel, dim3(ceil_div(npts, 32), ceil_div(N + 1, 32)), dim3(256), 0, stream, N, npts, kn, knT);
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(npts, 32), ceil_div(N + 1, 32)), dim3(256), 0, stream, npts, N + 1, kn, (size_t)(N + 1), knT, (size_t)npts);
+    // Many epochs: values = Y X as one fp64 MFMA GEMM per chunk of points, with the rows of the spherical harmonic matrix
+    // Y[pt][p] = PK[p][pt] cs[rank(p)][pt] generated inside the kernel from per-point tables (MODE_SYNTH of gemm.hip): the
+    // recursion runs once per point instead of once per point and group of 16 epochs.
+    if (B >= 48) {
+        const int Pfull = (N + 1) * (N + 1);
+        const int chunk = (int)std::min<long long>(npts, std::max<long long>(128, ((1LL << 31) / 8 / Pfull) / 128 * 128));    // 2 GB of Legendre table
+        double *X = nullptr, *xr = nullptr, *pkT = nullptr, *csr = nullptr, *Cc = nullptr;
+        int* rslot = nullptr;
+        int rc = SHG_OK;
+        if (hipMallocAsync((void**)&xr, (size_t)B * Pfull * sizeof(double), stream) != hipSuccess ||
+            hipMallocAsync((void**)&X, (size_t)B * Pfull * sizeof(double), stream) != hipSuccess ||
+            hipMallocAsync((void**)&pkT, (size_t)chunk * Pfull * sizeof(double), stream) != hipSuccess ||
+            hipMallocAsync((void**)&csr, (size_t)(2 * N + 1) * chunk * sizeof(double), stream) != hipSuccess ||
+            hipMallocAsync((void**)&Cc, (size_t)chunk * B * sizeof(double), stream) != hipSuccess ||
+            hipMallocAsync((void**)&rslot, (size_t)Pfull * sizeof(int), stream) != hipSuccess)
+            rc = fail(SHG_ERR_NOMEM, "shg_synthesis_points: workspace allocation failed");
+        if (rc == SHG_OK) rc = shg_ravel(anm, B, N, 0, N, xr, stream);
+        if (rc == SHG_OK) {
+            hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(B, 32), ceil_div(Pfull, 32)), dim3(256), 0, stream, B, Pfull, xr, (size_t)Pfull, X, (size_t)B);
+            for (int c0 = 0; c0 < npts && rc == SHG_OK; c0 += chunk) {
+                const int nc = std::min(chunk, npts - c0);
+                hipLaunchKernelGGL(synth_point_tables_kernel, dim3(ceil_div(nc, 64)), dim3(64), 0, stream, N, nc, colat + c0, lon + c0, knT + c0,
+                                   (size_t)npts, tab, tab + a.size(), pkT, csr, rslot);
+                rc = synth_generic(pkT, nc, csr, nc, rslot, 1, (long long)1 << 40, nc, X, Pfull, B, Cc, stream);
+                if (rc) break;
+                hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(nc, 32), ceil_div(B, 32)), dim3(256), 0, stream, nc, B, Cc, (size_t)B, values + c0, (size_t)npts);
+            }
+        }
+        for (void* q : {(void*)X, (void*)xr, (void*)pkT, (void*)csr, (void*)Cc, (void*)rslot, (void*)knT, (void*)tab})
+            if (q) (void)hipFreeAsync(q, stream);
+        if (rc) return rc;
+        SHG_HIP(hipGetLastError());
+        return SHG_OK;
+    }
     hipLaunchKernelGGL(synthesis_points_kernel, dim3(ceil_div(npts, 64), ceil_div(B, kPtEpochs)), dim3(64), (size_t)(N + 1) * 2 * kPtEpochs * sizeof(double), stream, N, npts, B, colat, lon,
                        knT, tab, tab + a.size(), anm, values);
     (void)hipFreeAsync(knT, stream);

@@ -261,6 +261,22 @@ def test_point_list_path(golden):
     assert relerr(a, b) < TOL
 
 
+@pytest.mark.parametrize('npts,N,B', [(3001, 30, 50), (777, 45, 96), (130, 12, 49)])
+def test_point_list_many_epochs(npts, N, B):
+    """Long time series on a point list take the GEMM path (rows of the spherical harmonic matrix generated inside the fp64
+    MFMA kernel from per-point tables); compared with the oracle and with the recursion kernel that short series use."""
+    lon, lat = inputs.scattered_points(21, npts)
+    grid = ga.grid.IrregularGrid(lon, lat)
+    batch = np.stack([inputs.coefficients(400 + e, N) for e in range(B)])
+    vals = ga.engine.to_host(ga.gravityfield.synthesize(batch, grid, 'ewh'))
+    assert vals.shape == (B, npts)
+    ker = orc.KernelTable('ewh', love())
+    for e in (0, B // 2, B - 1):
+        assert relerr(vals[e], orc.synthesis_points(batch[e], lon, lat, ker)) < TOL
+    short = np.vstack([ga.engine.to_host(ga.gravityfield.synthesize(batch[e0:e0 + 16], grid, 'ewh')) for e0 in range(0, B, 16)])
+    assert relerr(vals, short) < 1e-13
+
+
 def test_monthly_files_to_grids(tmp_path):
     """monthly SDS files -> TimeSeries -> one batched synthesis; every epoch equals the oracle's synthesis
     of the coefficients the file holds."""
