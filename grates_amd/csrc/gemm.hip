@@ -38,6 +38,7 @@ struct GemmParams {
     int p_off;              // min_degree^2: first degree-wise index covered by the covariance matrix
     long long row0;         // first flat grid row (lat0 * nlon) of the band
     double* partial;        // [gridDim.x][M] per-column-block partial row sums
+    int pkt;                // generated A: Legendre table stored transposed, pkd[p][row] (point lists)
 };
 
 // SYM (covariance mode only): Sigma is symmetric and only its upper triangle is used,
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
                 for (int b = 0; b < 4; ++b) {
                     if (rok && colok[b]) {
                         const int pf = n0 + wc * 64 + b * 16 + fr + P.p_off;
-                        const double aval = P.pkd[gi * P.ldp + pf] * P.csr[(size_t)colslot[b] * P.ldcs + gj];
+                        const double pkv = PKT ? P.pkd[(size_t)pf * P.ldp + R] : P.pkd[gi * P.ldp + pf];
+                        const double aval = pkv * P.csr[(size_t)colslot[b] * P.ldcs + gj];
                         s = fma(acc[a][b][r], aval, s);
                     }
                 }
@@ -449,6 +451,9 @@ static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream, bool s
         if (symmetric) {
             SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_COVPROP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((gemm_f64_kernel<MODE_COVPROP, false, true>), grid, dim3(256), lds, stream, P);
+        } else if (P.pkt) {
+            SHG_HIP(hipFuncSetAttribute((const void*)gemm_f64_kernel<MODE_COVPROP, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((gemm_f64_kernel<MODE_COVPROP, false, false, true>), grid, dim3(256), lds, stream, P);
         } else if (vec) {
             SHG_GEMM_LAUNCH(MODE_COVPROP, true);
         } else {
@@ -481,14 +486,16 @@ int synth_generic(const double* pkd, int ldp, const double* csr, int ldcs, const
     G.jmod = jmod;
     G.p_off = 0;
     G.row0 = 0;
+    G.pkt = 1;
     return launch_gemm(MODE_SYNTH, G, stream);
 }
 
 // sigma[r] = sqrt(a_r^T Sigma a_r) for M rows whose A entries are products of two table entries
 int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
                     long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
-                    hipStream_t stream, bool symmetric) {
+                    hipStream_t stream, bool symmetric, bool transposed_table) {
     GemmParams G = {};
+    G.pkt = transposed_table ? 1 : 0;
     G.M = M;
     G.N = Pn;
     G.K = Pn;
@@ -659,5 +666,5 @@ static int covprop_diag_impl(shg_plan* p, const double* cov, int nmin, int lat0,
         return SHG_OK;
     }
     return covprop_generic(p->pk_deg, Pfull, p->cs_slot, p->nlon, p->rslot, p->nlon, p->nlon, (long long)lat0 * p->nlon, (int)M, cov, Pn,
-                           nmin * nmin, p->cov_partial, sigma, p, stream, symmetric);
+                           nmin * nmin, p->cov_partial, sigma, p, stream, symmetric, false);
 }

@@ -31,17 +31,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, cons
     }
 }
 
-__device__ inline double rec_a_pt(int ni, int mi) {
-    const double n = ni, m = mi;
-    if (ni == mi + 1) return sqrt((double)(2 * ni + 1));
-    return sqrt((2.0 * n - 1.0) / (n - m) * (2.0 * n + 1.0) / (n + m));
-}
-__device__ inline double rec_b_pt(int ni, int mi) {
-    const double n = ni, m = mi;
-    if (ni == mi + 1) return 0.0;
-    return sqrt((2.0 * n + 1.0) / (2.0 * n - 3.0) * (n - m - 1.0) / (n - m) * (n + m - 1.0) / (n + m));
-}
-
 // One wave = 64 points x up to 16 epochs.  For every order m the coefficients C_nm, S_nm (n = m..N) of the 16 epochs are first
 // gathered into LDS with ordinary vector loads (many in flight; fetched through wave-uniform scalar loads instead, 32 dependent
 // cache misses per (n, m) made the kernel 80 times slower), then the degree loop reads them as LDS broadcasts.
@@ -108,57 +97,8 @@ __global__ __launch_bounds__(64) void synthesis_points_kernel(int N, int npts, i
     }
 }
 
-// per-point tables of the covariance kernel: pkd[pt][p] (degree-wise, min_degree 0), csr[r][pt]
-__global__ void covprop_point_tables_kernel(int N, int npts, const double* __restrict__ colat, const double* __restrict__ lon,
-                                            const double* __restrict__ kn, double* __restrict__ pkd, double* __restrict__ csr,
-                                            int* __restrict__ rslot) {
-    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pt >= npts) return;
-    const int P = (N + 1) * (N + 1);
-    const double th = colat[pt], lam = lon[pt];
-    const double t = cos(th), st = sin(th);
-    double pmm = 1.0;
-    for (int m = 0; m <= N; ++m) {
-        if (m == 1)
-            pmm = sqrt(3.0) * st;
-        else if (m >= 2)
-            pmm = sqrt((2.0 * m + 1.0) / (2.0 * m)) * st * pmm;
-        const double arg = (double)m * lam;
-        if (m == 0) {
-            csr[pt] = 1.0;
-        } else {
-            csr[(size_t)(2 * m - 1) * npts + pt] = cos(arg);
-            csr[(size_t)(2 * m) * npts + pt] = sin(arg);
-        }
-        double p1 = pmm, p2 = 0.0;
-        for (int n = m; n <= N; ++n) {
-            if (n > m) {
-                const double p = (rec_a_pt(n, m) * t) * p1 - rec_b_pt(n, m) * p2;
-                p2 = p1;
-                p1 = p;
-            }
-            const double pk = p1 * kn[(size_t)pt * (N + 1) + n];
-            const int base = n * n;
-            if (m == 0) {
-                pkd[(size_t)pt * P + base] = pk;
-            } else {
-                pkd[(size_t)pt * P + base + 2 * m - 1] = pk;
-                pkd[(size_t)pt * P + base + 2 * m] = pk;
-            }
-            if (pt == 0) {
-                if (m == 0) {
-                    rslot[base] = 0;
-                } else {
-                    rslot[base + 2 * m - 1] = 2 * m - 1;
-                    rslot[base + 2 * m] = 2 * m;
-                }
-            }
-        }
-    }
-}
-
-// tables of the GEMM path of the point-list synthesis: pkT[p][pt] (degree-wise index p, min_degree 0; lanes = points, so
-// every store runs along the points), csr[r][pt], rslot[p]
+// per-point tables of the generated-operand GEMM (point-list covariance propagation and synthesis of long series):
+// pkT[p][pt] (degree-wise index p, min_degree 0; lanes = points, so every store runs along the points), csr[r][pt], rslot[p]
 __global__ void synth_point_tables_kernel(int N, int npts, const double* __restrict__ colat, const double* __restrict__ lon,
                                           const double* __restrict__ knT, size_t ld_kn, const double* __restrict__ arec,
                                           const double* __restrict__ brec, double* __restrict__ pkT, double* __restrict__ csr,
@@ -213,7 +153,7 @@ int synth_generic(const double* pkd, int ldp, const double* csr, int ldcs, const
 
 int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
                     long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
-                    hipStream_t stream, bool symmetric);
+                    hipStream_t stream, bool symmetric, bool transposed_table);
 
 }  // namespace shg
 
@@ -293,20 +233,28 @@ extern "C" int shg_covprop_points(int N, const double* colat, const double* lon,
         return SHG_OK;
     }
     SHG_REQUIRE(cov != nullptr, "shg_covprop_points: NULL covariance");
-    double *pkd = nullptr, *csr = nullptr, *partial = nullptr;
+    // per-point tables, Legendre table transposed (pkT[p][point]): consecutive lanes of the generated-operand kernel are
+    // consecutive points (43 -> 55 TFLOP/s against the point-major table)
+    std::vector<double> a, b;
+    recursion_tables(N, a, b);
+    double *pkT = nullptr, *csr = nullptr, *partial = nullptr, *knT = nullptr, *tab = nullptr;
     int* rslot = nullptr;
     const int ncolblocks = ceil_div(Pn, 128);
-    if (hipMallocAsync((void**)&pkd, (size_t)npts * Pfull * sizeof(double), stream) != hipSuccess ||
+    if (hipMallocAsync((void**)&pkT, (size_t)npts * Pfull * sizeof(double), stream) != hipSuccess ||
         hipMallocAsync((void**)&csr, (size_t)(2 * N + 1) * npts * sizeof(double), stream) != hipSuccess ||
         hipMallocAsync((void**)&rslot, (size_t)Pfull * sizeof(int), stream) != hipSuccess ||
-        hipMallocAsync((void**)&partial, (size_t)ncolblocks * npts * sizeof(double), stream) != hipSuccess)
+        hipMallocAsync((void**)&partial, (size_t)ncolblocks * npts * sizeof(double), stream) != hipSuccess ||
+        hipMallocAsync((void**)&knT, (size_t)(N + 1) * npts * sizeof(double), stream) != hipSuccess ||
+        hipMallocAsync((void**)&tab, 2 * a.size() * sizeof(double), stream) != hipSuccess)
         return fail(SHG_ERR_NOMEM, "shg_covprop_points: workspace allocation failed");
-    hipLaunchKernelGGL(covprop_point_tables_kernel, dim3(ceil_div(npts, 64)), dim3(64), 0, stream, N, npts, colat, lon, kn, pkd, csr, rslot);
-    int rc = covprop_generic(pkd, Pfull, csr, npts, rslot, 1, (long long)1 << 40, 0, npts, cov, Pn, nmin * nmin, partial, sigma, nullptr, stream, false);
-    (void)hipFreeAsync(pkd, stream);
-    (void)hipFreeAsync(csr, stream);
-    (void)hipFreeAsync(rslot, stream);
-    (void)hipFreeAsync(partial, stream);
+    SHG_HIP(hipMemcpyAsync(tab, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    SHG_HIP(hipMemcpyAsync(tab + a.size(), b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    SHG_HIP(hipStreamSynchronize(stream));           // the host vectors go out of scope
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(npts, 32), ceil_div(N + 1, 32)), dim3(256), 0, stream, npts, N + 1, kn, (size_t)(N + 1), knT, (size_t)npts);
+    hipLaunchKernelGGL(synth_point_tables_kernel, dim3(ceil_div(npts, 64)), dim3(64), 0, stream, N, npts, colat, lon, knT, (size_t)npts, tab,
+                       tab + a.size(), pkT, csr, rslot);
+    int rc = covprop_generic(pkT, npts, csr, npts, rslot, 1, (long long)1 << 40, 0, npts, cov, Pn, nmin * nmin, partial, sigma, nullptr, stream, false, true);
+    for (void* q : {(void*)pkT, (void*)csr, (void*)rslot, (void*)partial, (void*)knT, (void*)tab}) (void)hipFreeAsync(q, stream);
     if (rc) return rc;
     SHG_HIP(hipGetLastError());
     return SHG_OK;
