@@ -90,6 +90,9 @@ def main():
     b40 = rng.standard_normal((16, 41, 41)) * 1e-10
     ms = device_ms(lambda: ga.gravityfield.synthesize(b40, irr, 'ewh'), reps=3, warmup=1)
     emit('point-list synthesis d/o 40, 100000 points x 16 epochs', ms)
+    b96 = torch.from_numpy(rng.standard_normal((240, 97, 97)) * 1e-10).cuda()
+    ms = device_ms(lambda: ga.gravityfield.synthesize(b96, irr, 'ewh'), reps=3, warmup=1)
+    emit('point-list synthesis d/o 96, 100000 points x 240 epochs (GEMM with generated harmonics)', ms, TFLOPs=round(2.0 * 100000 * 97 ** 2 * 240 / ms / 1e9, 1))
 
     # analysis: d/o 96 from 0.5 degree (reference: 142 s per epoch on 8 cores)
     pa = plan_for(g05, 96, 'potential')
