@@ -55,6 +55,12 @@ def surface_factors(grid_kernel, max_degree, latitude, GM, R, a, f):
     return colat, radius, kn
 
 
+def _check_operand(left, right, accepted, symbol):
+    """The reference's operand check of its arithmetic operators: a TypeError with Python's own wording."""
+    if not isinstance(right, accepted):
+        raise TypeError("unsupported operand type(s) for {0}: '{1}' and '{2}'".format(symbol, str(type(left)), str(type(right))))
+
+
 class PotentialCoefficients:
     """
     A set of potential coefficients: ``anm[n, m]`` = C_nm, ``anm[m-1, n]`` = S_nm.
@@ -120,8 +126,7 @@ class PotentialCoefficients:
 
     # ---- arithmetic (grates/gravityfield.py:189-228) ----------------------------------------------------
     def __add__(self, other):
-        if not isinstance(other, PotentialCoefficients):
-            raise TypeError("unsupported operand type(s) for +: '" + str(type(self)) + "' and '" + str(type(other)) + "'")
+        _check_operand(self, other, PotentialCoefficients, '+')
         # the other set is brought to this set's GM and R first; the sum takes the larger of the two degrees (and, as
         # upstream, the left operand's epoch and constants)
         rescaled = other.anm * ((other.R / self.R) ** _degree_array(other.max_degree) * (other.GM / self.GM))
@@ -136,21 +141,18 @@ class PotentialCoefficients:
         return total
 
     def __sub__(self, other):
-        if not isinstance(other, PotentialCoefficients):
-            raise TypeError("unsupported operand type(s) for -: '" + str(type(self)) + "' and '" + str(type(other)) + "'")
-        return self + (other * -1)
+        _check_operand(self, other, PotentialCoefficients, '-')
+        return self + other * -1
 
-    def __mul__(self, other):
-        if not isinstance(other, (int, float)):
-            raise TypeError("unsupported operand type(s) for *: '" + str(type(self)) + "' and '" + str(type(other)) + "'")
-        result = self.copy()
-        result.anm *= other
-        return result
+    def __mul__(self, factor):
+        _check_operand(self, factor, (int, float), '*')
+        scaled = self.copy()
+        scaled.anm *= factor
+        return scaled
 
-    def __truediv__(self, other):
-        if not isinstance(other, (int, float)):
-            raise TypeError("unsupported operand type(s) for /: '" + str(type(self)) + "' and '" + str(type(other)) + "'")
-        return self * (1.0 / other)
+    def __truediv__(self, divisor):
+        _check_operand(self, divisor, (int, float), '/')
+        return self * (1.0 / divisor)
 
     # ---- spectra ---------------------------------------------------------------------------------------------
     def degree_amplitudes(self, max_order=None, kernel='potential'):
@@ -352,18 +354,16 @@ class TimeSeries:
             summed.append(self.__data[k] + other[k])
         return TimeSeries(summed)
 
-    def __mul__(self, other):
-        if not isinstance(other, (int, float)):
-            raise TypeError("unsupported operand type(s) for *: '" + str(type(self)) + "' and '" + str(type(other)) + "'")
-        return TimeSeries([d.copy() * other for d in self.__data])
+    def __mul__(self, factor):
+        _check_operand(self, factor, (int, float), '*')
+        return TimeSeries([d.copy() * factor for d in self.__data])
 
-    def __truediv__(self, other):
-        if not isinstance(other, (int, float)):
-            raise TypeError("unsupported operand type(s) for *: '" + str(type(self)) + "' and '" + str(type(other)) + "'")
-        return self * (1.0 / other)
+    def __truediv__(self, divisor):
+        _check_operand(self, divisor, (int, float), '*')          # (upstream reports '*' here as well)
+        return self * (1.0 / divisor)
 
     def __sub__(self, other):
-        return self + (other * -1)
+        return self + other * -1
 
     def sort(self):
         self.__data.sort(key=lambda d: d.epoch)
