@@ -15,7 +15,7 @@ namespace shg {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDA = 17;     // As[row][k], 17-double rows: the 16 rows x 4 k of one fragment read hit distinct banks
+constexpr int LDA = 18;     // As[row][k], 18-double rows: the 16 rows x 2 k a half wave reads in one LDS cycle fall into 32 distinct bank pairs
 constexpr int LDB = 144;    // Bs[k][col], 128 + 16 pad
 
 enum { MODE_PLAIN = 0, MODE_COVPROP = 1, MODE_SYNTH = 2 };      // SYNTH: A generated like COVPROP, C stored like PLAIN
