@@ -129,3 +129,43 @@ def gsm_file_text(seed, max_degree, start='2010-03-01T00:00:00.00', end='2010-03
                 s = 0.0
             lines.append('GRCOF2 {0:4d} {1:4d} {2: .12E} {3: .12E} {4:.4E} {5:.4E} 20100301.0000 20100401.0000 nnnn'.format(n, m, c, s, abs(c) * 1e-3, abs(s) * 1e-3))
     return (header + '\n'.join(lines) + '\n').encode('ascii')
+
+
+def sinex_file_text(seed, min_degree, max_degree, lower=False):
+    """Synthetic SINEX normal-equation file (bytes), storage scheme 6c: statistics, right-hand side vector with one record
+    per coefficient (degree-wise order, columns as in the SINEX 2.02 parameter records) and the normal matrix as one
+    triangle in rows of up to three values."""
+    rng = np.random.default_rng(seed)
+    names = []
+    for n in range(min_degree, max_degree + 1):
+        names.append(('CN', n, 0))
+        for m in range(1, n + 1):
+            names.append(('CN', n, m))
+            names.append(('SN', n, m))
+    p = len(names)
+    g = rng.standard_normal((p + 8, p))
+    normals = g.T @ g
+    rhs = normals @ (rng.standard_normal(p) * 1e-9)
+    out = ['%=SNX 2.02 TST 26:001:00000 TST 02:091:00000 02:120:86399 C {0:5d} 2'.format(p),
+           '*-------------------------------------------------------------------------------',
+           '+FILE/REFERENCE',
+           ' DESCRIPTION        synthetic normal equations',
+           ' OUTPUT             parity fixture',
+           '-FILE/REFERENCE',
+           '+SOLUTION/STATISTICS',
+           '*_STATISTICAL PARAMETER________ __VALUE(S)____________']
+    for label, value in (('NUMBER OF OBSERVATIONS', 12345.0), ('NUMBER OF UNKNOWNS', float(p)), ('NUMBER OF DEGREES OF FREEDOM', 12345.0 - p),
+                         ('WEIGHTED SQUARE SUM OF O-C', 9.87654321012345e+03)):
+        out.append(' {0:<30s} {1:22.15e}'.format(label, value))
+    out += ['-SOLUTION/STATISTICS', '+SOLUTION/NORMAL_EQUATION_VECTOR', '*INDEX TYPE__ CODE PT SOLN _REF_EPOCH__ UNIT S __RIGHT_HAND_SIDE____']
+    for k, (cs, n, m) in enumerate(names):
+        out.append(' {0:5d} {1:<6s} {2:4d} -- {3:4d} 02:106:00000 ---- 2 {4:21.14e}'.format(k + 1, cs, n, m, rhs[k]))
+    out.append('-SOLUTION/NORMAL_EQUATION_VECTOR')
+    tag = 'SOLUTION/NORMAL_EQUATION_MATRIX ' + ('L' if lower else 'U')
+    out += ['+' + tag, '*PARA1 PARA2 ____PARA2+0__________ ____PARA2+1__________ ____PARA2+2__________']
+    for r in range(p):
+        first, last = (0, r + 1) if lower else (r, p)
+        for c in range(first, last, 3):
+            out.append(' {0:5d} {1:5d}'.format(r + 1, c + 1) + ''.join(' {0:21.14e}'.format(v) for v in normals[r, c:min(c + 3, last)]))
+    out += ['-' + tag, '%ENDSNX']
+    return ('\n'.join(out) + '\n').encode('ascii')

@@ -438,8 +438,24 @@ def g13():
     save('g13_io', **out)
 
 
+def g14():
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, seed, nmin, nmax, lower in (('u', 90, 2, 8, False), ('l', 91, 0, 5, True)):
+            path = os.path.join(tmp, 'normals_{0}.snx'.format(tag))
+            with open(path, 'wb') as f:
+                f.write(inputs.sinex_file_text(seed, nmin, nmax, lower))
+            N, n, lPl, obs_count = grates.io.loadsinexnormals(path)
+            out['sinex_{0}_N'.format(tag)] = N
+            out['sinex_{0}_n'.format(tag)] = n
+            out['sinex_{0}_lPl'.format(tag)] = lPl
+            out['sinex_{0}_obs_count'.format(tag)] = np.array(obs_count)
+    save('g14_sinex', **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
         if not only or fn.__name__ in only:
             fn()

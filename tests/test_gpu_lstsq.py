@@ -191,3 +191,22 @@ def test_smoother_against_oracle(dim, order, epochs):
     assert relerr(x[:, 1:], mcr) < tol
     combined.compute_covariance(sparse=True)
     assert relerr(combined.matrix.to_array(), lo.to_array(ref['matrix'])) < tol_inv
+
+
+def test_sinex_normals_solved_on_device(golden, tmp_path):
+    """SINEX file -> NormalEquations -> blocked Cholesky solve on the GPU (SURVEY 8f rank 3 feeding rank 1): the solution
+    against numpy.linalg.solve of the matrix the reference read from the same file (tests/golden/g14_sinex.npz)."""
+    g = golden('g14_sinex')
+    path = tmp_path / 'normals_u.snx'
+    path.write_bytes(inputs.sinex_file_text(90, 2, 8))
+    for block_size in (16, 2048):                                            # 5 ragged blocks / one block
+        ne = ga.io.load_normal_equations(str(path), block_size=block_size)
+        assert ne.observation_count == int(g['sinex_u_obs_count'])
+        np.testing.assert_array_equal(ne.to_array()[0], np.triu(g['sinex_u_N']))
+        x = ne.solve()
+        expected = np.linalg.solve(g['sinex_u_N'], g['sinex_u_n'])
+        assert x.shape == (77, 1) and relerr(x, expected) < 1e-10            # cond(N) ~ 1e3
+        assert ne.status == 'cholesky_factor' and ne.monte_carlo_vectors.shape == (77, 100)
+        sigma = ne.posterior_sigma(x)
+        r = g["sinex_u_lPl"][0] - (g["sinex_u_n"].T @ expected).item()
+        assert abs(sigma - np.sqrt(r / (12345 - 77))) < 1e-10 * sigma

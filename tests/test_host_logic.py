@@ -343,3 +343,39 @@ def test_file_feeders(golden, tmp_path):
     assert series[0].max_degree == 7 and series[1].max_degree == 12
     with pytest.raises(ValueError):
         ga.io.load_time_series([str(tmp_path / 'model_a.gfc')], loader=ga.io.loadgfc)
+
+
+def test_sinex_normal_equations_reader(golden, tmp_path):
+    """SINEX normal equations (grates/io.py:725-760) against what the reference read from the same
+    synthetic files (tests/golden/g14_sinex.npz): matrix, right-hand side, l'Pl and the observation count, bit-exact."""
+    import gzip
+    g = golden('g14_sinex')
+    for tag, seed, nmin, nmax, lower in (('u', 90, 2, 8, False), ('l', 91, 0, 5, True)):
+        path = tmp_path / 'normals_{0}.snx'.format(tag)
+        path.write_bytes(inputs.sinex_file_text(seed, nmin, nmax, lower))
+        N, n, lPl, obs_count = ga.io.loadsinexnormals(str(path))
+        np.testing.assert_array_equal(N, g['sinex_{0}_N'.format(tag)])
+        np.testing.assert_array_equal(n, g['sinex_{0}_n'.format(tag)])
+        np.testing.assert_array_equal(lPl, g['sinex_{0}_lPl'.format(tag)])
+        assert obs_count == int(g['sinex_{0}_obs_count'.format(tag)]) and isinstance(obs_count, int)
+        np.testing.assert_array_equal(N, N.T)
+    # block list: the right-hand side records carry the coefficient numbering (degree-wise here)
+    blocks = {b.block_type: b for b in ga.io.loadsinex(str(tmp_path / 'normals_u.snx'))}
+    assert set(blocks) == {b'SOLUTION/STATISTICS', b'SOLUTION/NORMAL_EQUATION_VECTOR', b'SOLUTION/NORMAL_EQUATION_MATRIX'}
+    rhs = blocks[b'SOLUTION/NORMAL_EQUATION_VECTOR']
+    assert rhs.sigmax is None and rhs.parameter_count() == 77
+    assert (rhs.basis[0], rhs.degree[0], rhs.order[0]) == ('CN', 2, 0) and (rhs.basis[-1], rhs.degree[-1], rhs.order[-1]) == ('SN', 8, 8)
+    assert blocks[b'SOLUTION/STATISTICS'].parameters == 77 and blocks[b'SOLUTION/STATISTICS'].degrees_of_freedom == 12345 - 77
+    with gzip.open(tmp_path / 'normals_u.snx.gz', 'wb') as f:
+        f.write(inputs.sinex_file_text(90, 2, 8))
+    np.testing.assert_array_equal(ga.io.loadsinexnormals(str(tmp_path / 'normals_u.snx.gz'))[0], g['sinex_u_N'])
+    # a file without the statistics block is not a normal-equation file
+    text = inputs.sinex_file_text(90, 2, 8).decode()
+    cut = text[:text.index('+SOLUTION/STATISTICS')] + text[text.index('+SOLUTION/NORMAL_EQUATION_VECTOR'):]
+    (tmp_path / 'no_stat.snx').write_text(cut)
+    with pytest.raises(ValueError, match='storage schemes 6b or 6c'):
+        ga.io.loadsinexnormals(str(tmp_path / 'no_stat.snx'))
+    # unsupported parameter type
+    (tmp_path / 'bad.snx').write_text(text.replace(' CN     ', ' STAX   ', 1))
+    with pytest.raises(ValueError, match='not supported'):
+        ga.io.loadsinex(str(tmp_path / 'bad.snx'))
