@@ -585,6 +585,213 @@ class CoefficientSequenceFlatArray(CoefficientSequence):
 
 
 # -------------------------------------------------------------------------------------------------------
+# space-domain representations on point lists (grates/gravityfield.py:484-785)
+# -------------------------------------------------------------------------------------------------------
+
+_POINT_CHUNK_BYTES = 2 << 30      # device table of one block of nodal points
+
+
+def _point_harmonics_adjoint(points, max_degree, values, upward=None):
+    """
+    sum_p values[p] Y_nm(theta_p, lambda_p) [(R / r_p)^(n+1)] as a device array [N+1, N+1] (coefficient layout): the adjoint
+    of the point-list synthesis.  The harmonics of a block of points are built on the device (Legendre recursion and
+    cos / sin tables of the C-ABI), the sum over the points is one transposed fp64 GEMM per block.
+    `upward` = reference radius R: scale degree n by (R / r_p)^(n+1).
+    """
+    torch = engine.require_gpu()
+    colat = utilities.colatitude(points.latitude, points.semimajor_axis, points.flattening)
+    size = (max_degree + 1) ** 2
+    chunk = max(int(_POINT_CHUNK_BYTES // (8 * size)), 1)
+    v = engine.to_device(np.ascontiguousarray(values, dtype=float)).reshape(-1, 1)
+    out = torch.zeros((size, 1), dtype=torch.float64, device=v.device)
+    for start in range(0, colat.size, chunk):
+        block = slice(start, min(start + chunk, colat.size))
+        Y = engine.trigonometric_functions(max_degree, points.longitude[block])
+        Y *= engine.legendre_functions(max_degree, colat[block])
+        if upward is not None:
+            radius = utilities.geocentric_radius(points.latitude[block], points.semimajor_axis, points.flattening)
+            kn = np.power((upward / radius)[:, np.newaxis], np.arange(max_degree + 1, dtype=int) + 1)
+            from .grid import _degree_scale_array
+            Y *= _degree_scale_array(kn, max_degree)
+        engine.gemm(Y.reshape(Y.shape[0], size), v[block], transa=True, beta=1.0, out=out)
+    return out.reshape(max_degree + 1, max_degree + 1)
+
+
+class SurfaceMasCons:
+    """
+    Point masses / surface elements on a grid whose values are a gravity field functional `kernel`
+    (grates/gravityfield.py:484-570).  Arithmetic is point-wise on the values.
+    """
+
+    def __init__(self, point_distribution, kernel):
+        self.point_distribution = point_distribution
+        if self.point_distribution.values is None:
+            self.point_distribution.values = np.zeros(self.point_distribution.point_count)
+        self.kernel = kernel
+        self.epoch = None
+
+    def copy(self):
+        other = SurfaceMasCons(self.point_distribution.copy(), self.kernel)
+        other.epoch = self.epoch
+        return other
+
+    def is_compatible(self, other):
+        return self.point_distribution.is_compatible(other.point_distribution)
+
+    @property
+    def values(self):
+        return self.point_distribution.values
+
+    @values.setter
+    def values(self, val):
+        self.point_distribution.values = val
+
+    def __combine(self, other, symbol, sign):
+        _check_operand(self, other, SurfaceMasCons, symbol)
+        if not self.is_compatible(other):
+            raise ValueError("point distributions of '" + str(type(self)) + "' instances are not compatible")
+        result = self.copy()
+        result.values = result.values + sign * other.values
+        return result
+
+    def __add__(self, other):
+        return self.__combine(other, '+', 1.0)
+
+    def __sub__(self, other):
+        return self.__combine(other, '-', -1.0)
+
+    def __mul__(self, other):
+        _check_operand(self, other, (int, float), '*')
+        result = self.copy()
+        result.values = result.values * other
+        return result
+
+    def __truediv__(self, other):
+        _check_operand(self, other, (int, float), '/')
+        return self * (1.0 / other)
+
+    def to_potential_coefficients(self, min_degree, max_degree, GM=3.9860044150e+14, R=6.3781363000e+06):
+        """
+        Spherical harmonic analysis of the mascon values through the analysis operator of the point distribution.
+        (Upstream hands the builtin ``round`` to the grid in place of R, grates/gravityfield.py:570, and cannot run; R is
+        passed here.)
+        """
+        return self.point_distribution.to_potential_coefficients(min_degree, max_degree, self.kernel, GM, R)
+
+
+class RadialBasisFunctions:
+    """
+    Gravity field as radial basis functions at the nodal points of `point_distribution`: shape factors `K` in the
+    coefficient layout [N+1, N+1], frequency band min_degree .. max_degree (grates/gravityfield.py:652-785).
+    """
+
+    def __init__(self, point_distribution, K, min_degree, max_degree, GM=3.9860044150e+14, R=6.3781363000e+06):
+        self.__K = K.copy()
+        self.point_distribution = point_distribution.copy()
+        self.__min_degree = min_degree
+        self.__max_degree = max_degree
+        self.GM = GM
+        self.R = R
+        self.epoch = None
+        self.values = np.zeros((self.point_distribution.size))
+
+    def copy(self):
+        rbf = RadialBasisFunctions(self.point_distribution.copy(), self.__K, self.__min_degree, self.__max_degree, self.GM, self.R)
+        rbf.epoch = self.epoch
+        rbf.values = self.values.copy()
+        return rbf
+
+    @property
+    def values(self):
+        return self.point_distribution.values
+
+    @values.setter
+    def values(self, val):
+        self.point_distribution.values = val
+
+    def is_compatible(self, other):
+        return self.point_distribution.is_compatible(other.point_distribution)
+
+    def to_potential_coefficients(self, blocking_factor=256):
+        """
+        anm = K * sum_p values[p] (R / r_p)^(n+1) Y_nm(p) (grates/gravityfield.py:705-727; all degrees 0 .. max_degree, as
+        upstream).  `blocking_factor` is accepted for compatibility: the blocks are sized for the device (2 GB tables).
+        """
+        coefficients = PotentialCoefficients(self.GM, self.R)
+        total = _point_harmonics_adjoint(self.point_distribution, self.__max_degree, self.values, upward=self.R)
+        coefficients.anm = engine.to_host(total) * self.__K
+        coefficients.epoch = self.epoch
+        return coefficients
+
+    def to_potential_coefficients_matrix(self, blocking_factor=256):
+        """F [P, points] with coefficients (degree-wise, min_degree .. max_degree) = F values
+        (grates/gravityfield.py:729-764)."""
+        points = self.point_distribution
+        colat = utilities.colatitude(points.latitude, points.semimajor_axis, points.flattening)
+        radius = utilities.geocentric_radius(points.latitude, points.semimajor_axis, points.flattening)
+        kn = np.power((self.R / radius)[:, np.newaxis], np.arange(self.__max_degree + 1, dtype=int) + 1)
+        from .grid import _degree_scale_array
+        Y = engine.trigonometric_functions(self.__max_degree, points.longitude)
+        Y *= engine.legendre_functions(self.__max_degree, colat)
+        Y *= _degree_scale_array(kn, self.__max_degree)
+        Y *= engine.to_device(self.__K)
+        return engine.to_host(engine.ravel(Y, self.__min_degree, self.__max_degree).T.contiguous())
+
+    def to_grid(self, grid=None, kernel='ewh'):
+        """gridded values through the spherical harmonic representation (grates/gravityfield.py:766-785)"""
+        from .grid import GeographicGrid
+        return self.to_potential_coefficients().to_grid(GeographicGrid() if grid is None else grid, kernel)
+
+
+class AnisotropicBasisFunctions:
+    """
+    Gravity field as anisotropic kernel functions at the nodal points: `K` [P, P] acts on the degree-wise vector of the
+    point harmonics, band min_degree .. max_degree (grates/gravityfield.py:573-649).
+    """
+
+    def __init__(self, point_distribution, K, min_degree, max_degree, GM=3.9860044150e+14, R=6.3781363000e+06):
+        self.__K = K.copy()
+        self.point_distribution = point_distribution
+        self.__min_degree = min_degree
+        self.__max_degree = max_degree
+        self.GM = GM
+        self.R = R
+        self.epoch = None
+        self.values = np.zeros((self.point_distribution.size))
+
+    @property
+    def values(self):
+        return self.point_distribution.values
+
+    @values.setter
+    def values(self, val):
+        self.point_distribution.values = val
+
+    def is_compatible(self, other):
+        return self.point_distribution.is_compatible(other.point_distribution)
+
+    def to_potential_coefficients(self):
+        """x = K (Y^T values) as potential coefficients (degrees below min_degree zero): the coefficient vector the
+        reference forms per block of nodal points inside to_grid (grates/gravityfield.py:637-639)."""
+        total = _point_harmonics_adjoint(self.point_distribution, self.__max_degree, self.values)
+        y = engine.ravel(total.unsqueeze(0), self.__min_degree, self.__max_degree)
+        x = engine.gemm(engine.to_device(self.__K), y.reshape(-1, 1))
+        coefficients = PotentialCoefficients(self.GM, self.R)
+        coefficients.anm = utilities.unravel_coefficients(engine.to_host(x).ravel(), self.__min_degree, self.__max_degree)
+        coefficients.epoch = self.epoch
+        return coefficients
+
+    def to_grid(self, grid=None, kernel='ewh'):
+        """
+        Gridded values: the kernel coefficient vector K Y^T values is synthesised on the parallels of `grid` with the
+        kernel factors, the upward continuation (R / r)^(n+1) and GM / R (grates/gravityfield.py:604-649) -- the regular
+        grid synthesis of the hot path.
+        """
+        from .grid import GeographicGrid
+        return self.to_potential_coefficients().to_grid(GeographicGrid() if grid is None else grid, kernel)
+
+
+# -------------------------------------------------------------------------------------------------------
 # reference fields (grates/gravityfield.py:1474-1574)
 # -------------------------------------------------------------------------------------------------------
 

@@ -169,3 +169,15 @@ def sinex_file_text(seed, min_degree, max_degree, lower=False):
             out.append(' {0:5d} {1:5d}'.format(r + 1, c + 1) + ''.join(' {0:21.14e}'.format(v) for v in normals[r, c:min(c + 3, last)]))
     out += ['-' + tag, '%ENDSNX']
     return ('\n'.join(out) + '\n').encode('ascii')
+
+
+def basis_function_case(seed, count, min_degree, max_degree):
+    """Nodal points, values and shape factors of the space-domain representations: K_rbf [N+1, N+1] (coefficient layout),
+    K_aniso [P, P] for the band min_degree .. max_degree."""
+    rng = np.random.default_rng(seed)
+    lon, lat = scattered_points(seed + 1, count)
+    values = rng.standard_normal(count) * 1e-3
+    k_rbf = rng.uniform(0.5, 1.5, (max_degree + 1, max_degree + 1))
+    p = (max_degree + 1) ** 2 - min_degree ** 2
+    k_aniso = rng.standard_normal((p, p)) / p
+    return lon, lat, values, k_rbf, k_aniso

@@ -454,8 +454,30 @@ def g14():
     save('g14_sinex', **out)
 
 
+def g15():
+    out = {}
+    lon, lat, values, k_rbf, k_aniso = inputs.basis_function_case(100, 700, 2, 12)
+    rbf = grates.gravityfield.RadialBasisFunctions(grates.grid.IrregularGrid(lon, lat), k_rbf, 2, 12)
+    rbf.values = values
+    out['rbf_anm'] = rbf.to_potential_coefficients().anm
+    F = rbf.to_potential_coefficients_matrix()
+    out['rbf_matrix_cols10'] = F[:, ::10]                      # every tenth nodal point; F @ values pins the rest
+    out['rbf_matrix_times_values'] = F @ values
+    out['rbf_grid_ewh'] = rbf.to_grid(grates.grid.GeographicGrid(10.0, 10.0), 'ewh').value_array
+    aniso = grates.gravityfield.AnisotropicBasisFunctions(grates.grid.IrregularGrid(lon, lat), k_aniso, 2, 12)
+    aniso.values = values
+    out['aniso_grid_ewh'] = aniso.to_grid(grates.grid.GeographicGrid(10.0, 10.0), 'ewh').value_array
+    out['aniso_grid_potential'] = aniso.to_grid(grates.grid.GeographicGrid(10.0, 10.0), 'potential').value_array
+    a = grates.gravityfield.SurfaceMasCons(grates.grid.IrregularGrid(lon, lat), 'ewh')
+    b = a.copy()
+    a.values = values
+    b.values = values[::-1].copy()
+    out['mascon_arith'] = ((a + b) * 3 - a / 4.0).values
+    save('g15_basis_functions', **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()

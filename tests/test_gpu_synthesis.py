@@ -293,3 +293,54 @@ def test_monthly_files_to_grids(tmp_path):
     for k in (0, 3, 5):
         ref = orc.synthesis_regular(ga.io.loadgsm(names[k]).anm, grid.meridians, grid.parallels, kernel)
         assert relerr(grids[k].value_array, ref) < 1e-12
+
+
+def test_basis_function_representations_golden(golden):
+    """RadialBasisFunctions / AnisotropicBasisFunctions / SurfaceMasCons (grates/gravityfield.py:484-785)
+    against the reference on 700 scattered nodal points, band 2..12 (tests/golden/g15_basis_functions.npz)."""
+    g = golden('g15_basis_functions')
+    lon, lat, values, k_rbf, k_aniso = inputs.basis_function_case(100, 700, 2, 12)
+    rbf = ga.gravityfield.RadialBasisFunctions(ga.grid.IrregularGrid(lon, lat), k_rbf, 2, 12)
+    assert rbf.values.shape == (700,) and not rbf.values.any()
+    rbf.values = values
+    gf = rbf.to_potential_coefficients()
+    assert relerr(gf.anm, g['rbf_anm']) < 1e-12
+    F = rbf.to_potential_coefficients_matrix()
+    assert F.shape == (165, 700)
+    assert relerr(F[:, ::10], g['rbf_matrix_cols10']) < 1e-12
+    assert relerr(F @ values, g['rbf_matrix_times_values']) < 1e-12
+    assert relerr(rbf.to_grid(ga.grid.GeographicGrid(10.0, 10.0), 'ewh').value_array, g['rbf_grid_ewh']) < 1e-12
+    other = rbf.copy()
+    other.values[:] = 0.0
+    assert rbf.values.any() and rbf.is_compatible(other)
+
+    # small device blocks: the sum over the nodal points is accumulated block by block
+    saved = ga.gravityfield._POINT_CHUNK_BYTES
+    ga.gravityfield._POINT_CHUNK_BYTES = 8 * 13 * 13 * 96
+    try:
+        assert relerr(rbf.to_potential_coefficients().anm, g['rbf_anm']) < 1e-12
+    finally:
+        ga.gravityfield._POINT_CHUNK_BYTES = saved
+
+    aniso = ga.gravityfield.AnisotropicBasisFunctions(ga.grid.IrregularGrid(lon, lat), k_aniso, 2, 12)
+    aniso.values = values
+    assert relerr(aniso.to_grid(ga.grid.GeographicGrid(10.0, 10.0), 'ewh').value_array, g['aniso_grid_ewh']) < 1e-12
+    assert relerr(aniso.to_grid(ga.grid.GeographicGrid(10.0, 10.0), 'potential').value_array, g['aniso_grid_potential']) < 1e-12
+
+    a = ga.gravityfield.SurfaceMasCons(ga.grid.IrregularGrid(lon, lat), 'ewh')
+    b = a.copy()
+    a.values = values
+    b.values = values[::-1].copy()
+    np.testing.assert_allclose(((a + b) * 3 - a / 4.0).values, g['mascon_arith'], rtol=1e-15, atol=0)
+    with pytest.raises(TypeError):
+        a + 1.0
+    with pytest.raises(TypeError):
+        a * b
+    with pytest.raises(ValueError):
+        a + ga.gravityfield.SurfaceMasCons(ga.grid.IrregularGrid(lon[:10], lat[:10]), 'ewh')
+    # analysis of mascon values = analysis of the same values on the grid itself
+    lon2, lat2 = inputs.scattered_points(5, 400)
+    pts = ga.grid.IrregularGrid(lon2, lat2)
+    pts.values = np.random.default_rng(3).standard_normal(400)
+    expected = pts.to_potential_coefficients(0, 8, 'ewh').anm
+    assert relerr(ga.gravityfield.SurfaceMasCons(pts, 'ewh').to_potential_coefficients(0, 8).anm, expected) < 1e-13
