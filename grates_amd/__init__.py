@@ -15,5 +15,5 @@ from . import filter
 from . import lstsq
 from . import io
 
-__all__ = ['data', 'engine', 'filter', 'gravityfield', 'grid', 'kernel', 'utilities']
+__all__ = ['data', 'engine', 'filter', 'gravityfield', 'grid', 'io', 'kernel', 'lstsq', 'utilities']
 __version__ = '0.1.0'

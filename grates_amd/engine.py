@@ -303,6 +303,19 @@ def covprop_points(max_degree, colat, lon, kn, cov, min_degree):
     return out
 
 
+def epoch_rms(values, acc=None, count=0):
+    """acc [M] (+)= sum over the epochs of values [B, M] squared (device); count > 0 finishes with sqrt(acc / count)."""
+    torch = require_gpu()
+    v = to_device(values)
+    if v.dim() != 2 or not v.is_contiguous():
+        v = v.reshape(v.shape[0], -1).contiguous()
+    accumulate = acc is not None
+    if acc is None:
+        acc = torch.empty((v.shape[1],), dtype=torch.float64, device=v.device)
+    _lib.call('shg_epoch_rms', _ptr(v), v.shape[0], v.shape[1], int(accumulate), int(count), _ptr(acc), _stream())
+    return acc
+
+
 def orderwise_filter(blocks_packed, block_offsets, block_max_degree, anm):
     """blocks_packed: 1d device tensor, block_offsets: int64 device tensor [2Nb+1]; anm [B, N+1, N+1]."""
     torch = require_gpu()

@@ -400,13 +400,17 @@ class TimeSeries:
             out[k, :] = d.values[0:count]
         return out
 
-    def to_coefficient_batch(self):
-        """Stack anm of all epochs into [T, N+1, N+1] (zero-padded to the largest degree): GPU batch layout."""
-        nmax = max(d.max_degree for d in self.__data)
-        out = np.zeros((len(self.__data), nmax + 1, nmax + 1))
-        for k, d in enumerate(self.__data):
+    @staticmethod
+    def _stack(fields):
+        nmax = max(d.max_degree for d in fields)
+        out = np.zeros((len(fields), nmax + 1, nmax + 1))
+        for k, d in enumerate(fields):
             out[k, 0:d.max_degree + 1, 0:d.max_degree + 1] = d.anm
         return out
+
+    def to_coefficient_batch(self):
+        """Stack anm of all epochs into [T, N+1, N+1] (zero-padded to the largest degree): GPU batch layout."""
+        return TimeSeries._stack(self.__data)
 
     def to_grid(self, grid=None, kernel='ewh', as_tensor=False):
         """
@@ -443,10 +447,97 @@ class TimeSeries:
             d.values = observations[k, :]
         return trend
 
+    def bin(self, bin_center_epochs, func=np.mean):
+        """
+        Aggregate the series in bins: every element goes to the nearest bin centre, `func` (default: mean) is applied to the
+        elements of a bin, the result carries the centre as epoch (grates/gravityfield.py:1014-1045).  An empty bin is an
+        error (upstream fails on it while assigning the epoch).  As upstream, numpy.mean of PotentialCoefficients ends in a
+        TypeError (division by a numpy integer): pass e.g. ``lambda v: sum(v[1:], v[0]) * (1.0 / len(v))``.
+        """
+        centers = list(bin_center_epochs)
+        nearest = [int(np.argmin([abs((e - c).total_seconds()) for c in centers])) for e in self.epochs()]
+        binned = []
+        for k, center in enumerate(centers):
+            members = [self.__data[i] for i, b in enumerate(nearest) if b == k]
+            if not members:
+                raise ValueError('no element of the time series falls into the bin centred at {0}'.format(center))
+            value = func(members)
+            value.epoch = center
+            binned.append(value)
+        return TimeSeries(binned)
+
     def append(self, other):
         for _, d in other.items():
             self.__data.append(d)
         self.sort()
+
+
+class TimeVariableGravityField:
+    """Sum of constituents (trend, oscillations, time series ...) that implement `evaluate_at`
+    (grates/gravityfield.py:788-812)."""
+
+    def __init__(self, constituents):
+        self.constituents = constituents
+
+    def evaluate_at(self, epoch):
+        return np.sum([c.evaluate_at(epoch) for c in self.constituents])
+
+
+class Trend:
+    """Linear trend V (t - t0); `time_scale` is the time unit of the coefficients in days (grates/gravityfield.py:1054-1094)."""
+
+    def __init__(self, gravity_field, reference_epoch, time_scale=365.25):
+        self.__data = gravity_field.copy()
+        self.__reference_epoch = reference_epoch
+        self.__time_scale = time_scale
+
+    def evaluate_at(self, epoch):
+        dt = (epoch - self.__reference_epoch).total_seconds() / (86400 * self.__time_scale)
+        output = self.__data * dt
+        output.epoch = epoch
+        return output
+
+
+class Oscillation:
+    """V_c cos 2 pi (t - t0) / T + V_s sin 2 pi (t - t0) / T with the period T in days (grates/gravityfield.py:1097-1140)."""
+
+    def __init__(self, gravity_field_cosine, gravity_field_sine, period, reference_epoch):
+        self.__data_cosine = gravity_field_cosine.copy()
+        self.__data_sine = gravity_field_sine.copy()
+        self.__reference_epoch = reference_epoch
+        self.__period = period
+
+    def evaluate_at(self, epoch):
+        dt = (epoch - self.__reference_epoch).total_seconds() / (86400 * self.__period)
+        output = self.__data_cosine * np.cos(2 * np.pi * dt) + self.__data_sine * np.sin(2 * np.pi * dt)
+        output.epoch = epoch
+        return output
+
+
+def gridded_rms(temporal_gravityfield, epochs, kernel='ewh', base_grid=None, batch=240):
+    """
+    RMS over `epochs` of a time variable gravity field in the space domain (grates/gravityfield.py:1143-1172).  The fields of up
+    to `batch` epochs are synthesised in one call of the batched synthesis and reduced on the device (`shg_epoch_rms`: squares
+    added in epoch order); only the RMS grid comes back to the host.
+    """
+    from .grid import GeographicGrid
+    base_grid = GeographicGrid() if base_grid is None else base_grid
+    epochs = list(epochs)
+    acc = None
+    for start in range(0, len(epochs), batch):
+        fields = [temporal_gravityfield.evaluate_at(t) for t in epochs[start:start + batch]]
+        last = start + len(fields) == len(epochs)
+        uniform = all(isinstance(f, PotentialCoefficients) and f.GM == fields[0].GM and f.R == fields[0].R for f in fields)
+        if uniform:
+            values = synthesize(TimeSeries._stack(fields), base_grid, kernel, fields[0].GM, fields[0].R)
+            acc = engine.epoch_rms(values.reshape(len(fields), -1), acc, len(epochs) if last else 0)
+        else:                                                  # mixed constants or other representations: one synthesis per field
+            for k, field in enumerate(fields):
+                values = engine.to_device(field.to_grid(base_grid, kernel=kernel).values).reshape(1, -1)
+                acc = engine.epoch_rms(values, acc, len(epochs) if last and k == len(fields) - 1 else 0)
+    rms_grid = base_grid.copy()
+    rms_grid.values = engine.to_host(acc) if acc is not None else np.full(base_grid.point_count, np.nan)
+    return rms_grid
 
 
 # -------------------------------------------------------------------------------------------------------

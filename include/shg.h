@@ -88,6 +88,12 @@ int shg_synthesis(shg_plan* plan, const double* anm, int B, double* grid, void* 
 int shg_synthesis_points(int N, const double* colat, const double* lon, const double* kn, int npts,
                          const double* anm, int B, double* values, void* stream);
 
+/* RMS over the epochs of a batch of grids, the reduction of gridded_rms (grates/gravityfield.py:1164-1170):
+ *   acc[i] = (accumulate ? acc[i] : 0) + sum_b values[b][i]^2   (epoch order, no FMA);   count > 0: acc[i] = sqrt(acc[i] / count).
+ * values [B][M] (grids of a batch, flattened), acc [M].  Batches are chained with accumulate = 1, the last call passes the
+ * number of epochs as count. */
+int shg_epoch_rms(const double* values, int B, long long M, int accumulate, long long count, double* acc, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Parity hooks for the table functions
  *   shg_legendre          utilities.legendre_functions            (grates/utilities.py:13-59)

@@ -476,8 +476,30 @@ def g15():
     save('g15_basis_functions', **out)
 
 
+def g16():
+    import datetime as dt
+    out = {}
+    gfs = [potential_coefficients(inputs.coefficients(110 + k, 20)) for k in range(3)]
+    t0 = dt.datetime(2005, 1, 1)
+    series = []
+    for k in range(6):
+        gf = potential_coefficients(inputs.coefficients(120 + k, 20))
+        gf.epoch = t0 + dt.timedelta(days=61 * k)
+        series.append(gf)
+    model = grates.gravityfield.TimeVariableGravityField([grates.gravityfield.Trend(gfs[0], t0),
+                                                          grates.gravityfield.Oscillation(gfs[1], gfs[2], 365.25, t0),
+                                                          grates.gravityfield.TimeSeries(series)])
+    epochs = [t0 + dt.timedelta(days=9.5 * k) for k in range(30)]
+    out['model_anm_at_7'] = model.evaluate_at(epochs[7]).anm
+    out['rms_ewh_5deg'] = grates.gravityfield.gridded_rms(model, epochs, 'ewh', grates.grid.GeographicGrid(5.0, 5.0)).values
+    binned = grates.gravityfield.TimeSeries(series).bin([t0 + dt.timedelta(days=30), t0 + dt.timedelta(days=200), t0 + dt.timedelta(days=290)],
+                                                           func=lambda members: sum(members[1:], members[0]) * (1.0 / len(members)))
+    out['binned_anm'] = np.array([d.anm for _, d in binned.items()])
+    save('g16_time_variable', **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
         if not only or fn.__name__ in only:
             fn()

@@ -344,3 +344,66 @@ def test_basis_function_representations_golden(golden):
     pts.values = np.random.default_rng(3).standard_normal(400)
     expected = pts.to_potential_coefficients(0, 8, 'ewh').anm
     assert relerr(ga.gravityfield.SurfaceMasCons(pts, 'ewh').to_potential_coefficients(0, 8).anm, expected) < 1e-13
+
+
+def test_time_variable_field_and_gridded_rms_golden(golden):
+    """Trend + Oscillation + TimeSeries evaluated at 30 epochs, synthesised in batches and reduced to an RMS grid on the
+    device (grates/gravityfield.py:788-812, 1054-1172; tests/golden/g16_time_variable.npz)."""
+    g = golden('g16_time_variable')
+
+    def field(seed):
+        gf = ga.gravityfield.PotentialCoefficients()
+        gf.anm = inputs.coefficients(seed, 20)
+        return gf
+    t0 = datetime.datetime(2005, 1, 1)
+    series = []
+    for k in range(6):
+        gf = field(120 + k)
+        gf.epoch = t0 + datetime.timedelta(days=61 * k)
+        series.append(gf)
+    gfm = ga.gravityfield
+    model = gfm.TimeVariableGravityField([gfm.Trend(field(110), t0), gfm.Oscillation(field(111), field(112), 365.25, t0), gfm.TimeSeries(series)])
+    epochs = [t0 + datetime.timedelta(days=9.5 * k) for k in range(30)]
+    at7 = model.evaluate_at(epochs[7])
+    assert at7.epoch == epochs[7]
+    np.testing.assert_allclose(at7.anm, g['model_anm_at_7'], rtol=0, atol=1e-24)       # values ~1e-10
+    grid = ga.grid.GeographicGrid(5.0, 5.0)
+    for batch in (240, 7, 1):                                                          # one batch / 4 full + 1 ragged / per epoch
+        rms = gfm.gridded_rms(model, epochs, 'ewh', grid, batch=batch)
+        assert type(rms) is ga.grid.GeographicGrid and rms.values.shape == (36 * 72,)
+        assert relerr(rms.values, g['rms_ewh_5deg']) < 1e-12
+    # fields with different constants take the per-epoch route
+    class Rescaled:
+        def evaluate_at(self, epoch):
+            gf = model.evaluate_at(epoch)
+            if epoch.day % 2:
+                other = ga.gravityfield.PotentialCoefficients(GM=gf.GM * (1 + 1e-9), R=gf.R)
+                other.anm = gf.anm / (1 + 1e-9)
+                gf = other
+            return gf
+    assert relerr(gfm.gridded_rms(Rescaled(), epochs, 'ewh', grid).values, g['rms_ewh_5deg']) < 1e-12
+
+    binned = gfm.TimeSeries(series).bin([t0 + datetime.timedelta(days=30), t0 + datetime.timedelta(days=200), t0 + datetime.timedelta(days=290)],
+                                        func=lambda members: sum(members[1:], members[0]) * (1.0 / len(members)))
+    assert binned.epochs()[1] == t0 + datetime.timedelta(days=200)
+    np.testing.assert_allclose(np.array([d.anm for _, d in binned.items()]), g['binned_anm'], rtol=0, atol=1e-25)
+    with pytest.raises(ValueError):
+        gfm.TimeSeries(series).bin([t0, t0 + datetime.timedelta(days=5000)], func=lambda m: m[0])
+    with pytest.raises(TypeError):
+        gfm.TimeSeries(series).bin([t0])                                               # numpy.mean: as upstream
+
+
+def test_epoch_rms_kernel_properties():
+    """shg_epoch_rms through the C ABI: chained batches = one batch, bit for bit (same order of additions); ragged sizes."""
+    import torch
+    from grates_amd import engine
+    v = torch.randn((37, 100003), dtype=torch.float64, device='cuda')
+    whole = engine.epoch_rms(v, None, 37)
+    acc = engine.epoch_rms(v[:16], None, 0)
+    acc = engine.epoch_rms(v[16:19], acc, 0)
+    acc = engine.epoch_rms(v[19:], acc, 37)
+    assert torch.equal(whole, acc)
+    expected = torch.sqrt((v * v).sum(dim=0) / 37)
+    assert float((whole - expected).abs().max()) < 1e-14
+    empty = engine.epoch_rms(v[:0], None, 0)
+    assert float(empty.abs().max()) == 0.0

@@ -75,6 +75,8 @@ def main():
     one = batch[0:1].contiguous()
     ms = device_ms(lambda: plan.synthesis(one), reps=20)
     emit('synthesis d/o 96 -> 0.25 deg, single epoch (latency)', ms)
+    ms = device_ms(lambda: ga.engine.epoch_rms(out.reshape(240, -1), None, 240), reps=20)
+    emit('RMS over 240 epochs of 0.25 deg grids (shg_epoch_rms, reduction of gridded_rms)', ms, GBs=round(8 * 241 * 720 * 1440 / ms / 1e6, 1))
     del out
 
     # d/o 180 synthesis (staged path: panel does not fit LDS)
