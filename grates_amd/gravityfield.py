@@ -437,15 +437,20 @@ class TimeSeries:
         return out
 
     def detrend(self, basis_functions):
-        """Estimate and remove a parametric temporal model in place (grates/gravityfield.py:1002-1012)."""
+        """
+        Estimate and remove a parametric temporal model in place (grates/gravityfield.py:1002-1012); `basis_functions` are
+        `utilities.Polynomial` / `utilities.Oscillation` instances.  The pseudo-inverse of the [T, k] design matrix is host work;
+        the two products over all coefficients (k x T x P and T x k x P) run on the fp64 GEMM of the device.
+        """
         t = self.epochs()
         design = np.hstack([bf.design_matrix(t) for bf in basis_functions])
-        observations = self.to_array()
-        trend = np.linalg.pinv(design) @ observations
-        observations -= design @ trend
+        observations = engine.to_device(self.to_array())
+        trend = engine.gemm(np.linalg.pinv(design), observations)
+        engine.gemm(design, trend, alpha=-1.0, beta=1.0, out=observations)
+        residuals = engine.to_host(observations)
         for k, d in enumerate(self.__data):
-            d.values = observations[k, :]
-        return trend
+            d.values = residuals[k, :]
+        return engine.to_host(trend)
 
     def bin(self, bin_center_epochs, func=np.mean):
         """

@@ -6,6 +6,9 @@ libshg and return NumPy arrays like the reference does (pass ``as_tensor=True`` 
 device).  Index maps and ellipsoid geometry are tiny host-side helpers.
 """
 
+import abc
+import datetime
+
 import numpy as np
 
 from . import engine
@@ -182,3 +185,53 @@ def kaula_array(min_degree, max_degree, kaula_factor=1e-10, kaula_power=4.0):
         out[n, 0:n + 1] = value
         out[0:n, n] = value
     return out
+
+
+# ---- temporal basis functions (grates/utilities.py:462-557): design matrices of TimeSeries.detrend -----------------------
+
+def _mjd(epoch):
+    """modified Julian date of a datetime with the reference's arithmetic: whole days + seconds / 86400 (microseconds
+    dropped; grates/time.py:37-38)"""
+    delta = epoch - datetime.datetime(1858, 11, 17)
+    return delta.days + delta.seconds / 86400.0
+
+
+class TemporalBasisFunction(metaclass=abc.ABCMeta):
+    """A parametric model of time; `design_matrix(epochs)` returns its [len(epochs), parameter count] design matrix."""
+
+    def __init__(self, reference_epoch):
+        self._reference_epoch = reference_epoch
+
+    def _days(self, epochs):
+        t = np.array([_mjd(e) for e in epochs])
+        if self._reference_epoch is not None:
+            t -= _mjd(self._reference_epoch)
+        return t
+
+    @abc.abstractmethod
+    def design_matrix(self, epochs):
+        pass
+
+
+class Oscillation(TemporalBasisFunction):
+    """a cos(2 pi (t - t0) / T) + b sin(2 pi (t - t0) / T), period T in days (without a reference epoch t is the MJD)."""
+
+    def __init__(self, period, reference_epoch=None):
+        super().__init__(reference_epoch)
+        self.__period = period
+
+    def design_matrix(self, epochs):
+        phase = 2 * np.pi / self.__period * self._days(epochs)
+        return np.column_stack((np.cos(phase), np.sin(phase)))
+
+
+class Polynomial(TemporalBasisFunction):
+    """sum_k a_k (t - t0)^k for k = 0 .. degree, t in days."""
+
+    def __init__(self, degree, reference_epoch=None):
+        super().__init__(reference_epoch)
+        self.__degree = degree
+
+    def design_matrix(self, epochs):
+        t = self._days(epochs)
+        return np.column_stack([np.ones(t.size)] + [t ** k for k in range(1, self.__degree + 1)])

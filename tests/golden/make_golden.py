@@ -495,6 +495,18 @@ def g16():
     binned = grates.gravityfield.TimeSeries(series).bin([t0 + dt.timedelta(days=30), t0 + dt.timedelta(days=200), t0 + dt.timedelta(days=290)],
                                                            func=lambda members: sum(members[1:], members[0]) * (1.0 / len(members)))
     out['binned_anm'] = np.array([d.anm for _, d in binned.items()])
+    # detrend: bias + drift + annual oscillation removed from a series of 40 epochs
+    rng = np.random.default_rng(130)
+    fields = []
+    for k in range(40):
+        gf = potential_coefficients(inputs.coefficients(140, 15) * (1 + 0.01 * k) + inputs.coefficients(141, 15) * np.sin(2 * np.pi * k * 30.4 / 365.25)
+                                    + rng.standard_normal((16, 16)) * 1e-12)
+        gf.epoch = t0 + dt.timedelta(days=30.4 * k)
+        fields.append(gf)
+    ts = grates.gravityfield.TimeSeries(fields)
+    out['detrend_parameters'] = ts.detrend([grates.utilities.Polynomial(1, t0), grates.utilities.Oscillation(365.25, t0)])
+    out['detrend_residuals'] = ts.to_array()
+    out['design_no_reference'] = np.hstack((grates.utilities.Polynomial(2).design_matrix(epochs[:5]), grates.utilities.Oscillation(182.625).design_matrix(epochs[:5])))
     save('g16_time_variable', **out)
 
 

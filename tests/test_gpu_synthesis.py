@@ -407,3 +407,24 @@ def test_epoch_rms_kernel_properties():
     assert float((whole - expected).abs().max()) < 1e-14
     empty = engine.epoch_rms(v[:0], None, 0)
     assert float(empty.abs().max()) == 0.0
+
+
+def test_detrend_golden(golden):
+    """TimeSeries.detrend with bias + drift + annual oscillation over 40 epochs (grates/gravityfield.py:993-1012): estimated
+    parameters and residual series against the reference (tests/golden/g16_time_variable.npz); the products run on the device."""
+    g = golden('g16_time_variable')
+    t0 = datetime.datetime(2005, 1, 1)
+    rng = np.random.default_rng(130)
+    fields = []
+    for k in range(40):
+        gf = ga.gravityfield.PotentialCoefficients()
+        gf.anm = inputs.coefficients(140, 15) * (1 + 0.01 * k) + inputs.coefficients(141, 15) * np.sin(2 * np.pi * k * 30.4 / 365.25) \
+            + rng.standard_normal((16, 16)) * 1e-12
+        gf.epoch = t0 + datetime.timedelta(days=30.4 * k)
+        fields.append(gf)
+    ts = ga.gravityfield.TimeSeries(fields)
+    parameters = ts.detrend([ga.utilities.Polynomial(1, t0), ga.utilities.Oscillation(365.25, t0)])
+    assert isinstance(parameters, np.ndarray) and parameters.shape == (4, 256)
+    assert relerr(parameters, g['detrend_parameters']) < 1e-11
+    assert relerr(ts.to_array(), g['detrend_residuals']) < 1e-9                     # residuals are 1e-2 of the signal
+    assert np.abs(ts.to_array()).max() < 1e-11

@@ -379,3 +379,20 @@ def test_sinex_normal_equations_reader(golden, tmp_path):
     (tmp_path / 'bad.snx').write_text(text.replace(' CN     ', ' STAX   ', 1))
     with pytest.raises(ValueError, match='not supported'):
         ga.io.loadsinex(str(tmp_path / 'bad.snx'))
+
+
+def test_temporal_basis_functions(golden):
+    """Design matrices of utilities.Polynomial / Oscillation (grates/utilities.py:462-557) against the reference, bit for bit;
+    without a reference epoch the time argument is the modified Julian date."""
+    g = golden('g16_time_variable')
+    t0 = datetime.datetime(2005, 1, 1)
+    epochs = [t0 + datetime.timedelta(days=9.5 * k) for k in range(5)]
+    design = np.hstack((ga.utilities.Polynomial(2).design_matrix(epochs), ga.utilities.Oscillation(182.625).design_matrix(epochs)))
+    np.testing.assert_array_equal(design, g['design_no_reference'])
+    assert design[0, 1] == 53371.0                                                   # MJD of 2005-01-01
+    d = ga.utilities.Polynomial(1, t0).design_matrix(epochs)
+    np.testing.assert_array_equal(d, np.column_stack((np.ones(5), 9.5 * np.arange(5))))
+    assert ga.utilities.Polynomial(0).design_matrix(epochs).shape == (5, 1)
+    assert issubclass(ga.utilities.Oscillation, ga.utilities.TemporalBasisFunction)
+    with pytest.raises(TypeError):
+        ga.utilities.TemporalBasisFunction(None)
