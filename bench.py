@@ -142,6 +142,16 @@ def covariance_leg(args, rank, world, barrier, reduce_device='cuda'):
                                     'executed_GFLOP': (2.0 * nlat * P * P + 2.0 * nlat * nlon * (2 * N + 1) ** 2) / 1e9,
                                     'max_rel_diff_vs_general': float(((rows - sigma).abs().max() / sigma.abs().max()).item())}
         del sigma_sep
+        # the same for a symmetric Sigma (only the slot pairs s >= s' of B_i are formed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sigma_sep = plan.covariance_propagation(cov, 0, method='separable', symmetric=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rows = sigma_sep.reshape(nlat, nlon)[lat0:lat1].reshape(-1)
+        out['separable_variant']['symmetric_full_grid_seconds'] = dt
+        out['separable_variant']['symmetric_max_rel_diff_vs_general'] = float(((rows - sigma).abs().max() / sigma.abs().max()).item())
+        del sigma_sep
     if world == 1 and args.cov_cpu_parallels > 0:
         from oracle import shg_oracle as orc
         ker = orc.KernelTable(KERNEL, ga.data.load_love_numbers()[0])

@@ -41,6 +41,7 @@ PROTOTYPES = {
     'shg_covprop_diag': [c_plan_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_covprop_diag_symmetric': [c_plan_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_covprop_diag_separable': [c_plan_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_covprop_diag_separable_symmetric': [c_plan_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_epoch_rms': [c_double_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, c_double_p, ctypes.c_void_p],
     'shg_symmetry_defect': [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_covprop_points': [ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],

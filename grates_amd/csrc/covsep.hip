@@ -23,21 +23,39 @@ int covprop_build_cs_table(shg_plan* p, hipStream_t stream);   // gemm.hip
 
 constexpr int kSepSlotChunk = 32;      // slots whose G matrices are alive at one time
 
-// out[a][b] = cov[perm[a]][perm[b]]; one workgroup per output row.  The gathered reads touch one sector per element, but
-// the source row (P doubles) stays in L2 while the workgroup walks it, so HBM sees every byte once.
-__global__ __launch_bounds__(256) void covsep_permute_kernel(int Pn, const int* __restrict__ perm, const double* __restrict__ cov,
-                                                             double* __restrict__ out) {
+constexpr int kPermSegment = 8192;     // doubles of a source row staged in LDS at one time (64 KB: two workgroups per CU)
+
+// out[a][b] = cov[perm[a]][perm[b]]; one workgroup per output row.  The source row is read in contiguous segments into LDS,
+// the gather happens there: HBM sees coalesced reads and writes only (a gather straight from memory touches one 64-byte
+// sector per element: 8.8 ms for 8.6 GB at d/o 180).  `pairs` lists, segment by segment, the output positions b whose source
+// perm[b] lies in the segment as (b, perm[b] - segment start), b ascending: slot-major order makes them runs of consecutive b.
+__global__ __launch_bounds__(1024) void covsep_permute_kernel(int Pn, const int* __restrict__ perm, const int2* __restrict__ pairs,
+                                                              const int* __restrict__ pair_off, const double* __restrict__ cov,
+                                                              double* __restrict__ out) {
+    __shared__ double seg[kPermSegment];
     const int a = blockIdx.x;
     const double* src = cov + (size_t)perm[a] * Pn;
     double* dst = out + (size_t)a * Pn;
-    for (int b = threadIdx.x; b < Pn; b += 256) dst[b] = src[perm[b]];
+    for (int s0 = 0, k = 0; s0 < Pn; s0 += kPermSegment, ++k) {
+        const int len = min(kPermSegment, Pn - s0);
+        for (int e = threadIdx.x; e < len; e += 1024) seg[e] = __builtin_nontemporal_load(src + s0 + e);
+        __syncthreads();
+        const int e1 = pair_off[k + 1];
+        for (int e = pair_off[k] + threadIdx.x; e < e1; e += 1024) {
+            const int2 bq = pairs[e];
+            dst[bq.x] = seg[bq.y];
+        }
+        __syncthreads();
+    }
 }
 
 // Bm[i][s][sc0 + c] = sum_k PK_s[k][i] G_c[(soff[s] + k)][i] for a tile of 32 parallels x 32 slots of the chunk.
 // Reads run along the parallels (contiguous in both tables), the result tile is transposed through LDS so that the writes
 // run along the slots.
+// half != 0 (symmetric Sigma): G_c holds only the rows of the slots >= c (the shorter ones: a quarter of the G traffic of
+// the general case); the entries s > c are written twice their value, the entries s < c as zero, so that t^T Bm t is unchanged.
 __global__ __launch_bounds__(256) void covsep_contract_kernel(int N, int nmin, int Pn, int nb, int ldlat, int lat0, int S, int sc0, int nsc,
-                                                              const int* __restrict__ soff, const double* __restrict__ pk,
+                                                              int half, const int* __restrict__ soff, const double* __restrict__ pk,
                                                               const double* __restrict__ G, double* __restrict__ Bm) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
@@ -54,13 +72,17 @@ __global__ __launch_bounds__(256) void covsep_contract_kernel(int N, int nmin, i
     const double* g[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) g[q] = G + (size_t)min(c0 + ty + 8 * q, nsc - 1) * slab + (size_t)soff[s] * nb + ic;
-    for (int k = 0; k < ns; ++k) {
+    const bool skip = half && s < sc0 + c0;                        // the whole tile lies above the diagonal
+    for (int k = 0; k < (skip ? 0 : ns); ++k) {
         const double pv = pkrow[(size_t)k * ldlat];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = fma(pv, g[q][(size_t)k * nb], acc[q]);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) tile[tx][ty + 8 * q] = acc[q];
+    for (int q = 0; q < 4; ++q) {
+        const int c = sc0 + c0 + ty + 8 * q;
+        tile[tx][ty + 8 * q] = !half || s == c ? acc[q] : (s > c ? 2.0 * acc[q] : 0.0);        // rows s < c of G_c do not exist
+    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -86,7 +108,7 @@ __global__ __launch_bounds__(256) void covsep_reduce_kernel(int S, int nlon, int
 
 using namespace shg;
 
-extern "C" int shg_covprop_diag_separable(shg_plan* p, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream_) {
+static int covprop_diag_separable(shg_plan* p, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream_, bool half) {
     SHG_REQUIRE(p != nullptr, "shg_covprop_diag_separable: NULL plan");
     SHG_REQUIRE(nmin >= 0 && nmin <= p->N + 1, "shg_covprop_diag_separable: min_degree %d out of range", nmin);
     SHG_REQUIRE(lat0 >= 0 && lat1 <= p->nlat && lat0 <= lat1, "shg_covprop_diag_separable: bad band [%d, %d)", lat0, lat1);
@@ -114,10 +136,26 @@ extern "C" int shg_covprop_diag_separable(shg_plan* p, const double* cov, int nm
         for (int k = 0; k < ns; ++k) perm[(size_t)soff[s] + k] = (n0 + k) * (n0 + k) - nmin * nmin + s;
         soff[s + 1] = soff[s] + ns;
     }
-    int *soff_d = nullptr, *perm_d = nullptr;
+    // output positions grouped by the segment of the source row they come from
+    const int nseg = ceil_div(Pn, kPermSegment);
+    std::vector<int> pair_off(nseg + 1, 0);
+    std::vector<int2> pairs((size_t)Pn);
+    for (int b = 0; b < Pn; ++b) ++pair_off[perm[b] / kPermSegment + 1];
+    for (int k = 0; k < nseg; ++k) pair_off[k + 1] += pair_off[k];
+    {
+        std::vector<int> fill(pair_off.begin(), pair_off.end() - 1);
+        for (int b = 0; b < Pn; ++b) {
+            const int k = perm[b] / kPermSegment;
+            pairs[(size_t)fill[k]++] = make_int2(b, perm[b] - k * kPermSegment);
+        }
+    }
+    int *soff_d = nullptr, *perm_d = nullptr, *pair_off_d = nullptr;
+    int2* pairs_d = nullptr;
     double *Sp = nullptr, *G = nullptr, *Bm = nullptr, *Y = nullptr;
     if (workspace_alloc((void**)&soff_d, soff.size() * sizeof(int), stream) != hipSuccess ||
         workspace_alloc((void**)&perm_d, perm.size() * sizeof(int), stream) != hipSuccess ||
+        workspace_alloc((void**)&pairs_d, pairs.size() * sizeof(int2), stream) != hipSuccess ||
+        workspace_alloc((void**)&pair_off_d, pair_off.size() * sizeof(int), stream) != hipSuccess ||
         workspace_alloc((void**)&Sp, (size_t)Pn * Pn * sizeof(double), stream) != hipSuccess ||
         workspace_alloc((void**)&G, (size_t)kSepSlotChunk * Pn * nb * sizeof(double), stream) != hipSuccess ||
         workspace_alloc((void**)&Bm, (size_t)nb * S * S * sizeof(double), stream) != hipSuccess ||
@@ -126,8 +164,10 @@ extern "C" int shg_covprop_diag_separable(shg_plan* p, const double* cov, int nm
                     ((double)Pn * Pn + (double)kSepSlotChunk * Pn * nb + (double)nb * S * S + (double)nb * S * nlon) * 8e-9);
     SHG_HIP(hipMemcpyAsync(soff_d, soff.data(), soff.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     SHG_HIP(hipMemcpyAsync(perm_d, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    SHG_HIP(hipMemcpyAsync(pairs_d, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+    SHG_HIP(hipMemcpyAsync(pair_off_d, pair_off.data(), pair_off.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     SHG_HIP(hipStreamSynchronize(stream));                              // the host vectors go out of scope at return
-    hipLaunchKernelGGL(covsep_permute_kernel, dim3(Pn), dim3(256), 0, stream, Pn, perm_d, cov, Sp);
+    hipLaunchKernelGGL(covsep_permute_kernel, dim3(Pn), dim3(1024), 0, stream, Pn, perm_d, pairs_d, pair_off_d, cov, Sp);
 
     {
         ProfileScope ps(p, 3, stream);
@@ -138,16 +178,18 @@ extern "C" int shg_covprop_diag_separable(shg_plan* p, const double* cov, int nm
                 // the cosine and the sine slot of an order have the same coefficients count and the same PK rows: one batched launch
                 const int pair = (s >= 1 && (s & 1) == 1 && c + 1 < nsc) ? 2 : 1;
                 double* Gc = G + (size_t)c * Pn * nb;
+                const int row0 = half ? soff[s] : 0;                      // symmetric Sigma: only the rows of this slot and the later ones
                 if (ns <= 0)
                     SHG_HIP(hipMemsetAsync(Gc, 0, (size_t)pair * Pn * nb * sizeof(double), stream));
                 else
-                    rc = gemm_ex(false, false, Pn, nb, ns, 1.0, Sp + soff[s], Pn, ns, p->pk + (size_t)(order_offset(N, m) + n0 - m) * p->ldlat + lat0,
-                                 p->ldlat, 0, 0.0, Gc, nb, (long long)Pn * nb, pair, false, stream);
+                    rc = gemm_ex(false, false, Pn - row0, nb, ns, 1.0, Sp + (size_t)row0 * Pn + soff[s], Pn, ns,
+                                 p->pk + (size_t)(order_offset(N, m) + n0 - m) * p->ldlat + lat0, p->ldlat, 0, 0.0, Gc + (size_t)row0 * nb, nb,
+                                 (long long)Pn * nb, pair, false, stream);
                 c += pair;
             }
             if (rc) break;
             hipLaunchKernelGGL(covsep_contract_kernel, dim3(ceil_div(nb, 32), S, ceil_div(nsc, 32)), dim3(256), 0, stream, N, nmin, Pn, nb, p->ldlat,
-                               lat0, S, sc0, nsc, soff_d, p->pk, G, Bm);
+                               lat0, S, sc0, nsc, half ? 1 : 0, soff_d, p->pk, G, Bm);
         }
         if (rc == SHG_OK)
             rc = gemm_ex(false, false, S, nlon, S, 1.0, Bm, S, (long long)S * S, p->cs_slot, nlon, 0, 0.0, Y, nlon, (long long)S * nlon, nb, false, stream);
@@ -156,6 +198,8 @@ extern "C" int shg_covprop_diag_separable(shg_plan* p, const double* cov, int nm
     }
     (void)hipFreeAsync(soff_d, stream);
     (void)hipFreeAsync(perm_d, stream);
+    (void)hipFreeAsync(pairs_d, stream);
+    (void)hipFreeAsync(pair_off_d, stream);
     (void)hipFreeAsync(Sp, stream);
     (void)hipFreeAsync(G, stream);
     (void)hipFreeAsync(Bm, stream);
@@ -163,4 +207,14 @@ extern "C" int shg_covprop_diag_separable(shg_plan* p, const double* cov, int nm
     if (rc) return rc;
     SHG_HIP(hipGetLastError());
     return SHG_OK;
+}
+
+extern "C" int shg_covprop_diag_separable(shg_plan* p, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream) {
+    return covprop_diag_separable(p, cov, nmin, lat0, lat1, sigma, stream, false);
+}
+
+// Sigma symmetric (not checked: shg_symmetry_defect): B_i is symmetric as well, only the slot pairs s >= s' are formed --
+// half of the GEMM work and a quarter of the G traffic.  Reads the entries (p, q) of Sigma with slot(p) >= slot(q).
+extern "C" int shg_covprop_diag_separable_symmetric(shg_plan* p, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream) {
+    return covprop_diag_separable(p, cov, nmin, lat0, lat1, sigma, stream, true);
 }

@@ -152,13 +152,14 @@ class Plan:
         if method not in ('direct', 'separable'):
             raise ValueError("method must be 'direct' or 'separable'")
         with torch.cuda.device(self.device):
-            if method == 'separable':
-                _lib.call('shg_covprop_diag_separable', self._handle, _ptr(c), int(min_degree), int(lat0), int(lat1), _ptr(out), _stream())
-                return out
             if symmetric is None:
                 defect = torch.zeros(1, dtype=torch.float64, device=self.device)
                 _lib.call('shg_symmetry_defect', _ptr(c), P, P, _ptr(defect), _stream())
                 symmetric = float(defect.item()) == 0.0
+            if method == 'separable':
+                _lib.call('shg_covprop_diag_separable_symmetric' if symmetric else 'shg_covprop_diag_separable', self._handle, _ptr(c),
+                          int(min_degree), int(lat0), int(lat1), _ptr(out), _stream())
+                return out
             _lib.call('shg_covprop_diag_symmetric' if symmetric else 'shg_covprop_diag', self._handle, _ptr(c), int(min_degree), int(lat0), int(lat1),
                       _ptr(out), _stream())
         return out

@@ -135,6 +135,9 @@ int shg_symmetry_defect(const double* S, int n, int ld, double* defect, void* st
  * 2 nlat P^2 flops instead of 2 nlat nlon P^2 (d/o 180, 0.5 deg: 8e11 instead of 5.6e14); differs from shg_covprop_diag by
  * summation order only.  Workspace: about P^2 + 32 P nlat doubles (17 GB at d/o 180 for the full grid). */
 int shg_covprop_diag_separable(shg_plan* plan, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream);
+/* cov symmetric (caller's promise, cf. shg_symmetry_defect): B_i is symmetric too and only its slot pairs s >= s' are formed,
+ * half the work of shg_covprop_diag_separable. */
+int shg_covprop_diag_separable_symmetric(shg_plan* plan, const double* cov, int nmin, int lat0, int lat1, double* sigma, void* stream);
 
 /* Point-list variant  (grates/grid.py:1096-1120): colat, lon [npts]; kn [npts][N+1]; sigma [npts] */
 int shg_covprop_points(int N, const double* colat, const double* lon, const double* kn, int npts,

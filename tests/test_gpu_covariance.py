@@ -163,9 +163,18 @@ def test_separable_variant_matches_direct_path_and_oracle(golden, N, step, nmin)
         assert relerr(sep, ref) < TOL_SIGMA
     band = grid.covariance_propagation(cov, nmin, N, kernel='ewh', parallel_range=(2, 9), method='separable')
     assert relerr(band, direct.reshape(grid.parallels.size, -1)[2:9].ravel()) < 1e-12
+    # symmetric matrix: only the slot pairs s <= s' are formed (promised by the caller / detected on the device)
+    assert np.array_equal(cov, cov.T)
+    half = grid.covariance_propagation(cov, nmin, N, kernel='ewh', method='separable', symmetric=True)
+    assert relerr(half, direct) < 1e-12
+    auto = grid.covariance_propagation(cov, nmin, N, kernel='ewh', method='separable', symmetric=None)
+    np.testing.assert_array_equal(auto, half)
+    band = grid.covariance_propagation(cov, nmin, N, kernel='ewh', parallel_range=(2, 9), method='separable', symmetric=True)
+    assert relerr(band, direct.reshape(grid.parallels.size, -1)[2:9].ravel()) < 1e-12
     skew = cov + np.triu(np.random.default_rng(3).standard_normal(cov.shape) * np.abs(cov).max() * 1e-3, 1)
     a = grid.covariance_propagation(skew, nmin, N, kernel='potential')
     b = grid.covariance_propagation(skew, nmin, N, kernel='potential', method='separable')
+    np.testing.assert_array_equal(grid.covariance_propagation(skew, nmin, N, kernel='potential', method='separable', symmetric=None), b)   # not symmetric: full path
     ok = np.isfinite(a)
     np.testing.assert_array_equal(np.isfinite(b), ok)
     assert relerr(b[ok], a[ok]) < 1e-11
