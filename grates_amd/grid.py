@@ -393,6 +393,106 @@ class GaussGrid(RegularGrid):
         return grid
 
 
+class ReuterGrid(IrregularGrid):
+    """
+    Reuter grid of a given level: level + 1 parallels at equal spacing on the unit sphere, on each of them as many points as
+    keep the spherical distance to the neighbours near pi / level; poles are single points.  The sphere is mapped onto the
+    ellipsoid by `latitude_mapping` ('geocentric', 'authalic' or 'conformal') (grates/grid.py:1207-1278).  The usual nodal
+    point distribution of `RadialBasisFunctions` / `SurfaceMasCons`; area elements are those of the unit sphere.
+    """
+
+    def __init__(self, level, a=6378137.0, f=298.2572221010**-1, latitude_mapping='geocentric'):
+        mappings = {'authalic': authalic2geodetic, 'geocentric': geocentric2geodetic, 'conformal': conformal2geodetic}
+        if latitude_mapping.lower() not in mappings:
+            raise ValueError('Unknown latitude mapping "{0}".'.format(latitude_mapping))
+        dlat = np.pi / level
+        polar_cap = 2 * np.pi * (1 - np.cos(dlat * 0.5))
+        latitude, counts, areas = [0.5 * np.pi], [1], [polar_cap]
+        for k in range(1, level):
+            theta = k * dlat
+            count = int(2 * np.pi / np.arccos((np.cos(dlat) - np.cos(theta) ** 2) / (np.sin(theta) ** 2)))
+            latitude.append(np.pi * 0.5 - theta)
+            counts.append(count)
+            areas.append(4 * np.pi / count * np.sin(0.5 * dlat) * np.cos(latitude[-1]))
+        latitude.append(-0.5 * np.pi)
+        counts.append(1)
+        areas.append(polar_cap)
+        latitude = mappings[latitude_mapping.lower()](np.array(latitude), f)
+        lon = [np.zeros(1) if k in (0, level) else np.mod((np.arange(n) + 1.5) * 2 * np.pi / n + np.pi, 2 * np.pi) - np.pi
+               for k, n in enumerate(counts)]
+        super().__init__(np.concatenate(lon), np.repeat(latitude, counts), np.repeat(np.array(areas), counts), a, f)
+        self.__level, self.__mapping = level, latitude_mapping
+
+    def copy(self):
+        # (upstream's copy falls back to the geocentric mapping; the mapping is kept here)
+        other = ReuterGrid(self.__level, self.semimajor_axis, self.flattening, self.__mapping)
+        other.values = None if self.values is None else self.values.copy()
+        other.epoch = self.epoch
+        return other
+
+
+# -------------------------------------------------------------------------------------------------------
+# latitude mappings between the ellipsoid and the sphere (grates/grid.py:2047-2110)
+# -------------------------------------------------------------------------------------------------------
+
+def _sine_series(beta, e2, table):
+    """beta + sum_j (sum_k c_jk e2^k) sin(2 j beta) for the rows (j, {k: c_jk}) of `table`"""
+    result = np.array(beta, dtype=float, copy=True)
+    for harmonic, coefficients in table:
+        result = result + sum(c * e2 ** k for k, c in coefficients.items()) * np.sin(2 * harmonic * beta)
+    return result
+
+
+def _authalic_q(sin_latitude, e):
+    return (1 - e ** 2) * sin_latitude / (1 - e ** 2 * sin_latitude ** 2) - (1 - e ** 2) / (2 * e) * np.log((1 - e * sin_latitude) / (1 + e * sin_latitude))
+
+
+def authalic_radius(a=6378137.0, f=298.2572221010**-1):
+    """radius of the sphere with the surface area of the ellipsoid"""
+    return a * np.sqrt(_authalic_q(1.0, np.sqrt(f * (2 - f))) * 0.5)
+
+
+def geodetic2authalic(latitude, f=298.2572221010**-1):
+    if f == 0.0:
+        return latitude
+    e = np.sqrt(f * (2 - f))
+    return np.arcsin(_authalic_q(np.sin(latitude), e) / _authalic_q(1.0, e))
+
+
+# series in e^2 as the reference evaluates them (including its denominators 181400 and 997920)
+_AUTHALIC_TO_GEODETIC = ((1, {1: 1 / 3, 2: 31 / 180, 3: 517 / 5040, 4: 120389 / 181400, 5: 1362254 / 29937600}),
+                         (2, {2: 23 / 360, 3: 251 / 3780, 4: 102287 / 1814400, 5: 450739 / 997920}),
+                         (3, {3: 761 / 45360, 4: 47561 / 1814400, 5: 434501 / 14968800}),
+                         (4, {4: 6059 / 1209600, 5: 625511 / 59875200}),
+                         (5, {5: 48017 / 29937600}))
+_CONFORMAL_TO_GEODETIC = ((1, {1: 1 / 2, 2: 5 / 24, 3: 1 / 12, 4: 13 / 360}),
+                          (2, {2: 7 / 48, 3: 29 / 240, 4: 811 / 11520}),
+                          (3, {3: 7 / 120, 4: 81 / 1120}),
+                          (4, {4: 4279 / 161280}))
+
+
+def authalic2geodetic(beta, f=298.2572221010**-1):
+    return _sine_series(beta, f * (2 - f), _AUTHALIC_TO_GEODETIC)
+
+
+def conformal2geodetic(beta, f=298.2572221010**-1):
+    return _sine_series(beta, f * (2 - f), _CONFORMAL_TO_GEODETIC)
+
+
+def geodetic2conformal(latitude, f=298.2572221010**-1):
+    e = np.sqrt(f * (2 - f))
+    sin_latitude = np.sin(latitude)
+    return 2 * np.arctan2(np.sqrt((1 + sin_latitude) * (1 - e * sin_latitude) ** e), np.sqrt((1 - sin_latitude) * (1 + e * sin_latitude) ** e)) - np.pi * 0.5
+
+
+def geocentric2geodetic(beta, f=298.2572221010**-1):
+    return np.arctan2(np.sin(beta), np.cos(beta) * (1 - f) ** 2)
+
+
+def geodetic2geocentric(latitude, f=298.2572221010**-1):
+    return np.arctan2((1 - f) ** 2 * np.sin(latitude), np.cos(latitude))
+
+
 # -------------------------------------------------------------------------------------------------------
 # coordinate helpers (grates/grid.py:1893-2044)
 # -------------------------------------------------------------------------------------------------------

@@ -510,8 +510,23 @@ def g16():
     save('g16_time_variable', **out)
 
 
+def g17():
+    out = {}
+    for mapping in ('geocentric', 'authalic', 'conformal'):
+        grid = grates.grid.ReuterGrid(18, latitude_mapping=mapping)
+        out['reuter18_' + mapping] = np.vstack((grid.longitude, grid.latitude, grid.area))
+    beta = np.linspace(-0.5 * np.pi, 0.5 * np.pi, 37)
+    g = grates.grid
+    out['mappings'] = np.vstack((g.geodetic2authalic(beta), g.authalic2geodetic(beta), g.geodetic2conformal(beta), g.conformal2geodetic(beta),
+                                 g.geodetic2geocentric(beta), g.geocentric2geodetic(beta)))
+    out['authalic_radius'] = np.array(g.authalic_radius())
+    gf = potential_coefficients(inputs.coefficients(150, 40))
+    out['reuter30_ewh'] = gf.to_grid(grates.grid.ReuterGrid(30), kernel='ewh').values
+    save('g17_reuter', **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17):
         if not only or fn.__name__ in only:
             fn()

@@ -428,3 +428,14 @@ def test_detrend_golden(golden):
     assert relerr(parameters, g['detrend_parameters']) < 1e-11
     assert relerr(ts.to_array(), g['detrend_residuals']) < 1e-9                     # residuals are 1e-2 of the signal
     assert np.abs(ts.to_array()).max() < 1e-11
+
+
+def test_synthesis_on_reuter_grid_golden(golden):
+    """to_grid on the points of ReuterGrid(30) through the point-list kernel against the reference (g17_reuter.npz)."""
+    g = golden('g17_reuter')
+    gf = ga.gravityfield.PotentialCoefficients()
+    gf.anm = inputs.coefficients(150, 40)
+    grid = ga.grid.ReuterGrid(30)
+    out = gf.to_grid(grid, kernel='ewh')
+    assert type(out) is ga.grid.ReuterGrid and out.values.shape == g['reuter30_ewh'].shape
+    assert relerr(out.values, g['reuter30_ewh']) < 1e-12
