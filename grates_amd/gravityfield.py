@@ -694,6 +694,7 @@ def _point_harmonics_adjoint(points, max_degree, values, upward=None):
     cos / sin tables of the C-ABI), the sum over the points is one transposed fp64 GEMM per block.
     `upward` = reference radius R: scale degree n by (R / r_p)^(n+1).
     """
+    from .grid import _degree_scale_array
     torch = engine.require_gpu()
     colat = utilities.colatitude(points.latitude, points.semimajor_axis, points.flattening)
     size = (max_degree + 1) ** 2
@@ -707,7 +708,6 @@ def _point_harmonics_adjoint(points, max_degree, values, upward=None):
         if upward is not None:
             radius = utilities.geocentric_radius(points.latitude[block], points.semimajor_axis, points.flattening)
             kn = np.power((upward / radius)[:, np.newaxis], np.arange(max_degree + 1, dtype=int) + 1)
-            from .grid import _degree_scale_array
             Y *= _degree_scale_array(kn, max_degree)
         engine.gemm(Y.reshape(Y.shape[0], size), v[block], transa=True, beta=1.0, out=out)
     return out.reshape(max_degree + 1, max_degree + 1)
