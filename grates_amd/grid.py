@@ -73,6 +73,27 @@ class Grid(metaclass=abc.ABCMeta):
         lon, lat = self.longitude, self.latitude
         return spherical_distance(lon[:, np.newaxis], lat[:, np.newaxis], lon[np.newaxis, :], lat[np.newaxis, :], r=1)
 
+    def subset(self, mask):
+        """The points selected by the boolean `mask` as a new grid: a RegularGrid when they still form full parallels and
+        meridians, an IrregularGrid otherwise (grates/grid.py:303-327).  Values are not carried over (as upstream)."""
+        mask = np.asarray(mask, dtype=bool).ravel()
+        points = IrregularGrid(self.longitude[mask], self.latitude[mask], None if self.area is None else self.area[mask],
+                               self.semimajor_axis, self.flattening)
+        try:
+            return points.to_regular()
+        except ValueError:
+            return points
+
+    def nn_index(self, lon, lat):
+        """For every grid point the indices of the sample points (lon, lat) whose nearest grid point it is, by 3D euclidean
+        distance (grates/grid.py:329-356)."""
+        import scipy.spatial
+        sample = IrregularGrid(np.atleast_1d(lon), np.atleast_1d(lat), a=self.semimajor_axis, f=self.flattening).cartesian_coordinates()
+        _, nearest = scipy.spatial.cKDTree(self.cartesian_coordinates()).query(sample)
+        order = np.argsort(nearest, kind='stable')
+        bounds = np.searchsorted(nearest[order], np.arange(self.point_count + 1))
+        return [order[bounds[k]:bounds[k + 1]] for k in range(self.point_count)]
+
     # ---- linear operators ------------------------------------------------------------------------------------------
     @abc.abstractmethod
     def synthesis_matrix_per_order(self, m, min_degree, max_degree, kernel, GM, R):

@@ -428,3 +428,25 @@ def test_reuter_grid_and_latitude_mappings(golden):
     inner = beta[1:-1]
     np.testing.assert_allclose(G.geocentric2geodetic(G.geodetic2geocentric(inner)), inner, rtol=0, atol=1e-15)
     np.testing.assert_allclose(G.conformal2geodetic(G.geodetic2conformal(inner)), inner, rtol=0, atol=1e-11)   # series truncated at e^8
+
+
+def test_grid_subset_and_nearest_neighbour_index():
+    """Grid.subset / Grid.nn_index (grates/grid.py:303-356): host helpers around the point lists."""
+    grid = ga.grid.GeographicGrid(10.0, 10.0)
+    lon, lat = grid.longitude, grid.latitude
+    box = (np.abs(lon) < np.radians(45)) & (np.abs(lat) < np.radians(30))
+    part = grid.subset(box)
+    assert isinstance(part, ga.grid.RegularGrid) and part.point_count == int(box.sum())
+    assert part.parallels.size * part.meridians.size == part.point_count
+    rng = np.random.default_rng(0)
+    ragged = grid.subset(rng.uniform(size=grid.point_count) < 0.3)
+    assert type(ragged) is ga.grid.IrregularGrid and ragged.semimajor_axis == grid.semimajor_axis
+    slon, slat = inputs.scattered_points(3, 500)
+    index = grid.nn_index(slon, slat)
+    assert len(index) == grid.point_count
+    np.testing.assert_array_equal(np.sort(np.concatenate(index)), np.arange(500))          # every sample exactly once
+    xyz = grid.cartesian_coordinates()
+    sample = ga.grid.IrregularGrid(slon, slat).cartesian_coordinates()
+    k = int(np.argmax([len(i) for i in index]))
+    for j in index[k]:
+        assert np.argmin(np.sum((xyz - sample[j]) ** 2, axis=1)) == k
