@@ -63,6 +63,15 @@ __device__ inline void pair_exchange(double x, double y, unsigned long long odd,
 }
 
 
+// value of the lane 8 positions away inside the row of 16 lanes (DPP row_ror:8)
+__device__ inline double swap_half_row(double x) {
+    const long long bits = __builtin_bit_cast(long long, x);
+    const int lo = (int)bits, hi = (int)(bits >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned int)lo2);
+}
+
 constexpr int kEpochTile = 8;    // epochs handled together by one wave of the Legendre stage
 constexpr int kLatTile = 64;     // parallels per wave of the Legendre stage (lane <-> parallel)
 
@@ -74,6 +83,8 @@ struct shg_plan {
     int N = 0, nlat = 0, nlon = 0;
     int ldlat = 0;          // nlat rounded up to 64: leading dimension of per-parallel tables / F
     bool sym4 = false;      // 4-fold longitude symmetry path
+    bool sym16 = false;     // 16-fold longitude symmetry (equi-angular cell-centred meridians, nlon % 16 == 0): synthesis_fold16.hip
+    double* trig16 = nullptr;   // [column tiles][k-steps][64 lanes][2] cos / signed sin stream of the 16-fold kernel
     bool sym_ns = false;    // parallels (colatitude and kn rows) symmetric about the equator
     int ngroups = 1;        // 4 (sym4) or 1
     int goff[5] = {0, 0, 0, 0, 0};   // first K slot of each group (multiples of 4), goff[ngroups] = K
@@ -119,6 +130,7 @@ struct shg_plan {
     int* octinfo_d = nullptr;   // [Qtot] order | octet-in-order << 8 of every octet of the fragment-ordered tables
     int* itemtab_d = nullptr;   // work items of the fused kernel's Legendre stage, [8 waves][nrec][4]
     int itemtab_nrec = 0, itemtab_ntrip = 0;
+    int itemtab_fold16 = -1;    // panel slot convention of the work items: 0 = 4-fold kernel, 1 = 16-fold kernel
     int* blockmap_d = nullptr;  // XCD-aware (epoch tile, parallel tile) order of the fused kernel's workgroups
     int blockmap_nbt = 0, blockmap_nit = 0;
     std::vector<char> ns_badrow;    // per northern parallel: mirror image deviates too much to share the northern table
@@ -132,13 +144,11 @@ struct shg_plan {
     size_t cpk4_size = 0;
     int cpk4_variant = 0;       // layout the workspace was last zero-initialised for
     size_t cpk4_zeroed = 0;
-    double* panel = nullptr;    // two-kernel synthesis: [B/4][nit][K][64] Legendre-stage output in LDS-image order
-    size_t panel_size = 0;
     // analysis operator cache (analysis.hip): H[S][N+1][nlat] for the weights with checksum ana_key and min degree ana_nmin
     double* ana_H = nullptr;
     double ana_key[2] = {0.0, 0.0};
     int ana_nmin = -1;
-    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused kernel, 3 Legendre kernel + longitude kernel, 4 fused kernel without the north-south symmetry, 5 fused kernel with 32-row panels (two workgroups per CU)
+    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 4 the same without the north-south symmetry, 5 fused kernel with 32-row panels (two workgroups per CU), 6 fused 16-fold kernel, 7 the same without the north-south symmetry
 
     // optional per-kernel event timing (shg_plan_profile)
     bool profiling = false;
@@ -151,8 +161,15 @@ namespace shg {
 int plan_alloc_workspace(shg_plan* p);
 int fused_chunk_for(const shg_plan* p);
 int build_pk_table(shg_plan* p, hipStream_t stream);
-int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream);
+int build_pkf_table(shg_plan* p, bool ns, bool fold16, hipStream_t stream);
+int build_blockmap(shg_plan* p, int nbt, int nit, hipStream_t stream);
+int pack_coefficients_fused(shg_plan* p, bool ns, bool sigma, const double* anm, int B, hipStream_t stream);
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
+bool has_sixteenfold_symmetry(int nlon, const double* lon);
+int fold16_layout(int N, int nk[5], int slot[5], int cnt[5], std::vector<int>* order_slot);
+int fold16_applicable(const shg_plan* p);
+int build_trig16(shg_plan* p, const double* lon_h);
+int synthesis_fold16(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 int fused32_applicable(const shg_plan* p);
 int synthesis_fused32(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 

@@ -647,6 +647,7 @@ static int covprop_diag_impl(shg_plan* p, const double* cov, int nmin, int lat0,
             SHG_HIP(hipStreamSynchronize(stream));
             (void)hipFree(p->cov_partial);
             p->cov_partial = nullptr;
+            p->cov_partial_size = 0;                 // a failed grow must not leave the old size behind
         }
         if (hipMalloc((void**)&p->cov_partial, need * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "covariance propagation workspace (%zu doubles)", need);
         p->cov_partial_size = need;

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(64) void pkf_table_kernel(int N, int ldlat, int nit
 
 // coefficients of 4 epochs in MFMA-fragment order:  cpk4[bt][octet][fk * 8 + c/s * 4 + epoch][s]  (A operand rows 0-3 =
 // C_nm of the 4 epochs, rows 4-7 = S_nm; rows 8-15 are zero and not stored)
-__global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, int Qtot, const int* __restrict__ qoff,
+// sigma != 0 (16-fold kernel, synthesis_fold16.hip): S_nm of the orders with m mod 8 in {5, 6, 7} are stored negated
+__global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, int Qtot, int sigma, const int* __restrict__ qoff,
                                                                   const double* __restrict__ anm, double* __restrict__ cpk4) {
     const int E = (N + 1) * (N + 1);
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -99,8 +100,9 @@ __global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, i
         cs = 1;
     }
     double* dst = cpk4 + (((size_t)bt * Qtot + qoff[m] + (nl >> 3)) * 32 + (nl & 3) * 8 + cs * 4) * 2 + ((nl >> 2) & 1);
+    const double sg = (sigma && cs && (m & 7) > 4) ? -1.0 : 1.0;
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) dst[bb * 2] = (bt * 4 + bb < B) ? anm[(size_t)(bt * 4 + bb) * E + e] : 0.0;
+    for (int bb = 0; bb < 4; ++bb) dst[bb * 2] = (bt * 4 + bb < B) ? sg * anm[(size_t)(bt * 4 + bb) * E + e] : 0.0;
 }
 
 // North-south symmetric grids (colat[nlat-1-i] = pi - colat[i], equal kn rows): P_nm(pi - theta) = (-1)^(n-m) P_nm(theta), so
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(64) void pkf_ns_table_kernel(int N, int nlat, int l
     }
 }
 
+// scatter form of the NS repack (32-row kernel, synthesis_fused32.hip)
 __global__ __launch_bounds__(256) void pack_coefficients4_ns_kernel(int N, int B, int Qtot, const int* __restrict__ qoff,
                                                                      const double* __restrict__ anm, double* __restrict__ cpk4) {
     const int E = (N + 1) * (N + 1);
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void pack_coefficients4_ns_kernel(int N, int B
 // Gather form of the NS repack: one thread per 16-byte element of the fragment-ordered table (fully coalesced writes, every
 // element written, padding included: no zero-fill of the workspace); the two degrees of an element are read from the epoch's
 // coefficient triangle, which stays in L2.  octinfo[octet] = order | (octet index inside the order) << 8.
-__global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N, int B, int Qtot, const int* __restrict__ octinfo,
+__global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N, int B, int Qtot, int sigma, const int* __restrict__ octinfo,
                                                                             const double* __restrict__ anm, double* __restrict__ cpk4) {
     const int t = blockIdx.x * 256 + threadIdx.x;                  // (octet, lane)
     if (t >= Qtot * 64) return;
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N
         const bool ok = n <= N && b < B && !(cs == 1 && m == 0);
         const size_t e = cs == 0 ? (size_t)n * (N + 1) + m : (size_t)(m - 1) * (N + 1) + n;
         v[s_] = ok ? anm[(size_t)b * E + e] : 0.0;
+        if (sigma && cs && (m & 7) > 4) v[s_] = -v[s_];
     }
     *reinterpret_cast<double2*>(cpk4 + ((size_t)bt * Qtot * 64 + t) * 2) = make_double2(v[0], v[1]);
 }
@@ -211,18 +215,8 @@ struct FusedParams {
     const int* blockmap;      // [blocks][2] (epoch tile, parallel tile) of every workgroup, or NULL for the plain order
     const int* badmap;        // NS variant: [nit] -1, or rank of the block among those whose mirrored parallels need their own table
     const double* trig;       // [ncb * 8][K][16]
-    const double* panel;      // two-kernel variant: [B/4][nit][K][64] panels written by legendre_mfma_kernel
     double* G;
 };
-
-// value of the lane 8 positions away inside the row of 16 lanes (DPP row_ror:8)
-__device__ inline double swap_half_row(double x) {
-    const long long bits = __builtin_bit_cast(long long, x);
-    const int lo = (int)bits, hi = (int)(bits >> 32);
-    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true);
-    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned int)lo2);
-}
 
 // One work item of phase 1: two row octets (4 k-steps, 16 degrees) of order m starting at octet j0 of that order.
 struct LegendreItem {
@@ -249,7 +243,7 @@ struct LegendreItem {
 #define SHG_STAMP(ev)
 #endif
 
-template <bool FROM_PANEL, bool NS>
+template <bool NS>
 __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     extern __shared__ double As[];                     // panel [K][kPanelStride]
 
@@ -268,27 +262,10 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     SHG_STAMP(0);
 
     // ---- zero the padding slots of the panel
-    for (int g = 0; g < 4 && !FROM_PANEL; ++g)
+    for (int g = 0; g < 4; ++g)
         for (int s = P.goff[g] + P.gcount[g]; s < P.goff[g + 1]; ++s)
             if (tid < 64) As[s * kPanelStride + tid] = 0.0;
 
-    // ---- two-kernel variant: the panel was computed by legendre_mfma_kernel; copy the contiguous K x 64 image into LDS
-    if (FROM_PANEL) {
-        const double* src = P.panel + ((size_t)bt * P.nit + it) * P.K * 64;
-        for (int p0 = 0; p0 < P.K * 32; p0 += 512 * 4) {          // 4 pieces of 16 B per thread in flight
-            double2 v[4];
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const int p = min(p0 + h * 512 + tid, P.K * 32 - 1);
-                v[h] = *reinterpret_cast<const double2*>(src + 2 * p);
-            }
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const int p = p0 + h * 512 + tid;
-                if (p < P.K * 32) *reinterpret_cast<double2*>(&As[(p >> 5) * kPanelStride + (p & 31) * 2]) = v[h];
-            }
-        }
-    }
     // cos/sin fragments (B operand of the longitude stage) of the first body: fetched ahead of the Legendre stage, so that the
     // longitude stage starts without an exposed L2 round trip
     const double* tbase = P.trig + ((size_t)wave * P.K + fk) * 16 + fr;      // + cb * cb_stride + body * 256 + u * 64
@@ -296,7 +273,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
 
     // ---- phase 1: Legendre stage.  Orders are distributed over the 8 waves; items of 4 k-steps are double
     //      buffered in two named register sets so that the fragments of item t+1 are in flight while item t runs.
-    if (!FROM_PANEL && !(P.dbg & 2)) {
+    if (!(P.dbg & 2)) {
         // plain layout: octet = 8 degrees, A rows 8-15 are zero (not stored);  NS layout: octet = 16 degrees, all 16 rows used
         constexpr int ASTRIDE = NS ? 128 : 64;                        // doubles per octet of the coefficient table
         const int bad = NS ? P.badmap[it] : -1;                       // block-uniform
@@ -544,70 +521,6 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     SHG_STAMP(12);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Two-kernel variant, stage 1: Legendre stage as its own high-occupancy kernel (no LDS, ~40 VGPRs, 8 waves per SIMD hide the
-// L2 latency that the fused kernel exposes).  One wave = (8 epochs, 16 parallels, one order m):
-//   D[(c/s, epoch)][parallel] = sum_n coef[(c/s, epoch)][n] * PK_m[n][parallel]       all 16 MFMA rows are used
-// and the result is written in the exact LDS image of the longitude kernel, [B/4][nit][K][64] (512 contiguous bytes per store).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_coefficients8_kernel(int N, int B, const double* __restrict__ anm, double* __restrict__ cpk8) {
-    const int E = (N + 1) * (N + 1);
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E) return;
-    const int bt = blockIdx.y;
-    const int r = e / (N + 1), c = e % (N + 1);
-    int idx, cs;
-    if (c <= r) {
-        idx = order_offset(N, c) + r - c;
-        cs = 0;
-    } else {
-        idx = order_offset(N, r + 1) + c - (r + 1);
-        cs = 1;
-    }
-    double* dst = cpk8 + (((size_t)bt * packed_count(N) + idx) * 2 + cs) * 8;
-#pragma unroll
-    for (int bb = 0; bb < 8; bb += 2) {
-        const double v0 = (bt * 8 + bb < B) ? anm[(size_t)(bt * 8 + bb) * E + e] : 0.0;
-        const double v1 = (bt * 8 + bb + 1 < B) ? anm[(size_t)(bt * 8 + bb + 1) * E + e] : 0.0;
-        *reinterpret_cast<double2*>(dst + bb) = make_double2(v0, v1);
-    }
-}
-
-__global__ __launch_bounds__(256) void legendre_mfma_kernel(int N, int ldlat, int K, int nit, int Ppk, int g0, int g1, int g2, int g3,
-                                                            const double* __restrict__ cpk8, const double* __restrict__ pk,
-                                                            double* __restrict__ panel) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m = blockIdx.y * 4 + wave;
-    if (m > N) return;
-    const int it = blockIdx.x % nit, bt8 = blockIdx.x / nit;
-    const int fr = lane & 15, fk = lane >> 4;
-    const int off = order_offset(N, m);
-    const int cnt = N + 1 - m;
-    const double* a_base = cpk8 + ((size_t)bt8 * Ppk + off) * 16 + fr;      // + n_local * 16
-    const double* b_base = pk + (size_t)off * ldlat + it * 16 + fr;         // + n_local * ldlat
-    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < cnt; k0 += 8) {
-        const int n0 = k0 + fk, n1 = k0 + 4 + fk;
-        const int c0 = min(n0, cnt - 1), c1 = min(n1, cnt - 1);
-        const double a0 = a_base[(size_t)c0 * 16], a1 = a_base[(size_t)c1 * 16];
-        const double b0 = b_base[(size_t)c0 * ldlat], b1 = b_base[(size_t)c1 * ldlat];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(n0 < cnt ? a0 : 0.0, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(n1 < cnt ? a1 : 0.0, b1, acc1, 0, 0, 0);
-    }
-    // C/D layout: row = (lane >> 4) + 4 reg = c/s * 8 + epoch, col = lane & 15 = parallel.
-    //   reg 0: cosine, epochs 0-3; reg 1: cosine, epochs 4-7; reg 2: sine, epochs 0-3; reg 3: sine, epochs 4-7
-    // panel row = (epoch & 3) * 16 + parallel = lane, epoch tile of 4 = bt8 * 2 + (reg & 1)
-    const int sc = (m & 1 ? g0 : 0) + (m >> 1);                                       // group offsets are multiples of 16
-    const int ss = g0 + g1 + (m & 1 ? g2 : 0) + ((m & 1) ? (m >> 1) : (m >> 1) - 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (r >= 2 && m == 0) break;
-        const int slot = r >= 2 ? ss : sc;
-        panel[(((size_t)(bt8 * 2 + (r & 1)) * nit + it) * K + slot) * 64 + lane] = acc0[r] + acc1[r];
-    }
-}
-
 static size_t fused_lds_bytes(int K) { return (size_t)K * kPanelStride * sizeof(double); }
 
 // non-zero when the fused kernel applies: 4-fold symmetric meridians and a panel that fits the 160 KiB LDS
@@ -629,11 +542,12 @@ int build_pk_table(shg_plan* p, hipStream_t stream) {
 }
 
 // fragment-ordered table of the fused kernel (and the octet offsets both fragment-ordered tables share)
-static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, hipStream_t stream);
+static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, bool fold16, hipStream_t stream);
 
-int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream) {
+// fold16: the work items carry the panel slots of the 16-fold kernel (synthesis_fold16.hip) instead of those of the 4-fold one
+int build_pkf_table(shg_plan* p, bool ns, bool fold16, hipStream_t stream) {
     const int variant = ns ? 2 : 1;
-    if (p->pkf && p->pkf_variant == variant) return SHG_OK;
+    if (p->pkf && p->pkf_variant == variant && p->itemtab_fold16 == (fold16 ? 1 : 0)) return SHG_OK;
     if (p->pkf) {                                       // the other layout was built before (explicit path switch)
         SHG_HIP(hipDeviceSynchronize());
         (void)hipFree(p->pkf);
@@ -667,7 +581,7 @@ int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream) {
         hipLaunchKernelGGL(pkf_table_kernel, dim3(p->ldlat / 64, N + 1), dim3(64), 0, stream, N, p->ldlat, nit, q, p->qoff, p->ct, p->pmm,
                            p->knT, p->arec, p->brec, p->pkf);
     SHG_HIP(hipGetLastError());
-    const int rc_items = build_item_table(p, od, qoff, stream);
+    const int rc_items = build_item_table(p, od, qoff, fold16, stream);
     if (rc_items) return rc_items;
     p->pkf_variant = variant;
     return SHG_OK;
@@ -679,8 +593,13 @@ int build_pkf_table(shg_plan* p, bool ns, hipStream_t stream) {
 //   z    = panel slot of the cosine part | (panel slot of the sine part + 1) << 16   (0 in the upper half: order 0)
 //   w    = bit 0 item valid, bit 1 second octet valid, bit 2 last item of its order
 // padded per wave to 4 * ntrip + 8 records (the kernel runs ntrip trips of four items and prefetches one trip ahead).
-static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, hipStream_t stream) {
+static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, bool fold16, hipStream_t stream) {
     const int N = p->N;
+    std::vector<int> slot16;
+    if (fold16) {
+        int nk[5], sl[5], cn[5];
+        fold16_layout(N, nk, sl, cn, &slot16);
+    }
     std::vector<std::vector<int>> rec(8);
     size_t longest = 0;
     for (int m = 0; m <= N; ++m) {                       // orders by decreasing length, each to the wave with the fewest items so far
@@ -694,10 +613,11 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, h
             const int even_shift = p->fold0 ? 1 : 0;
             const int slot_c = m == 0 && p->fold0 ? p->K_f : go[m & 1] + (m >> 1) - ((m & 1) ? 0 : even_shift);
             const int slot_s = m >= 1 ? go[2 + (m & 1)] + ((m & 1) ? (m >> 1) : (m >> 1) - 1) + 1 : 0;
+            const int zrec = fold16 ? slot16[m] : (slot_c | (slot_s << 16));
             for (int j0 = 0; j0 < q; j0 += 2) {
                 const int o0 = qoff[m] + j0, o1 = o0 + (j0 + 1 < q ? 1 : 0);
                 const int flags = 1 | ((j0 + 1) * od < cnt ? 2 : 0) | (j0 + 2 >= q ? 4 : 0);
-                rec[w].insert(rec[w].end(), {o0, o1, slot_c | (slot_s << 16), flags});
+                rec[w].insert(rec[w].end(), {o0, o1, zrec, flags});
             }
         }
     }
@@ -732,12 +652,13 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, h
     SHG_HIP(hipMemcpyAsync(p->itemtab_d, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     SHG_HIP(hipStreamSynchronize(stream));                             // the host vector goes out of scope
     p->itemtab_nrec = nrec;
+    p->itemtab_fold16 = fold16 ? 1 : 0;
     p->itemtab_ntrip = ntrip;
     return SHG_OK;
 }
 
 // (epoch tile, parallel tile) of every workgroup in XCD-aware order, cached in the plan per (epoch tiles, parallel tiles)
-static int build_blockmap(shg_plan* p, int nbt, int nit, hipStream_t stream) {
+int build_blockmap(shg_plan* p, int nbt, int nit, hipStream_t stream) {
     if (p->blockmap_d && p->blockmap_nbt == nbt && p->blockmap_nit == nit) return SHG_OK;
     constexpr int XCDS = 8;
     const int total = nbt * nit;
@@ -775,31 +696,24 @@ static int build_blockmap(shg_plan* p, int nbt, int nit, hipStream_t stream) {
     return SHG_OK;
 }
 
-// variant 2: single fused kernel; variant 3: Legendre stage as its own kernel + longitude kernel reading the panels
-int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
-    if (fused_chunk_for(p) == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
-    const bool two_kernel = p->path == 3;
-    const bool ns = !two_kernel && p->sym_ns && p->path != 4;      // north-south symmetric variant (path 4 forces the plain one)
-    int rc = two_kernel ? build_pk_table(p, stream) : build_pkf_table(p, ns, stream);
-    if (rc) return rc;
+// Repack of the coefficient batch into MFMA-fragment order (workspace p->cpk4: [nbt][Qtot][32][2], NS: [nbt][Qtot][64][2]);
+// sigma: sign convention of the 16-fold kernel.
+int pack_coefficients_fused(shg_plan* p, bool ns, bool sigma, const double* anm, int B, hipStream_t stream) {
     const int nbt = ceil_div(B, 4);
-    const int nbt8 = ceil_div(B, 8);
-    const int Ppk = packed_count(p->N);
-    const int nit = ns ? ceil_div(p->nlat / 2, 8) : ceil_div(p->nlat, 16);
-    const int variant = two_kernel ? 3 : (ns ? 4 : 2);
-    // coefficient workspace: [nbt][Qtot][32][2] (fused), [nbt][Qtot][64][2] (fused, NS) or [nbt8][Ppk][2][8] (two-kernel)
-    const size_t need = two_kernel ? (size_t)nbt8 * Ppk * 16 : (size_t)nbt * p->Qtot * (ns ? 128 : 64);
+    const int variant = ns ? 4 : 2;
+    const size_t need = (size_t)nbt * p->Qtot * (ns ? 128 : 64);
     if (need > p->cpk4_size) {
         if (p->cpk4) {
             SHG_HIP(hipStreamSynchronize(stream));
             (void)hipFree(p->cpk4);
             p->cpk4 = nullptr;
+            p->cpk4_size = 0;
+            p->cpk4_zeroed = 0;
         }
         if (hipMalloc((void**)&p->cpk4, need * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "coefficient workspace allocation failed");
         p->cpk4_size = need;
-        p->cpk4_zeroed = 0;
     }
-    // sine slots of order 0 and the padding rows of the octets are never written by the pack kernels and must read as
+    // sine slots of order 0 and the padding rows of the octets are never written by the scatter kernel and must read as
     // zero (layouts differ per variant)
     if (need > 0 && (p->cpk4_variant != variant || p->cpk4_zeroed < need)) {
         SHG_HIP(hipMemsetAsync(p->cpk4, 0, p->cpk4_size * sizeof(double), stream));
@@ -807,12 +721,32 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
         p->cpk4_zeroed = p->cpk4_size;
     }
     const int E = (p->N + 1) * (p->N + 1);
+    ProfileScope ps(p, 0, stream);
+    if (ns)
+        hipLaunchKernelGGL(pack_coefficients4_ns_gather_kernel, dim3(ceil_div(p->Qtot * 64, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot,
+                           sigma ? 1 : 0, p->octinfo_d, anm, p->cpk4);
+    else
+        hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, sigma ? 1 : 0, p->qoff, anm,
+                           p->cpk4);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
+    if (fused_chunk_for(p) == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
+    const bool ns = p->sym_ns && p->path != 4;      // north-south symmetric variant (path 4 forces the plain one)
+    int rc = build_pkf_table(p, ns, false, stream);
+    if (rc) return rc;
+    const int nbt = ceil_div(B, 4);
+    const int nit = ns ? ceil_div(p->nlat / 2, 8) : ceil_div(p->nlat, 16);
+    rc = pack_coefficients_fused(p, ns, false, anm, B, stream);
+    if (rc) return rc;
     FusedParams P;
     P.N = p->N;
     P.nlat = p->nlat;
     P.nlon = p->nlon;
     P.ldlat = p->ldlat;
-    const bool fold = p->fold0 && !two_kernel;        // the panel kernel of the two-kernel variant writes the unfolded layout
+    const bool fold = p->fold0;
     P.K = fold ? p->K_f : p->K;
     P.slot0 = fold ? p->K_f : -1;
     P.ncol = p->ncol;
@@ -820,7 +754,7 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.nit = nit;
     P.ns = ns ? 1 : 0;
     P.nh = p->nlat / 2;
-    P.Ppk = Ppk;
+    P.Ppk = packed_count(p->N);
     P.ncb = ceil_div(p->ncoltiles, 8);
     for (int g = 0; g < 5; ++g) P.goff[g] = fold ? p->goff_f[g] : p->goff[g];
     const int N = p->N;
@@ -843,55 +777,19 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
         P.blockmap = p->blockmap_d;
     }
     P.trig = fold ? p->trig_f : p->trig;
-    P.panel = nullptr;
     P.G = grid;
 #ifdef SHG_TIMELINE
     P.tl = getenv("SHG_TIMELINE_PTR") ? (unsigned long long*)strtoull(getenv("SHG_TIMELINE_PTR"), nullptr, 0) : nullptr;
 #endif
     const size_t lds = fused_lds_bytes(fold ? p->K_f + 1 : p->K);
     const dim3 grid_dim((unsigned)(nbt * P.nit));
-    if (two_kernel) {
-        const size_t pneed = (size_t)2 * nbt8 * nit * p->K * 64;
-        if (pneed > p->panel_size) {
-            if (p->panel) {
-                SHG_HIP(hipStreamSynchronize(stream));
-                (void)hipFree(p->panel);
-                p->panel = nullptr;
-            }
-            if (hipMalloc((void**)&p->panel, pneed * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "panel workspace allocation failed (%zu doubles)", pneed);
-            p->panel_size = pneed;
-            SHG_HIP(hipMemsetAsync(p->panel, 0, pneed * sizeof(double), stream));      // padding slots stay zero
-        }
-        {
-            ProfileScope ps(p, 0, stream);
-            hipLaunchKernelGGL(pack_coefficients8_kernel, dim3(ceil_div(E, 256), nbt8), dim3(256), 0, stream, p->N, B, anm, p->cpk4);
-        }
-        {
-            ProfileScope ps(p, 1, stream);
-            hipLaunchKernelGGL(legendre_mfma_kernel, dim3((unsigned)(nbt8 * nit), ceil_div(N + 1, 4)), dim3(256), 0, stream, N, p->ldlat, p->K, nit,
-                               Ppk, p->goff[1], p->goff[2] - p->goff[1], p->goff[3] - p->goff[2], p->goff[4] - p->goff[3], p->cpk4, p->pk, p->panel);
-        }
-        P.panel = p->panel;
-        ProfileScope ps(p, 2, stream);
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((synthesis_fused_kernel<true, false>), grid_dim, dim3(512), lds, stream, P);
+    ProfileScope ps(p, 2, stream);
+    if (ns) {
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((synthesis_fused_kernel<true>), grid_dim, dim3(512), lds, stream, P);
     } else {
-        {
-            ProfileScope ps(p, 0, stream);
-            if (ns)
-                hipLaunchKernelGGL(pack_coefficients4_ns_gather_kernel, dim3(ceil_div(p->Qtot * 64, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot,
-                                   p->octinfo_d, anm, p->cpk4);
-            else
-                hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, p->qoff, anm, p->cpk4);
-        }
-        ProfileScope ps(p, 2, stream);
-        if (ns) {
-            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((synthesis_fused_kernel<false, true>), grid_dim, dim3(512), lds, stream, P);
-        } else {
-            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((synthesis_fused_kernel<false, false>), grid_dim, dim3(512), lds, stream, P);
-        }
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((synthesis_fused_kernel<false>), grid_dim, dim3(512), lds, stream, P);
     }
     SHG_HIP(hipGetLastError());
     return SHG_OK;

@@ -378,10 +378,11 @@ int synthesis_fused32(shg_plan* p, const double* anm, int B, double* grid, hipSt
             SHG_HIP(hipStreamSynchronize(stream));
             (void)hipFree(p->cpk4);
             p->cpk4 = nullptr;
+            p->cpk4_size = 0;                        // a failed grow must not leave the old size behind
+            p->cpk4_zeroed = 0;
         }
         if (hipMalloc((void**)&p->cpk4, need * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "coefficient workspace allocation failed");
         p->cpk4_size = need;
-        p->cpk4_zeroed = 0;
     }
     if (need > 0 && (p->cpk4_variant != 4 || p->cpk4_zeroed < need)) {      // same coefficient layout as the NS variant of synthesis_fused.hip
         SHG_HIP(hipMemsetAsync(p->cpk4, 0, p->cpk4_size * sizeof(double), stream));
