@@ -83,8 +83,8 @@ struct shg_plan {
     int N = 0, nlat = 0, nlon = 0;
     int ldlat = 0;          // nlat rounded up to 64: leading dimension of per-parallel tables / F
     bool sym4 = false;      // 4-fold longitude symmetry path
-    bool sym16 = false;     // 16-fold longitude symmetry (equi-angular cell-centred meridians, nlon % 16 == 0): synthesis_fold16.hip
-    double* trig16 = nullptr;   // [column tiles][k-steps][64 lanes][2] cos / signed sin stream of the 16-fold kernel
+    int rotR = 0;           // rotations of the meridian set used by the rotation-folded kernel (synthesis_rot.hip): 6, 3 or 0 = not applicable
+    double* rot_trig = nullptr; // [column tiles][k-steps][64 lanes][2] cos / signed sin stream of that kernel
     bool sym_ns = false;    // parallels (colatitude and kn rows) symmetric about the equator
     int ngroups = 1;        // 4 (sym4) or 1
     int goff[5] = {0, 0, 0, 0, 0};   // first K slot of each group (multiples of 4), goff[ngroups] = K
@@ -130,7 +130,7 @@ struct shg_plan {
     int* octinfo_d = nullptr;   // [Qtot] order | octet-in-order << 8 of every octet of the fragment-ordered tables
     int* itemtab_d = nullptr;   // work items of the fused kernel's Legendre stage, [8 waves][nrec][4]
     int itemtab_nrec = 0, itemtab_ntrip = 0;
-    int itemtab_fold16 = -1;    // panel slot convention of the work items: 0 = 4-fold kernel, 1 = 16-fold kernel
+    int itemtab_rot = -1;       // panel slot convention of the work items: 0 = 4-fold kernel, R = rotation-folded kernel
     int* blockmap_d = nullptr;  // XCD-aware (epoch tile, parallel tile) order of the fused kernel's workgroups
     int blockmap_nbt = 0, blockmap_nit = 0;
     std::vector<char> ns_badrow;    // per northern parallel: mirror image deviates too much to share the northern table
@@ -148,7 +148,7 @@ struct shg_plan {
     double* ana_H = nullptr;
     double ana_key[2] = {0.0, 0.0};
     int ana_nmin = -1;
-    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 4 the same without the north-south symmetry, 5 fused kernel with 32-row panels (two workgroups per CU), 6 fused 16-fold kernel, 7 the same without the north-south symmetry
+    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 4 the same without the north-south symmetry, 5 fused kernel with 32-row panels (two workgroups per CU), 6 rotation-folded fused kernel, 7 the same without the north-south symmetry
 
     // optional per-kernel event timing (shg_plan_profile)
     bool profiling = false;
@@ -161,15 +161,15 @@ namespace shg {
 int plan_alloc_workspace(shg_plan* p);
 int fused_chunk_for(const shg_plan* p);
 int build_pk_table(shg_plan* p, hipStream_t stream);
-int build_pkf_table(shg_plan* p, bool ns, bool fold16, hipStream_t stream);
+int build_pkf_table(shg_plan* p, bool ns, int rotR, hipStream_t stream);
 int build_blockmap(shg_plan* p, int nbt, int nit, hipStream_t stream);
-int pack_coefficients_fused(shg_plan* p, bool ns, bool sigma, const double* anm, int B, hipStream_t stream);
+int pack_coefficients_fused(shg_plan* p, bool ns, int rotR, const double* anm, int B, hipStream_t stream);
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
-bool has_sixteenfold_symmetry(int nlon, const double* lon);
-int fold16_layout(int N, int nk[5], int slot[5], int cnt[5], std::vector<int>* order_slot);
-int fold16_applicable(const shg_plan* p);
-int build_trig16(shg_plan* p, const double* lon_h);
-int synthesis_fold16(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
+bool has_rotation_symmetry(int nlon, const double* lon, int R);
+int rot_layout(int R, int N, int nk[4], int cnt[4], std::vector<int>* order_slot);
+int rot_applicable(const shg_plan* p);
+int build_rot_trig(shg_plan* p, const double* lon_h);
+int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 int fused32_applicable(const shg_plan* p);
 int synthesis_fused32(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 

@@ -200,7 +200,8 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
     p->ldlat = round_up(nlat, kLatTile);
     p->sym4 = has_fourfold_symmetry(nlon, lon_h);
     p->sym_ns = has_north_south_symmetry(N, nlat, colat_h, kn_h, p->ns_badmap, p->ns_nbad, p->ns_badrow);
-    p->sym16 = p->sym4 && has_sixteenfold_symmetry(nlon, lon_h);
+    // rotation-folded kernel: R = 6 where nlon / 6 is a multiple of 16 (0.25 degree grid), else R = 3 (0.5 degree grid)
+    p->rotR = has_rotation_symmetry(nlon, lon_h, 6) ? 6 : has_rotation_symmetry(nlon, lon_h, 3) ? 3 : 0;
 
     // ---- K slots of the longitude stage
     if (p->sym4) {
@@ -295,7 +296,7 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
         shg_plan_destroy(p);
         return rc;
     }
-    if (p->sym16 && fold16_applicable(p) && (rc = build_trig16(p, lon_h))) {
+    if (rot_applicable(p) && (rc = build_rot_trig(p, lon_h))) {
         shg_plan_destroy(p);
         return rc;
     }
@@ -306,7 +307,7 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
 extern "C" int shg_plan_destroy(shg_plan* p) {
     if (!p) return SHG_OK;
     double* ptrs[] = {p->ct, p->st, p->pmm, p->knT, p->arec, p->brec, p->trig, p->trig_f, p->lon, p->colat,
-                      p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->pkf, p->pkf32, p->cpk4, p->cov_partial, p->ana_H, p->trig16};
+                      p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->pkf, p->pkf32, p->cpk4, p->cov_partial, p->ana_H, p->rot_trig};
     if (p->rslot) (void)hipFree(p->rslot);
     if (p->qoff) (void)hipFree(p->qoff);
     if (p->badmap_d) (void)hipFree(p->badmap_d);
@@ -334,7 +335,7 @@ extern "C" int shg_plan_set_path(shg_plan* p, int path) {
     SHG_REQUIRE(path >= 0 && path <= 7 && path != 3, "shg_plan_set_path: path %d not in {0, 1, 2, 4, 5, 6, 7}", path);
     SHG_REQUIRE(path != 5 || fused32_applicable(p), "shg_plan_set_path: the two-workgroup fused kernel needs both grid symmetries and K <= 416 (K = %d)", p->K);
     SHG_REQUIRE((path != 2 && path != 4) || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
-    SHG_REQUIRE(path < 6 || fold16_applicable(p), "shg_plan_set_path: 16-fold kernel not applicable (needs equi-angular meridians with nlon %% 16 == 0, nlon >= 256, and a panel within the LDS)");
+    SHG_REQUIRE(path < 6 || rot_applicable(p), "shg_plan_set_path: rotation-folded kernel not applicable (needs equi-angular meridians with nlon %% 96 == 0 or nlon %% 48 == 0, nlon >= 192, and a panel within the LDS)");
     p->path = path;
     return SHG_OK;
 }
@@ -344,10 +345,10 @@ extern "C" int shg_plan_info(const shg_plan* p, int64_t which[8]) {
     which[0] = p->N;
     which[1] = p->nlat;
     which[2] = p->nlon;
-    which[3] = (p->sym4 ? 1 : 0) | (p->sym_ns ? 2 : 0) | (p->sym16 ? 4 : 0);
+    which[3] = (p->sym4 ? 1 : 0) | (p->sym_ns ? 2 : 0) | (p->rotR ? 4 : 0);
     which[4] = p->chunk;
     which[5] = p->K;
-    which[6] = (p->path >= 2 || (p->path == 0 && (fold16_applicable(p) || fused_chunk_for(p) != 0 || fused32_applicable(p)))) ? 1 : 0;
+    which[6] = (p->path >= 2 || (p->path == 0 && (rot_applicable(p) || fused_chunk_for(p) != 0 || fused32_applicable(p)))) ? 1 : 0;
     which[7] = p->path;
     return SHG_OK;
 }

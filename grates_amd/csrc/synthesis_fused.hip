@@ -81,8 +81,8 @@ __global__ __launch_bounds__(64) void pkf_table_kernel(int N, int ldlat, int nit
 
 // coefficients of 4 epochs in MFMA-fragment order:  cpk4[bt][octet][fk * 8 + c/s * 4 + epoch][s]  (A operand rows 0-3 =
 // C_nm of the 4 epochs, rows 4-7 = S_nm; rows 8-15 are zero and not stored)
-// sigma != 0 (16-fold kernel, synthesis_fold16.hip): S_nm of the orders with m mod 8 in {5, 6, 7} are stored negated
-__global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, int Qtot, int sigma, const int* __restrict__ qoff,
+// rotR != 0 (rotation-folded kernel, synthesis_rot.hip): S_nm of the orders with 2 (m mod R) > R are stored negated
+__global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, int Qtot, int rotR, const int* __restrict__ qoff,
                                                                   const double* __restrict__ anm, double* __restrict__ cpk4) {
     const int E = (N + 1) * (N + 1);
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void pack_coefficients4_kernel(int N, int B, i
         cs = 1;
     }
     double* dst = cpk4 + (((size_t)bt * Qtot + qoff[m] + (nl >> 3)) * 32 + (nl & 3) * 8 + cs * 4) * 2 + ((nl >> 2) & 1);
-    const double sg = (sigma && cs && (m & 7) > 4) ? -1.0 : 1.0;
+    const double sg = (rotR && cs && 2 * (m % rotR) > rotR) ? -1.0 : 1.0;
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) dst[bb * 2] = (bt * 4 + bb < B) ? sg * anm[(size_t)(bt * 4 + bb) * E + e] : 0.0;
 }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void pack_coefficients4_ns_kernel(int N, int B
 // Gather form of the NS repack: one thread per 16-byte element of the fragment-ordered table (fully coalesced writes, every
 // element written, padding included: no zero-fill of the workspace); the two degrees of an element are read from the epoch's
 // coefficient triangle, which stays in L2.  octinfo[octet] = order | (octet index inside the order) << 8.
-__global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N, int B, int Qtot, int sigma, const int* __restrict__ octinfo,
+__global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N, int B, int Qtot, int rotR, const int* __restrict__ octinfo,
                                                                             const double* __restrict__ anm, double* __restrict__ cpk4) {
     const int t = blockIdx.x * 256 + threadIdx.x;                  // (octet, lane)
     if (t >= Qtot * 64) return;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N
         const bool ok = n <= N && b < B && !(cs == 1 && m == 0);
         const size_t e = cs == 0 ? (size_t)n * (N + 1) + m : (size_t)(m - 1) * (N + 1) + n;
         v[s_] = ok ? anm[(size_t)b * E + e] : 0.0;
-        if (sigma && cs && (m & 7) > 4) v[s_] = -v[s_];
+        if (rotR && cs && 2 * (m % rotR) > rotR) v[s_] = -v[s_];
     }
     *reinterpret_cast<double2*>(cpk4 + ((size_t)bt * Qtot * 64 + t) * 2) = make_double2(v[0], v[1]);
 }
@@ -542,12 +542,12 @@ int build_pk_table(shg_plan* p, hipStream_t stream) {
 }
 
 // fragment-ordered table of the fused kernel (and the octet offsets both fragment-ordered tables share)
-static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, bool fold16, hipStream_t stream);
+static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, int rotR, hipStream_t stream);
 
-// fold16: the work items carry the panel slots of the 16-fold kernel (synthesis_fold16.hip) instead of those of the 4-fold one
-int build_pkf_table(shg_plan* p, bool ns, bool fold16, hipStream_t stream) {
+// rotR != 0: the work items carry the panel slots of the rotation-folded kernel (synthesis_rot.hip) instead of those of the 4-fold one
+int build_pkf_table(shg_plan* p, bool ns, int rotR, hipStream_t stream) {
     const int variant = ns ? 2 : 1;
-    if (p->pkf && p->pkf_variant == variant && p->itemtab_fold16 == (fold16 ? 1 : 0)) return SHG_OK;
+    if (p->pkf && p->pkf_variant == variant && p->itemtab_rot == rotR) return SHG_OK;
     if (p->pkf) {                                       // the other layout was built before (explicit path switch)
         SHG_HIP(hipDeviceSynchronize());
         (void)hipFree(p->pkf);
@@ -581,7 +581,7 @@ int build_pkf_table(shg_plan* p, bool ns, bool fold16, hipStream_t stream) {
         hipLaunchKernelGGL(pkf_table_kernel, dim3(p->ldlat / 64, N + 1), dim3(64), 0, stream, N, p->ldlat, nit, q, p->qoff, p->ct, p->pmm,
                            p->knT, p->arec, p->brec, p->pkf);
     SHG_HIP(hipGetLastError());
-    const int rc_items = build_item_table(p, od, qoff, fold16, stream);
+    const int rc_items = build_item_table(p, od, qoff, rotR, stream);
     if (rc_items) return rc_items;
     p->pkf_variant = variant;
     return SHG_OK;
@@ -593,12 +593,12 @@ int build_pkf_table(shg_plan* p, bool ns, bool fold16, hipStream_t stream) {
 //   z    = panel slot of the cosine part | (panel slot of the sine part + 1) << 16   (0 in the upper half: order 0)
 //   w    = bit 0 item valid, bit 1 second octet valid, bit 2 last item of its order
 // padded per wave to 4 * ntrip + 8 records (the kernel runs ntrip trips of four items and prefetches one trip ahead).
-static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, bool fold16, hipStream_t stream) {
+static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, int rotR, hipStream_t stream) {
     const int N = p->N;
     std::vector<int> slot16;
-    if (fold16) {
-        int nk[5], sl[5], cn[5];
-        fold16_layout(N, nk, sl, cn, &slot16);
+    if (rotR) {
+        int nk[4], cn[4];
+        rot_layout(rotR, N, nk, cn, &slot16);
     }
     std::vector<std::vector<int>> rec(8);
     size_t longest = 0;
@@ -613,7 +613,7 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, b
             const int even_shift = p->fold0 ? 1 : 0;
             const int slot_c = m == 0 && p->fold0 ? p->K_f : go[m & 1] + (m >> 1) - ((m & 1) ? 0 : even_shift);
             const int slot_s = m >= 1 ? go[2 + (m & 1)] + ((m & 1) ? (m >> 1) : (m >> 1) - 1) + 1 : 0;
-            const int zrec = fold16 ? slot16[m] : (slot_c | (slot_s << 16));
+            const int zrec = rotR ? slot16[m] : (slot_c | (slot_s << 16));
             for (int j0 = 0; j0 < q; j0 += 2) {
                 const int o0 = qoff[m] + j0, o1 = o0 + (j0 + 1 < q ? 1 : 0);
                 const int flags = 1 | ((j0 + 1) * od < cnt ? 2 : 0) | (j0 + 2 >= q ? 4 : 0);
@@ -652,7 +652,7 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, b
     SHG_HIP(hipMemcpyAsync(p->itemtab_d, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     SHG_HIP(hipStreamSynchronize(stream));                             // the host vector goes out of scope
     p->itemtab_nrec = nrec;
-    p->itemtab_fold16 = fold16 ? 1 : 0;
+    p->itemtab_rot = rotR;
     p->itemtab_ntrip = ntrip;
     return SHG_OK;
 }
@@ -697,8 +697,8 @@ int build_blockmap(shg_plan* p, int nbt, int nit, hipStream_t stream) {
 }
 
 // Repack of the coefficient batch into MFMA-fragment order (workspace p->cpk4: [nbt][Qtot][32][2], NS: [nbt][Qtot][64][2]);
-// sigma: sign convention of the 16-fold kernel.
-int pack_coefficients_fused(shg_plan* p, bool ns, bool sigma, const double* anm, int B, hipStream_t stream) {
+// rotR: sign convention of the rotation-folded kernel (0 = none).
+int pack_coefficients_fused(shg_plan* p, bool ns, int rotR, const double* anm, int B, hipStream_t stream) {
     const int nbt = ceil_div(B, 4);
     const int variant = ns ? 4 : 2;
     const size_t need = (size_t)nbt * p->Qtot * (ns ? 128 : 64);
@@ -724,9 +724,9 @@ int pack_coefficients_fused(shg_plan* p, bool ns, bool sigma, const double* anm,
     ProfileScope ps(p, 0, stream);
     if (ns)
         hipLaunchKernelGGL(pack_coefficients4_ns_gather_kernel, dim3(ceil_div(p->Qtot * 64, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot,
-                           sigma ? 1 : 0, p->octinfo_d, anm, p->cpk4);
+                           rotR, p->octinfo_d, anm, p->cpk4);
     else
-        hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, sigma ? 1 : 0, p->qoff, anm,
+        hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, rotR, p->qoff, anm,
                            p->cpk4);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
@@ -735,11 +735,11 @@ int pack_coefficients_fused(shg_plan* p, bool ns, bool sigma, const double* anm,
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
     if (fused_chunk_for(p) == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
     const bool ns = p->sym_ns && p->path != 4;      // north-south symmetric variant (path 4 forces the plain one)
-    int rc = build_pkf_table(p, ns, false, stream);
+    int rc = build_pkf_table(p, ns, 0, stream);
     if (rc) return rc;
     const int nbt = ceil_div(B, 4);
     const int nit = ns ? ceil_div(p->nlat / 2, 8) : ceil_div(p->nlat, 16);
-    rc = pack_coefficients_fused(p, ns, false, anm, B, stream);
+    rc = pack_coefficients_fused(p, ns, 0, anm, B, stream);
     if (rc) return rc;
     FusedParams P;
     P.N = p->N;

@@ -1,0 +1,625 @@
+// Fused batched synthesis for grids whose meridians are invariant under lon -> -lon and under R rotations lon -> lon + 2 pi k / R
+// (an equi-angular cell-centred grid, grates/grid.py:1146-1151, with nlon a multiple of 2 R): every column of the fundamental
+// domain mu_c = (c + 1/2) dlon, c = 0 .. nlon / (2 R) - 1, has 2 R images s mu_c + 2 pi k / R, s = +-1, k = 0 .. R - 1.
+//
+// Same structure as synthesis_fused.hip (one workgroup = 4 epochs x 16 parallels; Legendre stage on MFMA into an LDS panel,
+// longitude stage on MFMA out of it), but the longitude stage evaluates its trigonometric sums on the fundamental domain only
+// and forms the 2 R images of a column in registers: the epilogue does the radix-R step of a decimation-in-frequency FFT, the
+// MFMAs the remaining DFT of nlon / (2 R) points.
+//
+// Orders m >= 1 fall into classes r = min(m mod R, R - m mod R) with sign s_m = +1 (m mod R <= R / 2) or -1, because
+//     cos(2 pi m k / R) = cos(2 pi r k / R),   sin(2 pi m k / R) = s_m sin(2 pi r k / R).
+// With the panel holding A_m = sum_n C_nm PK_nm and B'_m = s_m sum_n S_nm PK_nm (the sign is folded into the coefficient
+// repack) and the table T1 = cos(m mu), T2 = s_m sin(m mu), the sums per class
+//     CA = A T1,  SA = A T2,  CB = B' T1,  SB = B' T2          (r = 0 and r = R / 2 need CA and SB only)
+// give
+//     f(s mu + 2 pi k / R) = sum_r cos(2 pi r k / R) (CA_r + s SB_r) + sin(2 pi r k / R) (CB_r - s SA_r).
+//
+// R is chosen so that the images of a 16-column tile are whole 128-byte lines of the grid: nlon / R must be a multiple of 16.
+//   R = 6 (12 images; nlon % 96 == 0: the 0.25 degree grid): classes 0, 3 (two sums) and 1, 2 (four sums) = 12 accumulators per
+//          16 rows x 16 columns, 80 MFMAs at d/o 96 where the 4-fold kernel of synthesis_fused.hip issues 144 for the same outputs.
+// Measured on the way (d/o 96 -> 0.25 degree): R = 8 (16 images, 84 MFMAs for 16 x 16 x 16 outputs) computes faster but its
+// images start at multiples of nlon / 8 = 180 columns, i.e. at 32-byte instead of 128-byte boundaries, and the partial lines
+// cost more HBM time than the MFMAs save (0.9 - 1.3 ms against 0.63 ms with the same stores forced onto line boundaries).
+//
+// Operands of the longitude stage: A fragments (A_m, B'_m) come from the panel with one ds_read_b128 per k-step, B fragments
+// (T1, T2) are streamed from L2 by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction) into a private ring of six
+// 1 KB slots per wave, five pieces ahead of their use, and read back with one ds_read_b128: no registers are tied up by the
+// prefetch and the loop needs no compile-time knowledge of the class lengths.  The fragments of k-step p + 1 are read while
+// the MFMAs of k-step p run (two named register sets).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "common.h"
+
+#ifndef SHG_STORE_AUX
+#define SHG_STORE_AUX 2          // nt: the grids are streamed out and never re-read (see synthesis_fused.hip)
+#endif
+
+namespace shg {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kRingDepth = 5;                       // trig pieces in flight per wave
+constexpr int kRingSlots = 6;                       // ring slots (1 KB each) per wave
+constexpr int kRingDoubles = 8 * kRingSlots * 128;  // the rings of the 8 waves sit at the start of the LDS (DMA offsets < 64 KB)
+constexpr int kMaxClasses = 4;
+
+// class layout for R rotations: position of class r in the K sequence (two-sum classes first), and whether it has four sums
+template <int R>
+struct RotTraits;
+template <>
+struct RotTraits<6> {                               // r = 0, 3 (two sums), 1, 2 (four sums)
+    static constexpr int kClasses = 4, kTwo = 2, kAcc = 12;
+    static constexpr int kOrder[4] = {0, 3, 1, 2};
+};
+template <>
+struct RotTraits<3> {                               // r = 0 (two sums), 1 (four sums)
+    static constexpr int kClasses = 2, kTwo = 1, kAcc = 6;
+    static constexpr int kOrder[2] = {0, 1};
+};
+
+struct RotParams {
+    int N, nlat, nlon, B, nit, nh;
+    int nd;                   // columns of the fundamental domain = nlon / (2 R)
+    int nct;                  // column tiles of 16
+    int npieces;              // trig pieces (k-steps) per column tile = sum of cls_nk
+    int cls_nk[kMaxClasses];  // k-steps (4 orders each) of the classes in K order; their panel slots follow each other: class c starts at 4 * (nk[0] + .. + nk[c-1])
+    int cls_cnt[kMaxClasses]; // orders in each class (the slots up to 4 * cls_nk are zero padding)
+    int nslot;                // panel slots of the orders >= 1 = 4 * npieces; order 0 sits in slot nslot
+    int dbg;                  // experiment switches (SHG_DEBUG): 1 no stores, 2 no Legendre stage, 4 no longitude stage
+    int Qtot;
+    const double* cpk4;       // repacked coefficients (see synthesis_fused.hip), S_nm negated where s_m = -1
+    const double* pkf;
+    const int4* itemtab;
+    int nrec, ntrip;
+#ifdef SHG_TIMELINE
+    unsigned long long* tl;
+#endif
+    const int* blockmap;
+    const int* badmap;
+    const double* trig;       // [nct][npieces][64 lanes][2]: (cos(m mu), s_m sin(m mu)) of order slot 4 ks + lane / 16, column 16 ct + lane % 16
+    double* G;
+};
+
+#ifdef SHG_TIMELINE
+#define ROT_STAMP(ev)                                                                                         \
+    do {                                                                                                      \
+        if (P.tl && lane == 0) P.tl[((size_t)blockIdx.x * 8 + wave) * 16 + (ev)] = wall_clock64();            \
+    } while (0)
+#else
+#define ROT_STAMP(ev)
+#endif
+
+// LDS-DMA of one 1 KB piece: lane l copies 16 bytes from gbase + lane_off to LDS address lds_addr + 16 l.
+// M0 is saved and restored (the compiler reserves it); s_nop 4 covers a scalar write of the base just before the statement.
+__device__ __forceinline__ void glds16(const double* gbase, unsigned lane_off, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(gbase), "s"(lds_addr)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The 2 R images of one (row, column) from its sums, in place: acc[t] <- image t, t = k (s = +1, ascending columns) or R + k
+// (s = -1, descending columns).  X_r(s) = CA_r + s SB_r, Y_r(s) = CB_r - s SA_r.
+template <int R>
+__device__ __forceinline__ void rot_images(double4_t* acc, int r);
+
+// R = 6, accumulators 0 CA_0, 1 SB_0, 2 CA_3, 3 SB_3, 4-7 (CA, SA, CB, SB)_1, 8-11 (CA, SA, CB, SB)_2.  With g = sqrt(3) / 2:
+//   E_0 = X_0 + X_2,  E_1 = X_0 - X_2 / 2 + g Y_2,  E_2 = X_0 - X_2 / 2 - g Y_2        (classes 0, 2: period 3 in k)
+//   O_0 = X_1 + X_3,  O_1 = X_1 / 2 + g Y_1 - X_3,  O_2 = -X_1 / 2 + g Y_1 + X_3       (classes 1, 3: O_(k+3) = -O_k)
+//   f_k = E_k + O_k,  f_(k+3) = E_k - O_k,  k = 0, 1, 2.
+template <>
+__device__ __forceinline__ void rot_images<6>(double4_t* acc, int r) {
+    constexpr double g = 0.86602540378443864676;
+    const double ca0 = acc[0][r], sb0 = acc[1][r], ca3 = acc[2][r], sb3 = acc[3][r];
+    const double ca1 = acc[4][r], sa1 = acc[5][r], cb1 = acc[6][r], sb1 = acc[7][r];
+    const double ca2 = acc[8][r], sa2 = acc[9][r], cb2 = acc[10][r], sb2 = acc[11][r];
+#pragma unroll
+    for (int sgn = 0; sgn < 2; ++sgn) {
+        const double x0 = sgn ? ca0 - sb0 : ca0 + sb0, x3 = sgn ? ca3 - sb3 : ca3 + sb3;
+        const double x1 = sgn ? ca1 - sb1 : ca1 + sb1, y1 = sgn ? cb1 + sa1 : cb1 - sa1;
+        const double x2 = sgn ? ca2 - sb2 : ca2 + sb2, y2 = sgn ? cb2 + sa2 : cb2 - sa2;
+        const double t = fma(-0.5, x2, x0), q = g * y2;
+        const double e0 = x0 + x2, e1 = t + q, e2 = t - q;
+        const double u = fma(0.5, x1, -x3), v = g * y1;
+        const double o0 = x1 + x3, o1 = u + v, o2 = v - u;
+        acc[6 * sgn + 0][r] = e0 + o0;
+        acc[6 * sgn + 3][r] = e0 - o0;
+        acc[6 * sgn + 1][r] = e1 + o1;
+        acc[6 * sgn + 4][r] = e1 - o1;
+        acc[6 * sgn + 2][r] = e2 + o2;
+        acc[6 * sgn + 5][r] = e2 - o2;
+    }
+}
+
+// R = 3, accumulators 0 CA_0, 1 SB_0, 2-5 (CA, SA, CB, SB)_1:  f_0 = X_0 + X_1,  f_1,2 = X_0 - X_1 / 2 +- g Y_1.
+template <>
+__device__ __forceinline__ void rot_images<3>(double4_t* acc, int r) {
+    constexpr double g = 0.86602540378443864676;
+    const double ca0 = acc[0][r], sb0 = acc[1][r];
+    const double ca1 = acc[2][r], sa1 = acc[3][r], cb1 = acc[4][r], sb1 = acc[5][r];
+#pragma unroll
+    for (int sgn = 0; sgn < 2; ++sgn) {
+        const double x0 = sgn ? ca0 - sb0 : ca0 + sb0;
+        const double x1 = sgn ? ca1 - sb1 : ca1 + sb1, y1 = sgn ? cb1 + sa1 : cb1 - sa1;
+        const double t = fma(-0.5, x1, x0), q = g * y1;
+        acc[3 * sgn + 0][r] = x0 + x1;
+        acc[3 * sgn + 1][r] = t + q;
+        acc[3 * sgn + 2][r] = t - q;
+    }
+}
+
+template <bool NS, int R>
+__global__ __launch_bounds__(512) void synthesis_rot_kernel(RotParams P) {
+    using T = RotTraits<R>;
+    constexpr int kImages = 2 * R;
+    extern __shared__ __attribute__((aligned(16))) double As[];   // rings [8][kRingSlots][64][2], then panel [nslot + 1][64 rows][2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbt = (P.B + 3) >> 2;
+    const int bt = P.blockmap ? P.blockmap[2 * blockIdx.x] : (int)(blockIdx.x % nbt);
+    const int it = P.blockmap ? P.blockmap[2 * blockIdx.x + 1] : (int)(blockIdx.x / nbt);
+    const int i0 = it * 16;                             // plain layout: first parallel of the block
+    const int i0n = it * 8;                             // NS layout: first northern parallel of the block
+    const int fr = lane & 15, fk = lane >> 4;
+    ROT_STAMP(0);
+
+    double2_t* const panel = reinterpret_cast<double2_t*>(As + kRingDoubles);      // [(slot * 64 + row)]
+
+    // ---- zero the padding slots of the panel
+    {
+        int s0 = 0;
+        for (int c = 0; c < T::kClasses; ++c) {
+            for (int s = s0 + P.cls_cnt[c]; s < s0 + 4 * P.cls_nk[c]; ++s)
+                if (tid < 64) panel[s * 64 + tid] = (double2_t){0.0, 0.0};
+            s0 += 4 * P.cls_nk[c];
+        }
+    }
+
+    // ---- trig stream of this wave: units u = wave + 8 q, (row tile, column tile) = (u & 3, u >> 2); the pieces of unit q
+    //      are the npieces consecutive KB of column tile u >> 2.  The issue side runs kRingDepth pieces ahead of the consumer
+    //      and keeps issuing (re-reading the last piece) when the stream is exhausted, so that the count of DMAs in flight
+    //      is the same at every wait.
+    const int nunits = 4 * P.nct;
+    const int nq = wave < nunits ? (nunits - wave + 7) >> 3 : 0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)As;
+    const unsigned ring_lds = lds0 + (unsigned)wave * (kRingSlots * 1024);
+    const unsigned lane_off = (unsigned)lane * 16u;
+    const size_t ct_stride = (size_t)P.npieces * 128;
+    const double* iptr = P.trig + (size_t)(nq > 0 ? wave >> 2 : 0) * ct_stride;
+    int ileft = P.npieces, iq = 0, islot = 0;
+    auto issue_piece = [&]() {
+        glds16(iptr, lane_off, ring_lds + (unsigned)islot * 1024u);
+        islot = islot + 1 == kRingSlots ? 0 : islot + 1;
+        if (ileft > 1) {
+            --ileft;
+            iptr += 128;
+        } else if (iq + 1 < nq) {
+            ++iq;
+            ileft = P.npieces;
+            iptr = P.trig + (size_t)((wave + 8 * iq) >> 2) * ct_stride;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < kRingDepth; ++d) issue_piece();
+
+    // ---- phase 1: Legendre stage (see synthesis_fused.hip).  Orders are distributed over the 8 waves; the result of order m
+    //      is written as one 16-byte pair (A_m, B'_m) per panel row.
+    if (!(P.dbg & 2)) {
+        constexpr int ASTRIDE = NS ? 128 : 64;
+        const int bad = NS ? P.badmap[it] : -1;
+        const double* pkb = P.pkf + ((size_t)it * P.Qtot * 64 + lane) * 2;
+        int mode = NS && bad >= 0 ? 1 : 0;
+        int prow = lane;
+        const double* cf = NS ? P.cpk4 + ((size_t)bt * P.Qtot * 64 + lane) * 2
+                              : P.cpk4 + ((size_t)bt * P.Qtot * 32 + fk * 8 + (fr & 7)) * 2;
+        const bool arow = NS || fr < 8;
+        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+
+#define ROT_P1_ISSUE(rec, ALO, AHI, BLO, BHI)                                                \
+    do {                                                                                     \
+        ALO = *reinterpret_cast<const double2*>(cf + (size_t)(rec).x * ASTRIDE);             \
+        BLO = *reinterpret_cast<const double2*>(pkb + (size_t)(rec).x * 128);                \
+        AHI = *reinterpret_cast<const double2*>(cf + (size_t)(rec).y * ASTRIDE);             \
+        BHI = *reinterpret_cast<const double2*>(pkb + (size_t)(rec).y * 128);                \
+    } while (0)
+
+#define ROT_P1_CONSUME(rec, ALO, AHI, BLO, BHI)                                                                     \
+    do {                                                                                                            \
+        const bool lo_ = arow && ((rec).w & 1);                                                                     \
+        const bool hi_ = arow && ((rec).w & 2);                                                                     \
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.x : 0.0, BLO.x, acc0, 0, 0, 0);                       \
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.y : 0.0, BLO.y, acc1, 0, 0, 0);                       \
+        if ((rec).w & 2) {                                                                                          \
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.x : 0.0, BHI.x, acc0, 0, 0, 0);                   \
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.y : 0.0, BHI.y, acc1, 0, 0, 0);                   \
+        }                                                                                                           \
+        if ((rec).w & 4) {                                  /* last item of an order: see synthesis_fused.hip */     \
+            double vc_ = acc0[0] + acc1[0], vs_ = acc0[1] + acc1[1];                                                \
+            if (NS) {                                                                                               \
+                const double oc_ = acc0[2] + acc1[2], os_ = acc0[3] + acc1[3];                                      \
+                const double rc_ = swap_half_row(fr < 8 ? vc_ : oc_), rs_ = swap_half_row(fr < 8 ? vs_ : os_);      \
+                vc_ = (mode == 0 && fr >= 8) ? rc_ - oc_ : vc_ + rc_;                                               \
+                vs_ = (mode == 0 && fr >= 8) ? rs_ - os_ : vs_ + rs_;                                               \
+            }                                                                                                       \
+            if (!NS || mode == 0 || fr < 8) panel[(rec).z * 64 + prow] = (double2_t){vc_, vs_};                     \
+            acc0 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
+            acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
+        }                                                                                                           \
+    } while (0)
+
+        double2 xal = {0, 0}, xah = {0, 0}, xbl = {0, 0}, xbh = {0, 0};
+        double2 yal = {0, 0}, yah = {0, 0}, ybl = {0, 0}, ybh = {0, 0};
+        double2 zal = {0, 0}, zah = {0, 0}, zbl = {0, 0}, zbh = {0, 0};
+        double2 wal = {0, 0}, wah = {0, 0}, wbl = {0, 0}, wbh = {0, 0};
+        const int4* recs = P.itemtab + (size_t)wave * P.nrec;
+        for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
+            if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
+                mode = 2;
+                prow = lane + 8;
+                pkb = P.pkf + ((size_t)(P.nit + bad) * P.Qtot * 64 + lane) * 2;
+            }
+            int4 c0 = recs[0], c1 = recs[1], c2 = recs[2];
+            int4 n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
+            ROT_P1_ISSUE(c0, xal, xah, xbl, xbh);
+            ROT_P1_ISSUE(c1, yal, yah, ybl, ybh);
+            ROT_P1_ISSUE(c2, zal, zah, zbl, zbh);
+            for (int trip = 0; trip < P.ntrip; ++trip) {
+                const int4 a3 = n0, a4 = n1, a5 = n2, a6 = n3;
+                const int4* nr = recs + 4 * trip + 7;
+                n0 = nr[0];
+                n1 = nr[1];
+                n2 = nr[2];
+                n3 = nr[3];
+                ROT_P1_ISSUE(a3, wal, wah, wbl, wbh);
+                ROT_P1_CONSUME(c0, xal, xah, xbl, xbh);
+                ROT_P1_ISSUE(a4, xal, xah, xbl, xbh);
+                ROT_P1_CONSUME(c1, yal, yah, ybl, ybh);
+                ROT_P1_ISSUE(a5, yal, yah, ybl, ybh);
+                ROT_P1_CONSUME(c2, zal, zah, zbl, zbh);
+                ROT_P1_ISSUE(a6, zal, zah, zbl, zbh);
+                ROT_P1_CONSUME(a3, wal, wah, wbl, wbh);
+                c0 = a4;
+                c1 = a5;
+                c2 = a6;
+            }
+        }
+#undef ROT_P1_ISSUE
+#undef ROT_P1_CONSUME
+    }
+    ROT_STAMP(1);
+    __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
+    ROT_STAMP(2);
+
+    auto grid_row = [&](int s) { return NS ? (s < 8 ? i0n + s : P.nlat - 1 - (i0n + s - 8)) : i0 + s; };
+    auto slot_valid = [&](int s) { return NS ? i0n + (s & 7) < P.nh : i0 + s < P.nlat; };
+
+    // ---- phase 2: longitude stage
+    const bool pair_stores = (P.nd & 1) == 0;
+    const int grid_bytes = P.nlat * P.nlon * 8;        // one epoch's grid; < 2^31 (checked on the host)
+    const int n2 = P.nlon >> 1, nR = P.nlon / R;
+    const double2_t* const ringp = reinterpret_cast<const double2_t*>(As) + wave * (kRingSlots * 64) + lane;   // + slot * 64
+    // all units of a wave lie in the same row tile: (wave + 8 q) & 3 = wave & 3
+    const int rt = wave & 3;
+    const double2_t* const prow = panel + rt * 16 + fr + fk * 64;        // + 256 p: k-step p of the flat class sequence
+    int cslot = 0, pf = 0;                                               // ring slot / k-step (inside its unit) of the next fetch
+    // Fragments of the next k-step of the flat (unit, k-step) sequence -> (T_, AB_): one more trig piece issued, the piece of
+    // this k-step waited for, ring slot and panel rows read.  Branch-free and unconditional (after the last k-step of the last
+    // unit it re-reads valid memory), so that hipcc keeps exact lgkmcnt counts across the loops: the MFMAs of k-step p then
+    // wait for their own fragments only (lgkmcnt(2)), not for the reads of k-step p + 1 issued just before them.
+    // The wait is always the strict one (all but the kRingDepth youngest operations done): stores of the previous epilogue
+    // that are still in flight are waited for too, which measured no different from counting them out.
+#define ROT_FETCH(T_, AB_)                                                                                \
+    do {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        issue_piece();                                                                                    \
+        wait_vmcnt<kRingDepth>();                                                                         \
+        T_ = ringp[cslot * 64];                                                                           \
+        cslot = cslot + 1 == kRingSlots ? 0 : cslot + 1;                                                  \
+        AB_ = prow[pf * 256];                                                                             \
+        pf = pf + 1 == P.npieces ? 0 : pf + 1;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    } while (0)
+#define ROT_MFMA2(A0, T_, AB_)                                                                            \
+    acc[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, acc[A0], 0, 0, 0);                        \
+    acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, acc[A0 + 1], 0, 0, 0)
+#define ROT_MFMA4(A0, T_, AB_)                                                                            \
+    acc[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, acc[A0], 0, 0, 0);                        \
+    acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.y, acc[A0 + 1], 0, 0, 0);                \
+    acc[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, acc[A0 + 2], 0, 0, 0);                \
+    acc[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, acc[A0 + 3], 0, 0, 0)
+    // one class: k-steps in pairs on the register sets (tx, abx) / (ty, aby); the current fragments are in (tx, abx) on entry
+    // and on exit, the fragments of the next k-step are fetched before the MFMAs of the current one are issued
+#define ROT_CLASS(C, MF, A0)                                                                              \
+    {                                                                                                     \
+        const int nk_ = P.cls_nk[C];                                                                      \
+        int i_ = 0;                                                                                       \
+        for (; i_ + 2 <= nk_; i_ += 2) {                                                                  \
+            ROT_FETCH(ty, aby);                                                                           \
+            MF(A0, tx, abx);                                                                              \
+            ROT_FETCH(tx, abx);                                                                           \
+            MF(A0, ty, aby);                                                                              \
+        }                                                                                                 \
+        if (i_ < nk_) {                                                                                   \
+            ROT_FETCH(ty, aby);                                                                           \
+            MF(A0, tx, abx);                                                                              \
+            tx = ty;                                                                                      \
+            abx = aby;                                                                                    \
+        }                                                                                                 \
+    }
+    double2_t tx = {0.0, 0.0}, abx = {0.0, 0.0}, ty = {0.0, 0.0}, aby = {0.0, 0.0};
+    if (nq > 0 && !(P.dbg & 4)) ROT_FETCH(tx, abx);
+    for (int q = 0; q < nq && !(P.dbg & 4); ++q) {
+        const int ct = (wave >> 2) + 2 * q;
+        double4_t acc[T::kAcc];
+#pragma unroll
+        for (int a = 0; a < T::kAcc; ++a) acc[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        {
+            // order 0 does not depend on the longitude: start value of CA_0 (C/D layout: row = fk + 4 reg, all columns)
+            const double2_t* z = panel + P.nslot * 64 + rt * 16 + fk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][r] = z[4 * r].x;
+        }
+#pragma unroll
+        for (int c = 0; c < T::kClasses; ++c) {
+            if (c < T::kTwo) {
+                ROT_CLASS(c, ROT_MFMA2, 2 * c)
+            } else {
+                ROT_CLASS(c, ROT_MFMA4, 2 * T::kTwo + 4 * (c - T::kTwo))
+            }
+        }
+        ROT_STAMP(3 + 2 * min(q, 3));
+
+        // ---- epilogue: the 2 R images of every column, in place
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rot_images<R>(acc, r);
+        const int b = bt * 4 + rt;
+        const bool epoch_ok = b < P.B && !(P.dbg & 1);
+        double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
+        if (pair_stores) {
+            // lanes (2 q, 2 q + 1) hold adjacent columns: after the exchange every lane owns two rows x two adjacent columns and
+            // stores 16 bytes.  Byte offset = lane part (row, column inside the tile) + wave-uniform part (image, column tile);
+            // lanes outside the grid carry an offset beyond the buffer and are dropped.
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Gb, 0, grid_bytes, 0x00020000);
+            const int par = fr & 1, ce = fr & ~1;
+            const int sa = fk + (par ? 8 : 0), sb = sa + 4;
+            const bool col_ok = epoch_ok && ct * 16 + ce < P.nd;
+            const unsigned row_a = col_ok && slot_valid(sa) ? (unsigned)grid_row(sa) * (unsigned)P.nlon * 8u : 0x80000000u;
+            const unsigned row_b = col_ok && slot_valid(sb) ? (unsigned)grid_row(sb) * (unsigned)P.nlon * 8u : 0x80000000u;
+            const unsigned asc = (unsigned)ce * 8u, desc = (unsigned)(14 - ce) * 8u;
+#pragma unroll
+            for (int t = 0; t < kImages; ++t) {
+                const int k = t < R ? t : t - R;
+                const bool ascending = t < R;
+                // first column of the tile's run: s = +1: (n2 + k nR) mod nlon + 16 ct;  s = -1: (n2 + k nR - nd) mod nlon + nd - 16 ct - 16
+                int w = n2 + k * nR - (ascending ? 0 : P.nd);
+                w = w >= P.nlon ? w - P.nlon : w;
+                const int soff = (ascending ? w + 16 * ct : w + P.nd - 16 * ct - 16) * 8;
+                double a_lo, a_hi, b_lo, b_hi;
+                pair_exchange(acc[t][0], acc[t][2], 0xAAAAAAAAAAAAAAAAull, a_lo, a_hi);
+                pair_exchange(acc[t][1], acc[t][3], 0xAAAAAAAAAAAAAAAAull, b_lo, b_hi);
+                const double2_t va = ascending ? (double2_t){a_lo, a_hi} : (double2_t){a_hi, a_lo};
+                const double2_t vb = ascending ? (double2_t){b_lo, b_hi} : (double2_t){b_hi, b_lo};
+                // The wave-uniform part goes into the vector offset, not into the scalar offset operand of the store: with a
+                // REGISTER soffset hipcc assumes that a 16-byte store's data registers may be overwritten by the very next VALU
+                // instruction (the documented exemption of the gfx9 store-data hazard) and schedules one there; on gfx950 that
+                // corrupted the low dword of the stored value in some lanes of some launches.
+                const unsigned lane_col = (ascending ? asc : desc) + (unsigned)soff;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, va), rsrc, row_a + lane_col, 0, SHG_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, vb), rsrc, row_b + lane_col, 0, SHG_STORE_AUX);
+            }
+        } else {
+            const int c = ct * 16 + fr;
+            if (epoch_ok && c < P.nd) {
+#pragma unroll
+                for (int t = 0; t < kImages; ++t) {
+                    const int k = t < R ? t : t - R;
+                    int w = n2 + k * nR - (t < R ? 0 : P.nd);
+                    w = w >= P.nlon ? w - P.nlon : w;
+                    const int j = t < R ? w + c : w + P.nd - 1 - c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (slot_valid(fk + 4 * r)) Gb[(size_t)grid_row(fk + 4 * r) * P.nlon + j] = acc[t][r];
+                }
+            }
+        }
+        ROT_STAMP(4 + 2 * min(q, 3));
+    }
+#undef ROT_CLASS
+#undef ROT_MFMA2
+#undef ROT_MFMA4
+#undef ROT_FETCH
+    wait_vmcnt<0>();          // the prefetched pieces of the (padded) stream must have landed before the LDS is released
+    ROT_STAMP(12);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+// class position in the K sequence (two-sum classes first) and sign of order m >= 1 for R rotations
+static inline void order_class(int R, int m, int& cls, int& sign) {
+    const int rho = m % R;
+    const int r = 2 * rho <= R ? rho : R - rho;
+    sign = 2 * rho <= R ? 1 : -1;
+    if (R == 6) {
+        static const int pos[4] = {0, 2, 3, 1};         // r -> position in (0, 3, 1, 2)
+        cls = pos[r];
+    } else {                                            // R == 3: (0, 1)
+        cls = r;
+    }
+}
+static inline int rot_classes(int R) { return R == 6 ? 4 : 2; }
+
+// sign of the sine coefficients of order m in the repacked coefficient table (0 = no rotation kernel)
+int rot_sigma_negative(int R, int m) { return R > 0 && 2 * (m % R) > R ? 1 : 0; }
+
+// True when the meridians are lon_j = -pi + (j + 1/2) 2 pi / nlon to within a few ulp of pi: every one of the 2 R images
+// s mu_c + 2 pi k / R of the fundamental domain mu_c = lon[nlon/2 + c] is a grid column.
+bool has_rotation_symmetry(int nlon, const double* lon, int R) {
+    if (nlon < 192 || nlon % (2 * R) != 0 || nlon % 2 != 0) return false;
+    if ((nlon / R) % 16 != 0) return false;              // images of a column tile = whole 128-byte lines
+    const double tol = 3e-15;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    const int n2 = nlon / 2, nR = nlon / R, nd = nlon / (2 * R);
+    for (int c = 0; c < nd; ++c) {
+        const long double mu = lon[n2 + c];
+        for (int k = 0; k < R; ++k) {
+            const int jp = (n2 + k * nR + c) % nlon, jm = (n2 + k * nR - 1 - c + nlon) % nlon;
+            long double dp = lon[jp] - (mu + 2 * pi * k / R), dm = lon[jm] - (-mu + 2 * pi * k / R);
+            dp -= 2 * pi * std::round((double)(dp / (2 * pi)));
+            dm -= 2 * pi * std::round((double)(dm / (2 * pi)));
+            if (std::fabs((double)dp) > tol || std::fabs((double)dm) > tol) return false;
+        }
+    }
+    return true;
+}
+
+// class layout of the panel / trig stream for degree N; returns the panel slots (without the order-0 slot)
+int rot_layout(int R, int N, int nk[kMaxClasses], int cnt[kMaxClasses], std::vector<int>* order_slot) {
+    const int nc = rot_classes(R);
+    for (int c = 0; c < kMaxClasses; ++c) cnt[c] = nk[c] = 0;
+    for (int m = 1; m <= N; ++m) {
+        int c, s;
+        order_class(R, m, c, s);
+        cnt[c]++;
+    }
+    int s = 0, slot[kMaxClasses];
+    for (int c = 0; c < nc; ++c) {
+        nk[c] = (cnt[c] + 3) / 4;
+        slot[c] = s;
+        s += 4 * nk[c];
+    }
+    if (order_slot) {
+        order_slot->assign(N + 1, 0);
+        int next[kMaxClasses];
+        for (int c = 0; c < nc; ++c) next[c] = slot[c];
+        for (int m = 1; m <= N; ++m) {
+            int c, sg;
+            order_class(R, m, c, sg);
+            (*order_slot)[m] = next[c]++;
+        }
+        (*order_slot)[0] = s;
+    }
+    return s;
+}
+
+static size_t rot_lds_bytes(int nslot) { return (size_t)kRingDoubles * 8 + (size_t)(nslot + 1) * 1024; }
+
+int rot_applicable(const shg_plan* p) {
+    if (p->rotR == 0) return 0;
+    if ((long long)p->nlat * p->nlon * 8 >= (1LL << 31)) return 0;
+    int nk[kMaxClasses], cnt[kMaxClasses];
+    const int nslot = rot_layout(p->rotR, p->N, nk, cnt, nullptr);
+    return rot_lds_bytes(nslot) <= 160 * 1024 ? 1 : 0;
+}
+
+// trig stream [nct][npieces][64][2] (+ one spare piece), built on the host like the other cos/sin tables (grates/utilities.py:272-273)
+int build_rot_trig(shg_plan* p, const double* lon_h) {
+    const int R = p->rotR, N = p->N, nlon = p->nlon, nd = nlon / (2 * R), nct = ceil_div(nd, 16);
+    int nk[kMaxClasses], cnt[kMaxClasses];
+    std::vector<int> order_slot;
+    const int nslot = rot_layout(R, N, nk, cnt, &order_slot);
+    const int npieces = nslot / 4;
+    std::vector<int> slot_order(nslot, -1);
+    for (int m = 1; m <= N; ++m) slot_order[order_slot[m]] = m;
+    std::vector<double> tab(((size_t)nct * npieces + 1) * 128, 0.0);
+    for (int ct = 0; ct < nct; ++ct)
+        for (int ks = 0; ks < npieces; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int m = slot_order[4 * ks + (l >> 4)], c = 16 * ct + (l & 15);
+                if (m < 0 || c >= nd) continue;
+                int cls, sg;
+                order_class(R, m, cls, sg);
+                const double arg = (double)m * lon_h[nlon / 2 + c];
+                double* dst = &tab[(((size_t)ct * npieces + ks) * 64 + l) * 2];
+                dst[0] = std::cos(arg);
+                dst[1] = sg * std::sin(arg);
+            }
+    SHG_HIP(hipMalloc((void**)&p->rot_trig, tab.size() * sizeof(double)));
+    SHG_HIP(hipMemcpy(p->rot_trig, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    return SHG_OK;
+}
+
+template <int R>
+static int launch_rot(shg_plan* p, bool ns, const RotParams& P, size_t lds, dim3 grid_dim, hipStream_t stream) {
+    if (ns) {
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((synthesis_rot_kernel<true, R>), grid_dim, dim3(512), lds, stream, P);
+    } else {
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((synthesis_rot_kernel<false, R>), grid_dim, dim3(512), lds, stream, P);
+    }
+    return SHG_OK;
+}
+
+int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
+    if (!rot_applicable(p)) return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel not applicable to this plan");
+    const int R = p->rotR;
+    const bool ns = p->sym_ns && p->path != 7;
+    int rc = build_pkf_table(p, ns, R, stream);
+    if (rc) return rc;
+    const int nbt = ceil_div(B, 4);
+    const int nit = ns ? ceil_div(p->nlat / 2, 8) : ceil_div(p->nlat, 16);
+    rc = pack_coefficients_fused(p, ns, R, anm, B, stream);
+    if (rc) return rc;
+    RotParams P;
+    P.N = p->N;
+    P.nlat = p->nlat;
+    P.nlon = p->nlon;
+    P.B = B;
+    P.nit = nit;
+    P.nh = p->nlat / 2;
+    P.nd = p->nlon / (2 * R);
+    P.nct = ceil_div(P.nd, 16);
+    P.nslot = rot_layout(R, p->N, P.cls_nk, P.cls_cnt, nullptr);
+    P.npieces = P.nslot / 4;
+    const char* dbg_env = getenv("SHG_DEBUG");
+    P.dbg = dbg_env ? atoi(dbg_env) : 0;
+    P.Qtot = p->Qtot;
+    P.cpk4 = p->cpk4;
+    P.pkf = p->pkf;
+    P.itemtab = reinterpret_cast<const int4*>(p->itemtab_d);
+    P.nrec = p->itemtab_nrec;
+    P.ntrip = p->itemtab_ntrip;
+    P.badmap = p->badmap_d;
+    P.blockmap = nullptr;
+    if (!(P.dbg & 2048)) {
+        rc = build_blockmap(p, nbt, nit, stream);
+        if (rc) return rc;
+        P.blockmap = p->blockmap_d;
+    }
+    P.trig = p->rot_trig;
+    P.G = grid;
+#ifdef SHG_TIMELINE
+    P.tl = getenv("SHG_TIMELINE_PTR") ? (unsigned long long*)strtoull(getenv("SHG_TIMELINE_PTR"), nullptr, 0) : nullptr;
+#endif
+    const size_t lds = rot_lds_bytes(P.nslot);
+    const dim3 grid_dim((unsigned)(nbt * nit));
+    ProfileScope ps(p, 2, stream);
+    rc = R == 6 ? launch_rot<6>(p, ns, P, lds, grid_dim, stream) : launch_rot<3>(p, ns, P, lds, grid_dim, stream);
+    if (rc) return rc;
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+}  // namespace shg
