@@ -186,7 +186,7 @@ def main():
     ap.add_argument('--ramp', type=int, default=300, help='untimed launches before the warm-up steps (device clock ramp)')
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass (0 = library default)')
-    ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'panel'], help='synthesis kernel path')
+    ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'fused_plain', 'fused32', 'rot', 'rot_plain'], help='synthesis kernel path')
     ap.add_argument('--cpu-sample', type=int, default=16, help='solutions timed on the CPU baseline (0 = skip)')
     ap.add_argument('--cov-parallels', type=int, default=8, help='parallels of the d/o-180 covariance-propagation leg per GPU (0 = skip)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only to rehearse on one GPU)")
@@ -268,7 +268,7 @@ def main():
     if rank == 0:
         info = plan.info()
         per_solution = algorithmic_bytes_per_solution(MAX_DEGREE, nlat, nlon)
-        main_kernel = 'synthesis_fused_kernel' if info['fused'] else 'lon_stage_kernel<4>'
+        main_kernel = ('synthesis_rot_kernel' if info['rotation_symmetry'] and args.path in ('auto', 'rot', 'rot_plain') else 'synthesis_fused_kernel') if info['fused'] else 'lon_stage_kernel<4>'
         lon_ms, lon_launches = prof.get('lon_stage', (0.0, 0))
         launches_per_step = lon_launches / max(args.steps, 1)
         epochs_per_launch = B / max(launches_per_step, 1e-9)
@@ -291,7 +291,8 @@ def main():
             'config': {'workload': 'batch of {0} monthly solutions d/o {1} -> {2} deg GeographicGrid ({3}x{4}), kernel {5}, per GPU'.format(
                 B, MAX_DEGREE, GRID_STEP, nlat, nlon, KERNEL),
                 'max_degree': MAX_DEGREE, 'epochs_per_gpu': B, 'grid': [nlat, nlon], 'parallelism': 'epochs sharded over {0} GPU(s), no collective'.format(world),
-                'fused_kernel': info['fused'], 'fourfold_symmetry': info['fourfold_symmetry'], 'untimed_ramp_launches': args.ramp},
+                'fused_kernel': info['fused'], 'fourfold_symmetry': info['fourfold_symmetry'], 'rotation_folded_kernel': info['rotation_symmetry'] and args.path in ('auto', 'rot', 'rot_plain'),
+                'untimed_ramp_launches': args.ramp},
             'roofline': {
                 'kernel': main_kernel, 'bound': 'hbm',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -345,7 +345,7 @@ extern "C" int shg_plan_info(const shg_plan* p, int64_t which[8]) {
     which[0] = p->N;
     which[1] = p->nlat;
     which[2] = p->nlon;
-    which[3] = (p->sym4 ? 1 : 0) | (p->sym_ns ? 2 : 0) | (p->rotR ? 4 : 0);
+    which[3] = (p->sym4 ? 1 : 0) | (p->sym_ns ? 2 : 0) | (rot_applicable(p) ? 4 : 0);
     which[4] = p->chunk;
     which[5] = p->K;
     which[6] = (p->path >= 2 || (p->path == 0 && (rot_applicable(p) || fused_chunk_for(p) != 0 || fused32_applicable(p)))) ? 1 : 0;

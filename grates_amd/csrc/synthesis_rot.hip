@@ -43,8 +43,11 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kRingDepth = 5;                       // trig pieces in flight per wave
-constexpr int kRingSlots = 6;                       // ring slots (1 KB each) per wave
+#ifndef SHG_RING_DEPTH
+#define SHG_RING_DEPTH 5
+#endif
+constexpr int kRingDepth = SHG_RING_DEPTH;         // trig pieces in flight per wave
+constexpr int kRingSlots = kRingDepth + 1;          // ring slots (1 KB each) per wave
 constexpr int kRingDoubles = 8 * kRingSlots * 128;  // the rings of the 8 waves sit at the start of the LDS (DMA offsets < 64 KB)
 constexpr int kMaxClasses = 4;
 
@@ -81,7 +84,7 @@ struct RotParams {
 #endif
     const int* blockmap;
     const int* badmap;
-    const double* trig;       // [nct][npieces][64 lanes][2]: (cos(m mu), s_m sin(m mu)) of order slot 4 ks + lane / 16, column 16 ct + lane % 16
+    const double* trig;       // [column tile][npieces][64 lanes][2]: (cos(m mu), s_m sin(m mu)) of order slot 4 ks + lane / 16, column 16 ct + lane % 16
     double* G;
 };
 
@@ -166,10 +169,200 @@ __device__ __forceinline__ void rot_images<3>(double4_t* acc, int r) {
     }
 }
 
+// Trig stream and fragment registers of one consumer wave; in the persistent kernel they live across tiles.
+struct RotStream {
+    const double* iptr;       // next piece to issue
+    const double* ibase;      // first piece of the column tile being issued
+    const double* ifirst;     // first piece of the wave's first column tile (wave >> 2), ilast: of its last one
+    const double* ilast;
+    int irem;                 // pieces of the current column tile left to issue
+    unsigned im0, ring_lds;   // LDS address of the next ring slot to fill / of the wave's first slot
+    int cslot, pf;            // ring slot / k-step (inside its unit) of the next fetch
+    double2_t tx, abx;        // fragments of the next k-step to compute
+};
+
+// The issue side walks the column tiles of its wave on its own: (wave >> 2), + 2, ..., then again from the start for the next tile.
+__device__ __forceinline__ void rot_stream_init(RotStream& S, const RotParams& P, const double* As, int wave) {
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)As;
+    S.ring_lds = lds0 + (unsigned)wave * (kRingSlots * 1024);
+    S.im0 = S.ring_lds;
+    const int ct0 = min(wave >> 2, P.nct - 1);
+    const int nq = (P.nct - ct0 + 1) >> 1;                          // column tiles of this wave
+    S.ifirst = P.trig + (size_t)ct0 * P.npieces * 128;
+    S.ilast = S.ifirst + (size_t)(nq - 1) * 2 * P.npieces * 128;
+    S.ibase = S.ifirst;
+    S.iptr = S.ifirst;
+    S.irem = P.npieces;
+    S.cslot = 0;
+    S.pf = 0;
+    S.tx = (double2_t){0.0, 0.0};
+    S.abx = (double2_t){0.0, 0.0};
+}
+
+__device__ __forceinline__ void rot_issue_piece(RotStream& S, const RotParams& P, unsigned lane_off) {
+    glds16(S.iptr, lane_off, S.im0);
+    S.im0 = S.im0 + 1024 == S.ring_lds + kRingSlots * 1024 ? S.ring_lds : S.im0 + 1024;
+    const bool more = S.irem > 1;
+    const double* nbase = S.ibase == S.ilast ? S.ifirst : S.ibase + 2 * P.npieces * 128;
+    S.ibase = more ? S.ibase : nbase;
+    S.iptr = more ? S.iptr + 128 : nbase;
+    S.irem = more ? S.irem - 1 : P.npieces;
+}
+
+// Longitude stage + epilogue of one wave for the tile (bt, it).  A unit = (row tile wave & 3, column tile ct), ct = wave >> 2,
+// (wave >> 2) + 2, ...  (Taking the column tiles of a row tile from a common counter, so that the older wave of a SIMD, which
+// wins every MFMA issue slot and runs ~1.3 times faster, takes more of them, measured 16 % slower: the four waves that work
+// on the same column tile then drift apart and no longer share the trig pieces in the L1.)
+// On entry (S.tx, S.abx) hold the fragments of the first k-step; on exit those of the first k-step of column tile wave >> 2
+// again (trig part; the panel part is re-read by the caller once the next panel is there).
+template <bool NS, int R>
+__device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As, const double2_t* panel, RotStream& S, int wave, int lane,
+                                           int bt, int it) {
+    using T = RotTraits<R>;
+    constexpr int kImages = 2 * R;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int i0 = it * 16, i0n = it * 8;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    auto grid_row = [&](int s) { return NS ? (s < 8 ? i0n + s : P.nlat - 1 - (i0n + s - 8)) : i0 + s; };
+    auto slot_valid = [&](int s) { return NS ? i0n + (s & 7) < P.nh : i0 + s < P.nlat; };
+
+    const int grid_bytes = P.nlat * P.nlon * 8;        // one epoch's grid; < 2^31 (checked on the host)
+    const int n2 = P.nlon >> 1, nR = P.nlon / R;
+    const double2_t* const ringp = reinterpret_cast<const double2_t*>(As) + wave * (kRingSlots * 64) + lane;   // + slot * 64
+    // all units of a wave lie in the same row tile: (wave + 8 q) & 3 = wave & 3
+    const int rt = wave & 3;
+    const double2_t* const prow = panel + rt * 16 + fr + fk * 64;        // + 256 p: k-step p of the flat class sequence
+    // Fragments of the next k-step of the flat (unit, k-step) sequence -> (T_, AB_): one more trig piece issued, the piece of
+    // this k-step waited for, ring slot and panel rows read.  Branch-free and unconditional (after the last k-step of the last
+    // unit it re-reads valid memory), so that hipcc keeps exact lgkmcnt counts across the loops: the MFMAs of k-step p then
+    // wait for their own fragments only (lgkmcnt(2)), not for the reads of k-step p + 1 issued just before them.
+    // The wait is always the strict one (all but the kRingDepth youngest operations done): stores of the previous epilogue
+    // that are still in flight are waited for too, which measured no different from counting them out.
+#define ROT_FETCH(T_, AB_)                                                                                \
+    do {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        rot_issue_piece(S, P, lane_off);                                                                  \
+        wait_vmcnt<kRingDepth>();                                                                         \
+        T_ = ringp[S.cslot * 64];                                                                         \
+        S.cslot = S.cslot + 1 == kRingSlots ? 0 : S.cslot + 1;                                            \
+        AB_ = prow[S.pf * 256];                                                                           \
+        S.pf = S.pf + 1 == P.npieces ? 0 : S.pf + 1;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    } while (0)
+#ifdef SHG_ROT_SETPRIO
+#define ROT_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define ROT_PRIO(x)
+#endif
+#define ROT_MFMA2(A0, T_, AB_)                                                                            \
+    ROT_PRIO(1);                                                                                          \
+    acc[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, acc[A0], 0, 0, 0);                        \
+    acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, acc[A0 + 1], 0, 0, 0);                \
+    ROT_PRIO(0)
+#define ROT_MFMA4(A0, T_, AB_)                                                                            \
+    ROT_PRIO(1);                                                                                          \
+    acc[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, acc[A0], 0, 0, 0);                        \
+    acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.y, acc[A0 + 1], 0, 0, 0);                \
+    acc[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, acc[A0 + 2], 0, 0, 0);                \
+    acc[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, acc[A0 + 3], 0, 0, 0);                \
+    ROT_PRIO(0)
+    // one class: k-steps in pairs on the register sets (tx, abx) / (ty, aby); the current fragments are in (tx, abx) on entry
+    // and on exit, the fragments of the next k-step are fetched before the MFMAs of the current one are issued
+#define ROT_CLASS(C, MF, A0)                                                                              \
+    {                                                                                                     \
+        const int nk_ = P.cls_nk[C];                                                                      \
+        int i_ = 0;                                                                                       \
+        for (; i_ + 2 <= nk_; i_ += 2) {                                                                  \
+            ROT_FETCH(ty, aby);                                                                           \
+            MF(A0, tx, abx);                                                                              \
+            ROT_FETCH(tx, abx);                                                                           \
+            MF(A0, ty, aby);                                                                              \
+        }                                                                                                 \
+        if (i_ < nk_) {                                                                                   \
+            ROT_FETCH(ty, aby);                                                                           \
+            MF(A0, tx, abx);                                                                              \
+            tx = ty;                                                                                      \
+            abx = aby;                                                                                    \
+        }                                                                                                 \
+    }
+    double2_t tx = S.tx, abx = S.abx, ty = {0.0, 0.0}, aby = {0.0, 0.0};
+    const int ct0 = wave >> 2;
+    for (int ct = ct0, q = 0; ct < P.nct; ct += 2, ++q) {
+        (void)q;
+        double4_t acc[T::kAcc];
+#pragma unroll
+        for (int a = 0; a < T::kAcc; ++a) acc[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        {
+            // order 0 does not depend on the longitude: start value of CA_0 (C/D layout: row = fk + 4 reg, all columns)
+            const double2_t* z = panel + P.nslot * 64 + rt * 16 + fk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][r] = z[4 * r].x;
+        }
+#pragma unroll
+        for (int c = 0; c < T::kClasses; ++c) {
+            if (c < T::kTwo) {
+                ROT_CLASS(c, ROT_MFMA2, 2 * c)
+            } else {
+                ROT_CLASS(c, ROT_MFMA4, 2 * T::kTwo + 4 * (c - T::kTwo))
+            }
+        }
+        ROT_STAMP(3 + 2 * min(q, 3));
+
+        // ---- epilogue: the 2 R images of every column, in place
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (!(P.dbg & 128)) rot_images<R>(acc, r);
+        const int b = bt * 4 + rt;
+        const bool epoch_ok = b < P.B && !(P.dbg & 1);
+        double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
+        {
+            // lanes (2 q, 2 q + 1) hold adjacent columns: after the exchange every lane owns two rows x two adjacent columns and
+            // stores 16 bytes.  Byte offset = lane part (row, column inside the tile) + wave-uniform part (image, column tile);
+            // lanes outside the grid carry an offset beyond the buffer and are dropped.
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Gb, 0, grid_bytes, 0x00020000);
+            const int par = fr & 1, ce = fr & ~1;
+            const int sa = fk + (par ? 8 : 0), sb = sa + 4;
+            const bool col_ok = epoch_ok && ct * 16 + ce < P.nd;
+            const unsigned row_a = col_ok && slot_valid(sa) ? (unsigned)grid_row(sa) * (unsigned)P.nlon * 8u : 0x80000000u;
+            const unsigned row_b = col_ok && slot_valid(sb) ? (unsigned)grid_row(sb) * (unsigned)P.nlon * 8u : 0x80000000u;
+            const unsigned asc = (unsigned)ce * 8u, desc = (unsigned)(14 - ce) * 8u;
+#pragma unroll
+            for (int t = 0; t < kImages; ++t) {
+                const int k = t < R ? t : t - R;
+                const bool ascending = t < R;
+                // first column of the tile's run: s = +1: (n2 + k nR) mod nlon + 16 ct;  s = -1: (n2 + k nR - nd) mod nlon + nd - 16 ct - 16
+                int w = n2 + k * nR - (ascending ? 0 : P.nd);
+                w = w >= P.nlon ? w - P.nlon : w;
+                const int soff = (ascending ? w + 16 * ct : w + P.nd - 16 * ct - 16) * 8;
+                double a_lo = acc[t][0], a_hi = acc[t][2], b_lo = acc[t][1], b_hi = acc[t][3];
+                if (!(P.dbg & 256)) {
+                    pair_exchange(acc[t][0], acc[t][2], 0xAAAAAAAAAAAAAAAAull, a_lo, a_hi);
+                    pair_exchange(acc[t][1], acc[t][3], 0xAAAAAAAAAAAAAAAAull, b_lo, b_hi);
+                }
+                const double2_t va = ascending ? (double2_t){a_lo, a_hi} : (double2_t){a_hi, a_lo};
+                const double2_t vb = ascending ? (double2_t){b_lo, b_hi} : (double2_t){b_hi, b_lo};
+                // The wave-uniform part goes into the vector offset, not into the scalar offset operand of the store: with a
+                // REGISTER soffset hipcc assumes that a 16-byte store's data registers may be overwritten by the very next VALU
+                // instruction (the documented exemption of the gfx9 store-data hazard) and schedules one there; on gfx950 that
+                // corrupted the low dword of the stored value in some lanes of some launches.
+                const unsigned lane_col = (ascending ? asc : desc) + (unsigned)soff;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, va), rsrc, row_a + lane_col, 0, SHG_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, vb), rsrc, row_b + lane_col, 0, SHG_STORE_AUX);
+            }
+        }
+        ROT_STAMP(4 + 2 * min(q, 3));
+    }
+    S.tx = tx;
+    S.abx = abx;
+#undef ROT_CLASS
+#undef ROT_MFMA2
+#undef ROT_MFMA4
+#undef ROT_FETCH
+}
+
 template <bool NS, int R>
 __global__ __launch_bounds__(512) void synthesis_rot_kernel(RotParams P) {
     using T = RotTraits<R>;
-    constexpr int kImages = 2 * R;
     extern __shared__ __attribute__((aligned(16))) double As[];   // rings [8][kRingSlots][64][2], then panel [nslot + 1][64 rows][2]
 
     const int tid = threadIdx.x;
@@ -178,8 +371,6 @@ __global__ __launch_bounds__(512) void synthesis_rot_kernel(RotParams P) {
     const int nbt = (P.B + 3) >> 2;
     const int bt = P.blockmap ? P.blockmap[2 * blockIdx.x] : (int)(blockIdx.x % nbt);
     const int it = P.blockmap ? P.blockmap[2 * blockIdx.x + 1] : (int)(blockIdx.x / nbt);
-    const int i0 = it * 16;                             // plain layout: first parallel of the block
-    const int i0n = it * 8;                             // NS layout: first northern parallel of the block
     const int fr = lane & 15, fk = lane >> 4;
     ROT_STAMP(0);
 
@@ -195,32 +386,12 @@ __global__ __launch_bounds__(512) void synthesis_rot_kernel(RotParams P) {
         }
     }
 
-    // ---- trig stream of this wave: units u = wave + 8 q, (row tile, column tile) = (u & 3, u >> 2); the pieces of unit q
-    //      are the npieces consecutive KB of column tile u >> 2.  The issue side runs kRingDepth pieces ahead of the consumer
-    //      and keeps issuing (re-reading the last piece) when the stream is exhausted, so that the count of DMAs in flight
-    //      is the same at every wait.
-    const int nunits = 4 * P.nct;
-    const int nq = wave < nunits ? (nunits - wave + 7) >> 3 : 0;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)As;
-    const unsigned ring_lds = lds0 + (unsigned)wave * (kRingSlots * 1024);
-    const unsigned lane_off = (unsigned)lane * 16u;
-    const size_t ct_stride = (size_t)P.npieces * 128;
-    const double* iptr = P.trig + (size_t)(nq > 0 ? wave >> 2 : 0) * ct_stride;
-    int ileft = P.npieces, iq = 0, islot = 0;
-    auto issue_piece = [&]() {
-        glds16(iptr, lane_off, ring_lds + (unsigned)islot * 1024u);
-        islot = islot + 1 == kRingSlots ? 0 : islot + 1;
-        if (ileft > 1) {
-            --ileft;
-            iptr += 128;
-        } else if (iq + 1 < nq) {
-            ++iq;
-            ileft = P.npieces;
-            iptr = P.trig + (size_t)((wave + 8 * iq) >> 2) * ct_stride;
-        }
-    };
+    // ---- trig stream of this wave.  The issue side runs kRingDepth pieces ahead of the consumer and never stops (when a wave has
+    //      no further column tile it re-reads pieces), so that the count of DMAs in flight is the same at every wait.
+    RotStream S;
+    rot_stream_init(S, P, As, wave);
 #pragma unroll
-    for (int d = 0; d < kRingDepth; ++d) issue_piece();
+    for (int d = 0; d < kRingDepth; ++d) rot_issue_piece(S, P, (unsigned)lane * 16u);
 
     // ---- phase 1: Legendre stage (see synthesis_fused.hip).  Orders are distributed over the 8 waves; the result of order m
     //      is written as one 16-byte pair (A_m, B'_m) per panel row.
@@ -310,145 +481,18 @@ __global__ __launch_bounds__(512) void synthesis_rot_kernel(RotParams P) {
     __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
     ROT_STAMP(2);
 
-    auto grid_row = [&](int s) { return NS ? (s < 8 ? i0n + s : P.nlat - 1 - (i0n + s - 8)) : i0 + s; };
-    auto slot_valid = [&](int s) { return NS ? i0n + (s & 7) < P.nh : i0 + s < P.nlat; };
-
     // ---- phase 2: longitude stage
-    const bool pair_stores = (P.nd & 1) == 0;
-    const int grid_bytes = P.nlat * P.nlon * 8;        // one epoch's grid; < 2^31 (checked on the host)
-    const int n2 = P.nlon >> 1, nR = P.nlon / R;
-    const double2_t* const ringp = reinterpret_cast<const double2_t*>(As) + wave * (kRingSlots * 64) + lane;   // + slot * 64
-    // all units of a wave lie in the same row tile: (wave + 8 q) & 3 = wave & 3
-    const int rt = wave & 3;
-    const double2_t* const prow = panel + rt * 16 + fr + fk * 64;        // + 256 p: k-step p of the flat class sequence
-    int cslot = 0, pf = 0;                                               // ring slot / k-step (inside its unit) of the next fetch
-    // Fragments of the next k-step of the flat (unit, k-step) sequence -> (T_, AB_): one more trig piece issued, the piece of
-    // this k-step waited for, ring slot and panel rows read.  Branch-free and unconditional (after the last k-step of the last
-    // unit it re-reads valid memory), so that hipcc keeps exact lgkmcnt counts across the loops: the MFMAs of k-step p then
-    // wait for their own fragments only (lgkmcnt(2)), not for the reads of k-step p + 1 issued just before them.
-    // The wait is always the strict one (all but the kRingDepth youngest operations done): stores of the previous epilogue
-    // that are still in flight are waited for too, which measured no different from counting them out.
-#define ROT_FETCH(T_, AB_)                                                                                \
-    do {                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        issue_piece();                                                                                    \
-        wait_vmcnt<kRingDepth>();                                                                         \
-        T_ = ringp[cslot * 64];                                                                           \
-        cslot = cslot + 1 == kRingSlots ? 0 : cslot + 1;                                                  \
-        AB_ = prow[pf * 256];                                                                             \
-        pf = pf + 1 == P.npieces ? 0 : pf + 1;                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-    } while (0)
-#define ROT_MFMA2(A0, T_, AB_)                                                                            \
-    acc[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, acc[A0], 0, 0, 0);                        \
-    acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, acc[A0 + 1], 0, 0, 0)
-#define ROT_MFMA4(A0, T_, AB_)                                                                            \
-    acc[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, acc[A0], 0, 0, 0);                        \
-    acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.y, acc[A0 + 1], 0, 0, 0);                \
-    acc[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, acc[A0 + 2], 0, 0, 0);                \
-    acc[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, acc[A0 + 3], 0, 0, 0)
-    // one class: k-steps in pairs on the register sets (tx, abx) / (ty, aby); the current fragments are in (tx, abx) on entry
-    // and on exit, the fragments of the next k-step are fetched before the MFMAs of the current one are issued
-#define ROT_CLASS(C, MF, A0)                                                                              \
-    {                                                                                                     \
-        const int nk_ = P.cls_nk[C];                                                                      \
-        int i_ = 0;                                                                                       \
-        for (; i_ + 2 <= nk_; i_ += 2) {                                                                  \
-            ROT_FETCH(ty, aby);                                                                           \
-            MF(A0, tx, abx);                                                                              \
-            ROT_FETCH(tx, abx);                                                                           \
-            MF(A0, ty, aby);                                                                              \
-        }                                                                                                 \
-        if (i_ < nk_) {                                                                                   \
-            ROT_FETCH(ty, aby);                                                                           \
-            MF(A0, tx, abx);                                                                              \
-            tx = ty;                                                                                      \
-            abx = aby;                                                                                    \
-        }                                                                                                 \
+    if ((wave >> 2) < P.nct && !(P.dbg & 4)) {
+        const double2_t* const ringp = reinterpret_cast<const double2_t*>(As) + wave * (kRingSlots * 64) + lane;
+        rot_issue_piece(S, P, (unsigned)lane * 16u);       // fragments of the first k-step
+        wait_vmcnt<kRingDepth>();
+        S.tx = ringp[0];
+        S.cslot = 1;
+        S.abx = panel[(wave & 3) * 16 + fr + fk * 64];
+        S.pf = P.npieces > 1 ? 1 : 0;
+        rot_phase2<NS, R>(P, As, panel, S, wave, lane, bt, it);
     }
-    double2_t tx = {0.0, 0.0}, abx = {0.0, 0.0}, ty = {0.0, 0.0}, aby = {0.0, 0.0};
-    if (nq > 0 && !(P.dbg & 4)) ROT_FETCH(tx, abx);
-    for (int q = 0; q < nq && !(P.dbg & 4); ++q) {
-        const int ct = (wave >> 2) + 2 * q;
-        double4_t acc[T::kAcc];
-#pragma unroll
-        for (int a = 0; a < T::kAcc; ++a) acc[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        {
-            // order 0 does not depend on the longitude: start value of CA_0 (C/D layout: row = fk + 4 reg, all columns)
-            const double2_t* z = panel + P.nslot * 64 + rt * 16 + fk;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[0][r] = z[4 * r].x;
-        }
-#pragma unroll
-        for (int c = 0; c < T::kClasses; ++c) {
-            if (c < T::kTwo) {
-                ROT_CLASS(c, ROT_MFMA2, 2 * c)
-            } else {
-                ROT_CLASS(c, ROT_MFMA4, 2 * T::kTwo + 4 * (c - T::kTwo))
-            }
-        }
-        ROT_STAMP(3 + 2 * min(q, 3));
-
-        // ---- epilogue: the 2 R images of every column, in place
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rot_images<R>(acc, r);
-        const int b = bt * 4 + rt;
-        const bool epoch_ok = b < P.B && !(P.dbg & 1);
-        double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
-        if (pair_stores) {
-            // lanes (2 q, 2 q + 1) hold adjacent columns: after the exchange every lane owns two rows x two adjacent columns and
-            // stores 16 bytes.  Byte offset = lane part (row, column inside the tile) + wave-uniform part (image, column tile);
-            // lanes outside the grid carry an offset beyond the buffer and are dropped.
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Gb, 0, grid_bytes, 0x00020000);
-            const int par = fr & 1, ce = fr & ~1;
-            const int sa = fk + (par ? 8 : 0), sb = sa + 4;
-            const bool col_ok = epoch_ok && ct * 16 + ce < P.nd;
-            const unsigned row_a = col_ok && slot_valid(sa) ? (unsigned)grid_row(sa) * (unsigned)P.nlon * 8u : 0x80000000u;
-            const unsigned row_b = col_ok && slot_valid(sb) ? (unsigned)grid_row(sb) * (unsigned)P.nlon * 8u : 0x80000000u;
-            const unsigned asc = (unsigned)ce * 8u, desc = (unsigned)(14 - ce) * 8u;
-#pragma unroll
-            for (int t = 0; t < kImages; ++t) {
-                const int k = t < R ? t : t - R;
-                const bool ascending = t < R;
-                // first column of the tile's run: s = +1: (n2 + k nR) mod nlon + 16 ct;  s = -1: (n2 + k nR - nd) mod nlon + nd - 16 ct - 16
-                int w = n2 + k * nR - (ascending ? 0 : P.nd);
-                w = w >= P.nlon ? w - P.nlon : w;
-                const int soff = (ascending ? w + 16 * ct : w + P.nd - 16 * ct - 16) * 8;
-                double a_lo, a_hi, b_lo, b_hi;
-                pair_exchange(acc[t][0], acc[t][2], 0xAAAAAAAAAAAAAAAAull, a_lo, a_hi);
-                pair_exchange(acc[t][1], acc[t][3], 0xAAAAAAAAAAAAAAAAull, b_lo, b_hi);
-                const double2_t va = ascending ? (double2_t){a_lo, a_hi} : (double2_t){a_hi, a_lo};
-                const double2_t vb = ascending ? (double2_t){b_lo, b_hi} : (double2_t){b_hi, b_lo};
-                // The wave-uniform part goes into the vector offset, not into the scalar offset operand of the store: with a
-                // REGISTER soffset hipcc assumes that a 16-byte store's data registers may be overwritten by the very next VALU
-                // instruction (the documented exemption of the gfx9 store-data hazard) and schedules one there; on gfx950 that
-                // corrupted the low dword of the stored value in some lanes of some launches.
-                const unsigned lane_col = (ascending ? asc : desc) + (unsigned)soff;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, va), rsrc, row_a + lane_col, 0, SHG_STORE_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, vb), rsrc, row_b + lane_col, 0, SHG_STORE_AUX);
-            }
-        } else {
-            const int c = ct * 16 + fr;
-            if (epoch_ok && c < P.nd) {
-#pragma unroll
-                for (int t = 0; t < kImages; ++t) {
-                    const int k = t < R ? t : t - R;
-                    int w = n2 + k * nR - (t < R ? 0 : P.nd);
-                    w = w >= P.nlon ? w - P.nlon : w;
-                    const int j = t < R ? w + c : w + P.nd - 1 - c;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (slot_valid(fk + 4 * r)) Gb[(size_t)grid_row(fk + 4 * r) * P.nlon + j] = acc[t][r];
-                }
-            }
-        }
-        ROT_STAMP(4 + 2 * min(q, 3));
-    }
-#undef ROT_CLASS
-#undef ROT_MFMA2
-#undef ROT_MFMA4
-#undef ROT_FETCH
-    wait_vmcnt<0>();          // the prefetched pieces of the (padded) stream must have landed before the LDS is released
+    wait_vmcnt<0>();          // the prefetched pieces of the stream must have landed before the LDS is released
     ROT_STAMP(12);
 }
 
@@ -477,7 +521,7 @@ int rot_sigma_negative(int R, int m) { return R > 0 && 2 * (m % R) > R ? 1 : 0; 
 // s mu_c + 2 pi k / R of the fundamental domain mu_c = lon[nlon/2 + c] is a grid column.
 bool has_rotation_symmetry(int nlon, const double* lon, int R) {
     if (nlon < 192 || nlon % (2 * R) != 0 || nlon % 2 != 0) return false;
-    if ((nlon / R) % 16 != 0) return false;              // images of a column tile = whole 128-byte lines
+    if ((nlon / R) % 16 != 0) return false;              // images of a column tile = whole 128-byte lines (nd = nlon / (2 R) is then even: 16-byte pair stores)
     const double tol = 3e-15;
     const long double pi = 3.141592653589793238462643383279502884L;
     const int n2 = nlon / 2, nR = nlon / R, nd = nlon / (2 * R);
@@ -523,10 +567,10 @@ int rot_layout(int R, int N, int nk[kMaxClasses], int cnt[kMaxClasses], std::vec
     return s;
 }
 
-static size_t rot_lds_bytes(int nslot) { return (size_t)kRingDoubles * 8 + (size_t)(nslot + 1) * 1024; }
+static size_t rot_lds_bytes(int nslot) { return (size_t)kRingDoubles * 8 + (size_t)(nslot + 1) * 1024; }      // rings, panel
 
 int rot_applicable(const shg_plan* p) {
-    if (p->rotR == 0) return 0;
+    if (p->rotR == 0 || p->N < 1) return 0;
     if ((long long)p->nlat * p->nlon * 8 >= (1LL << 31)) return 0;
     int nk[kMaxClasses], cnt[kMaxClasses];
     const int nslot = rot_layout(p->rotR, p->N, nk, cnt, nullptr);
@@ -617,6 +661,7 @@ int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream
     const dim3 grid_dim((unsigned)(nbt * nit));
     ProfileScope ps(p, 2, stream);
     rc = R == 6 ? launch_rot<6>(p, ns, P, lds, grid_dim, stream) : launch_rot<3>(p, ns, P, lds, grid_dim, stream);
+
     if (rc) return rc;
     SHG_HIP(hipGetLastError());
     return SHG_OK;

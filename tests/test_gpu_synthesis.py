@@ -204,8 +204,8 @@ def test_fused_and_staged_paths(N, dlon, dlat):
     assert plan.info()['fourfold_symmetry'] and plan.info()['fused']
     assert plan.info()['north_south_symmetry'] == (grid.parallels.size % 2 == 0)
     fused32_ok = plan.info()['north_south_symmetry'] and plan.info()['k_slots'] * 48 * 8 <= 160 * 1024
-    for path in ('fused', 'fused_plain', 'fused32', 'panel', 'staged'):
-        if path == 'fused32' and not fused32_ok:
+    for path in ('fused', 'fused_plain', 'fused32', 'staged', 'rot', 'rot_plain', 'auto'):
+        if (path == 'fused32' and not fused32_ok) or (path in ('rot', 'rot_plain') and not plan.info()['rotation_symmetry']):
             with pytest.raises(ga._lib.ShgError):
                 plan.set_path(path)
             continue
@@ -214,6 +214,58 @@ def test_fused_and_staged_paths(N, dlon, dlat):
         for nb in (1, 3, 4, 5, 7):
             out = ga.engine.to_host(plan.synthesis(batch[0:nb]))
             assert relerr(out, ref[0:nb]) < TOL, (path, nb)
+
+
+@pytest.mark.parametrize('N,nlon,nlat,B', [(96, 1440, 720, 5), (96, 1440, 18, 9), (31, 1440, 36, 4), (6, 1440, 16, 1), (1, 2880, 8, 2), (2, 192, 6, 3),
+                                          (45, 192, 90, 6), (60, 720, 360, 5), (96, 720, 10, 8), (17, 240, 120, 3), (100, 480, 24, 4)])
+def test_rotation_folded_kernel(N, nlon, nlat, B):
+    """The rotation-folded kernel (12 images per column where nlon % 96 == 0, 6 where nlon % 48 == 0) against the oracle: long and
+    short class lists (padding slots), partial column tiles, a single column tile (waves without work), ragged batch sizes."""
+    grid = ga.grid.GeographicGrid(360.0 / nlon, 180.0 / nlat)
+    ker = orc.KernelTable('ewh', love())
+    batch = np.stack([inputs.coefficients(4000 + N * 10 + e, N) for e in range(B)])
+    nref = min(B, 3)
+    ref = np.stack([orc.synthesis_regular(batch[e], grid.meridians, grid.parallels, ker) for e in range(nref)])
+    plan = ga.engine.Plan(N, *_tables(grid, N, 'ewh'))
+    info = plan.info()
+    assert info['rotation_symmetry'] and info['fused'] and info['north_south_symmetry']
+    outs = {}
+    for path in ('auto', 'rot', 'rot_plain', 'fused'):
+        plan.set_path(path)
+        outs[path] = ga.engine.to_host(plan.synthesis(batch))
+        assert relerr(outs[path][0:nref], ref) < TOL, path
+    assert np.array_equal(outs['auto'], outs['rot'])                    # the automatic choice is this kernel
+    assert relerr(outs['rot'], outs['fused']) < TOL                     # all epochs against the 4-fold kernel
+    plan.set_path('rot')
+    for nb in (1, 2, 3):                                                # partial epoch tiles: bit-identical to the full batch
+        if nb < B:
+            assert np.array_equal(ga.engine.to_host(plan.synthesis(batch[0:nb])), outs['rot'][0:nb])
+
+
+def test_rotation_folded_kernel_applicability():
+    pot = orc.KernelTable('potential')
+    # parallels without the north-south symmetry: plain variant; meridians off the equi-angular raster: other kernels
+    mer = np.linspace(-np.pi, np.pi, 480, endpoint=False) + np.pi / 480
+    par = np.linspace(1.4, -1.1, 37)
+    anm = inputs.coefficients(77, 40)
+    grid = ga.grid.RegularGrid(mer, par)
+    plan = ga.engine.Plan(40, *_tables(grid, 40, 'potential'))
+    assert plan.info()['rotation_symmetry'] and not plan.info()['north_south_symmetry']
+    ref = orc.synthesis_regular(anm, mer, par, pot)
+    for path in ('auto', 'rot', 'fused'):
+        plan.set_path(path)
+        assert relerr(ga.engine.to_host(plan.synthesis(anm)), ref) < TOL, path
+    shifted = ga.engine.Plan(40, *_tables(ga.grid.RegularGrid(mer + 1e-9, par), 40, 'potential'))
+    assert not shifted.info()['rotation_symmetry']
+    with pytest.raises(ga._lib.ShgError):
+        shifted.set_path('rot')
+    for nlon in (360, 180, 1000):                        # nlon / R not a multiple of 16 for R = 6 and R = 3
+        g = ga.grid.GeographicGrid(360.0 / nlon, 5.0)
+        assert not ga.engine.Plan(10, *_tables(g, 10, 'potential')).info()['rotation_symmetry']
+    high = ga.engine.Plan(120, *_tables(ga.grid.GeographicGrid(0.5, 2.0), 120, 'potential'))       # panel beyond the LDS
+    assert not high.info()['rotation_symmetry']
+    with pytest.raises(ga._lib.ShgError):
+        high.set_path('rot')
 
 
 def test_fused_path_limits():
