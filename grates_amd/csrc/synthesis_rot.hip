@@ -257,11 +257,13 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
 #define ROT_MFMA2(A0, T_, AB_)                                                                            \
     ROT_PRIO(1);                                                                                          \
     acc[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, acc[A0], 0, 0, 0);                        \
+    ROT_PRIO(2);                                                                                          \
     acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, acc[A0 + 1], 0, 0, 0);                \
     ROT_PRIO(0)
 #define ROT_MFMA4(A0, T_, AB_)                                                                            \
     ROT_PRIO(1);                                                                                          \
     acc[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, acc[A0], 0, 0, 0);                        \
+    ROT_PRIO(2);                                                                                          \
     acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.y, acc[A0 + 1], 0, 0, 0);                \
     acc[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, acc[A0 + 2], 0, 0, 0);                \
     acc[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, acc[A0 + 3], 0, 0, 0);                \
