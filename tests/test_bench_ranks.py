@@ -1,0 +1,148 @@
+"""
+bench.py's rank function under gloo with world size 2 on the CPU: epoch-sharded synthesis timing, the covariance leg over
+real latitude bands (grates_amd.distributed.latitude_bands) with the all_gather of the per-band sigma, max-over-ranks
+timing, one JSON line on rank 0 -- and the launcher that `python bench.py --gpus N` uses when no launcher started it.
+The GPU work is replaced by a stand-in workload of the same interface (bench.GpuWorkload): the kernels themselves are
+covered by the -m gpu tests, here the multi-rank plumbing of the benchmark is.
+"""
+
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+class StubWorkload:
+    """CPU stand-in with the interface of bench.GpuWorkload; sigma(i, j) = sqrt(1 + i * nlon + j) for grid point (i, j)."""
+    device = 'cpu'
+
+    def __init__(self, args, rank, world, local_rank):
+        self.args, self.rank, self.world = args, rank, world
+        self.steps_done = 0
+
+    def synchronize(self):
+        pass
+
+    def setup_synthesis(self):
+        self.nlat, self.nlon = 12, 24
+        self.kernel_name = 'stub_kernel'
+        self.config = {'stub': True}
+        self.x = torch.ones(1000, dtype=torch.float64)
+
+    def synthesis_step(self):
+        self.x = self.x * 1.0000001
+        self.steps_done += 1
+
+    def profile(self, enable):
+        self.profiling = enable
+        self.mark = self.steps_done
+
+    def profile_read(self):
+        n = self.steps_done - self.mark
+        self.mark = self.steps_done
+        return {'lon_stage': (0.5 * n, n)} if n else {}
+
+    def release_synthesis(self):
+        del self.x
+
+    def cpu_baseline(self, sample):
+        return {'value': 1.0, 'unit': 'solutions/s', 'cores': 1, 'kind': 'port', 'sample': 'stub'}
+
+    def setup_covariance(self):
+        self.cov_nlat, self.cov_nlon, self.P = 7, 5, 9
+        self.cov_recipe = 'stub'
+        self.cov_calls = 0
+
+    def covariance_band(self, lat0, lat1, **kw):
+        self.cov_calls += 1
+        return torch.sqrt(1.0 + torch.arange(lat0 * self.cov_nlon, lat1 * self.cov_nlon, dtype=torch.float64))
+
+    def cov_profile(self, enable):
+        self.cov_mark = self.cov_calls
+
+    def cov_profile_read(self):
+        n = self.cov_calls - self.cov_mark
+        self.cov_mark = self.cov_calls
+        return {'covprop': (2.0 * n, n)} if n else {}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    args = bench.parse_args(['--gpus', str(world), '--steps', '4', '--warmup', '2', '--ramp', '3', '--epochs', '6', '--backend', 'gloo',
+                             '--cov-repeats', '2'])
+    lines = []
+    result = bench.run_rank(args, workload_factory=StubWorkload, emit=lines.append)
+    assert (result is not None) == (rank == 0) and len(lines) == (1 if rank == 0 else 0)
+    if rank == 0:
+        with open(os.path.join(out_dir, 'line.json'), 'w') as f:
+            f.write(lines[0])
+
+
+def _expected_sigma():
+    return torch.sqrt(1.0 + torch.arange(7 * 5, dtype=torch.float64)).numpy()       # the stand-in's own arithmetic
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_rank_function_gloo(world, tmp_path):
+    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    line = json.loads(open(tmp_path / 'line.json').read())
+    assert line['metric'] == bench.METRIC and line['unit'] == 'solutions/s' and line['n_gpus'] == world
+    assert line['steps'] == 4 and line['warmup'] == 2 and line['scaling'] == 'weak' and line['dtype'] == 'f64'
+    assert line['value'] == pytest.approx(world * 6 * 4 / (line['ms_per_step'] * 4e-3))        # whole-job aggregate over all ranks
+    assert line['value_without_ramp'] > 0 and line['cpu_baseline'] is None                    # the CPU baseline runs at N = 1 only
+    assert line['roofline']['bound'] == 'hbm' and line['roofline']['avg_launch_ms'] == pytest.approx(0.5)
+    cov = line['covariance']
+    assert cov['n_gpus'] == world and cov['config']['repeats'] == 2 and len(cov['seconds_all']) == 2
+    # the gathered grid is the full grid whatever the number of bands (7 parallels: unequal bands)
+    assert cov['sigma_checksum'] == pytest.approx(_expected_sigma().sum(), rel=0, abs=1e-12)
+    import zlib
+    assert cov['sigma_crc32'] == zlib.crc32(_expected_sigma().tobytes()) & 0xffffffff
+
+
+def test_rank_function_single_process(monkeypatch):
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    args = bench.parse_args(['--steps', '3', '--warmup', '1', '--ramp', '0', '--epochs', '5', '--cov-repeats', '3'])
+    lines = []
+    line = bench.run_rank(args, workload_factory=StubWorkload, emit=lines.append)
+    assert json.loads(lines[0]) == json.loads(json.dumps(line))
+    assert line['n_gpus'] == 1 and line['cpu_baseline']['kind'] == 'port'
+    assert line['covariance']['sigma_checksum'] == pytest.approx(_expected_sigma().sum(), rel=0, abs=1e-12)
+    assert line['covariance']['seconds_min'] <= line['covariance']['seconds_median']
+
+
+def test_bare_multi_gpu_invocation_launches_ranks(monkeypatch):
+    """`python bench.py --gpus 2` with no launcher: a torch.distributed.run child is started and nothing else happens here."""
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    calls = []
+    monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.main(['--gpus', '2', '--steps', '5', '--warmup', '1'])
+    assert e.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '2'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and os.path.basename(cmd[cmd.index('--master-port') + 2]) == 'bench.py'
+    assert cmd[-6:] == ['--gpus', '2', '--steps', '5', '--warmup', '1'] and env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # under a launcher (RANK set) the same command line is a rank, not a launcher
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    with pytest.raises(SystemExit) as e:
+        bench.main(['--gpus', '2'])
+    assert 'WORLD_SIZE' in str(e.value.code) and len(calls) == 1
