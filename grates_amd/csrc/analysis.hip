@@ -200,6 +200,7 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     if (B == 0) return SHG_OK;
     SHG_REQUIRE(grid && area && anm, "shg_analysis: NULL pointer");
     hipStream_t stream = (hipStream_t)stream_;
+    PlanGuard guard(p, stream);
     const int N = p->N, S = 2 * N + 1, nlat = p->nlat, nlon = p->nlon;
     int rc = build_pk_table(p, stream);
     if (rc) return rc;

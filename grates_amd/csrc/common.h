@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "../../include/shg.h"
@@ -150,6 +151,12 @@ struct shg_plan {
     int ana_nmin = -1;
     int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 4 the same without the north-south symmetry, 5 fused kernel with 32-row panels (two workgroups per CU), 6 rotation-folded fused kernel, 7 the same without the north-south symmetry
 
+    // users of the plan are serialised (PlanGuard): its tables are built lazily and its workspaces are per plan, not per stream
+    std::mutex mtx;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+    hipEvent_t order_event = nullptr;
+
     // optional per-kernel event timing (shg_plan_profile)
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;    // pairs (start, stop)
@@ -172,6 +179,28 @@ int build_rot_trig(shg_plan* p, const double* lon_h);
 int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 int fused32_applicable(const shg_plan* p);
 int synthesis_fused32(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
+
+// Entry points that work on a plan hold this for their duration: one host thread at a time, and a call on another stream than
+// the previous one first waits (on the device) for everything that call has enqueued -- two streams or threads sharing a cached
+// plan can then not overwrite each other's packed coefficients, panels or partial sums, and a reallocation never frees a
+// buffer another stream still reads.  No cost while the stream stays the same.
+struct PlanGuard {
+    shg_plan* p;
+    std::unique_lock<std::mutex> lock;
+    PlanGuard(shg_plan* plan, hipStream_t stream) : p(plan), lock(plan->mtx) {
+        if (p->used && p->last_stream != stream) {
+            bool ordered = false;
+            if (p->order_event || hipEventCreateWithFlags(&p->order_event, hipEventDisableTiming) == hipSuccess)
+                ordered = hipEventRecord(p->order_event, p->last_stream) == hipSuccess && hipStreamWaitEvent(stream, p->order_event, 0) == hipSuccess;
+            if (!ordered) {                      // e.g. the previous stream no longer exists
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+            }
+        }
+        p->last_stream = stream;
+        p->used = true;
+    }
+};
 
 // RAII event pair around one kernel launch (no-op unless profiling is enabled on the plan)
 struct ProfileScope {

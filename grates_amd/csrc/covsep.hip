@@ -116,6 +116,7 @@ static int covprop_diag_separable(shg_plan* p, const double* cov, int nmin, int 
     if (nb == 0) return SHG_OK;
     SHG_REQUIRE(sigma != nullptr, "shg_covprop_diag_separable: NULL output");
     hipStream_t stream = (hipStream_t)stream_;
+    PlanGuard guard(p, stream);
     const int N = p->N, S = 2 * N + 1, nlon = p->nlon;
     const int Pn = (N + 1) * (N + 1) - nmin * nmin;
     if (Pn == 0) {

@@ -94,6 +94,9 @@ extern "C" int shg_orderwise_filter(const double* blocks_packed, const int64_t* 
     SHG_REQUIRE(blocks_packed && block_off && anm_in && anm_out, "shg_orderwise_filter: NULL pointer");
     SHG_REQUIRE(anm_in != anm_out, "shg_orderwise_filter: in-place operation is not supported");
     const size_t lds = (size_t)(N + 1) * kFiltEpochs * sizeof(double);
+    // the coefficient vectors of an order for 64 epochs sit in LDS: 64 KB by default, up to the 160 KB of a CU on request
+    SHG_REQUIRE(lds <= 160 * 1024, "shg_orderwise_filter: degree %d exceeds the LDS staging of the block kernel (max degree 319)", N);
+    if (lds > 64 * 1024) SHG_HIP(hipFuncSetAttribute((const void*)orderwise_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(orderwise_filter_kernel, dim3(2 * N + 1, ceil_div(B, kFiltEpochs)), dim3(1024), lds, (hipStream_t)stream_, Nb, N, B,
                        blocks_packed, (const long long*)block_off, anm_in, anm_out);
     SHG_HIP(hipGetLastError());

@@ -622,6 +622,7 @@ static int covprop_diag_impl(shg_plan* p, const double* cov, int nmin, int lat0,
     if (lat0 == lat1) return SHG_OK;
     SHG_REQUIRE(sigma != nullptr, "shg_covprop_diag: NULL output");
     hipStream_t stream = (hipStream_t)stream_;
+    PlanGuard guard(p, stream);
     const int Pfull = (p->N + 1) * (p->N + 1);
     const int Pn = Pfull - nmin * nmin;
     const long long M = (long long)(lat1 - lat0) * p->nlon;

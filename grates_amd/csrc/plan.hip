@@ -319,6 +319,7 @@ extern "C" int shg_plan_destroy(shg_plan* p) {
     for (double* q : ptrs)
         if (q) (void)hipFree(q);
     for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
+    if (p->order_event) (void)hipEventDestroy(p->order_event);
     delete p;
     return SHG_OK;
 }

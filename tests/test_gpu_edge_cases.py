@@ -87,3 +87,48 @@ def test_plan_reuse_and_cache():
     assert len(ga.engine._plan_cache) == n_plans + 1 and not np.allclose(a, c)
     ga.engine.clear_plan_cache()
     np.testing.assert_array_equal(gf.to_grid(grid, 'ewh').value_array, a)
+
+
+def test_shared_plan_on_two_streams_and_threads():
+    """A cached plan used from two torch streams and from two host threads: calls on a new stream wait for the
+    previous user's work on the device, host threads are serialised -- neither the workspaces nor the lazily built tables race."""
+    import threading
+    import torch
+    grid = ga.grid.GeographicGrid(0.5, 1.0)                    # rotation-folded kernel
+    N = 40
+    plan = ga.engine.Plan(N, *tables(grid, N, 'ewh'))
+    ker = orc.KernelTable('ewh', ga.data.load_love_numbers()[0])
+    batches = [np.stack([inputs.coefficients(3000 + 10 * s + e, N) for e in range(6)]) for s in range(2)]
+    refs = [np.stack([orc.synthesis_regular(b[e], grid.meridians, grid.parallels, ker) for e in (0, 5)]) for b in batches]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    dev = [torch.from_numpy(b).cuda() for b in batches]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for rep in range(20):                                      # alternate the streams call by call, different batch sizes
+        for s in (0, 1):
+            with torch.cuda.stream(streams[s]):
+                outs[s].append(plan.synthesis(dev[s][0:6 - (rep % 3)]))
+    torch.cuda.synchronize()
+    for s in (0, 1):
+        for rep, o in enumerate(outs[s]):
+            got = ga.engine.to_host(o)
+            assert relerr(got[0], refs[s][0]) < 1e-12, (s, rep)
+            if got.shape[0] == 6:
+                assert relerr(got[5], refs[s][1]) < 1e-12, (s, rep)
+
+    results = {}
+
+    def worker(s):
+        with torch.cuda.stream(streams[s]):
+            acc = [plan.synthesis(dev[s]) for _ in range(10)]
+            streams[s].synchronize()
+            results[s] = [ga.engine.to_host(a) for a in acc]
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for s in (0, 1):
+        for got in results[s]:
+            assert relerr(got[[0, 5]], refs[s]) < 1e-12

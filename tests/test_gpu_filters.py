@@ -83,16 +83,33 @@ def test_general_matrix_filter(golden):
         assert relerr(res[e], orc.general_matrix_filter(batch[e], W, 2, 20)) < TOL
 
 
+def test_orderwise_filter_above_degree_127():
+    """Blocks up to d/o 180: the 64-epoch LDS staging of the block kernel exceeds the 64 KB default (up to degree 319 it fits
+    the 160 KB of a CU; beyond that the kernel refuses)."""
+    nmax, T = 180, 70
+    normals = inputs.orderwise_normal_blocks(48, nmax)
+    blocks = orc.ddk_blocks(normals, 5)
+    flt = ga.filter.OrderWiseFilter(blocks)
+    batch = np.stack([inputs.coefficients(650 + e, nmax) for e in range(T)])
+    out = ga.engine.to_host(flt.filter_batch(batch))
+    for e in (0, 33, 69):
+        assert relerr(out[e], orc.orderwise_filter(batch[e], blocks)) < TOL
+    low = np.stack([inputs.coefficients(660 + e, 150) for e in range(3)])       # a field of lower degree than the blocks
+    out_low = ga.engine.to_host(flt.filter_batch(low))
+    assert relerr(out_low[2], orc.orderwise_filter(low[2], blocks)) < TOL
+
+
 def test_config3_ddk5_time_series_d120():
-    """BASELINE config 3: DDK5-type filter applied to a d/o-120 time series, block form vs full-matrix multiply."""
-    nmax, T = 120, 24
+    """BASELINE config 3 at its stated size: DDK5-type filter applied to a d/o-120 series of 240 epochs, block form vs
+    full-matrix multiply (14637 x 14637 x 240), both against the oracle on sample epochs."""
+    nmax, T = 120, 240
     normals = inputs.orderwise_normal_blocks(44, nmax)
     blocks = orc.ddk_blocks(normals, 5)
     flt = ga.filter.OrderWiseFilter(blocks)
     batch = np.stack([inputs.coefficients(600 + e, nmax) for e in range(T)])
     batch[:, 0:2, 0:2] = 0.0          # GRACE-type series carry no degree 0 / 1; the dense form ignores them as inputs
     out_blocks = ga.engine.to_host(flt.filter_batch(batch))
-    for e in (0, 11, 23):
+    for e in (0, 11, 127, 239):
         assert relerr(out_blocks[e], orc.orderwise_filter(batch[e], blocks)) < TOL
     dense = ga.filter.GeneralMatrix(flt.matrix(2, nmax), 2, nmax)             # 14637 x 14637 full normal-type matrix
     out_dense = ga.engine.to_host(dense.filter_batch(batch))
