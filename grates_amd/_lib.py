@@ -57,6 +57,9 @@ PROTOTYPES = {
     'shg_potrf': [ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
     'shg_trtri': [ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
     'shg_analysis': [c_plan_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_synthesis_matrix': [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_analysis_matrix': [c_plan_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_congruence': [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
 }
 STRING_GETTERS = ('shg_last_error', 'shg_version')
 

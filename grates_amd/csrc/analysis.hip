@@ -114,32 +114,30 @@ __global__ void analysis_scatter_kernel(int N, int nmin, int nb, int b0, const d
     out[sine ? (size_t)(m - 1) * (N + 1) + n : (size_t)n * (N + 1) + m] = X[((size_t)s * (N + 1) + a) * nb + b];
 }
 
-// two checksums of the S x nlat weight table (plain sum and index-weighted sum): key of the operator cache
-constexpr int kChecksumBlocks = 64;
-// two position-weighted sums of the area weights, per workgroup (fixed order; the host adds the 64 partial pairs): the key of
-// the cached analysis operator
-__global__ __launch_bounds__(256) void analysis_checksum_kernel(long long n, const double* __restrict__ w, double* __restrict__ out) {
-    __shared__ double r0[256], r1[256];
-    double s0 = 0.0, s1 = 0.0;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)kChecksumBlocks * 256) {
-        const double x = w[e];
-        s0 += x;
-        s1 += x * (double)(1 + (e % 1021));
-    }
-    r0[threadIdx.x] = s0;
-    r1[threadIdx.x] = s1;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if ((int)threadIdx.x < k) {
-            r0[threadIdx.x] += r0[threadIdx.x + k];
-            r1[threadIdx.x] += r1[threadIdx.x + k];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out[2 * blockIdx.x] = r0[0];
-        out[2 * blockIdx.x + 1] = r1[0];
-    }
+// number of entries in which the area weights differ from the ones the cached operator was built for (bitwise compare)
+__global__ __launch_bounds__(256) void analysis_compare_kernel(long long n, const double* __restrict__ a, const double* __restrict__ b,
+                                                               int* __restrict__ diff) {
+    int d = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256)
+        d |= __builtin_bit_cast(long long, a[e]) != __builtin_bit_cast(long long, b[e]) ? 1 : 0;
+    if (d) atomicOr(diff, 1);
+}
+
+// F[row(s, a)][(i, j)] = H_s[a][i] area[i][j] T_s(lon_j): the dense analysis operator in degree-wise row order
+// (grates/grid.py:698-730 assembles it order by order from M x (N + 1 - m) design matrices)
+__global__ __launch_bounds__(256) void analysis_matrix_kernel(int N, int nmin, int nlat, int nlon, const double* __restrict__ H,
+                                                              const double* __restrict__ area, const double* __restrict__ cs,
+                                                              double* __restrict__ F) {
+    const int i = blockIdx.x, a = blockIdx.y, s = blockIdx.z;
+    const int m = (s + 1) >> 1;
+    const bool sine = s > 0 && (s & 1) == 0;
+    const int n0 = max(m, nmin);
+    if (a >= N + 1 - n0) return;
+    const int n = n0 + a;
+    const size_t row = (size_t)n * n - (size_t)nmin * nmin + (m == 0 ? 0 : 2 * m - 1 + (sine ? 1 : 0));
+    const double h = H[((size_t)s * (N + 1) + a) * nlat + i];
+    double* out = F + row * ((size_t)nlat * nlon) + (size_t)i * nlon;
+    for (int j = threadIdx.x; j < nlon; j += 256) out[j] = h * area[(size_t)i * nlon + j] * cs[(size_t)s * nlon + j];
 }
 
 // builds p->ana_H for the weights w2 (device, [S][nlat]); returns SHG_ERR_INVALID if a normal matrix is not positive definite
@@ -153,8 +151,11 @@ static int build_analysis_operator(shg_plan* p, const double* w2, int nmin, hipS
         workspace_alloc((void**)&nmat, (size_t)S * R * R * sizeof(double), stream) != hipSuccess ||
         workspace_alloc((void**)&uinv, (size_t)S * R * R * sizeof(double), stream) != hipSuccess ||
         workspace_alloc((void**)&work, ((size_t)R * R + 128 * 128) * sizeof(double), stream) != hipSuccess ||
-        workspace_alloc((void**)&info, sizeof(int), stream) != hipSuccess)
+        workspace_alloc((void**)&info, sizeof(int), stream) != hipSuccess) {
+        for (void* q : {(void*)pks, (void*)pkw, (void*)nmat, (void*)uinv, (void*)work, (void*)info})
+            if (q) (void)hipFreeAsync(q, stream);
         return fail(SHG_ERR_NOMEM, "analysis operator workspace allocation failed");
+    }
     SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
     hipLaunchKernelGGL(analysis_gather_kernel, dim3(ceil_div(nlat, 128), R, S), dim3(128), 0, stream, N, nmin, nlat, p->ldlat, p->pk, w2, pks, pkw);
     // normal matrices N_s = PKw_s PKs_s^T
@@ -194,6 +195,59 @@ static int build_analysis_operator(shg_plan* p, const double* w2, int nmin, hipS
 
 using namespace shg;
 
+// The cached operator H (p->ana_H) for these area weights and this minimum degree; rebuilt when either differs from what it
+// was built for.  The weights are compared entry by entry on the device with the copy kept beside the operator.
+static int ensure_analysis_operator(shg_plan* p, const double* area, int nmin, hipStream_t stream) {
+    const int N = p->N, S = 2 * N + 1, nlat = p->nlat, nlon = p->nlon;
+    const size_t na = (size_t)nlat * nlon;
+    int rc = build_pk_table(p, stream);
+    if (rc) return rc;
+    rc = covprop_build_cs_table(p, stream);
+    if (rc) return rc;
+    bool valid = p->ana_H && p->ana_area && p->ana_nmin == nmin;
+    if (valid) {
+        int* diff = nullptr;
+        if (workspace_alloc((void**)&diff, sizeof(int), stream) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
+        int host = 0;
+        hipError_t e = hipMemsetAsync(diff, 0, sizeof(int), stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(analysis_compare_kernel, dim3(256), dim3(256), 0, stream, (long long)na, area, p->ana_area, diff);
+            e = hipMemcpyAsync(&host, diff, sizeof(int), hipMemcpyDeviceToHost, stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFreeAsync(diff, stream);
+        if (e != hipSuccess) return fail(SHG_ERR_HIP, "shg_analysis: weight comparison failed: %s", hipGetErrorString(e));
+        valid = host == 0;
+    }
+    if (valid) return SHG_OK;
+    p->ana_nmin = -1;
+    if (!p->ana_area && hipMalloc((void**)&p->ana_area, na * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "analysis weight copy allocation failed");
+    double* w2 = nullptr;
+    if (workspace_alloc((void**)&w2, (size_t)S * nlat * sizeof(double), stream) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
+    hipLaunchKernelGGL(weight_squares_kernel, dim3(nlat), dim3(256), 0, stream, S, nlat, nlon, area, p->cs_slot, w2);
+    rc = build_analysis_operator(p, w2, nmin, stream);
+    (void)hipFreeAsync(w2, stream);
+    if (rc) return rc;
+    SHG_HIP(hipMemcpyAsync(p->ana_area, area, na * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    p->ana_nmin = nmin;
+    return SHG_OK;
+}
+
+extern "C" int shg_analysis_matrix(shg_plan* p, const double* area, int nmin, double* F, void* stream_) {
+    SHG_REQUIRE(p != nullptr, "shg_analysis_matrix: NULL plan");
+    SHG_REQUIRE(nmin >= 0 && nmin <= p->N, "shg_analysis_matrix: min_degree %d out of range", nmin);
+    SHG_REQUIRE(area && F, "shg_analysis_matrix: NULL pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    PlanGuard guard(p, stream);
+    const int rc = ensure_analysis_operator(p, area, nmin, stream);
+    if (rc) return rc;
+    const int N = p->N;
+    hipLaunchKernelGGL(analysis_matrix_kernel, dim3(p->nlat, N + 1, 2 * N + 1), dim3(256), 0, stream, N, nmin, p->nlat, p->nlon, p->ana_H, area,
+                       p->cs_slot, F);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
 extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area, int nmin, int B, double* anm, void* stream_) {
     SHG_REQUIRE(p != nullptr, "shg_analysis: NULL plan");
     SHG_REQUIRE(B >= 0 && nmin >= 0, "shg_analysis: negative size");
@@ -202,45 +256,20 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     hipStream_t stream = (hipStream_t)stream_;
     PlanGuard guard(p, stream);
     const int N = p->N, S = 2 * N + 1, nlat = p->nlat, nlon = p->nlon;
-    int rc = build_pk_table(p, stream);
-    if (rc) return rc;
-    rc = covprop_build_cs_table(p, stream);
+    int rc = ensure_analysis_operator(p, area, nmin, stream);
     if (rc) return rc;
     SHG_HIP(hipMemsetAsync(anm, 0, (size_t)B * (N + 1) * (N + 1) * sizeof(double), stream));
 
     const int chunk = std::min(B, kAnaEpochChunk);
     const int R = N + 1;
-    double *wvt = nullptr, *gt = nullptr, *w2 = nullptr, *X = nullptr, *key_d = nullptr;
+    double *wvt = nullptr, *gt = nullptr, *X = nullptr;
     if (workspace_alloc((void**)&wvt, (size_t)nlon * chunk * nlat * sizeof(double), stream) != hipSuccess ||
         workspace_alloc((void**)&gt, (size_t)S * chunk * nlat * sizeof(double), stream) != hipSuccess ||
-        workspace_alloc((void**)&X, (size_t)S * R * chunk * sizeof(double), stream) != hipSuccess ||
-        workspace_alloc((void**)&key_d, 2 * kChecksumBlocks * sizeof(double), stream) != hipSuccess)
+        workspace_alloc((void**)&X, (size_t)S * R * chunk * sizeof(double), stream) != hipSuccess) {
+        for (void* q : {(void*)wvt, (void*)gt, (void*)X})
+            if (q) (void)hipFreeAsync(q, stream);
         return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
-    // operator cache: rebuilt when the area weights (or nmin) differ from those it was built for
-    hipLaunchKernelGGL(analysis_checksum_kernel, dim3(kChecksumBlocks), dim3(256), 0, stream, (long long)nlat * nlon, area, key_d);
-    double part[2 * kChecksumBlocks];
-    SHG_HIP(hipMemcpyAsync(part, key_d, sizeof(part), hipMemcpyDeviceToHost, stream));
-    SHG_HIP(hipStreamSynchronize(stream));
-    double key[2] = {0.0, 0.0};
-    for (int k = 0; k < kChecksumBlocks; ++k) {
-        key[0] += part[2 * k];
-        key[1] += part[2 * k + 1];
     }
-    if (!p->ana_H || p->ana_nmin != nmin || p->ana_key[0] != key[0] || p->ana_key[1] != key[1]) {
-        p->ana_nmin = -1;
-        if (workspace_alloc((void**)&w2, (size_t)S * nlat * sizeof(double), stream) != hipSuccess)
-            return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
-        hipLaunchKernelGGL(weight_squares_kernel, dim3(nlat), dim3(256), 0, stream, S, nlat, nlon, area, p->cs_slot, w2);
-        rc = build_analysis_operator(p, w2, nmin, stream);
-        (void)hipFreeAsync(w2, stream);
-        w2 = nullptr;
-        if (rc == SHG_OK) {
-            p->ana_nmin = nmin;
-            p->ana_key[0] = key[0];
-            p->ana_key[1] = key[1];
-        }
-    }
-
     for (int b0 = 0; b0 < B && rc == SHG_OK; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);
         const long long rows = (long long)nb * nlat;
@@ -260,7 +289,6 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     (void)hipFreeAsync(wvt, stream);
     (void)hipFreeAsync(gt, stream);
     (void)hipFreeAsync(X, stream);
-    (void)hipFreeAsync(key_d, stream);
     if (rc) return rc;
     SHG_HIP(hipGetLastError());
     return SHG_OK;

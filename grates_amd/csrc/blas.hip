@@ -749,3 +749,43 @@ extern "C" int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, vo
     (void)hipFreeAsync(work, stream);
     return rc;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Congruence transform  C = W S W^T  (filtered covariance matrix: W a filter matrix, S the coefficient covariance;
+// users of the reference write `W @ S @ W.T` with SpatialFilter.matrix(), grates/filter.py:74-95, 193-222, 481-509, ahead of
+// RegularGrid.covariance_propagation, grates/grid.py:792-839).  Two fp64 MFMA GEMMs; the second one forms the upper tiles only
+// and the strictly lower triangle is mirrored, so a symmetric S gives an exactly symmetric C.
+// ------------------------------------------------------------------------------------------------
+namespace shg {
+__global__ __launch_bounds__(256) void mirror_upper_kernel(int n, double* __restrict__ C, int ldc) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;                 // tile (bi, bj) of the upper triangle, bj >= bi
+    if (bj < bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = bi * 32 + k, c = bj * 32 + tx;
+        tile[k][tx] = (r < n && c < n) ? C[(size_t)r * ldc + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int r = bj * 32 + k, c = bi * 32 + tx;            // mirrored position
+        if (r < n && c < n && r > c) C[(size_t)r * ldc + c] = tile[tx][k];
+    }
+}
+}  // namespace shg
+
+extern "C" int shg_congruence(int n, int k, const double* W, int ldw, const double* S, int lds, double* C, int ldc, double* work, void* stream_) {
+    SHG_REQUIRE(n >= 0 && k >= 0, "shg_congruence: negative dimension");
+    if (n == 0) return SHG_OK;
+    SHG_REQUIRE(W && S && C && work, "shg_congruence: NULL pointer");
+    SHG_REQUIRE(ldw >= k && lds >= k && ldc >= n, "shg_congruence: leading dimension too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    // work [n][k] = W S;  C = work W^T (upper tiles), then the mirror image
+    int rc = shg::gemm_ex(false, false, n, k, k, 1.0, W, ldw, 0, S, lds, 0, 0.0, work, k, 0, 1, false, stream);
+    if (rc) return rc;
+    rc = shg::gemm_ex(false, true, n, n, k, 1.0, work, k, 0, W, ldw, 0, 0.0, C, ldc, 0, 1, true, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(shg::mirror_upper_kernel, dim3(shg::ceil_div(n, 32), shg::ceil_div(n, 32)), dim3(256), 0, stream, n, C, ldc);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}

@@ -145,9 +145,9 @@ struct shg_plan {
     size_t cpk4_size = 0;
     int cpk4_variant = 0;       // layout the workspace was last zero-initialised for
     size_t cpk4_zeroed = 0;
-    // analysis operator cache (analysis.hip): H[S][N+1][nlat] for the weights with checksum ana_key and min degree ana_nmin
+    // analysis operator cache (analysis.hip): H[S][N+1][nlat] for the area weights ana_area and min degree ana_nmin
     double* ana_H = nullptr;
-    double ana_key[2] = {0.0, 0.0};
+    double* ana_area = nullptr; // [nlat][nlon] copy of the area weights the operator was built for (compared on the device per call)
     int ana_nmin = -1;
     int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 4 the same without the north-south symmetry, 5 fused kernel with 32-row panels (two workgroups per CU), 6 rotation-folded fused kernel, 7 the same without the north-south symmetry
 

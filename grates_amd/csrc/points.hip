@@ -148,6 +148,25 @@ __global__ void synth_point_tables_kernel(int N, int npts, const double* __restr
     }
 }
 
+// A[pt][p - p0] = pkT[p][pt] csr[rslot[p]][pt] through 32 x 32 LDS tiles: reads run along the points, writes along the coefficients
+__global__ __launch_bounds__(256) void synthesis_matrix_kernel(int npts, int Pn, int p0, const double* __restrict__ pkT, const double* __restrict__ csr,
+                                                               const int* __restrict__ rslot, double* __restrict__ A, size_t lda) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const int q0 = blockIdx.x * 32, t0 = blockIdx.y * 32;         // coefficient / point tile
+    for (int k = ty; k < 32; k += 8) {
+        const int q = q0 + k, pt = t0 + tx;
+        double v = 0.0;
+        if (q < Pn && pt < npts) v = pkT[(size_t)(p0 + q) * npts + pt] * csr[(size_t)rslot[p0 + q] * npts + pt];
+        tile[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int pt = t0 + k, q = q0 + tx;
+        if (pt < npts && q < Pn) A[(size_t)pt * lda + q] = tile[tx][k];
+    }
+}
+
 int synth_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod, int M,
                   const double* X, int K, int N, double* C, hipStream_t stream);      // gemm.hip
 
@@ -255,6 +274,50 @@ extern "C" int shg_covprop_points(int N, const double* colat, const double* lon,
                        tab + a.size(), pkT, csr, rslot);
     int rc = covprop_generic(pkT, npts, csr, npts, rslot, 1, (long long)1 << 40, 0, npts, cov, Pn, nmin * nmin, partial, sigma, nullptr, stream, false, true);
     for (void* q : {(void*)pkT, (void*)csr, (void*)rslot, (void*)partial, (void*)knT, (void*)tab}) (void)hipFreeAsync(q, stream);
+    if (rc) return rc;
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+// Dense synthesis operator A [npts][Pn] (degree-wise columns from min_degree on) of a point list: one generation kernel per
+// chunk of points, straight into the caller's matrix (replaces Grid.synthesis_matrix, grates/grid.py:412-443, which stacks
+// per-order blocks on the host).
+extern "C" int shg_synthesis_matrix(int N, int nmin, const double* colat, const double* lon, const double* kn, int npts, double* A, void* stream_) {
+    SHG_REQUIRE(N >= 0 && npts >= 0 && nmin >= 0 && nmin <= N + 1, "shg_synthesis_matrix: bad size");
+    const int Pfull = (N + 1) * (N + 1), Pn = Pfull - nmin * nmin;
+    if (npts == 0 || Pn == 0) return SHG_OK;
+    SHG_REQUIRE(colat && lon && kn && A, "shg_synthesis_matrix: NULL pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<double> a, b;
+    recursion_tables(N, a, b);
+    const int chunk = (int)std::min<long long>(npts, std::max<long long>(128, ((1LL << 31) / 8 / Pfull) / 128 * 128));    // 2 GB of Legendre table
+    double *pkT = nullptr, *csr = nullptr, *knT = nullptr, *tab = nullptr;
+    int* rslot = nullptr;
+    int rc = SHG_OK;
+    if (hipMallocAsync((void**)&pkT, (size_t)chunk * Pfull * sizeof(double), stream) != hipSuccess ||
+        hipMallocAsync((void**)&csr, (size_t)(2 * N + 1) * chunk * sizeof(double), stream) != hipSuccess ||
+        hipMallocAsync((void**)&rslot, (size_t)Pfull * sizeof(int), stream) != hipSuccess ||
+        hipMallocAsync((void**)&knT, (size_t)(N + 1) * npts * sizeof(double), stream) != hipSuccess ||
+        hipMallocAsync((void**)&tab, 2 * a.size() * sizeof(double), stream) != hipSuccess)
+        rc = fail(SHG_ERR_NOMEM, "shg_synthesis_matrix: workspace allocation failed");
+    if (rc == SHG_OK) {
+        hipError_t e = hipMemcpyAsync(tab, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(tab + a.size(), b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);           // the host vectors go out of scope
+        if (e != hipSuccess) rc = fail(SHG_ERR_HIP, "shg_synthesis_matrix: table upload failed: %s", hipGetErrorString(e));
+    }
+    if (rc == SHG_OK) {
+        hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(npts, 32), ceil_div(N + 1, 32)), dim3(256), 0, stream, npts, N + 1, kn, (size_t)(N + 1), knT, (size_t)npts);
+        for (int c0 = 0; c0 < npts; c0 += chunk) {
+            const int nc = std::min(chunk, npts - c0);
+            hipLaunchKernelGGL(synth_point_tables_kernel, dim3(ceil_div(nc, 64)), dim3(64), 0, stream, N, nc, colat + c0, lon + c0, knT + c0,
+                               (size_t)npts, tab, tab + a.size(), pkT, csr, rslot);
+            hipLaunchKernelGGL(synthesis_matrix_kernel, dim3(ceil_div(Pn, 32), ceil_div(nc, 32)), dim3(256), 0, stream, nc, Pn, nmin * nmin, pkT, csr,
+                               rslot, A + (size_t)c0 * Pn, (size_t)Pn);
+        }
+    }
+    for (void* q : {(void*)pkT, (void*)csr, (void*)rslot, (void*)knT, (void*)tab})
+        if (q) (void)hipFreeAsync(q, stream);
     if (rc) return rc;
     SHG_HIP(hipGetLastError());
     return SHG_OK;

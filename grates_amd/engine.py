@@ -180,6 +180,17 @@ class Plan:
         return out[0] if single else out
 
 
+    def analysis_matrix(self, area, min_degree):
+        """Dense analysis operator F [P, nlat * nlon] (device tensor) for the area weights `area`: F @ values = analysis(values)."""
+        torch = _torch()
+        a = to_device(area, self.device).reshape(self.nlat, self.nlon)
+        P = (self.max_degree + 1) ** 2 - min_degree ** 2
+        out = torch.empty((P, self.nlat * self.nlon), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.call('shg_analysis_matrix', self._handle, _ptr(a), int(min_degree), _ptr(out), _stream())
+        return out
+
+
 _plan_cache = {}
 _PLAN_CACHE_LIMIT = 8
 
@@ -251,6 +262,40 @@ def trigonometric_functions(max_degree, lon):
     lam = to_device(np.atleast_1d(lon))
     out = torch.empty((lam.numel(), max_degree + 1, max_degree + 1), dtype=torch.float64, device=lam.device)
     _lib.call('shg_trigonometric', int(max_degree), _ptr(lam), lam.numel(), _ptr(out), _stream())
+    return out
+
+
+def synthesis_matrix(max_degree, min_degree, colat, lon, kn):
+    """Dense synthesis operator A [npts, P] (device tensor) of the points (colat, lon) with degree factors kn [npts, N+1]."""
+    torch = require_gpu()
+    th, lam, k = to_device(np.atleast_1d(colat)), to_device(np.atleast_1d(lon)), to_device(kn)
+    npts = th.numel()
+    if k.shape != (npts, max_degree + 1) or lam.numel() != npts:
+        raise ValueError('synthesis_matrix: colat, lon [npts] and kn [npts, max_degree + 1] expected')
+    P = (max_degree + 1) ** 2 - min_degree ** 2
+    out = torch.empty((npts, P), dtype=torch.float64, device=th.device)
+    _lib.call('shg_synthesis_matrix', int(max_degree), int(min_degree), _ptr(th), _ptr(lam), _ptr(k), npts, _ptr(out), _stream())
+    return out
+
+
+def scale_columns(F, w):
+    """F[:, j] *= w[j] in place (window function of Grid.window_matrix) on the device."""
+    torch = require_gpu()
+    F.mul_(to_device(w, F.device).reshape(1, -1))
+    return F
+
+
+def congruence(W, S):
+    """W S W^T on the fp64 MFMA GEMM (device tensors or arrays); exactly symmetric for a symmetric S."""
+    torch = require_gpu()
+    W = W if isinstance(W, torch.Tensor) and W.is_cuda and W.dtype == torch.float64 and W.is_contiguous() else to_device(W)
+    S = S if isinstance(S, torch.Tensor) and S.is_cuda and S.dtype == torch.float64 and S.is_contiguous() else to_device(S)
+    if W.dim() != 2 or S.dim() != 2 or S.shape[0] != S.shape[1] or W.shape[1] != S.shape[0]:
+        raise ValueError('congruence: W [n, k] and a square S [k, k] expected, got {0} and {1}'.format(tuple(W.shape), tuple(S.shape)))
+    n, k = W.shape
+    out = torch.empty((n, n), dtype=torch.float64, device=W.device)
+    work = torch.empty((n, k), dtype=torch.float64, device=W.device)
+    _lib.call('shg_congruence', n, k, _ptr(W), max(k, 1), _ptr(S), max(k, 1), _ptr(out), max(n, 1), _ptr(work), _stream())
     return out
 
 

@@ -38,6 +38,15 @@ class SpatialFilter(metaclass=abc.ABCMeta):
         """Filter a stack [T, N+1, N+1] of coefficient arrays on the GPU; returns a device tensor."""
         raise NotImplementedError
 
+    def filter_covariance(self, covariance_matrix, min_degree, max_degree):
+        """
+        Covariance matrix of the filtered coefficients, W Sigma W^T with W = self.matrix(min_degree, max_degree) and Sigma in
+        degree-wise order -- what scripts on the reference write as ``W @ cov @ W.T`` ahead of
+        ``RegularGrid.covariance_propagation`` (grates/filter.py:74-95, 193-222, 481-509; grates/grid.py:792-839).  Extension:
+        two fp64 MFMA GEMMs on the device (the second forms the upper tiles only); returns a device tensor [P, P].
+        """
+        return engine.congruence(self.matrix(min_degree, max_degree), covariance_matrix)
+
     def _filter_single(self, gravityfield):
         result = gravityfield.copy()
         result.anm = engine.to_host(self.filter_batch(gravityfield.anm[np.newaxis, :, :])[0])

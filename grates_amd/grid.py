@@ -99,24 +99,32 @@ class Grid(metaclass=abc.ABCMeta):
     def synthesis_matrix_per_order(self, m, min_degree, max_degree, kernel, GM, R):
         pass
 
+    def synthesis_matrix_device(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
+        """The dense synthesis operator as a device tensor [points, coefficients] (one generation kernel, shg_synthesis_matrix)."""
+        colat, lon, kn = self._point_tables(kernel, max_degree, GM, R)
+        return engine.synthesis_matrix(max_degree, min_degree, colat, lon, kn)
+
     def synthesis_matrix(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
         """Dense operator A (points x coefficients, degree-wise columns) mapping coefficients to grid values
         (grates/grid.py:412-443)."""
-        colat, lon, kn = self._point_tables(kernel, max_degree, GM, R)
-        Y = engine.trigonometric_functions(max_degree, lon)
-        Y *= engine.legendre_functions(max_degree, colat)
-        Y *= _degree_scale_array(kn, max_degree)
-        return engine.to_host(engine.ravel(Y, min_degree, max_degree))
+        return engine.to_host(self.synthesis_matrix_device(min_degree, max_degree, kernel, GM, R))
 
     @abc.abstractmethod
     def analysis_matrix(self, min_degree, max_degree, kernel, GM, R):
         pass
 
+    def analysis_matrix_device(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
+        """The dense analysis operator as a device tensor [coefficients, points]."""
+        return engine.to_device(self.analysis_matrix(min_degree, max_degree, kernel, GM, R))
+
     def window_matrix(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
-        """W = (F * values) A with the grid values as window function (grates/grid.py:472-475)."""
-        F = engine.to_device(self.analysis_matrix(min_degree, max_degree, kernel, GM, R))
-        F *= engine.to_device(self.values)
-        return engine.to_host(engine.dgemm(F, engine.to_device(self.synthesis_matrix(min_degree, max_degree, kernel, GM, R))))
+        """W = (F * values) A with the grid values as window function (grates/grid.py:472-475); both operators are generated
+        on the device and multiplied there, only W is copied back."""
+        if self.values is None:
+            raise TypeError('grid has no values to use as window function')           # upstream: ndarray *= None
+        F = self.analysis_matrix_device(min_degree, max_degree, kernel, GM, R)
+        engine.scale_columns(F, self.values)
+        return engine.to_host(engine.gemm(F, self.synthesis_matrix_device(min_degree, max_degree, kernel, GM, R)))
 
     def to_potential_coefficients(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
         """Spherical harmonic analysis through the full analysis matrix (grates/grid.py:498-507)."""
@@ -226,23 +234,15 @@ class RegularGrid(Grid):
         As = (Pm[:, None, :] * torch.sin(lam)[None, :, None]).reshape(-1, Pm.shape[1])
         return engine.to_host(Ac), engine.to_host(As)
 
-    def analysis_matrix(self, min_degree, max_degree, kernel, GM=_GM, R=_R):
-        """Dense analysis operator (coefficients x points), assembled by applying the per-order
-        least-squares analysis to unit grids on the GPU (grates/grid.py:698-730)."""
-        torch = engine.require_gpu()
+    def analysis_matrix_device(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
+        """The dense analysis operator as a device tensor [coefficients, points]: the cached per-order least-squares operator
+        of the plan written out by one kernel (shg_analysis_matrix)."""
         plan = self._plan(kernel, max_degree, GM, R)
-        area = engine.to_device(self.area).reshape(self.parallels.size, self.meridians.size)
-        M = self.point_count
-        P = (max_degree + 1) ** 2 - min_degree ** 2
-        out = torch.empty((P, M), dtype=torch.float64, device=area.device)
-        block = 256
-        for i0 in range(0, M, block):
-            i1 = min(i0 + block, M)
-            unit = torch.zeros((i1 - i0, M), dtype=torch.float64, device=area.device)
-            unit[torch.arange(i1 - i0), torch.arange(i0, i1)] = 1.0
-            anm = plan.analysis(unit.reshape(i1 - i0, self.parallels.size, self.meridians.size), area, min_degree)
-            out[:, i0:i1] = engine.ravel(anm, min_degree, max_degree).T
-        return engine.to_host(out)
+        return plan.analysis_matrix(self.area.reshape(self.parallels.size, self.meridians.size), min_degree)
+
+    def analysis_matrix(self, min_degree, max_degree, kernel, GM=_GM, R=_R):
+        """Dense analysis operator (coefficients x points): area-weighted least squares per order (grates/grid.py:698-730)."""
+        return engine.to_host(self.analysis_matrix_device(min_degree, max_degree, kernel, GM, R))
 
     def to_potential_coefficients(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
         """Area-weighted least-squares analysis, order by order, on the GPU (grates/grid.py:774-790)."""
@@ -271,6 +271,33 @@ class RegularGrid(Grid):
         sigma = engine.to_host(plan.covariance_propagation(covariance_matrix, min_degree, symmetric=symmetric, method=method))
         self.values = sigma
         return sigma.copy()
+
+    def covariance_blocks(self, covariance_matrix, min_degree, max_degree, kernel='potential', GM=_GM, R=_R, parallel_range=None):
+        """
+        The full covariance matrix of the points of every parallel, F Sigma F^T [nlon, nlon] with F the rows of the synthesis
+        matrix of that parallel -- the product the reference forms per parallel and of which covariance_propagation keeps
+        the diagonal (grates/grid.py:833-835).  Returns a device tensor [parallels, nlon, nlon] for the parallels
+        [i0, i1) = parallel_range (default: all); per parallel two fp64 MFMA GEMMs (nlon x P x P and nlon x P x nlon).
+        """
+        torch = engine.require_gpu()
+        i0, i1 = (0, self.parallels.size) if parallel_range is None else parallel_range
+        nlon = self.meridians.size
+        colat, _, kn = self._parallel_tables(kernel, max_degree, GM, R)
+        cov = engine.to_device(covariance_matrix)
+        P = (max_degree + 1) ** 2 - min_degree ** 2
+        if cov.dim() != 2 or cov.shape[0] != P or cov.shape[1] != P:
+            raise ValueError('covariance matrix must have shape ({0}, {0}), got {1}'.format(P, tuple(cov.shape)))
+        out = torch.empty((i1 - i0, nlon, nlon), dtype=torch.float64, device=cov.device)
+        band = max(1, min(i1 - i0, (1 << 28) // max(nlon * P, 1)))               # parallels per pass: 2 GB of synthesis-matrix rows
+        for b0 in range(i0, i1, band):
+            b1 = min(b0 + band, i1)
+            A = engine.synthesis_matrix(max_degree, min_degree, np.repeat(colat[b0:b1], nlon), np.tile(self.meridians, b1 - b0),
+                                        np.repeat(kn[b0:b1], nlon, axis=0))
+            T = engine.gemm(A, cov)
+            for i in range(b0, b1):
+                rows = slice((i - b0) * nlon, (i - b0 + 1) * nlon)
+                engine.gemm(T[rows], A[rows], transb=True, out=out[i - i0])
+        return out
 
 
 class IrregularGrid(Grid):

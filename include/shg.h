@@ -205,6 +205,22 @@ int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream)
  * ------------------------------------------------------------------------------------------------ */
 int shg_analysis(shg_plan* plan, const double* grid, const double* area, int nmin, int B, double* anm, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Full-matrix forms of the operators
+ *   shg_synthesis_matrix  dense synthesis operator of a point list, A [npts][Pn], Pn = (N+1)^2 - nmin^2 degree-wise
+ *                         columns: A[p][c] = kn[p][n] P_nm(colat_p) cos|sin(m lon_p)          (grates/grid.py:412-443)
+ *                         colat, lon [npts], kn [npts][N+1] device arrays
+ *   shg_analysis_matrix   dense analysis operator of a regular grid, F [Pn][nlat * nlon]: the least-squares operator of
+ *                         shg_analysis written out (F v = analysis of v)                      (grates/grid.py:698-730)
+ *   shg_congruence        C [n][n] = W [n][k] S [k][k] W^T: filtered covariance matrix `W @ S @ W.T` built from
+ *                         SpatialFilter.matrix() (grates/filter.py:74-95, 193-222, 481-509) ahead of the covariance
+ *                         propagation (grates/grid.py:792-839); two fp64 MFMA GEMMs, the second on the upper tiles only;
+ *                         work [n][k] scratch
+ * ------------------------------------------------------------------------------------------------ */
+int shg_synthesis_matrix(int N, int nmin, const double* colat, const double* lon, const double* kn, int npts, double* A, void* stream);
+int shg_analysis_matrix(shg_plan* plan, const double* area, int nmin, double* F, void* stream);
+int shg_congruence(int n, int k, const double* W, int ldw, const double* S, int lds, double* C, int ldc, double* work, void* stream);
+
 const char* shg_last_error(void);
 const char* shg_version(void);
 

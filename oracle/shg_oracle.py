@@ -388,9 +388,51 @@ def analysis_regular(values, area, min_degree, max_degree, meridians, parallels,
     return anm
 
 
+def analysis_matrix_regular(area, min_degree, max_degree, meridians, parallels, kernel, GM=GM_DEFAULT, R=R_DEFAULT,
+                            a=GRS80_A, f=GRS80_F):
+    """Dense analysis operator [P, nlat*nlon] in degree-wise row order, per order and per cos/sin
+    solve((A w)^T A, (A w)^T).  grid.py:665-696, 698-730"""
+    P = (max_degree + 1) ** 2 - min_degree ** 2
+    F = np.empty((P, area.size))
+    w = np.ravel(area)[:, np.newaxis]
+
+    def lsq(A):
+        return np.linalg.solve((A * w).T @ A, (A * w).T)
+
+    F[vector_indices(min_degree, max_degree, 0), :] = lsq(synthesis_matrix_per_order(0, min_degree, max_degree, meridians, parallels, kernel, GM, R, a, f))
+    for m in range(1, max_degree + 1):
+        Ac, As = synthesis_matrix_per_order(m, min_degree, max_degree, meridians, parallels, kernel, GM, R, a, f)
+        F[vector_indices(min_degree, max_degree, m, 'c'), :] = lsq(Ac)
+        F[vector_indices(min_degree, max_degree, m, 's'), :] = lsq(As)
+    return F
+
+
+def window_matrix_regular(values, area, min_degree, max_degree, meridians, parallels, kernel, GM=GM_DEFAULT, R=R_DEFAULT,
+                          a=GRS80_A, f=GRS80_F):
+    """W = (F * values) A, the grid values as window function.  grid.py:449-475"""
+    F = analysis_matrix_regular(area, min_degree, max_degree, meridians, parallels, kernel, GM, R, a, f)
+    return (F * np.ravel(values)) @ synthesis_matrix(min_degree, max_degree, meridians, parallels, kernel, GM, R, a, f)
+
+
 # ----------------------------------------------------------------------------------------------
 # covariance propagation                                           grates/grid.py:792-839, 1071-1120
 # ----------------------------------------------------------------------------------------------
+
+
+def covariance_blocks_regular(cov, min_degree, max_degree, meridians, parallels, kernel, rows, GM=GM_DEFAULT, R=R_DEFAULT,
+                              a=GRS80_A, f=GRS80_F):
+    """F Sigma F^T [nlon, nlon] for the parallels `rows`: the per-parallel product of which covariance_propagation keeps the
+    diagonal.  grid.py:825-835"""
+    colat, _, kn = kn_table(kernel, max_degree, parallels, GM, R, a, f)
+    Pnm = scale_packed_by_degree(legendre_functions(max_degree, colat), kn)
+    Pnm = ravel_coefficients(Pnm, min_degree, max_degree)
+    cs = ravel_coefficients(trigonometric_functions(max_degree, meridians), min_degree, max_degree)
+    out = []
+    for k in rows:
+        F = cs * Pnm[k:k + 1, :]
+        out.append(F @ cov @ F.T)
+    return np.stack(out)
+
 
 
 def covariance_propagation_regular(cov, min_degree, max_degree, meridians, parallels, kernel, GM=GM_DEFAULT, R=R_DEFAULT,

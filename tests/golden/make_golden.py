@@ -525,8 +525,47 @@ def g17():
     save('g17_reuter', **out)
 
 
+# ---- G18: full-matrix operators: window matrix, filtered covariance, per-parallel covariance blocks ----
+def g18():
+    out = {}
+    # window matrix (grid.py:449-475): grid values in [0, 1] as window function
+    g = grates.grid.GeographicGrid(5.0, 5.0)
+    g.values = np.random.default_rng(51).uniform(0.0, 1.0, g.point_count)
+    out['window_5deg_1_8_potential'] = g.window_matrix(1, 8, 'potential')
+    gg = grates.grid.GaussGrid(13)
+    gg.values = (np.random.default_rng(52).uniform(0.0, 1.0, gg.point_count) > 0.4).astype(float)
+    out['window_gauss13_0_10_ewh'] = gg.window_matrix(0, 10, 'ewh')
+    # filtered covariance W Sigma W^T (W = filter.matrix) ahead of the propagation, d/o 12 and d/o 20
+    for nmax, seed in ((12, 53), (20, 54)):
+        blocks = []
+        for k, nb in enumerate(inputs.orderwise_normal_blocks(seed, nmax)):
+            m = (k + 1) // 2
+            w = 1e11 * np.arange(m, nmax + 1, dtype=float) ** 4
+            w[w == 0] = 1.0
+            blocks.append(np.linalg.solve(nb + np.diag(w), nb))
+        flt = grates.filter.OrderWiseFilter(blocks)
+        W = flt.matrix(2, nmax)
+        cov = inputs.spd_covariance(seed + 10, W.shape[0])
+        filtered = W @ cov @ W.T
+        grid = grates.grid.GeographicGrid(5.0, 5.0)
+        out['filtered_sigma_n{0}_ewh'.format(nmax)] = grid.covariance_propagation(filtered, 2, nmax, kernel='ewh')
+        if nmax == 12:
+            out['filtered_cov_n12'] = filtered
+        gauss = grates.filter.Gaussian(400).matrix(2, nmax)
+        out['gauss_filtered_sigma_n{0}_potential'.format(nmax)] = grid.covariance_propagation(gauss @ cov @ gauss.T, 2, nmax, kernel='potential')
+    # per-parallel blocks F Sigma F^T (grid.py:833-835) for three parallels of the 5 degree grid at d/o 20
+    cov = inputs.spd_covariance(33, 21 * 21)
+    g = grates.grid.GeographicGrid(5.0, 5.0)
+    A = g.synthesis_matrix(0, 20, 'ewh')
+    nlon = g.meridians.size
+    for i in (0, 17, 35):
+        F = A[i * nlon:(i + 1) * nlon]
+        out['block_n20_5deg_ewh_{0}'.format(i)] = F @ cov @ F.T
+    save('g18_operators', **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17, g18):
         if not only or fn.__name__ in only:
             fn()

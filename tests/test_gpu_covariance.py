@@ -225,3 +225,48 @@ def test_full_size_properties_config4():
     cov.mul_(9.0)
     sep9 = plan.covariance_propagation(cov, 0, method='separable')
     assert float(((sep9 - 3.0 * sep).abs().max() / sep9.abs().max()).item()) < 1e-13
+
+
+def test_filtered_covariance_and_blocks_golden(golden):
+    """W Sigma W^T ahead of the propagation (SpatialFilter.filter_covariance) and the per-parallel blocks
+    F Sigma F^T (RegularGrid.covariance_blocks) against outputs of the reference (tests/golden/g18_operators.npz)."""
+    import torch
+    g = golden('g18_operators')
+    grid = ga.grid.GeographicGrid(5.0, 5.0)
+    for nmax, seed in ((12, 53), (20, 54)):
+        blocks = orc.ddk_blocks(inputs.orderwise_normal_blocks(seed, nmax), 5)
+        flt = ga.filter.OrderWiseFilter(blocks)
+        P = (nmax + 1) ** 2 - 4
+        cov = inputs.spd_covariance(seed + 10, P)
+        filtered = flt.filter_covariance(cov, 2, nmax)
+        assert isinstance(filtered, torch.Tensor) and tuple(filtered.shape) == (P, P)
+        assert torch.equal(filtered, filtered.T)                               # upper tiles mirrored: exactly symmetric
+        if nmax == 12:
+            assert relerr(ga.engine.to_host(filtered), g['filtered_cov_n12']) < 1e-12
+        sigma = grid.covariance_propagation(filtered, 2, nmax, kernel='ewh')
+        assert relerr(sigma, g['filtered_sigma_n{0}_ewh'.format(nmax)]) < 1e-11
+        sigma_sym = grid.covariance_propagation(filtered, 2, nmax, kernel='ewh', symmetric=True)
+        assert relerr(sigma_sym, g['filtered_sigma_n{0}_ewh'.format(nmax)]) < 1e-11
+        gauss = ga.filter.Gaussian(400).filter_covariance(cov, 2, nmax)
+        assert relerr(grid.covariance_propagation(gauss, 2, nmax, kernel='potential'), g['gauss_filtered_sigma_n{0}_potential'.format(nmax)]) < 1e-11
+    cov = inputs.spd_covariance(33, 21 * 21)
+    blocks = ga.engine.to_host(grid.covariance_blocks(cov, 0, 20, kernel='ewh'))
+    assert blocks.shape == (36, 72, 72)
+    for i in (0, 17, 35):
+        assert relerr(blocks[i], g['block_n20_5deg_ewh_{0}'.format(i)]) < 1e-12
+    # the diagonal of every block is what covariance_propagation returns; a band equals the same rows of the full result
+    sigma = grid.covariance_propagation(cov, 0, 20, kernel='ewh').reshape(36, 72)
+    assert relerr(np.sqrt(np.einsum('kii->ki', blocks)), sigma) < 1e-12
+    band = ga.engine.to_host(grid.covariance_blocks(cov, 0, 20, kernel='ewh', parallel_range=(16, 19)))
+    assert np.array_equal(band, blocks[16:19])
+
+
+def test_congruence_shapes_and_errors():
+    rng = np.random.default_rng(3)
+    for n, k in ((1, 1), (5, 9), (130, 67), (257, 300)):
+        W, S = rng.standard_normal((n, k)), rng.standard_normal((k, k))
+        S = S + S.T
+        out = ga.engine.to_host(ga.engine.congruence(W, S))
+        assert relerr(out, W @ S @ W.T) < 1e-13 and np.array_equal(out, out.T)
+    with pytest.raises(ValueError):
+        ga.engine.congruence(np.zeros((3, 4)), np.zeros((5, 5)))

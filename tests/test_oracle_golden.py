@@ -195,6 +195,32 @@ def test_covariance_propagation(golden):
     assert relerr(s, g['points_n20_ewh']) < 1e-12
 
 
+# ---------------------------------------------------------------- G18
+def test_full_matrix_operators(golden):
+    """Window matrix, filtered covariance ahead of the propagation and per-parallel covariance blocks."""
+    g = golden('g18_operators')
+    ewh, pot = orc.KernelTable('ewh', love(golden)), orc.KernelTable('potential')
+    mer, par, area = orc.geographic_grid(5.0, 5.0)
+    window = np.random.default_rng(51).uniform(0.0, 1.0, area.size)
+    assert relerr(orc.window_matrix_regular(window, area, 1, 8, mer, par, pot), g['window_5deg_1_8_potential']) < 1e-12
+    gm, gp, ga_ = orc.gauss_grid(13)
+    window = (np.random.default_rng(52).uniform(0.0, 1.0, ga_.size) > 0.4).astype(float)
+    assert relerr(orc.window_matrix_regular(window, ga_, 0, 10, gm, gp, ewh), g['window_gauss13_0_10_ewh']) < 1e-11
+    for nmax, seed in ((12, 53), (20, 54)):
+        blocks = orc.ddk_blocks(inputs.orderwise_normal_blocks(seed, nmax), 5)
+        W = orc.orderwise_matrix(blocks, 2, nmax)
+        cov = inputs.spd_covariance(seed + 10, W.shape[0])
+        filtered = W @ cov @ W.T
+        if nmax == 12:
+            assert relerr(filtered, g['filtered_cov_n12']) < 1e-12
+        assert relerr(orc.covariance_propagation_regular(filtered, 2, nmax, mer, par, ewh), g['filtered_sigma_n{0}_ewh'.format(nmax)]) < 1e-11
+        G = orc.gaussian_matrix(400, 2, nmax)
+        assert relerr(orc.covariance_propagation_regular(G @ cov @ G.T, 2, nmax, mer, par, pot), g['gauss_filtered_sigma_n{0}_potential'.format(nmax)]) < 1e-12
+    blocks = orc.covariance_blocks_regular(inputs.spd_covariance(33, 21 * 21), 0, 20, mer, par, ewh, (0, 17, 35))
+    for k, i in enumerate((0, 17, 35)):
+        assert relerr(blocks[k], g['block_n20_5deg_ewh_{0}'.format(i)]) < 1e-12
+
+
 # ---------------------------------------------------------------- G10
 def test_filters(golden):
     g = golden('g10_filter')
