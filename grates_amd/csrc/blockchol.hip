@@ -1,0 +1,325 @@
+// Sparse block Cholesky on the device: factorisation, triangular solves, sparse (Takahashi) and full inverse and the
+// factor / symmetric products of a symmetric positive definite block matrix of which the upper blocks are stored
+// ("Kalman smoother" normal equations: grates/lstsq.py:698-882, 950-968, 1026-1042).
+//
+// The matrix has nb block rows / columns with boundaries bounds[0 .. nb]; ptr[i * nb + j] is the device address of block
+// (i, j), row-major [rows_i][cols_j], or NULL where the block is zero.  Only blocks with j >= i are referenced.  The caller
+// (grates_amd/lstsq.py) owns the blocks, has allocated the fill-in of the factor (symbolic step on the host) and passes one
+// scratch matrix `inv[i]` [rows_i][rows_i] per block row that receives U_ii^-1: every triangular solve with a diagonal factor
+// block is a GEMM with that inverse.  One C call walks the whole matrix; all block operations are fp64 MFMA GEMMs
+// (blas.hip: gemm_ex), blocked Cholesky leaves (potrf_upper) and recursive-doubling triangular inverses (trtri_upper),
+// enqueued on the caller's stream without host synchronisation.
+//
+// Formulation (right-looking / outer-product forms; the results equal the reference's left-looking loops up to summation
+// order):
+//   factor   for r = 0 .. nb-1:  U_rr = chol(A_rr);  W_rc = U_rr^-T A_rc (c > r);  A_cd -= W_rc^T W_rd (r < c <= d)
+//   W^T x=b  for r ascending:    x_r = U_rr^-T b_r;  b_c -= W_rc^T x_r (c > r)
+//   W x = b  for r descending:   b_r -= sum_c W_rc x_c (c > r);  x_r = U_rr^-1 b_r
+//   Z = (W^T W)^-1 on the pattern of W (Takahashi), r descending with T_rk = U_rr^-1 W_rk:
+//            Z_rj = -sum_{k > r} T_rk Z_kj (j > r),   Z_rr = U_rr^-1 U_rr^-T - sum_{k > r} T_rk Z_rk^T
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace shg {
+
+int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
+            long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, hipStream_t stream);
+int potrf_upper(int n, double* A, int lda, double* work, int* info, hipStream_t stream);
+int trtri_upper(int n, const double* U, int ldu, double* X, int ldx, double* work, hipStream_t stream);
+
+namespace {
+
+struct BlockView {
+    int nb;
+    const int* bounds;
+    double* const* ptr;
+    int size(int i) const { return bounds[i + 1] - bounds[i]; }
+    double* at(int i, int j) const { return ptr[(size_t)i * nb + j]; }
+    int max_size() const {
+        int m = 0;
+        for (int i = 0; i < nb; ++i) m = std::max(m, size(i));
+        return m;
+    }
+};
+
+// C = alpha op(A) op(B) + beta C for whole blocks (leading dimension = column count of the block)
+inline int gemm(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb, double beta, double* C,
+                int ldc, bool upper, hipStream_t s) {
+    return gemm_ex(ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, upper, s);
+}
+
+struct Scratch {                       // stream-ordered scratch, released when the call returns
+    hipStream_t stream;
+    std::vector<void*> held;
+    explicit Scratch(hipStream_t s) : stream(s) {}
+    ~Scratch() {
+        for (void* p : held) (void)hipFreeAsync(p, stream);
+    }
+    double* get(size_t doubles) {
+        void* p = nullptr;
+        if (workspace_alloc(&p, std::max<size_t>(doubles, 1) * sizeof(double), stream) != hipSuccess) return nullptr;
+        held.push_back(p);
+        return (double*)p;
+    }
+};
+
+int check(const BlockView& V, double* const* inv, const char* who) {
+    SHG_REQUIRE(V.nb >= 0 && V.bounds && V.ptr, "%s: NULL block table", who);
+    for (int i = 0; i < V.nb; ++i) {
+        SHG_REQUIRE(V.size(i) > 0, "%s: empty block row %d", who, i);
+        SHG_REQUIRE(V.at(i, i) != nullptr, "%s: diagonal block %d is missing", who, i);
+        SHG_REQUIRE(!inv || inv[i] != nullptr, "%s: scratch for the inverse of diagonal block %d is missing", who, i);
+    }
+    return SHG_OK;
+}
+
+}  // namespace
+
+__global__ void merge_info_kernel(int* __restrict__ dst, const int* __restrict__ src, int offset) {
+    if (*dst == 0 && *src != 0) *dst = *src + offset;
+}
+
+}  // namespace shg
+
+using namespace shg;
+
+// A = W^T W in place (upper blocks); inv[r] <- U_rr^-1.  *info (device int, may be NULL): 1-based index of the first
+// non-positive pivot (counted over the whole matrix), 0 on success.
+extern "C" int shg_block_potrf(int nb, const int* bounds, double* const* ptr, double* const* inv, int* info, void* stream_) {
+    const BlockView V{nb, bounds, ptr};
+    int rc = check(V, inv, "shg_block_potrf");
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    Scratch scratch(stream);
+    const int dmax = V.max_size();
+    double* work = scratch.get((size_t)dmax * dmax + 128 * 128);
+    double* panel = scratch.get((size_t)dmax * dmax);
+    int* info_blk = (int*)scratch.get(1);
+    SHG_REQUIRE(work && panel && info_blk, "shg_block_potrf: workspace allocation failed");
+    if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
+    for (int r = 0; r < nb; ++r) {
+        const int dr = V.size(r);
+        double* Arr = V.at(r, r);
+        SHG_HIP(hipMemsetAsync(info_blk, 0, sizeof(int), stream));
+        rc = potrf_upper(dr, Arr, dr, work + (size_t)dmax * dmax, info_blk, stream);
+        if (rc) return rc;
+        if (info) hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, stream, info, info_blk, bounds[r] - bounds[0]);     // first failure wins
+        rc = trtri_upper(dr, Arr, dr, inv[r], dr, work, stream);
+        if (rc) return rc;
+        bool any = false;
+        for (int c = r + 1; c < nb; ++c) any |= V.at(r, c) != nullptr;
+        if (!any) continue;
+        // W_rc = U_rr^-T A_rc, through the panel scratch (the product cannot overwrite its own operand)
+        for (int c = r + 1; c < nb; ++c) {
+            double* Arc = V.at(r, c);
+            if (!Arc) continue;
+            const int dc = V.size(c);
+            rc = gemm(true, false, dr, dc, dr, 1.0, inv[r], dr, Arc, dc, 0.0, panel, dc, false, stream);
+            if (rc) return rc;
+            SHG_HIP(hipMemcpyAsync(Arc, panel, (size_t)dr * dc * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+        // trailing update A_cd -= W_rc^T W_rd
+        for (int c = r + 1; c < nb; ++c) {
+            const double* Wrc = V.at(r, c);
+            if (!Wrc) continue;
+            for (int d = c; d < nb; ++d) {
+                const double* Wrd = V.at(r, d);
+                if (!Wrd) continue;
+                double* Acd = V.at(c, d);
+                SHG_REQUIRE(Acd != nullptr, "shg_block_potrf: fill-in block (%d, %d) was not allocated", c, d);
+                rc = gemm(true, false, V.size(c), V.size(d), dr, -1.0, Wrc, V.size(c), Wrd, V.size(d), 1.0, Acd, V.size(d), c == d, stream);
+                if (rc) return rc;
+            }
+        }
+    }
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+// Solve W x = b (transpose == 0) or W^T x = b (transpose != 0) with the block factor; B [n][k] row-major with leading
+// dimension ldb holds b on entry and x on exit.
+extern "C" int shg_block_solve(int nb, const int* bounds, double* const* ptr, double* const* inv, int transpose, double* B, int k, int ldb,
+                               void* stream_) {
+    const BlockView V{nb, bounds, ptr};
+    int rc = check(V, inv, "shg_block_solve");
+    if (rc) return rc;
+    SHG_REQUIRE(k >= 0, "shg_block_solve: negative number of right-hand sides");
+    if (k == 0 || nb == 0) return SHG_OK;
+    SHG_REQUIRE(B != nullptr && ldb >= k, "shg_block_solve: bad right-hand side");
+    hipStream_t stream = (hipStream_t)stream_;
+    Scratch scratch(stream);
+    double* tmp = scratch.get((size_t)V.max_size() * k);
+    SHG_REQUIRE(tmp != nullptr, "shg_block_solve: workspace allocation failed");
+    auto rows = [&](int i) { return B + (size_t)(bounds[i] - bounds[0]) * ldb; };
+    if (transpose) {
+        for (int r = 0; r < nb; ++r) {
+            const int dr = V.size(r);
+            rc = gemm(true, false, dr, k, dr, 1.0, inv[r], dr, rows(r), ldb, 0.0, tmp, k, false, stream);           // x_r = U_rr^-T b_r
+            if (rc) return rc;
+            SHG_HIP(hipMemcpy2DAsync(rows(r), (size_t)ldb * sizeof(double), tmp, (size_t)k * sizeof(double), (size_t)k * sizeof(double), dr,
+                                     hipMemcpyDeviceToDevice, stream));
+            for (int c = r + 1; c < nb; ++c) {
+                const double* Wrc = V.at(r, c);
+                if (!Wrc) continue;
+                rc = gemm(true, false, V.size(c), k, dr, -1.0, Wrc, V.size(c), rows(r), ldb, 1.0, rows(c), ldb, false, stream);   // b_c -= W_rc^T x_r
+                if (rc) return rc;
+            }
+        }
+    } else {
+        for (int r = nb - 1; r >= 0; --r) {
+            const int dr = V.size(r);
+            for (int c = r + 1; c < nb; ++c) {
+                const double* Wrc = V.at(r, c);
+                if (!Wrc) continue;
+                rc = gemm(false, false, dr, k, V.size(c), -1.0, Wrc, V.size(c), rows(c), ldb, 1.0, rows(r), ldb, false, stream);  // b_r -= W_rc x_c
+                if (rc) return rc;
+            }
+            rc = gemm(false, false, dr, k, dr, 1.0, inv[r], dr, rows(r), ldb, 0.0, tmp, k, false, stream);           // x_r = U_rr^-1 b_r
+            if (rc) return rc;
+            SHG_HIP(hipMemcpy2DAsync(rows(r), (size_t)ldb * sizeof(double), tmp, (size_t)k * sizeof(double), (size_t)k * sizeof(double), dr,
+                                     hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+// Z = (W^T W)^-1 on the pattern of the factor W held by the blocks, in place (upper blocks); inv[r] = U_rr^-1 on entry.
+extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, double* const* ptr, double* const* inv, void* stream_) {
+    const BlockView V{nb, bounds, ptr};
+    int rc = check(V, inv, "shg_block_sparse_inverse");
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    Scratch scratch(stream);
+    const int dmax = V.max_size();
+    // T_rk = U_rr^-1 W_rk of the current block row: as many scratch blocks as the densest row has off-diagonal blocks
+    int most = 0;
+    for (int r = 0; r < nb; ++r) {
+        int cnt = 0;
+        for (int c = r + 1; c < nb; ++c) cnt += V.at(r, c) != nullptr;
+        most = std::max(most, cnt);
+    }
+    double* tbuf = scratch.get((size_t)std::max(most, 1) * dmax * dmax);
+    SHG_REQUIRE(tbuf != nullptr, "shg_block_sparse_inverse: workspace allocation failed");
+    std::vector<const double*> T(nb);
+    for (int r = nb - 1; r >= 0; --r) {
+        const int dr = V.size(r);
+        int used = 0;
+        std::fill(T.begin(), T.end(), nullptr);
+        for (int k = r + 1; k < nb; ++k) {
+            double* Wrk = V.at(r, k);
+            if (!Wrk) continue;
+            double* t = tbuf + (size_t)used++ * dmax * dmax;
+            rc = gemm(false, false, dr, V.size(k), dr, 1.0, inv[r], dr, Wrk, V.size(k), 0.0, t, V.size(k), false, stream);
+            if (rc) return rc;
+            T[k] = t;
+            SHG_HIP(hipMemsetAsync(Wrk, 0, (size_t)dr * V.size(k) * sizeof(double), stream));
+        }
+        rc = gemm(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, V.at(r, r), dr, false, stream);            // Z_rr = U^-1 U^-T ...
+        if (rc) return rc;
+        for (int j = nb - 1; j >= r; --j) {                                                                            // ... and the row, last block first
+            double* Zrj = V.at(r, j);
+            if (!Zrj) continue;
+            for (int k = r + 1; k < nb; ++k) {
+                if (!T[k]) continue;
+                const double* Zkj = k <= j ? V.at(k, j) : V.at(j, k);                                                  // Z_kj = Z_jk^T for k > j
+                if (!Zkj) continue;
+                if (k <= j)
+                    rc = gemm(false, false, dr, V.size(j), V.size(k), -1.0, T[k], V.size(k), Zkj, V.size(j), 1.0, Zrj, V.size(j), false, stream);
+                else
+                    rc = gemm(false, true, dr, V.size(j), V.size(k), -1.0, T[k], V.size(k), Zkj, V.size(k), 1.0, Zrj, V.size(j), false, stream);
+                if (rc) return rc;
+            }
+        }
+    }
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+// Full inverse (W^T W)^-1 from the factor, in place, upper blocks: every block (i, j), j >= i, must be allocated.
+//   X = W^-1 by block back substitution (X_jj = U_jj^-1, X_ij = -U_ii^-1 sum_{i < k <= j} W_ik X_kj), then Z_ij = sum_{k >= j} X_ik X_jk^T.
+extern "C" int shg_block_inverse(int nb, const int* bounds, double* const* ptr, double* const* inv, void* stream_) {
+    const BlockView V{nb, bounds, ptr};
+    int rc = check(V, inv, "shg_block_inverse");
+    if (rc) return rc;
+    for (int i = 0; i < nb; ++i)
+        for (int j = i; j < nb; ++j) SHG_REQUIRE(V.at(i, j) != nullptr, "shg_block_inverse: block (%d, %d) is not allocated", i, j);
+    hipStream_t stream = (hipStream_t)stream_;
+    Scratch scratch(stream);
+    const int dmax = V.max_size();
+    double* acc = scratch.get((size_t)dmax * dmax);
+    SHG_REQUIRE(acc != nullptr, "shg_block_inverse: workspace allocation failed");
+    // X = W^-1, column by column from the right; column j only needs the X blocks of column j below row i
+    for (int j = nb - 1; j >= 0; --j) {
+        const int dj = V.size(j);
+        for (int i = j - 1; i >= 0; --i) {
+            const int di = V.size(i);
+            // acc = sum_{i < k <= j} W_ik X_kj  with X_jj = inv[j] (W_ij itself is consumed here and replaced by X_ij)
+            rc = gemm(false, false, di, dj, dj, 1.0, V.at(i, j), dj, inv[j], dj, 0.0, acc, dj, false, stream);
+            if (rc) return rc;
+            for (int k = i + 1; k < j; ++k) {
+                rc = gemm(false, false, di, dj, V.size(k), 1.0, V.at(i, k), V.size(k), V.at(k, j), dj, 1.0, acc, dj, false, stream);     // X_kj already final
+                if (rc) return rc;
+            }
+            rc = gemm(false, false, di, dj, di, -1.0, inv[i], di, acc, dj, 0.0, V.at(i, j), dj, false, stream);
+            if (rc) return rc;
+        }
+    }
+    // careful with the order above: column j uses W_ik (k < j) of the columns to its left, which are still untouched factors,
+    // and X_kj of its own column.  Now the diagonal blocks become X_jj and Z = X X^T row by row, left to right.
+    for (int j = 0; j < nb; ++j)
+        SHG_HIP(hipMemcpyAsync(V.at(j, j), inv[j], (size_t)V.size(j) * V.size(j) * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    for (int i = 0; i < nb; ++i) {
+        const int di = V.size(i);
+        for (int j = i; j < nb; ++j) {
+            const int dj = V.size(j);
+            // Z_ij = sum_{k >= j} X_ik X_jk^T: X_ij (k = j) is read and overwritten by the same product -> through the scratch
+            rc = gemm(false, true, di, dj, dj, 1.0, V.at(i, j), dj, V.at(j, j), dj, 0.0, acc, dj, false, stream);
+            if (rc) return rc;
+            for (int k = j + 1; k < nb; ++k) {
+                rc = gemm(false, true, di, dj, V.size(k), 1.0, V.at(i, k), V.size(k), V.at(j, k), V.size(k), 1.0, acc, dj, false, stream);
+                if (rc) return rc;
+            }
+            // rows below i still need X_ij?  No: Z_i'j' with i' > i uses X_i'k only.  But Z_ij' (j' > j) of this row uses X_ik, k >= j' > j: not X_ij.
+            SHG_HIP(hipMemcpyAsync(V.at(i, j), acc, (size_t)di * dj * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+// Products with the stored blocks, V [n][k] = op B [n][k]:
+//   mode 0: V = W B (upper triangular factor);  mode 1: V_i = W_ji^T B_j of the LAST stored block j <= i (the reference's
+//   transposed branch assigns instead of accumulating, grates/lstsq.py:743: kept);  mode 2: V = N B, N symmetric, upper blocks stored
+extern "C" int shg_block_multiply(int nb, const int* bounds, double* const* ptr, int mode, const double* B, int k, int ldb, double* Vout, int ldv,
+                                  void* stream_) {
+    const BlockView V{nb, bounds, ptr};
+    SHG_REQUIRE(nb >= 0 && bounds && ptr, "shg_block_multiply: NULL block table");
+    SHG_REQUIRE(mode >= 0 && mode <= 2 && k >= 0, "shg_block_multiply: bad mode / size");
+    if (k == 0 || nb == 0) return SHG_OK;
+    SHG_REQUIRE(B && Vout && ldb >= k && ldv >= k && B != Vout, "shg_block_multiply: bad operands");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int n = bounds[nb] - bounds[0];
+    SHG_HIP(hipMemset2DAsync(Vout, (size_t)ldv * sizeof(double), 0, (size_t)k * sizeof(double), n, stream));
+    auto rb = [&](int i) { return B + (size_t)(bounds[i] - bounds[0]) * ldb; };
+    auto rv = [&](int i) { return Vout + (size_t)(bounds[i] - bounds[0]) * ldv; };
+    int rc = SHG_OK;
+    for (int i = 0; i < nb && !rc; ++i) {
+        if (mode == 1) {
+            for (int j = 0; j <= i && !rc; ++j)
+                if (V.at(j, i)) rc = gemm(true, false, V.size(i), k, V.size(j), 1.0, V.at(j, i), V.size(i), rb(j), ldb, 0.0, rv(i), ldv, false, stream);
+            continue;
+        }
+        for (int j = i; j < nb && !rc; ++j) {
+            const double* Aij = V.at(i, j);
+            if (!Aij) continue;
+            rc = gemm(false, false, V.size(i), k, V.size(j), 1.0, Aij, V.size(j), rb(j), ldb, 1.0, rv(i), ldv, false, stream);
+            if (!rc && mode == 2 && j > i) rc = gemm(true, false, V.size(j), k, V.size(i), 1.0, Aij, V.size(j), rb(i), ldb, 1.0, rv(j), ldv, false, stream);
+        }
+    }
+    if (rc) return rc;
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}

@@ -278,6 +278,61 @@ def synthesis_matrix(max_degree, min_degree, colat, lon, kn):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------
+# sparse block Cholesky (csrc/blockchol.hip): block tables are [nb, nb] uint64 arrays of device addresses (0 = no block)
+# ---------------------------------------------------------------------------------------------------
+
+def _table(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def block_potrf(bounds, blocks, inverses):
+    """In-place block Cholesky; returns 0 or the 1-based index of the first non-positive pivot."""
+    torch = require_gpu()
+    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
+    blocks, pb = _table(blocks)
+    inverses, pi = _table(inverses)
+    info = torch.zeros(1, dtype=torch.int32, device=device())
+    _lib.call('shg_block_potrf', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, pi, _ptr(info), _stream())
+    return int(info.item())
+
+
+def block_solve(bounds, blocks, inverses, transpose, B):
+    """B [n, k] <- W^-1 B or W^-T B in place (device tensor, contiguous last dimension)."""
+    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
+    blocks, pb = _table(blocks)
+    inverses, pi = _table(inverses)
+    _lib.call('shg_block_solve', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, pi, 1 if transpose else 0, _ptr(B), B.shape[1],
+              max(B.stride(0), 1), _stream())
+    return B
+
+
+def block_sparse_inverse(bounds, blocks, inverses):
+    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
+    blocks, pb = _table(blocks)
+    inverses, pi = _table(inverses)
+    _lib.call('shg_block_sparse_inverse', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, pi, _stream())
+
+
+def block_inverse(bounds, blocks, inverses):
+    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
+    blocks, pb = _table(blocks)
+    inverses, pi = _table(inverses)
+    _lib.call('shg_block_inverse', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, pi, _stream())
+
+
+def block_multiply(bounds, blocks, mode, B):
+    """mode 0: W B, 1: the reference's W^T B (assigning form), 2: N B with the upper blocks of a symmetric N."""
+    torch = require_gpu()
+    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
+    blocks, pb = _table(blocks)
+    out = torch.empty_like(B)
+    _lib.call('shg_block_multiply', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, int(mode), _ptr(B), B.shape[1], max(B.stride(0), 1),
+              _ptr(out), max(out.stride(0), 1), _stream())
+    return out
+
+
 def scale_columns(F, w):
     """F[:, j] *= w[j] in place (window function of Grid.window_matrix) on the device."""
     torch = require_gpu()

@@ -341,11 +341,47 @@ class BlockMatrix:
             self.__data[(i, j)] = _zeros(self.__block_shape(i, j))
         return self.__data[(i, j)]
 
-    def __factor_inverse(self, i):
-        """inverse of the upper triangular diagonal block i (computed once)"""
-        if i not in self.__inverse_factor:
-            self.__inverse_factor[i] = engine.trtri(self.__data[(i, i)])
-        return self.__inverse_factor[i]
+    # ---- numeric kernels: one libshg call per operation (csrc/blockchol.hip walks the blocks on the device) -------------------
+    def __square_bounds(self):
+        if len(self.__row_index) != len(self.__column_index) or np.any(np.asarray(self.__row_index) != np.asarray(self.__column_index)):
+            raise ValueError('operation needs a square block matrix with equal row and column blocks')
+        return np.ascontiguousarray(self.__row_index, dtype=np.int32)
+
+    def __block_table(self):
+        """device addresses of the stored blocks as an [nb, nb] table (0 = no block)"""
+        nb = self.shape[0]
+        table = np.zeros((nb, self.shape[1]), dtype=np.uint64)
+        for (i, j), block in self.__data.items():
+            table[i, j] = block.data_ptr()
+        return table
+
+    def __inverse_table(self):
+        """scratch matrices that hold the inverses of the diagonal factor blocks (kept until a block changes)"""
+        nb = self.shape[0]
+        table = np.zeros(nb, dtype=np.uint64)
+        for i in range(nb):
+            if i not in self.__inverse_factor:
+                size = self.__block_shape(i, i)[0]
+                self.__inverse_factor[i] = _zeros((size, size))
+            table[i] = self.__inverse_factor[i].data_ptr()
+        return table
+
+    def __allocate_fill(self):
+        """symbolic factorisation: eliminating block row r couples every pair of its off-diagonal blocks (r, c), (r, d), c <= d,
+        so block (c, d) of the factor is non-zero as well"""
+        nb = self.shape[0]
+        for i in range(nb):
+            if not self.__nz(i, i):
+                raise np.linalg.LinAlgError('diagonal block {0} of the matrix is empty'.format(i))
+        pattern = [sorted(c for c in range(r + 1, nb) if self.__nz(r, c)) for r in range(nb)]
+        for r in range(nb):
+            cols = pattern[r]
+            for a, c in enumerate(cols):
+                for d in cols[a:]:
+                    if not self.__nz(c, d):
+                        self.__data[(c, d)] = _zeros(self.__block_shape(c, d))
+                        if d != c:
+                            pattern[c] = sorted(set(pattern[c]) | {d})
 
     def cholesky(self):
         """
@@ -353,20 +389,12 @@ class BlockMatrix:
         upper triangular factor W (grates/lstsq.py:698-717).  Raises numpy.linalg.LinAlgError if a diagonal block is not
         positive definite.
         """
-        for row in range(self.shape[0]):
-            for r in range(row):
-                if not self.__nz(r, row):
-                    continue
-                for c in range(row, self.shape[1]):
-                    if self.__nz(r, c):
-                        engine.gemm(self.__data[(r, row)], self.__data[(r, c)], transa=True, alpha=-1.0, beta=1.0, out=self.__set_block(row, c))
-            engine.potrf(self.__data[(row, row)])
-            self.__inverse_factor.pop(row, None)
-            columns = [c for c in range(row + 1, self.shape[1]) if self.__nz(row, c)]
-            if columns:
-                Winv = self.__factor_inverse(row)
-                for c in columns:
-                    self.__data[(row, c)] = engine.gemm(Winv, self.__data[(row, c)], transa=True)
+        bounds = self.__square_bounds()
+        self.__allocate_fill()
+        self.__inverse_factor.clear()
+        pivot = engine.block_potrf(bounds, self.__block_table(), self.__inverse_table())
+        if pivot:
+            raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(pivot))
 
     def __vector(self, b):
         v = _dev(b)
@@ -376,100 +404,48 @@ class BlockMatrix:
         """v = W b or v = W^T b with the upper triangular factor (grates/lstsq.py:719-750).  As upstream, the transposed
         branch assigns instead of accumulating (lstsq.py:743)."""
         bd = self.__vector(b)
-        v = _zeros(bd.shape)
-        if transpose:
-            for i in range(self.shape[0]):
-                for j in range(i + 1):
-                    if self.__nz(j, i):
-                        engine.gemm(self.__data[(j, i)], bd[self.__row_slice(j)], transa=True, out=v[self.__row_slice(i)])
-        else:
-            for i in range(self.shape[0]):
-                for j in range(i, self.shape[1]):
-                    if self.__nz(i, j):
-                        engine.gemm(self.__data[(i, j)], bd[self.__row_slice(j)], beta=1.0, out=v[self.__row_slice(i)])
+        v = engine.block_multiply(self.__square_bounds(), self.__block_table(), 1 if transpose else 0, bd)
         return _like_input(v, b)
 
     def multiply_symmetric(self, b):
         """v = N b for a symmetric matrix of which only the upper triangle is stored (grates/lstsq.py:752-776)"""
         bd = self.__vector(b)
-        v = _zeros(bd.shape)
-        for i in range(self.shape[0]):
-            if self.__nz(i, i):
-                engine.gemm(self.__data[(i, i)], bd[self.__row_slice(i)], beta=1.0, out=v[self.__row_slice(i)])
-            for j in range(i + 1, self.shape[1]):
-                if self.__nz(i, j):
-                    engine.gemm(self.__data[(i, j)], bd[self.__row_slice(j)], beta=1.0, out=v[self.__row_slice(i)])
-                    engine.gemm(self.__data[(i, j)], bd[self.__row_slice(i)], transa=True, beta=1.0, out=v[self.__row_slice(j)])
-        return _like_input(v, b)
+        return _like_input(engine.block_multiply(self.__square_bounds(), self.__block_table(), 2, bd), b)
 
     def solve_triangular(self, b, transpose=False):
         """Solve W x = b or W^T x = b with the upper triangular block factor (grates/lstsq.py:778-821)."""
-        b_copy = self.__vector(b)
-        x = _zeros(b_copy.shape)
-        if transpose:
-            for row in range(self.shape[0]):
-                for column in range(row):
-                    if self.__nz(column, row):
-                        engine.gemm(self.__data[(column, row)], x[self.__row_slice(column)], transa=True, alpha=-1.0, beta=1.0,
-                                    out=b_copy[self.__row_slice(row)])
-                engine.gemm(self.__factor_inverse(row), b_copy[self.__row_slice(row)], transa=True, out=x[self.__row_slice(row)])
-        else:
-            for row in range(self.shape[0] - 1, -1, -1):
-                for column in range(self.shape[0] - 1, row, -1):
-                    if self.__nz(row, column):
-                        engine.gemm(self.__data[(row, column)], x[self.__row_slice(column)], alpha=-1.0, beta=1.0,
-                                    out=b_copy[self.__row_slice(row)])
-                engine.gemm(self.__factor_inverse(row), b_copy[self.__row_slice(row)], out=x[self.__row_slice(row)])
+        x = self.__vector(b)                                  # a copy: solved in place
+        self.__ensure_factor_inverses()
+        engine.block_solve(self.__square_bounds(), self.__block_table(), self.__inverse_table(), bool(transpose), x)
         return _like_input(x, b)
+
+    def __ensure_factor_inverses(self):
+        """inverses of the diagonal factor blocks that are not cached (a factor that was stored block by block rather than computed
+        by cholesky(): grates/lstsq.py:807, 817 invert / solve with the diagonal blocks on the fly)"""
+        for i in range(self.shape[0]):
+            if i not in self.__inverse_factor:
+                self.__inverse_factor[i] = engine.trtri(self.__data[(i, i)])
 
     def sparse_inverse(self):
         """
         Sparse inverse N^-1 = W^-1 W^-T on the pattern of the Cholesky factor W held by the matrix, in place
         (grates/lstsq.py:823-846).
         """
-        for i in range(self.shape[0] - 1, -1, -1):
-            Winv = self.__factor_inverse(i)
-            temporary_row = {}
-            for k in range(i + 1, self.shape[1]):
-                if self.__nz(i, k):
-                    temporary_row[k] = engine.gemm(Winv, self.__data[(i, k)])
-                    self.__data[(i, k)] = _zeros(self.__block_shape(i, k))
-            self._set_device(i, i, engine.gemm(Winv, Winv, transb=True))
-            for j in range(self.shape[0] - 1, i - 1, -1):
-                if not self.__nz(i, j):
-                    continue
-                for k in range(i + 1, self.shape[0]):
-                    if self.__nz(min(k, j), max(k, j)) and k in temporary_row:
-                        if k < j:
-                            engine.gemm(temporary_row[k], self.__data[(k, j)], alpha=-1.0, beta=1.0, out=self.__data[(i, j)])
-                        else:
-                            engine.gemm(temporary_row[k], self.__data[(j, k)], transb=True, alpha=-1.0, beta=1.0, out=self.__data[(i, j)])
+        self.__ensure_factor_inverses()
+        engine.block_sparse_inverse(self.__square_bounds(), self.__block_table(), self.__inverse_table())
+        self.__inverse_factor.clear()
 
     def inverse(self):
         """
         Full inverse N^-1 = W^-1 W^-T from the Cholesky factor W held by the matrix, in place, upper triangle
         (grates/lstsq.py:848-882).
         """
-        factor_inverse = {j: self.__factor_inverse(j) for j in range(self.shape[0])}
-        for j in range(self.shape[0] - 1, -1, -1):
-            self.__data[(j, j)] = factor_inverse[j]
-            for i in range(j - 1, -1, -1):
-                if self.__nz(i, j):
-                    self.__data[(i, j)] = engine.gemm(self.__data[(i, j)], self.__data[(j, j)])
-                for k in range(i + 1, j):
-                    if self.__nz(i, k) and self.__nz(k, j):
-                        engine.gemm(self.__data[(i, k)], self.__data[(k, j)], beta=1.0, out=self.__set_block(i, j))
-                if self.__nz(i, j):
-                    self.__data[(i, j)] = engine.gemm(factor_inverse[i], self.__data[(i, j)], alpha=-1.0)
-        for i in range(self.shape[0]):
-            self.__data[(i, i)] = engine.gemm(self.__data[(i, i)], self.__data[(i, i)], transb=True)
-            for j in range(i + 1, self.shape[0]):
-                if self.__nz(i, j):
-                    engine.gemm(self.__data[(i, j)], self.__data[(i, j)], transb=True, beta=1.0, out=self.__data[(i, i)])
-                    self.__data[(i, j)] = engine.gemm(self.__data[(i, j)], self.__data[(j, j)], transb=True)
-                for k in range(j + 1, self.shape[0]):
-                    if self.__nz(i, k) and self.__nz(j, k):
-                        engine.gemm(self.__data[(i, k)], self.__data[(j, k)], transb=True, beta=1.0, out=self.__set_block(i, j))
+        nb = self.shape[0]
+        for i in range(nb):
+            for j in range(i, nb):
+                self.__set_block(i, j)                        # the inverse of a banded factor is dense
+        self.__ensure_factor_inverses()
+        engine.block_inverse(self.__square_bounds(), self.__block_table(), self.__inverse_table())
         self.__inverse_factor.clear()
 
     def _scale(self, value):

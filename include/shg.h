@@ -199,6 +199,23 @@ int shg_axpby(int rows, int cols, double alpha, const double* X, int ldx, double
 int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Sparse block Cholesky of the block-banded normal equations ("Kalman smoother"), one call per operation: the blocks stay in
+ * HBM, the call walks them on the device (csrc/blockchol.hip).  nb block rows / columns with boundaries bounds[0..nb];
+ * ptr[i * nb + j] = device address of block (i, j) (row-major [rows_i][cols_j]) or NULL; blocks with j >= i are referenced;
+ * inv[i] = scratch [rows_i][rows_i] holding U_ii^-1 (written by shg_block_potrf, read by the others).
+ *   shg_block_potrf           N = W^T W in place, fill-in allocated by the caller       (grates/lstsq.py:698-717)
+ *   shg_block_solve           W x = b / W^T x = b for B [n][k] in place                 (grates/lstsq.py:778-821, 950-968)
+ *   shg_block_sparse_inverse  (W^T W)^-1 on the pattern of W (Takahashi), in place      (grates/lstsq.py:823-846, 1026-1042)
+ *   shg_block_inverse         full inverse, upper blocks, in place                      (grates/lstsq.py:848-882)
+ *   shg_block_multiply        V = W B (mode 0), the reference's W^T B (1), N B for a symmetric N (2)   (grates/lstsq.py:719-776)
+ * ------------------------------------------------------------------------------------------------ */
+int shg_block_potrf(int nb, const int* bounds, double* const* ptr, double* const* inv, int* info, void* stream);
+int shg_block_solve(int nb, const int* bounds, double* const* ptr, double* const* inv, int transpose, double* B, int k, int ldb, void* stream);
+int shg_block_sparse_inverse(int nb, const int* bounds, double* const* ptr, double* const* inv, void* stream);
+int shg_block_inverse(int nb, const int* bounds, double* const* ptr, double* const* inv, void* stream);
+int shg_block_multiply(int nb, const int* bounds, double* const* ptr, int mode, const double* B, int k, int ldb, double* V, int ldv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Analysis (area-weighted least squares per order)
  *   replaces RegularGrid.to_potential_coefficients                    (grates/grid.py:665-696, 752-790)
  *   grid [B][nlat][nlon]; area [nlat][nlon]; anm [B][N+1][N+1] (degrees < nmin left zero)

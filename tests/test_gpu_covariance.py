@@ -222,6 +222,12 @@ def test_full_size_properties_config4():
     direct = plan.covariance_propagation(cov, 0, 178, 181)
     sep = plan.covariance_propagation(cov, 0, method='separable')
     assert float(((sep.reshape(360, 720)[178:181].reshape(-1) - direct).abs().max() / direct.abs().max()).item()) < 1e-12
+    # the direct kernel on ALL 360 parallels (556 TFLOP, ~9 s) against the separable result, and bands against the full grid
+    full = plan.covariance_propagation(cov, 0)
+    assert float(((sep - full).abs().max() / full.abs().max()).item()) < 1e-12
+    assert torch.equal(full.reshape(360, 720)[178:181].reshape(-1), direct)
+    assert torch.equal(plan.covariance_propagation(cov, 0, 270, 360), full.reshape(360, 720)[270:360].reshape(-1))     # the 4-GPU share of the last rank
+    del full
     cov.mul_(9.0)
     sep9 = plan.covariance_propagation(cov, 0, method='separable')
     assert float(((sep9 - 3.0 * sep).abs().max() / sep9.abs().max()).item()) < 1e-13
