@@ -2,13 +2,15 @@
 // factor / symmetric products of a symmetric positive definite block matrix of which the upper blocks are stored
 // ("Kalman smoother" normal equations: grates/lstsq.py:698-882, 950-968, 1026-1042).
 //
-// The matrix has nb block rows / columns with boundaries bounds[0 .. nb]; ptr[i * nb + j] is the device address of block
-// (i, j), row-major [rows_i][cols_j], or NULL where the block is zero.  Only blocks with j >= i are referenced.  The caller
+// The matrix has nb block rows / columns with boundaries bounds[0 .. nb].  The stored blocks (j >= i only) come in compressed
+// row form: row i owns the entries rowptr[i] .. rowptr[i + 1] - 1, colidx[e] is the block column (ascending within a row, the
+// diagonal block first) and blk[e] the device address of the block, row-major [rows_i][cols_j].  The table is O(stored
+// blocks), so a chain of thousands of epochs (BASELINE config 5: 3650) costs nothing to describe.  The caller
 // (grates_amd/lstsq.py) owns the blocks, has allocated the fill-in of the factor (symbolic step on the host) and passes one
 // scratch matrix `inv[i]` [rows_i][rows_i] per block row that receives U_ii^-1: every triangular solve with a diagonal factor
 // block is a GEMM with that inverse.  One C call walks the whole matrix; all block operations are fp64 MFMA GEMMs
-// (blas.hip: gemm_ex), blocked Cholesky leaves (potrf_upper) and recursive-doubling triangular inverses (trtri_upper),
-// enqueued on the caller's stream without host synchronisation.
+// (blas.hip: gemm_ex) and a recursive Cholesky factorisation that yields the inverse of the factor in the same sweep
+// (potrf_inverse_upper), enqueued on the caller's stream without host synchronisation.
 //
 // Formulation (right-looking / outer-product forms; the results equal the reference's left-looking loops up to summation
 // order):
@@ -26,17 +28,27 @@ namespace shg {
 
 int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
             long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, hipStream_t stream);
-int potrf_upper(int n, double* A, int lda, double* work, int* info, hipStream_t stream);
-int trtri_upper(int n, const double* U, int ldu, double* X, int ldx, double* work, hipStream_t stream);
+int potrf_inverse_upper(int n, double* A, int lda, double* X, int ldx, double* work, int* info, hipStream_t stream);
+size_t potrf_inverse_work(int n);
 
 namespace {
 
 struct BlockView {
     int nb;
     const int* bounds;
-    double* const* ptr;
+    const int* rowptr;
+    const int* colidx;
+    double* const* blk;
     int size(int i) const { return bounds[i + 1] - bounds[i]; }
-    double* at(int i, int j) const { return ptr[(size_t)i * nb + j]; }
+    int begin(int i) const { return rowptr[i]; }
+    int end(int i) const { return rowptr[i + 1]; }
+    // block (i, j), j >= i, or NULL
+    double* at(int i, int j) const {
+        const int* lo = colidx + rowptr[i];
+        const int* hi = colidx + rowptr[i + 1];
+        const int* it = std::lower_bound(lo, hi, j);
+        return (it != hi && *it == j) ? blk[it - colidx] : nullptr;
+    }
     int max_size() const {
         int m = 0;
         for (int i = 0; i < nb; ++i) m = std::max(m, size(i));
@@ -66,10 +78,14 @@ struct Scratch {                       // stream-ordered scratch, released when 
 };
 
 int check(const BlockView& V, double* const* inv, const char* who) {
-    SHG_REQUIRE(V.nb >= 0 && V.bounds && V.ptr, "%s: NULL block table", who);
+    SHG_REQUIRE(V.nb >= 0 && V.bounds && V.rowptr && (V.nb == 0 || (V.colidx && V.blk)), "%s: NULL block table", who);
+    SHG_REQUIRE(V.nb == 0 || V.rowptr[0] == 0, "%s: rowptr must start at 0", who);
     for (int i = 0; i < V.nb; ++i) {
         SHG_REQUIRE(V.size(i) > 0, "%s: empty block row %d", who, i);
-        SHG_REQUIRE(V.at(i, i) != nullptr, "%s: diagonal block %d is missing", who, i);
+        SHG_REQUIRE(V.end(i) > V.begin(i) && V.colidx[V.begin(i)] == i && V.blk[V.begin(i)] != nullptr, "%s: diagonal block %d is missing", who, i);
+        for (int e = V.begin(i) + 1; e < V.end(i); ++e)
+            SHG_REQUIRE(V.colidx[e] > V.colidx[e - 1] && V.colidx[e] < V.nb && V.blk[e] != nullptr,
+                        "%s: block row %d: columns must ascend from the diagonal, inside the matrix, with non-NULL blocks", who, i);
         SHG_REQUIRE(!inv || inv[i] != nullptr, "%s: scratch for the inverse of diagonal block %d is missing", who, i);
     }
     return SHG_OK;
@@ -87,49 +103,42 @@ using namespace shg;
 
 // A = W^T W in place (upper blocks); inv[r] <- U_rr^-1.  *info (device int, may be NULL): 1-based index of the first
 // non-positive pivot (counted over the whole matrix), 0 on success.
-extern "C" int shg_block_potrf(int nb, const int* bounds, double* const* ptr, double* const* inv, int* info, void* stream_) {
-    const BlockView V{nb, bounds, ptr};
+extern "C" int shg_block_potrf(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int* info,
+                               void* stream_) {
+    const BlockView V{nb, bounds, rowptr, colidx, blk};
     int rc = check(V, inv, "shg_block_potrf");
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     Scratch scratch(stream);
     const int dmax = V.max_size();
-    double* work = scratch.get((size_t)dmax * dmax + 128 * 128);
+    double* work = scratch.get(potrf_inverse_work(dmax));
     double* panel = scratch.get((size_t)dmax * dmax);
     int* info_blk = (int*)scratch.get(1);
     SHG_REQUIRE(work && panel && info_blk, "shg_block_potrf: workspace allocation failed");
     if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
     for (int r = 0; r < nb; ++r) {
         const int dr = V.size(r);
-        double* Arr = V.at(r, r);
+        const int e0 = V.begin(r), e1 = V.end(r);
+        double* Arr = blk[e0];
         SHG_HIP(hipMemsetAsync(info_blk, 0, sizeof(int), stream));
-        rc = potrf_upper(dr, Arr, dr, work + (size_t)dmax * dmax, info_blk, stream);
+        rc = potrf_inverse_upper(dr, Arr, dr, inv[r], dr, work, info_blk, stream);      // factor and inverse in one recursive sweep
         if (rc) return rc;
         if (info) hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, stream, info, info_blk, bounds[r] - bounds[0]);     // first failure wins
-        rc = trtri_upper(dr, Arr, dr, inv[r], dr, work, stream);
-        if (rc) return rc;
-        bool any = false;
-        for (int c = r + 1; c < nb; ++c) any |= V.at(r, c) != nullptr;
-        if (!any) continue;
         // W_rc = U_rr^-T A_rc, through the panel scratch (the product cannot overwrite its own operand)
-        for (int c = r + 1; c < nb; ++c) {
-            double* Arc = V.at(r, c);
-            if (!Arc) continue;
-            const int dc = V.size(c);
-            rc = gemm(true, false, dr, dc, dr, 1.0, inv[r], dr, Arc, dc, 0.0, panel, dc, false, stream);
+        for (int e = e0 + 1; e < e1; ++e) {
+            const int dc = V.size(colidx[e]);
+            rc = gemm(true, false, dr, dc, dr, 1.0, inv[r], dr, blk[e], dc, 0.0, panel, dc, false, stream);
             if (rc) return rc;
-            SHG_HIP(hipMemcpyAsync(Arc, panel, (size_t)dr * dc * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            SHG_HIP(hipMemcpyAsync(blk[e], panel, (size_t)dr * dc * sizeof(double), hipMemcpyDeviceToDevice, stream));
         }
         // trailing update A_cd -= W_rc^T W_rd
-        for (int c = r + 1; c < nb; ++c) {
-            const double* Wrc = V.at(r, c);
-            if (!Wrc) continue;
-            for (int d = c; d < nb; ++d) {
-                const double* Wrd = V.at(r, d);
-                if (!Wrd) continue;
+        for (int e = e0 + 1; e < e1; ++e) {
+            const int c = colidx[e];
+            for (int f = e; f < e1; ++f) {
+                const int d = colidx[f];
                 double* Acd = V.at(c, d);
                 SHG_REQUIRE(Acd != nullptr, "shg_block_potrf: fill-in block (%d, %d) was not allocated", c, d);
-                rc = gemm(true, false, V.size(c), V.size(d), dr, -1.0, Wrc, V.size(c), Wrd, V.size(d), 1.0, Acd, V.size(d), c == d, stream);
+                rc = gemm(true, false, V.size(c), V.size(d), dr, -1.0, blk[e], V.size(c), blk[f], V.size(d), 1.0, Acd, V.size(d), c == d, stream);
                 if (rc) return rc;
             }
         }
@@ -140,9 +149,9 @@ extern "C" int shg_block_potrf(int nb, const int* bounds, double* const* ptr, do
 
 // Solve W x = b (transpose == 0) or W^T x = b (transpose != 0) with the block factor; B [n][k] row-major with leading
 // dimension ldb holds b on entry and x on exit.
-extern "C" int shg_block_solve(int nb, const int* bounds, double* const* ptr, double* const* inv, int transpose, double* B, int k, int ldb,
-                               void* stream_) {
-    const BlockView V{nb, bounds, ptr};
+extern "C" int shg_block_solve(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
+                               int transpose, double* B, int k, int ldb, void* stream_) {
+    const BlockView V{nb, bounds, rowptr, colidx, blk};
     int rc = check(V, inv, "shg_block_solve");
     if (rc) return rc;
     SHG_REQUIRE(k >= 0, "shg_block_solve: negative number of right-hand sides");
@@ -160,9 +169,9 @@ extern "C" int shg_block_solve(int nb, const int* bounds, double* const* ptr, do
             if (rc) return rc;
             SHG_HIP(hipMemcpy2DAsync(rows(r), (size_t)ldb * sizeof(double), tmp, (size_t)k * sizeof(double), (size_t)k * sizeof(double), dr,
                                      hipMemcpyDeviceToDevice, stream));
-            for (int c = r + 1; c < nb; ++c) {
-                const double* Wrc = V.at(r, c);
-                if (!Wrc) continue;
+            for (int e = V.begin(r) + 1; e < V.end(r); ++e) {
+                const int c = colidx[e];
+                const double* Wrc = blk[e];
                 rc = gemm(true, false, V.size(c), k, dr, -1.0, Wrc, V.size(c), rows(r), ldb, 1.0, rows(c), ldb, false, stream);   // b_c -= W_rc^T x_r
                 if (rc) return rc;
             }
@@ -170,9 +179,9 @@ extern "C" int shg_block_solve(int nb, const int* bounds, double* const* ptr, do
     } else {
         for (int r = nb - 1; r >= 0; --r) {
             const int dr = V.size(r);
-            for (int c = r + 1; c < nb; ++c) {
-                const double* Wrc = V.at(r, c);
-                if (!Wrc) continue;
+            for (int e = V.begin(r) + 1; e < V.end(r); ++e) {
+                const int c = colidx[e];
+                const double* Wrc = blk[e];
                 rc = gemm(false, false, dr, k, V.size(c), -1.0, Wrc, V.size(c), rows(c), ldb, 1.0, rows(r), ldb, false, stream);  // b_r -= W_rc x_c
                 if (rc) return rc;
             }
@@ -187,8 +196,9 @@ extern "C" int shg_block_solve(int nb, const int* bounds, double* const* ptr, do
 }
 
 // Z = (W^T W)^-1 on the pattern of the factor W held by the blocks, in place (upper blocks); inv[r] = U_rr^-1 on entry.
-extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, double* const* ptr, double* const* inv, void* stream_) {
-    const BlockView V{nb, bounds, ptr};
+extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
+                                        void* stream_) {
+    const BlockView V{nb, bounds, rowptr, colidx, blk};
     int rc = check(V, inv, "shg_block_sparse_inverse");
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
@@ -196,40 +206,32 @@ extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, double* const
     const int dmax = V.max_size();
     // T_rk = U_rr^-1 W_rk of the current block row: as many scratch blocks as the densest row has off-diagonal blocks
     int most = 0;
-    for (int r = 0; r < nb; ++r) {
-        int cnt = 0;
-        for (int c = r + 1; c < nb; ++c) cnt += V.at(r, c) != nullptr;
-        most = std::max(most, cnt);
-    }
+    for (int r = 0; r < nb; ++r) most = std::max(most, V.end(r) - V.begin(r) - 1);
     double* tbuf = scratch.get((size_t)std::max(most, 1) * dmax * dmax);
     SHG_REQUIRE(tbuf != nullptr, "shg_block_sparse_inverse: workspace allocation failed");
-    std::vector<const double*> T(nb);
+    auto T = [&](int e, int r) { return tbuf + (size_t)(e - V.begin(r) - 1) * dmax * dmax; };       // scratch of entry e of row r
     for (int r = nb - 1; r >= 0; --r) {
         const int dr = V.size(r);
-        int used = 0;
-        std::fill(T.begin(), T.end(), nullptr);
-        for (int k = r + 1; k < nb; ++k) {
-            double* Wrk = V.at(r, k);
-            if (!Wrk) continue;
-            double* t = tbuf + (size_t)used++ * dmax * dmax;
-            rc = gemm(false, false, dr, V.size(k), dr, 1.0, inv[r], dr, Wrk, V.size(k), 0.0, t, V.size(k), false, stream);
+        const int e0 = V.begin(r), e1 = V.end(r);
+        for (int e = e0 + 1; e < e1; ++e) {
+            const int dk = V.size(colidx[e]);
+            rc = gemm(false, false, dr, dk, dr, 1.0, inv[r], dr, blk[e], dk, 0.0, T(e, r), dk, false, stream);
             if (rc) return rc;
-            T[k] = t;
-            SHG_HIP(hipMemsetAsync(Wrk, 0, (size_t)dr * V.size(k) * sizeof(double), stream));
+            SHG_HIP(hipMemsetAsync(blk[e], 0, (size_t)dr * dk * sizeof(double), stream));
         }
-        rc = gemm(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, V.at(r, r), dr, false, stream);            // Z_rr = U^-1 U^-T ...
+        rc = gemm(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, blk[e0], dr, false, stream);               // Z_rr = U^-1 U^-T ...
         if (rc) return rc;
-        for (int j = nb - 1; j >= r; --j) {                                                                            // ... and the row, last block first
-            double* Zrj = V.at(r, j);
-            if (!Zrj) continue;
-            for (int k = r + 1; k < nb; ++k) {
-                if (!T[k]) continue;
+        for (int f = e1 - 1; f >= e0; --f) {                                                                           // ... and the row, last block first
+            const int j = colidx[f];
+            double* Zrj = blk[f];
+            for (int e = e0 + 1; e < e1; ++e) {
+                const int k = colidx[e];
                 const double* Zkj = k <= j ? V.at(k, j) : V.at(j, k);                                                  // Z_kj = Z_jk^T for k > j
                 if (!Zkj) continue;
                 if (k <= j)
-                    rc = gemm(false, false, dr, V.size(j), V.size(k), -1.0, T[k], V.size(k), Zkj, V.size(j), 1.0, Zrj, V.size(j), false, stream);
+                    rc = gemm(false, false, dr, V.size(j), V.size(k), -1.0, T(e, r), V.size(k), Zkj, V.size(j), 1.0, Zrj, V.size(j), false, stream);
                 else
-                    rc = gemm(false, true, dr, V.size(j), V.size(k), -1.0, T[k], V.size(k), Zkj, V.size(k), 1.0, Zrj, V.size(j), false, stream);
+                    rc = gemm(false, true, dr, V.size(j), V.size(k), -1.0, T(e, r), V.size(k), Zkj, V.size(k), 1.0, Zrj, V.size(j), false, stream);
                 if (rc) return rc;
             }
         }
@@ -240,12 +242,13 @@ extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, double* const
 
 // Full inverse (W^T W)^-1 from the factor, in place, upper blocks: every block (i, j), j >= i, must be allocated.
 //   X = W^-1 by block back substitution (X_jj = U_jj^-1, X_ij = -U_ii^-1 sum_{i < k <= j} W_ik X_kj), then Z_ij = sum_{k >= j} X_ik X_jk^T.
-extern "C" int shg_block_inverse(int nb, const int* bounds, double* const* ptr, double* const* inv, void* stream_) {
-    const BlockView V{nb, bounds, ptr};
+extern "C" int shg_block_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
+                                 void* stream_) {
+    const BlockView V{nb, bounds, rowptr, colidx, blk};
     int rc = check(V, inv, "shg_block_inverse");
     if (rc) return rc;
-    for (int i = 0; i < nb; ++i)
-        for (int j = i; j < nb; ++j) SHG_REQUIRE(V.at(i, j) != nullptr, "shg_block_inverse: block (%d, %d) is not allocated", i, j);
+    for (int i = 0; i < nb; ++i)                        // ascending columns from the diagonal: a full row has exactly nb - i entries
+        SHG_REQUIRE(V.end(i) - V.begin(i) == nb - i, "shg_block_inverse: block row %d is not fully allocated", i);
     hipStream_t stream = (hipStream_t)stream_;
     Scratch scratch(stream);
     const int dmax = V.max_size();
@@ -293,28 +296,32 @@ extern "C" int shg_block_inverse(int nb, const int* bounds, double* const* ptr, 
 // Products with the stored blocks, V [n][k] = op B [n][k]:
 //   mode 0: V = W B (upper triangular factor);  mode 1: V_i = W_ji^T B_j of the LAST stored block j <= i (the reference's
 //   transposed branch assigns instead of accumulating, grates/lstsq.py:743: kept);  mode 2: V = N B, N symmetric, upper blocks stored
-extern "C" int shg_block_multiply(int nb, const int* bounds, double* const* ptr, int mode, const double* B, int k, int ldb, double* Vout, int ldv,
-                                  void* stream_) {
-    const BlockView V{nb, bounds, ptr};
-    SHG_REQUIRE(nb >= 0 && bounds && ptr, "shg_block_multiply: NULL block table");
+extern "C" int shg_block_multiply(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, int mode, const double* B,
+                                  int k, int ldb, double* Vout, int ldv, void* stream_) {
+    const BlockView V{nb, bounds, rowptr, colidx, blk};
+    SHG_REQUIRE(nb >= 0 && bounds && rowptr && (nb == 0 || (colidx && blk)), "shg_block_multiply: NULL block table");
     SHG_REQUIRE(mode >= 0 && mode <= 2 && k >= 0, "shg_block_multiply: bad mode / size");
     if (k == 0 || nb == 0) return SHG_OK;
     SHG_REQUIRE(B && Vout && ldb >= k && ldv >= k && B != Vout, "shg_block_multiply: bad operands");
+    for (int i = 0; i < nb; ++i)
+        for (int e = V.begin(i); e < V.end(i); ++e)
+            SHG_REQUIRE(colidx[e] >= i && colidx[e] < nb && (e == V.begin(i) || colidx[e] > colidx[e - 1]) && blk[e] != nullptr,
+                        "shg_block_multiply: block row %d: columns must ascend within the upper triangle", i);
     hipStream_t stream = (hipStream_t)stream_;
     const int n = bounds[nb] - bounds[0];
     SHG_HIP(hipMemset2DAsync(Vout, (size_t)ldv * sizeof(double), 0, (size_t)k * sizeof(double), n, stream));
     auto rb = [&](int i) { return B + (size_t)(bounds[i] - bounds[0]) * ldb; };
     auto rv = [&](int i) { return Vout + (size_t)(bounds[i] - bounds[0]) * ldv; };
     int rc = SHG_OK;
+    // rows ascending and columns ascending within a row: in mode 1 the LAST stored block (j, i), j <= i, assigns V_i, as upstream
     for (int i = 0; i < nb && !rc; ++i) {
-        if (mode == 1) {
-            for (int j = 0; j <= i && !rc; ++j)
-                if (V.at(j, i)) rc = gemm(true, false, V.size(i), k, V.size(j), 1.0, V.at(j, i), V.size(i), rb(j), ldb, 0.0, rv(i), ldv, false, stream);
-            continue;
-        }
-        for (int j = i; j < nb && !rc; ++j) {
-            const double* Aij = V.at(i, j);
-            if (!Aij) continue;
+        for (int e = V.begin(i); e < V.end(i) && !rc; ++e) {
+            const int j = colidx[e];
+            const double* Aij = blk[e];
+            if (mode == 1) {
+                rc = gemm(true, false, V.size(j), k, V.size(i), 1.0, Aij, V.size(j), rb(i), ldb, 0.0, rv(j), ldv, false, stream);
+                continue;
+            }
             rc = gemm(false, false, V.size(i), k, V.size(j), 1.0, Aij, V.size(j), rb(j), ldb, 1.0, rv(i), ldv, false, stream);
             if (!rc && mode == 2 && j > i) rc = gemm(true, false, V.size(j), k, V.size(i), 1.0, Aij, V.size(j), rb(i), ldb, 1.0, rv(j), ldv, false, stream);
         }

@@ -287,49 +287,58 @@ def _table(a):
     return a, a.ctypes.data_as(ctypes.c_void_p)
 
 
-def block_potrf(bounds, blocks, inverses):
+class BlockTable:
+    """Stored upper blocks of a block matrix in compressed row form for the shg_block_* calls (include/shg.h):
+    `blocks` maps (i, j), j >= i, to a device tensor [rows_i, cols_j]."""
+
+    def __init__(self, bounds, blocks):
+        self.bounds = np.ascontiguousarray(bounds, dtype=np.int32)
+        nb = self.bounds.size - 1
+        keys = sorted(k for k in blocks if k[1] >= k[0])
+        self.rowptr = np.zeros(nb + 1, dtype=np.int32)
+        for i, _ in keys:
+            self.rowptr[i + 1] += 1
+        np.cumsum(self.rowptr, out=self.rowptr)
+        self.colidx = np.array([j for _, j in keys], dtype=np.int32)
+        self.address = np.array([blocks[k].data_ptr() for k in keys], dtype=np.uint64)
+        self.nb = nb
+
+    def args(self):
+        as_ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        return self.nb, as_ptr(self.bounds), as_ptr(self.rowptr), as_ptr(self.colidx), as_ptr(self.address)
+
+
+def block_potrf(table, inverses):
     """In-place block Cholesky; returns 0 or the 1-based index of the first non-positive pivot."""
     torch = require_gpu()
-    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
-    blocks, pb = _table(blocks)
     inverses, pi = _table(inverses)
     info = torch.zeros(1, dtype=torch.int32, device=device())
-    _lib.call('shg_block_potrf', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, pi, _ptr(info), _stream())
+    _lib.call('shg_block_potrf', *table.args(), pi, _ptr(info), _stream())
     return int(info.item())
 
 
-def block_solve(bounds, blocks, inverses, transpose, B):
+def block_solve(table, inverses, transpose, B):
     """B [n, k] <- W^-1 B or W^-T B in place (device tensor, contiguous last dimension)."""
-    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
-    blocks, pb = _table(blocks)
     inverses, pi = _table(inverses)
-    _lib.call('shg_block_solve', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, pi, 1 if transpose else 0, _ptr(B), B.shape[1],
-              max(B.stride(0), 1), _stream())
+    _lib.call('shg_block_solve', *table.args(), pi, 1 if transpose else 0, _ptr(B), B.shape[1], max(B.stride(0), 1), _stream())
     return B
 
 
-def block_sparse_inverse(bounds, blocks, inverses):
-    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
-    blocks, pb = _table(blocks)
+def block_sparse_inverse(table, inverses):
     inverses, pi = _table(inverses)
-    _lib.call('shg_block_sparse_inverse', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, pi, _stream())
+    _lib.call('shg_block_sparse_inverse', *table.args(), pi, _stream())
 
 
-def block_inverse(bounds, blocks, inverses):
-    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
-    blocks, pb = _table(blocks)
+def block_inverse(table, inverses):
     inverses, pi = _table(inverses)
-    _lib.call('shg_block_inverse', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, pi, _stream())
+    _lib.call('shg_block_inverse', *table.args(), pi, _stream())
 
 
-def block_multiply(bounds, blocks, mode, B):
+def block_multiply(table, mode, B):
     """mode 0: W B, 1: the reference's W^T B (assigning form), 2: N B with the upper blocks of a symmetric N."""
     torch = require_gpu()
-    bounds = np.ascontiguousarray(bounds, dtype=np.int32)
-    blocks, pb = _table(blocks)
     out = torch.empty_like(B)
-    _lib.call('shg_block_multiply', bounds.size - 1, bounds.ctypes.data_as(ctypes.c_void_p), pb, int(mode), _ptr(B), B.shape[1], max(B.stride(0), 1),
-              _ptr(out), max(out.stride(0), 1), _stream())
+    _lib.call('shg_block_multiply', *table.args(), int(mode), _ptr(B), B.shape[1], max(B.stride(0), 1), _ptr(out), max(out.stride(0), 1), _stream())
     return out
 
 

@@ -348,12 +348,8 @@ class BlockMatrix:
         return np.ascontiguousarray(self.__row_index, dtype=np.int32)
 
     def __block_table(self):
-        """device addresses of the stored blocks as an [nb, nb] table (0 = no block)"""
-        nb = self.shape[0]
-        table = np.zeros((nb, self.shape[1]), dtype=np.uint64)
-        for (i, j), block in self.__data.items():
-            table[i, j] = block.data_ptr()
-        return table
+        """the stored upper blocks in compressed row form (engine.BlockTable)"""
+        return engine.BlockTable(self.__square_bounds(), self.__data)
 
     def __inverse_table(self):
         """scratch matrices that hold the inverses of the diagonal factor blocks (kept until a block changes)"""
@@ -370,18 +366,21 @@ class BlockMatrix:
         """symbolic factorisation: eliminating block row r couples every pair of its off-diagonal blocks (r, c), (r, d), c <= d,
         so block (c, d) of the factor is non-zero as well"""
         nb = self.shape[0]
+        pattern = [set() for _ in range(nb)]
+        for (i, j) in self.__data:
+            if j > i:
+                pattern[i].add(j)
         for i in range(nb):
             if not self.__nz(i, i):
                 raise np.linalg.LinAlgError('diagonal block {0} of the matrix is empty'.format(i))
-        pattern = [sorted(c for c in range(r + 1, nb) if self.__nz(r, c)) for r in range(nb)]
         for r in range(nb):
-            cols = pattern[r]
+            cols = sorted(pattern[r])
             for a, c in enumerate(cols):
                 for d in cols[a:]:
                     if not self.__nz(c, d):
                         self.__data[(c, d)] = _zeros(self.__block_shape(c, d))
-                        if d != c:
-                            pattern[c] = sorted(set(pattern[c]) | {d})
+                    if d != c:
+                        pattern[c].add(d)
 
     def cholesky(self):
         """
@@ -389,10 +388,10 @@ class BlockMatrix:
         upper triangular factor W (grates/lstsq.py:698-717).  Raises numpy.linalg.LinAlgError if a diagonal block is not
         positive definite.
         """
-        bounds = self.__square_bounds()
+        self.__square_bounds()
         self.__allocate_fill()
         self.__inverse_factor.clear()
-        pivot = engine.block_potrf(bounds, self.__block_table(), self.__inverse_table())
+        pivot = engine.block_potrf(self.__block_table(), self.__inverse_table())
         if pivot:
             raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(pivot))
 
@@ -404,19 +403,19 @@ class BlockMatrix:
         """v = W b or v = W^T b with the upper triangular factor (grates/lstsq.py:719-750).  As upstream, the transposed
         branch assigns instead of accumulating (lstsq.py:743)."""
         bd = self.__vector(b)
-        v = engine.block_multiply(self.__square_bounds(), self.__block_table(), 1 if transpose else 0, bd)
+        v = engine.block_multiply(self.__block_table(), 1 if transpose else 0, bd)
         return _like_input(v, b)
 
     def multiply_symmetric(self, b):
         """v = N b for a symmetric matrix of which only the upper triangle is stored (grates/lstsq.py:752-776)"""
         bd = self.__vector(b)
-        return _like_input(engine.block_multiply(self.__square_bounds(), self.__block_table(), 2, bd), b)
+        return _like_input(engine.block_multiply(self.__block_table(), 2, bd), b)
 
     def solve_triangular(self, b, transpose=False):
         """Solve W x = b or W^T x = b with the upper triangular block factor (grates/lstsq.py:778-821)."""
         x = self.__vector(b)                                  # a copy: solved in place
         self.__ensure_factor_inverses()
-        engine.block_solve(self.__square_bounds(), self.__block_table(), self.__inverse_table(), bool(transpose), x)
+        engine.block_solve(self.__block_table(), self.__inverse_table(), bool(transpose), x)
         return _like_input(x, b)
 
     def __ensure_factor_inverses(self):
@@ -432,7 +431,7 @@ class BlockMatrix:
         (grates/lstsq.py:823-846).
         """
         self.__ensure_factor_inverses()
-        engine.block_sparse_inverse(self.__square_bounds(), self.__block_table(), self.__inverse_table())
+        engine.block_sparse_inverse(self.__block_table(), self.__inverse_table())
         self.__inverse_factor.clear()
 
     def inverse(self):
@@ -445,7 +444,7 @@ class BlockMatrix:
             for j in range(i, nb):
                 self.__set_block(i, j)                        # the inverse of a banded factor is dense
         self.__ensure_factor_inverses()
-        engine.block_inverse(self.__square_bounds(), self.__block_table(), self.__inverse_table())
+        engine.block_inverse(self.__block_table(), self.__inverse_table())
         self.__inverse_factor.clear()
 
     def _scale(self, value):

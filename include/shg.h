@@ -200,8 +200,9 @@ int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream)
 
 /* ------------------------------------------------------------------------------------------------
  * Sparse block Cholesky of the block-banded normal equations ("Kalman smoother"), one call per operation: the blocks stay in
- * HBM, the call walks them on the device (csrc/blockchol.hip).  nb block rows / columns with boundaries bounds[0..nb];
- * ptr[i * nb + j] = device address of block (i, j) (row-major [rows_i][cols_j]) or NULL; blocks with j >= i are referenced;
+ * HBM, the call walks them on the device (csrc/blockchol.hip).  nb block rows / columns with boundaries bounds[0..nb]; the
+ * stored blocks (j >= i) in compressed row form: entries rowptr[i] .. rowptr[i+1]-1 of row i, colidx[e] ascending from the
+ * diagonal, blk[e] = device address of block (i, colidx[e]) (row-major [rows_i][cols_j]);
  * inv[i] = scratch [rows_i][rows_i] holding U_ii^-1 (written by shg_block_potrf, read by the others).
  *   shg_block_potrf           N = W^T W in place, fill-in allocated by the caller       (grates/lstsq.py:698-717)
  *   shg_block_solve           W x = b / W^T x = b for B [n][k] in place                 (grates/lstsq.py:778-821, 950-968)
@@ -209,11 +210,13 @@ int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream)
  *   shg_block_inverse         full inverse, upper blocks, in place                      (grates/lstsq.py:848-882)
  *   shg_block_multiply        V = W B (mode 0), the reference's W^T B (1), N B for a symmetric N (2)   (grates/lstsq.py:719-776)
  * ------------------------------------------------------------------------------------------------ */
-int shg_block_potrf(int nb, const int* bounds, double* const* ptr, double* const* inv, int* info, void* stream);
-int shg_block_solve(int nb, const int* bounds, double* const* ptr, double* const* inv, int transpose, double* B, int k, int ldb, void* stream);
-int shg_block_sparse_inverse(int nb, const int* bounds, double* const* ptr, double* const* inv, void* stream);
-int shg_block_inverse(int nb, const int* bounds, double* const* ptr, double* const* inv, void* stream);
-int shg_block_multiply(int nb, const int* bounds, double* const* ptr, int mode, const double* B, int k, int ldb, double* V, int ldv, void* stream);
+int shg_block_potrf(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int* info, void* stream);
+int shg_block_solve(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int transpose, double* B,
+                    int k, int ldb, void* stream);
+int shg_block_sparse_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, void* stream);
+int shg_block_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, void* stream);
+int shg_block_multiply(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, int mode, const double* B, int k, int ldb,
+                       double* V, int ldv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Analysis (area-weighted least squares per order)

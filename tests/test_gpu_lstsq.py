@@ -210,3 +210,103 @@ def test_sinex_normals_solved_on_device(golden, tmp_path):
         sigma = ne.posterior_sigma(x)
         r = g["sinex_u_lPl"][0] - (g["sinex_u_n"].T @ expected).item()
         assert abs(sigma - np.sqrt(r / (12345 - 77))) < 1e-10 * sigma
+
+
+def _config5_blocks(t, d, gen, torch):
+    """epoch t of the seeded full-size system: N_tt = G G^T / d + 4 I (SPD), N_t,t+1 = R / d (spectral norm ~ 2 / sqrt(d))"""
+    gen.manual_seed(50_000 + t)
+    G = torch.randn((d, d + 8), dtype=torch.float64, device='cuda', generator=gen)
+    D = ga.engine.gemm(G, G, transb=True, alpha=1.0 / d)
+    D.diagonal().add_(4.0)
+    R = torch.randn((d, d), dtype=torch.float64, device='cuda', generator=gen) / d
+    return D, R
+
+
+def test_full_size_config5_chain():
+    """BASELINE config 5 at its stated size: 3650 daily epochs of a d/o-40 state (d = 1681), VAR(1) coupling, solved with the
+    1 + 100 right-hand sides of NormalEquations.solve and followed by the sparse inverse (grates/lstsq.py:950-968, 1026-1042).
+    The chain is built on the device from per-epoch seeds (3 x 82.5 GB: matrix, coupling blocks, inverses of the diagonal factor
+    blocks; on a card with less free memory the chain is shortened, never below 64 epochs) and checked through properties that
+    need no reference run: the residual ||N x - n|| / ||n|| with N regenerated from the seeds, symmetry of the covariance
+    blocks and the identity (N N^-1)_tt = I, which for a block-tridiagonal N only involves blocks of the sparse inverse."""
+    import json
+    import os
+    import time
+    import torch
+    d, T = 1681, 3650
+    free, _ = torch.cuda.mem_get_info()
+    fit = int((free - 30e9) // (3 * d * d * 8))          # 30 GB for the right-hand sides, the scratch and the checks
+    T = min(T, fit)
+    assert T >= 64, 'not enough free device memory for a 64-epoch chain'
+    gen = torch.Generator(device='cuda')
+    idx = np.arange(0, (T + 1) * d, d)
+    bm = ls.BlockMatrix(idx, idx)
+    for t in range(T):
+        D, R = _config5_blocks(t, d, gen, torch)
+        bm._set_device(t, t, D)
+        if t + 1 < T:
+            bm._set_device(t, t + 1, R)
+    gen.manual_seed(49_999)
+    rhs = torch.randn((T * d, 1), dtype=torch.float64, device='cuda', generator=gen)
+    signs = torch.randint(0, 2, (T * d, 100), device='cuda', generator=gen).double() * 2.0 - 1.0
+    ne = ls.NormalEquations(bm, rhs, 0.0, T * d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x = ne.solve(signs=signs)
+    torch.cuda.synchronize()
+    t_solve = time.perf_counter() - t0
+    xs = torch.cat((x, ne.monte_carlo_vectors[:, :3]), dim=1)
+    bs = rhs
+    del signs
+    ne.monte_carlo_vectors = None
+
+    # N [x, z1, z2, z3] block row by block row against regenerated blocks (rocBLAS products): the residual of the solution, and for
+    # the Monte-Carlo vectors z = W^-1 xi (upstream solves only the back substitution for them) z^T N z = |W z|^2 = |xi|^2 = T d
+    num = torch.zeros((), dtype=torch.float64, device='cuda')
+    quad = torch.zeros(3, dtype=torch.float64, device='cuda')
+    prev = None
+    for t in range(T):
+        D, R = _config5_blocks(t, d, gen, torch)
+        own = xs[t * d:(t + 1) * d]
+        Nx = D @ own
+        if t + 1 < T:
+            Nx += R @ xs[(t + 1) * d:(t + 2) * d]
+        if prev is not None:
+            Nx += prev.t() @ xs[(t - 1) * d:t * d]
+        num += ((Nx[:, 0] - bs[t * d:(t + 1) * d, 0]) ** 2).sum()
+        quad += (own[:, 1:] * Nx[:, 1:]).sum(dim=0)
+        prev = R
+    residual = float(torch.sqrt(num) / bs[:, 0].norm())
+    quad_defect = float((quad / (T * d) - 1.0).abs().max())
+    assert residual < 1e-13 and quad_defect < 1e-13, (residual, quad_defect)
+
+    t0 = time.perf_counter()
+    ne.compute_covariance(sparse=True)
+    torch.cuda.synchronize()
+    t_inv = time.perf_counter() - t0
+    eye = torch.eye(d, dtype=torch.float64, device='cuda')
+    worst_sym = worst_id = 0.0
+    for t in sorted({0, 1, T // 3, T // 2, T - 2, T - 1}):
+        Z = bm.device_block(t, t)
+        worst_sym = max(worst_sym, float((Z - Z.t()).abs().max() / Z.abs().max()))
+        assert float(Z.diagonal().min()) > 0.0
+        D, R = _config5_blocks(t, d, gen, torch)
+        acc = D @ Z
+        if t + 1 < T:
+            acc += R @ bm.device_block(t, t + 1).t()
+        if t > 0:
+            acc += _config5_blocks(t - 1, d, gen, torch)[1].t() @ bm.device_block(t - 1, t)
+        worst_id = max(worst_id, float((acc - eye).abs().max()))
+    assert worst_sym < 1e-13 and worst_id < 1e-12, (worst_sym, worst_id)
+    record = {'path': 'config5 full size: block-banded smoother', 'epochs': T, 'dim': d, 'order': 1, 'right_hand_sides': 101,
+              'factor_and_solve_s': round(t_solve, 3), 'sparse_inverse_s': round(t_inv, 3),
+              'epochs_per_s': round(T / (t_solve + t_inv), 1), 'residual': residual, 'monte_carlo_quadratic_form_defect': quad_defect,
+              'covariance_asymmetry_max': worst_sym, 'identity_defect_max': worst_id}
+    print(json.dumps(record))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'config5_full_size.json'), 'w') as f:
+            f.write(json.dumps(record) + '\n')
+    except OSError:
+        pass
