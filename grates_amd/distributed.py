@@ -136,6 +136,124 @@ def _gather_blocks(tensors, group=None):
     return out
 
 
+class _PartitionedChain:
+    """
+    Nested dissection of a symmetric positive definite block-tridiagonal matrix whose block rows (epochs) are distributed over
+    the ranks in contiguous ranges, with the last epoch of every rank but the last as separator: the factored interior chain of
+    this rank, Y = A_II^-1 [C_left, C_right, b] for its two coupling blocks and the right-hand side, and the factored
+    separator (Schur complement) system, which every rank holds redundantly after ONE all_gather of 5 d x d blocks (and a few
+    vectors) per rank.  A second, small all_gather beforehand hands every rank the coupling block to its left separator.
+    """
+
+    def __init__(self, diag, upper, rhs, group):
+        import torch
+        import torch.distributed as dist
+        from . import engine
+        from .lstsq import BlockMatrix
+        self.torch, self.engine, self.group = torch, engine, group
+        self.rank = rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.n_loc = n_loc = len(diag)
+        self.last = last = rank == world - 1
+        if n_loc < (1 if last else 2):
+            raise ValueError('every rank but the last needs at least two epochs (got {0})'.format(n_loc))
+        self.sizes = sizes = [int(b.shape[0]) for b in diag]
+        self.bounds = bounds = np.concatenate(([0], np.cumsum(sizes)))
+        device = diag[0].device
+        self.k = k = 0 if rhs is None else rhs.shape[1]
+
+        def zeros(r, c):
+            return torch.zeros((r, c), dtype=torch.float64, device=device)
+        self.zeros = zeros
+
+        def chain(blocks_d, blocks_u):
+            index = np.concatenate(([0], np.cumsum([int(b.shape[0]) for b in blocks_d])))
+            bm = BlockMatrix(index, index)
+            for i, b in enumerate(blocks_d):
+                bm._set_device(i, i, b.clone())
+            for i, b in enumerate(blocks_u):
+                bm._set_device(i, i + 1, b.clone())
+            return bm
+
+        self.ni = ni = n_loc if (last or world == 1) else n_loc - 1         # interior epochs
+        self.n_int = n_int = int(bounds[ni])
+        if world == 1:
+            self.interior = chain(diag, upper[:n_loc - 1])
+            self.interior.cholesky()
+            return
+
+        # coupling to the left separator: N[s_(g-1), t0] lives on the previous rank
+        d_sep = sizes[-1]
+        boundary = upper[n_loc - 1] if not last else zeros(d_sep, d_sep)
+        if not last and boundary.shape[1] != boundary.shape[0]:
+            raise ValueError('partitioned solve expects equal block sizes at the rank boundaries')
+        boundaries = _gather_blocks([boundary.contiguous()], group)           # collective: every rank takes part
+        self.left = left = boundaries[rank - 1][0] if rank > 0 else None      # [d_sep_left, d_first]
+        self.right = upper[ni - 1] if not last else None                      # N[t1-2, t1-1]
+
+        self.interior = interior = chain(diag[:ni], upper[:ni - 1])
+        interior.cholesky()
+        columns = [rhs[:n_int]] if k else []
+        if left is not None:                                                # C_left = left^T in the first interior block rows
+            cl = zeros(n_int, left.shape[0])
+            cl[:sizes[0]] = left.t()
+            columns.append(cl)
+        if not last:                                                        # C_right = N[t1-2, t1-1] in the last interior block rows
+            cr = zeros(n_int, d_sep)
+            cr[int(bounds[ni - 1]):n_int] = upper[ni - 1]
+            columns.append(cr)
+        W = torch.cat(columns, dim=1).contiguous()
+        del columns
+        Z = interior.solve_triangular(interior.solve_triangular(W, transpose=True))
+        del W
+        self.zb = Z[:, :k]
+        pos = k
+        self.ZL = self.ZR = None
+        if left is not None:
+            self.ZL = Z[:, pos:pos + left.shape[0]]
+            pos += left.shape[0]
+        if not last:
+            self.ZR = Z[:, pos:pos + d_sep]
+        self.Y = Z[:, k:]                                                   # [Y_left, Y_right]
+        zb, ZL, ZR = self.zb, self.ZL, self.ZR
+
+        first = slice(0, sizes[0])
+        tail = slice(int(bounds[ni - 1]), n_int)
+        # Schur complement pieces of this rank's interior chain (d = separator block size; equal sizes at the boundaries)
+        self.d = d = d_sep if not last else left.shape[0]
+        kk = max(k, 1)
+        has_b = k > 0
+        S_ll = engine.gemm(left, ZL[first].contiguous()) if left is not None else zeros(d, d)
+        b_l = engine.gemm(left, zb[first].contiguous()) if (left is not None and has_b) else zeros(d, kk)
+        S_lr = engine.gemm(left, ZR[first].contiguous()) if (left is not None and not last) else zeros(d, d)
+        S_rr = engine.gemm(upper[ni - 1], ZR[tail].contiguous(), transa=True) if not last else zeros(d, d)
+        b_r = engine.gemm(upper[ni - 1], zb[tail].contiguous(), transa=True) if (not last and has_b) else zeros(d, kk)
+        sep_d = diag[n_loc - 1] if not last else zeros(d, d)
+        sep_b = rhs[n_int:] if (not last and has_b) else zeros(d, kk)
+        gathered = _gather_blocks([sep_d.contiguous(), S_ll, S_lr, S_rr, sep_b.contiguous(), b_l, b_r], group)
+
+        # separator system (world - 1 block rows), held redundantly on every rank
+        self.nsep = nsep = world - 1
+        index = np.arange(0, (nsep + 1) * d, d)
+        self.reduced = reduced = BlockMatrix(index, index)
+        self.red_rhs = red_rhs = zeros(nsep * d, kk)
+        for i in range(nsep):
+            own, nxt = gathered[i], gathered[i + 1]
+            block = own[0].clone()
+            engine.axpby(-1.0, own[3], 1.0, block)                           # - S_rr of the chain on its left
+            engine.axpby(-1.0, nxt[1], 1.0, block)                           # - S_ll of the chain on its right
+            reduced._set_device(i, i, block)
+            if i + 1 < nsep:
+                coupling = zeros(d, d)
+                engine.axpby(-1.0, nxt[2], 0.0, coupling)                    # - S_lr of the chain between separators i and i + 1
+                reduced._set_device(i, i + 1, coupling)
+            r = red_rhs[i * d:(i + 1) * d]
+            engine.axpby(1.0, own[4], 0.0, r)
+            engine.axpby(-1.0, own[6], 1.0, r)
+            engine.axpby(-1.0, nxt[5], 1.0, r)
+        reduced.cholesky()
+
+
 def solve_block_tridiagonal_partitioned(diag, upper, rhs, group=None):
     """
     Solve the symmetric positive definite block-tridiagonal system N x = b whose block rows (epochs) are distributed over the
@@ -148,116 +266,80 @@ def solve_block_tridiagonal_partitioned(diag, upper, rhs, group=None):
         rhs       [sum of block sizes, columns]
     and receives x for its epochs.  Every rank but the last needs at least two epochs.
 
-    Scheme (nested dissection with the last epoch of every rank but the last as separator): each rank factors its interior
-    chain with the block Cholesky of grates_amd.lstsq.BlockMatrix (sequential in epochs, all ranks concurrently) and solves it
-    for the right-hand side and for its two coupling blocks; ONE all_gather (RCCL) collects the separator blocks and the Schur
-    complement pieces (5 d x d blocks and a few vectors per rank), every rank solves the small separator system redundantly and
-    back-substitutes.  A second small all_gather beforehand hands every rank the coupling block to its left separator.
+    Scheme (nested dissection with the last epoch of every rank but the last as separator, _PartitionedChain): each rank factors
+    its interior chain with the block Cholesky of grates_amd.lstsq.BlockMatrix (sequential in epochs, all ranks concurrently)
+    and solves it for the right-hand side and for its two coupling blocks; ONE all_gather (RCCL) collects the separator blocks
+    and the Schur complement pieces, every rank solves the small separator system redundantly and back-substitutes.
     """
-    import torch
-    import torch.distributed as dist
-    from . import engine
-    from .lstsq import BlockMatrix
-    torch_cat = torch.cat
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    n_loc = len(diag)
-    last = rank == world - 1
-    if n_loc < (1 if last else 2):
-        raise ValueError('every rank but the last needs at least two epochs (got {0})'.format(n_loc))
-    sizes = [int(b.shape[0]) for b in diag]
-    bounds = np.concatenate(([0], np.cumsum(sizes)))
-    k = rhs.shape[1]
-
-    def chain(blocks_d, blocks_u):
-        index = np.concatenate(([0], np.cumsum([int(b.shape[0]) for b in blocks_d])))
-        bm = BlockMatrix(index, index)
-        for i, b in enumerate(blocks_d):
-            bm._set_device(i, i, b.clone())
-        for i, b in enumerate(blocks_u):
-            bm._set_device(i, i + 1, b.clone())
-        return bm
-
-    if world == 1:
-        bm = chain(diag, upper[:n_loc - 1])
-        bm.cholesky()
-        return bm.solve_triangular(bm.solve_triangular(rhs, transpose=True))
-
-    # coupling to the left separator: N[s_(g-1), t0] lives on the previous rank
-    d_sep = sizes[-1]
-    boundary = upper[n_loc - 1] if not last else torch.zeros((d_sep, d_sep), dtype=torch.float64, device=rhs.device)
-    if not last and boundary.shape[1] != boundary.shape[0]:
-        raise ValueError('partitioned solve expects equal block sizes at the rank boundaries')
-    boundaries = _gather_blocks([boundary.contiguous()], group)           # collective: every rank takes part
-    left = boundaries[rank - 1][0] if rank > 0 else None                  # [d_sep_left, d_first]
-
-    ni = n_loc if last else n_loc - 1                                   # interior epochs
-    interior = chain(diag[:ni], upper[:ni - 1])
-    interior.cholesky()
-    n_int = int(bounds[ni])
-    columns = [rhs[:n_int]]
-    if left is not None:                                                # C_left = left^T in the first interior block rows
-        cl = torch.zeros((n_int, left.shape[0]), dtype=torch.float64, device=rhs.device)
-        cl[:sizes[0]] = left.t()
-        columns.append(cl)
-    if not last:                                                        # C_right = N[t1-2, t1-1] in the last interior block rows
-        cr = torch.zeros((n_int, d_sep), dtype=torch.float64, device=rhs.device)
-        cr[int(bounds[ni - 1]):n_int] = upper[ni - 1]
-        columns.append(cr)
-    W = torch_cat(columns, dim=1).contiguous()
-    Z = interior.solve_triangular(interior.solve_triangular(W, transpose=True))
-    zb = Z[:, :k]
-    pos = k
-    ZL = ZR = None
-    if left is not None:
-        ZL = Z[:, pos:pos + left.shape[0]]
-        pos += left.shape[0]
-    if not last:
-        ZR = Z[:, pos:pos + d_sep]
-
-    def zeros(r, c):
-        return torch.zeros((r, c), dtype=torch.float64, device=rhs.device)
-
-    first = slice(0, sizes[0])
-    tail = slice(int(bounds[ni - 1]), n_int)
-    # Schur complement pieces of this rank's interior chain (d = separator block size; equal sizes at the boundaries)
-    d = d_sep if not last else left.shape[0]
-    S_ll = engine.gemm(left, ZL[first].contiguous()) if left is not None else zeros(d, d)
-    b_l = engine.gemm(left, zb[first].contiguous()) if left is not None else zeros(d, k)
-    S_lr = engine.gemm(left, ZR[first].contiguous()) if (left is not None and not last) else zeros(d, d)
-    S_rr = engine.gemm(upper[ni - 1], ZR[tail].contiguous(), transa=True) if not last else zeros(d, d)
-    b_r = engine.gemm(upper[ni - 1], zb[tail].contiguous(), transa=True) if not last else zeros(d, k)
-    sep_d = diag[n_loc - 1] if not last else zeros(d, d)
-    sep_b = rhs[n_int:] if not last else zeros(d, k)
-    gathered = _gather_blocks([sep_d.contiguous(), S_ll, S_lr, S_rr, sep_b.contiguous(), b_l, b_r], group)
-
-    # separator system (world - 1 block rows), solved redundantly on every rank
-    nsep = world - 1
-    index = np.arange(0, (nsep + 1) * d, d)
-    reduced = BlockMatrix(index, index)
-    red_rhs = zeros(nsep * d, k)
-    for i in range(nsep):
-        own, nxt = gathered[i], gathered[i + 1]
-        block = own[0].clone()
-        engine.axpby(-1.0, own[3], 1.0, block)                           # - S_rr of the chain on its left
-        engine.axpby(-1.0, nxt[1], 1.0, block)                           # - S_ll of the chain on its right
-        reduced._set_device(i, i, block)
-        if i + 1 < nsep:
-            coupling = zeros(d, d)
-            engine.axpby(-1.0, nxt[2], 0.0, coupling)                    # - S_lr of the chain between separators i and i + 1
-            reduced._set_device(i, i + 1, coupling)
-        r = red_rhs[i * d:(i + 1) * d]
-        engine.axpby(1.0, own[4], 0.0, r)
-        engine.axpby(-1.0, own[6], 1.0, r)
-        engine.axpby(-1.0, nxt[5], 1.0, r)
-    reduced.cholesky()
-    x_sep = reduced.solve_triangular(reduced.solve_triangular(red_rhs, transpose=True))
-
+    pc = _PartitionedChain(diag, upper, rhs, group)
+    if pc.world == 1:
+        return pc.interior.solve_triangular(pc.interior.solve_triangular(rhs, transpose=True))
+    engine, d, rank = pc.engine, pc.d, pc.rank
+    x_sep = pc.reduced.solve_triangular(pc.reduced.solve_triangular(pc.red_rhs, transpose=True))
     # back substitution of the interior chain
-    x_int = zb.clone()
-    if left is not None:
-        engine.gemm(ZL.contiguous(), x_sep[(rank - 1) * d:rank * d], alpha=-1.0, beta=1.0, out=x_int)
-    if not last:
-        engine.gemm(ZR.contiguous(), x_sep[rank * d:(rank + 1) * d], alpha=-1.0, beta=1.0, out=x_int)
-        return torch_cat((x_int, x_sep[rank * d:(rank + 1) * d]), dim=0)
+    x_int = pc.zb.clone()
+    if pc.left is not None:
+        engine.gemm(pc.ZL.contiguous(), x_sep[(rank - 1) * d:rank * d], alpha=-1.0, beta=1.0, out=x_int)
+    if not pc.last:
+        engine.gemm(pc.ZR.contiguous(), x_sep[rank * d:(rank + 1) * d], alpha=-1.0, beta=1.0, out=x_int)
+        return pc.torch.cat((x_int, x_sep[rank * d:(rank + 1) * d]), dim=0)
     return x_int
+
+
+def sparse_inverse_block_tridiagonal_partitioned(diag, upper, group=None):
+    """
+    Block-tridiagonal part of N^-1 (the covariance blocks NormalEquations.compute_covariance(sparse=True) leaves in the matrix,
+    grates/lstsq.py:823-846, 1026-1042) for a chain whose epochs are distributed over the ranks like in
+    solve_block_tridiagonal_partitioned (same arguments without the right-hand side).
+
+    Returns (Zdiag, Zupper): Zdiag[k] = (N^-1)[t0+k, t0+k] and Zupper[k] = (N^-1)[t0+k, t0+k+1] for the epochs of this rank
+    (the last rank returns one coupling block less).
+
+    With I the interior epochs of a rank, S the separators and Y = A_II^-1 A_IS (two coupling blocks per rank):
+        Z_SS = (A_SS - A_SI A_II^-1 A_IS)^-1       band of the inverse of the separator system (Takahashi, redundantly)
+        Z_IS = -Y Z_SS                             only the blocks next to the separators are kept
+        Z_II = A_II^-1 + Y Z_SS Y^T                band of A_II^-1 by the Takahashi recursion of the interior chain, plus a
+                                                   rank-2d correction per block (two GEMMs per block)
+    The only collectives are the two all_gathers of the factorisation and one more of a single d x d block per rank (the
+    covariance block that couples a separator to the first epoch of the next rank is computed by that next rank).
+    """
+    pc = _PartitionedChain(diag, upper, None, group)
+    torch, engine = pc.torch, pc.engine
+    ni, bounds = pc.ni, pc.bounds
+    if pc.world == 1:
+        pc.interior.sparse_inverse()
+        return ([pc.interior.device_block(t, t) for t in range(ni)], [pc.interior.device_block(t, t + 1) for t in range(ni - 1)])
+    d, rank, last = pc.d, pc.rank, pc.last
+    pc.reduced.sparse_inverse()
+    sep = pc.reduced.device_block
+    # Z_SS restricted to the (at most two) separators next to this rank's chain
+    parts = []
+    if pc.left is not None:
+        row = [sep(rank - 1, rank - 1)] + ([sep(rank - 1, rank)] if not last else [])
+        parts.append(torch.cat(row, dim=1))
+    if not last:
+        row = ([sep(rank - 1, rank).t()] if pc.left is not None else []) + [sep(rank, rank)]
+        parts.append(torch.cat(row, dim=1))
+    M = torch.cat(parts, dim=0).contiguous()
+    dl = d if pc.left is not None else 0
+    Y = pc.Y.contiguous()
+    P = engine.gemm(Y, M)                                                   # [n_int, dl + dr] = Y Z_SS
+    pc.interior.sparse_inverse()
+    rows = lambda t: slice(int(bounds[t]), int(bounds[t + 1]))          # noqa: E731
+    Zdiag, Zupper = [], []
+    for t in range(ni):
+        block = pc.interior.device_block(t, t)
+        engine.gemm(P[rows(t)], Y[rows(t)], transb=True, beta=1.0, out=block)
+        Zdiag.append(block)
+        if t + 1 < ni:
+            block = pc.interior.device_block(t, t + 1)
+            engine.gemm(P[rows(t)], Y[rows(t + 1)], transb=True, beta=1.0, out=block)
+            Zupper.append(block)
+    # blocks next to the separators: Z[t, r] = -(Y Z_SS)[t, r],  Z[l, t] = -(Y Z_SS)[t, l]^T
+    to_left = (-P[rows(0), :dl]).t().contiguous() if pc.left is not None else pc.zeros(d, pc.sizes[0])
+    from_right = _gather_blocks([to_left], pc.group)
+    if not last:
+        Zupper.append((-P[rows(ni - 1), dl:]).contiguous())
+        Zdiag.append(sep(rank, rank))
+        Zupper.append(from_right[rank + 1][0])
+    return Zdiag, Zupper

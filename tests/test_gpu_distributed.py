@@ -46,6 +46,10 @@ def _worker(rank, world, port, epochs, dim, columns, result_dir):
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     x = gd.solve_block_tridiagonal_partitioned([dev(b) for b in diag[t0:t1]], [dev(b) for b in upper[t0:t1]], dev(rhs[t0 * dim:t1 * dim]))
     np.save(os.path.join(result_dir, 'x_{0}.npy'.format(rank)), x.cpu().numpy())
+    Zd, Zu = gd.sparse_inverse_block_tridiagonal_partitioned([dev(b) for b in diag[t0:t1]], [dev(b) for b in upper[t0:t1]])
+    assert len(Zd) == t1 - t0 and len(Zu) == (t1 - t0 if rank < world - 1 else t1 - t0 - 1)
+    np.save(os.path.join(result_dir, 'zd_{0}.npy'.format(rank)), np.stack([b.cpu().numpy() for b in Zd]))
+    np.save(os.path.join(result_dir, 'zu_{0}.npy'.format(rank)), np.stack([b.cpu().numpy() for b in Zu]))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -70,9 +74,21 @@ def test_partitioned_smoother_solve(world, epochs, dim, tmp_path):
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     one = gd.solve_block_tridiagonal_partitioned([dev(b) for b in diag], [dev(b) for b in upper], dev(rhs)).cpu().numpy()
     assert relerr(one, ref) < 1e-10
+    # covariance blocks of the partitioned sparse inverse against the dense inverse
+    Zref = np.linalg.inv(N)
+    zd = np.concatenate([np.load(os.path.join(str(tmp_path), 'zd_{0}.npy'.format(r))) for r in range(world)])
+    zu = np.concatenate([np.load(os.path.join(str(tmp_path), 'zu_{0}.npy'.format(r))) for r in range(world)])
+    assert zd.shape == (epochs, dim, dim) and zu.shape == (epochs - 1, dim, dim)
+    scale = np.abs(Zref).max()
+    for t in range(epochs):
+        assert np.abs(zd[t] - Zref[t * dim:(t + 1) * dim, t * dim:(t + 1) * dim]).max() < 1e-10 * scale
+        if t + 1 < epochs:
+            assert np.abs(zu[t] - Zref[t * dim:(t + 1) * dim, (t + 1) * dim:(t + 2) * dim]).max() < 1e-10 * scale
+    Zd1, Zu1 = gd.sparse_inverse_block_tridiagonal_partitioned([dev(b) for b in diag], [dev(b) for b in upper])
+    assert relerr(np.stack([b.cpu().numpy() for b in Zd1]), zd) < 1e-10 and relerr(np.stack([b.cpu().numpy() for b in Zu1]), zu) < 1e-10
 
 
-def test_partitioned_smoother_rejects_single_epoch_ranks():
+def test_partitioned_smoother_single_process_single_epoch():
     from grates_amd import distributed as gd
     import torch.distributed as dist
     assert not dist.is_initialized()
