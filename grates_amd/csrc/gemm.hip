@@ -13,8 +13,19 @@
 namespace shg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
+#ifndef SHG_GEMM_X
+#define SHG_GEMM_X 0                    // experiment switches (timing only, results are wrong): 1 no A products, 2 no barrier
+#endif                                  // in the K loop, 4 no operand loads in the K loop, 8 no LDS stores in the K loop, 16 Sigma tile not staged, 32 A tile not
+                                        // staged, 64 no Legendre factor
+#ifndef SHG_GEMM_PRIO
+#define SHG_GEMM_PRIO 1                 // wave priority raised while a tile is staged (1: until the barrier, 2: through it, 3: through the last k-step)
+#endif
+#ifndef SHG_GEMM_INTERLEAVE
+#define SHG_GEMM_INTERLEAVE 1           // operand loads dealt between the MFMAs (0: experiment switch, loads in a row)
+#endif
 constexpr int LDA = 18;     // As[row][k], 18-double rows: the 16 rows x 2 k a half wave reads in one LDS cycle fall into 32 distinct bank pairs
 constexpr int LDB = 144;    // Bs[k][col], 128 + 16 pad
 
@@ -31,15 +42,32 @@ struct GemmParams {
     // covariance propagation
     const double* pkd;      // [nlat][ldp]  kn-scaled Legendre functions in degree-wise order (min_degree 0)
     int ldp;
+    int pk_rows;            // rows of pkd (regular grids: bounds the buffer descriptor of the Legendre table)
     const double* csr;      // [2N+1][nlon] 1, cos(lon), sin(lon), cos(2 lon), ... : row = rank of the coefficient inside its degree
     const int* rslot;       // [ldp] rank inside the degree of every degree-wise index
+    const unsigned* csoff;  // [ldp + 16] byte offset rank * ldcs * 8 of the cos/sin row of every degree-wise index (regular grids)
     int ldcs;               // leading dimension of csr (nlon, or the point count for point lists)
     long long idiv, jmod;   // flat row R -> table row R / idiv, table column R % jmod (regular grid: both nlon)
     int p_off;              // min_degree^2: first degree-wise index covered by the covariance matrix
     long long row0;         // first flat grid row (lat0 * nlon) of the band
     double* partial;        // [gridDim.x][M] per-column-block partial row sums
     int pkt;                // generated A: Legendre table stored transposed, pkd[p][row] (point lists)
+#ifdef SHG_TIMELINE
+    unsigned long long* tl; // profiling build: [blocks][4 waves][8] cycle sums of the K-loop phases (tools/gemm_phases.py)
+#endif
 };
+
+// profiling build only: shader-clock cycles spent in the phases of the K loop, summed per wave on the scalar unit
+#ifdef SHG_TIMELINE
+#define SHG_TL_MARK(i)                                          \
+    do {                                                        \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        tl_sum[i] += now_ - tl_prev;                            \
+        tl_prev = now_;                                         \
+    } while (0)
+#else
+#define SHG_TL_MARK(i)
+#endif
 
 // SYM (covariance mode only): Sigma is symmetric and only its upper triangle is used,
 //   sigma2[r] = sum_c [ sum_{p<c} 2 A[r][p] Sigma[p][c] + A[r][c] Sigma[c][c] ] A[r][c]:
@@ -61,6 +89,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     const int fr = lane & 15, fk = lane >> 4;
     // wave-uniform half of the K tile a thread generates in COVPROP mode: keeps the degree / rank bookkeeping on the scalar unit
     const int khalf = __builtin_amdgcn_readfirstlane(tid >> 7);
+    // regular-grid covariance propagation: operands come through buffer loads (see fetch_full)
+    // (not the symmetric variant: with its weighting code hipcc runs out of registers, spills the prefetched operands inside the
+    //  loop and the result of the spilled build is wrong in the last row quad of every wave tile; it keeps the global-load form)
+    constexpr bool BUF = (MODE == MODE_COVPROP) && !PKT && !SYM;
     // PLAIN: column block fastest.  COVPROP: row block fastest -- the blocks resident at one time then walk the same
     // 33 MB column panel of Sigma together and it is fetched from HBM once instead of once per row block.
     const int m0 = (MODE == MODE_PLAIN ? blockIdx.y : blockIdx.x) * BM;
@@ -136,41 +168,82 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     const unsigned b_voff0 = (unsigned)((VEC ? min(n0 + b_col, P.N - 2) : min(n0 + b_col, P.N - 1)) * 8);
     const unsigned b_voff1 = (unsigned)(min(n0 + b_col + 1, P.N - 1) * 8);
 
-    // COVPROP: ranks (inside their degree) of the eight degree-wise indices a thread generates in the next K tile, read from
-    // the rank table with scalar loads (constant address space: uniform loads from it are scalar loads)
+    // COVPROP: ranks (inside their degree) of the eight degree-wise indices a thread generates in the K tile it fetches next,
+    // read from the rank table with scalar loads (constant address space: uniform loads from it are scalar loads)
     int rank[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto load_ranks = [&](int k0) {
+        if (BUF) return;
         const crank_t* rs = reinterpret_cast<const crank_t*>(reinterpret_cast<unsigned long long>(P.rslot));
 #pragma unroll
         for (int h = 0; h < 8; ++h) rank[h] = rs[min(k0 + khalf + 2 * h, P.K - 1) + P.p_off];      // (the table ends at p_off + K)
     };
     if (MODE != MODE_PLAIN) load_ranks(0);
-    auto fetch_full = [&](int k0) {
-        if (MODE == MODE_PLAIN) {
-            const double* ak = a_base + k0;                           // uniform
+    // BUF: every operand load of a full K tile is a buffer load "descriptor (scalar) + lane offset (vector, fixed for the whole
+    // kernel) + scalar offset", so that nothing but the load itself is issued per operand: the general form above spends ~140
+    // scalar instructions per K tile on 64-bit row addresses, ~2000 cycles in which the wave issues no MFMA -- as long as the
+    // 64 MFMAs of the other wave of the SIMD take, which leaves no slack and idles the pipe 16 % of the time.
+    //   cos/sin: descriptor of the table, lane offset = meridian, scalar offset = rank * ldcs * 8 read as ONE 16-dword scalar load
+    //            from the offset table (entries k0 + khalf + 2 h of the tile sit at the even positions)
+    //   PK:      descriptor of the block's first table row, lane offset = table row of the lane (+ 16 h: immediate), scalar
+    //            offset (k0 + khalf) * 8
+    //   Sigma:   descriptor rebuilt per tile at row k0 (the matrix exceeds 4 GB), lane offset = column, scalar offset = row * ldb * 8
+    typedef unsigned uint16_v __attribute__((ext_vector_type(16), aligned(4)));
+    typedef const uint16_v __attribute__((address_space(4))) coff16_t;
+    uint16_v csoffs = {};
+    auto load_offsets = [&](int k0) {           // (the table is padded by 16 entries: no clamping)
+        if (BUF) csoffs = *reinterpret_cast<coff16_t*>(reinterpret_cast<unsigned long long>(P.csoff + (P.p_off + k0 + khalf)));
+    };
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    };
+    const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.csr), 0, 0xffffffffu, 0x00020000);
+    // (the Legendre descriptor ends with the table: the A operand is requested one tile ahead as well, and the request for the
+    //  tile after the last one of the last parallel reads as zero instead of leaving the allocation)
+    const unsigned pk_bytes = BUF ? (unsigned)(((long long)P.pk_rows * P.ldp - (pk_base - P.pkd)) * 8) : 0u;
+    const __amdgpu_buffer_rsrc_t rs_pk = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pk_base), 0, pk_bytes, 0x00020000);
+    unsigned brow_soff[4] = {0, 0, 0, 0};
+    if (BUF) {
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const unsigned off = pin(a_voff[h]);
-                if (VEC) {
-                    const double2 t = at2(ak, off);
-                    areg[2 * h] = t.x;
-                    areg[2 * h + 1] = t.y;
-                } else {
-                    areg[2 * h] = at(ak, off);
-                    areg[2 * h + 1] = at(ak + 1, off);
-                }
-            }
-        } else {
-            // degree-wise index p = n^2 + r: the rank r inside the degree selects the cos/sin row (table lookup on the scalar unit)
-            const double* pk = pk_base + k0 + khalf;                  // uniform
-            const unsigned poff = pin(pk_voff), coff = pin(cs_voff);
+        for (int h = 0; h < 4; ++h) brow_soff[h] = (unsigned)((size_t)(b_k + 4 * h) * P.ldb * 8);
+        load_offsets(0);
+    }
+    // (BUF) rows h0 .. h1-1 of the generated A operand of the K tile at k0, and its Sigma rows.  The Sigma descriptor ends with
+    // the matrix: rows beyond K read as zero, so a tile may be requested speculatively (the loop asks one tile ahead of need)
+    auto fetch_A = [&](int k0, int h0, int h1) {
+        const unsigned ksoff = (unsigned)(k0 + khalf) * 8u;          // uniform
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                areg[h] = PKT ? at(pk_base + (size_t)(k0 + khalf + 2 * h) * P.ldp, poff) : at(pk + 2 * h, poff);
-                creg[h] = at(P.csr + (size_t)rank[h] * P.ldcs, coff);
-            }
-            load_ranks(k0 + BK);                                      // for the next K tile: a whole tile ahead of their use
+        for (int h = h0; h < h1; ++h) {
+            areg[h] = bload(rs_pk, pk_voff + 16 * h, ksoff);
+            creg[h] = bload(rs_cs, cs_voff, csoffs[2 * h]);
         }
+    };
+    const unsigned b_row_bytes = (unsigned)P.ldb * 8u;
+    const int b_rows_cap = (int)(0xffffffffu / max(b_row_bytes, 1u));        // rows that fit the 32-bit range of a descriptor
+    auto fetch_B = [&](int k0) {
+        const int left = max(P.K - k0, 0);                           // uniform: rows from k0 to the end of Sigma (32-bit scalar arithmetic)
+        const unsigned records = left > b_rows_cap ? 0xffffffffu : (unsigned)left * b_row_bytes;
+        const __amdgpu_buffer_rsrc_t rs_b =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.B + (size_t)min(k0, P.K) * P.ldb), 0, records, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (VEC) {
+                const uint4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff0, brow_soff[h], 0);
+                breg[h] = __builtin_bit_cast(double2, v);
+            } else {
+                breg[h] = make_double2(bload(rs_b, b_voff0, brow_soff[h]), bload(rs_b, b_voff1, brow_soff[h]));
+            }
+        }
+    };
+    // The operand loads of a full K tile in three parts, each issued between the MFMAs of one k-step (SHG_TILE_HEAD):
+    //   PLAIN          part 0: A            part 1: B
+    //   generated A    part 0: A rows 0-3   part 1: A rows 4-7   part 2: Sigma / X
+    //   BUF            behind the barrier, under the last k-step of the previous tile: Sigma and A rows 0-3; part 0: A rows 4-7
+    constexpr int NLOAD0 = MODE == MODE_PLAIN ? (VEC ? 4 : 8) : 8;
+    constexpr int NLOADA = 8;                                        // BUF: loads of A rows 0-3
+    constexpr int NLOAD1 = MODE == MODE_PLAIN ? (VEC ? 4 : 8) : (BUF ? 0 : 8);
+    constexpr int NLOAD2 = (MODE == MODE_PLAIN || BUF) ? 0 : (VEC ? 4 : 8);
+    constexpr int NLOADB = VEC ? 4 : 8;
+    auto fetch_old_B = [&](int k0) {
         const unsigned boff0 = pin(b_voff0), boff1 = pin(b_voff1);
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -179,6 +252,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
                 breg[h] = at2(brow, boff0);
             else
                 breg[h] = make_double2(at(brow, boff0), at(brow, boff1));
+        }
+    };
+    auto fetch_part = [&](int k0, int part) {
+        if (MODE == MODE_PLAIN) {
+            if (part == 0) {
+                const double* ak = a_base + k0;                       // uniform
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const unsigned off = pin(a_voff[h]);
+                    if (VEC) {
+                        const double2 t = at2(ak, off);
+                        areg[2 * h] = t.x;
+                        areg[2 * h + 1] = t.y;
+                    } else {
+                        areg[2 * h] = at(ak, off);
+                        areg[2 * h + 1] = at(ak + 1, off);
+                    }
+                }
+            } else if (part == 1) {
+                fetch_old_B(k0);
+            }
+        } else if (BUF) {
+            if (part == 0) fetch_A(k0, 4, 8);        // rows 0-3 and Sigma were requested behind the previous barrier
+        } else if (part < 2) {
+            // degree-wise index p = n^2 + r: the rank r inside the degree selects the cos/sin row (table lookup on the scalar unit)
+            const double* pk = pk_base + k0 + khalf;                  // uniform
+            const unsigned poff = pin(pk_voff), coff = pin(cs_voff);
+#pragma unroll
+            for (int h = 4 * part; h < 4 * part + 4; ++h) {
+                areg[h] = PKT ? at(pk_base + (size_t)(k0 + khalf + 2 * h) * P.ldp, poff) : at(pk + 2 * h, poff);
+                creg[h] = at(P.csr + (size_t)rank[h] * P.ldcs, coff);
+            }
+        } else {
+            fetch_old_B(k0);
+        }
+    };
+    auto fetch_full = [&](int k0) {
+        fetch_part(k0, 0);
+        fetch_part(k0, 1);
+        fetch_part(k0, 2);
+        if (BUF) {
+            fetch_A(k0, 0, 4);
+            fetch_B(k0);
         }
     };
     // last partial K tile: same addresses with k clamped, entries beyond K zeroed
@@ -211,21 +327,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
             breg[h] = gk < P.K ? make_double2(x, y) : make_double2(0.0, 0.0);
         }
     };
+    typedef double __attribute__((address_space(3))) lds_store_t;
+    typedef double dbl2_v __attribute__((ext_vector_type(2)));
+    typedef dbl2_v __attribute__((address_space(3))) lds_store2_t;
+    lds_store_t* a_stage_base = (lds_store_t*)(As[0] + (MODE == MODE_PLAIN ? (tid >> 3) * LDA + a_kk : (tid & 127) * LDA + khalf));
+    lds_store_t* b_stage_base = (lds_store_t*)(Bs[0] + b_k * LDB + b_col);
+    asm volatile("" : "+v"(a_stage_base));
+    asm volatile("" : "+v"(b_stage_base));
     auto stage = [&](int buf) {
         if (MODE == MODE_PLAIN) {
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const int row = (tid >> 3) + 32 * h;
-                As[buf][row * LDA + a_kk] = areg[2 * h];
-                As[buf][row * LDA + a_kk + 1] = areg[2 * h + 1];
+                lds_store_t* dst = a_stage_base + buf * (BM * LDA) + 32 * h * LDA;
+                dst[0] = areg[2 * h];
+                dst[1] = areg[2 * h + 1];
             }
-        } else {
-            const int row = tid & 127, kb = khalf;
+        } else if (!(SHG_GEMM_X & 32)) {
 #pragma unroll
-            for (int h = 0; h < 8; ++h) As[buf][row * LDA + 2 * h + kb] = areg[h] * creg[h];
+            for (int h = 0; h < 8; ++h) a_stage_base[buf * (BM * LDA) + 2 * h] = (SHG_GEMM_X & 1) ? areg[h] : ((SHG_GEMM_X & 64) ? creg[h] : areg[h] * creg[h]);
         }
+        if (SHG_GEMM_X & 16) return;
 #pragma unroll
-        for (int h = 0; h < 4; ++h) *reinterpret_cast<double2*>(&Bs[buf][(b_k + 4 * h) * LDB + b_col]) = breg[h];
+        for (int h = 0; h < 4; ++h) *(lds_store2_t*)(b_stage_base + buf * (BK * LDB) + 4 * h * LDB) = (dbl2_v){breg[h].x, breg[h].y};
     };
     // SYM: weights of the Sigma tile rows k0 + b_k + 4 h inside the diagonal block (applied to breg before staging)
     auto weight_diagonal = [&](int k0) {
@@ -243,89 +366,195 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    // fragments of k-step ks + 1 are read from LDS while the 16 MFMAs of k-step ks run (two named fragment sets)
-    auto compute = [&](int buf) {
-        const double* Ab = As[buf] + (wr * 64 + fr) * LDA + fk;
-        const double* Bb = Bs[buf] + fk * LDB + wc * 64 + fr;
-        double af0[4], bf0[4], af1[4], bf1[4];
-#define SHG_FRAGS(af, bf, ks)                                                              \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a) af[a] = Ab[a * 16 * LDA + (ks) * 4];     \
-    _Pragma("unroll") for (int b = 0; b < 4; ++b) bf[b] = Bb[(ks) * 4 * LDB + b * 16]
-#define SHG_MFMA16(af, bf)                                                                 \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                         \
-        _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0)
-        SHG_FRAGS(af0, bf0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        SHG_FRAGS(af1, bf1, 1);
-        SHG_MFMA16(af0, bf0);
-        __builtin_amdgcn_sched_barrier(0);
-        SHG_FRAGS(af0, bf0, 2);
-        SHG_MFMA16(af1, bf1);
-        __builtin_amdgcn_sched_barrier(0);
-        SHG_FRAGS(af1, bf1, 3);
-        SHG_MFMA16(af0, bf0);
-        __builtin_amdgcn_sched_barrier(0);
-        SHG_MFMA16(af1, bf1);
-#undef SHG_FRAGS
-#undef SHG_MFMA16
-    };
+    // K tile = 4 k-steps of 16 MFMAs.  The fragments of k-step ks + 1 are requested from LDS BEFORE the MFMAs of k-step ks are
+    // issued (two fragment sets; the scheduling barriers pin that order -- left alone, hipcc issues the reads after the MFMAs
+    // that free their registers and every k-step then waits a full LDS round trip on an idle pipe), and the loop is rotated:
+    // the last k-step of a tile is issued after the barrier that publishes the next tile, behind the request for that tile's
+    // first fragments, so the LDS latency after the barrier is covered as well.
+    double af0[4], bf0[4], af1[4], bf1[4];
+    // Every fragment is one ds_read_b64 "lane base + 16-bit immediate": the bases are opaque to the compiler (it would split the
+    // 72 KB of offsets differently and add to the base with a VALU instruction per k-step) and the B reads are volatile, which
+    // keeps them from being paired into ds_read2_b64, whose 8-bit offsets need such an add as well.  An integer VALU instruction
+    // costs the MFMA pipe more than a tenth of an MFMA (profiles/r01_mfma64_issue.txt).
+    typedef double __attribute__((address_space(3))) lds_double_t;       // 32-bit LDS addresses: the bases stay ds_read / ds_write operands
+    const lds_double_t* a_frag_base = (const lds_double_t*)(As[0] + (wr * 64 + fr) * LDA + fk);
+    const lds_double_t* b_frag_base = (const lds_double_t*)(Bs[0] + fk * LDB + wc * 64 + fr);
+    asm volatile("" : "+v"(a_frag_base));
+    asm volatile("" : "+v"(b_frag_base));
+#define SHG_FRAGS(af, bf, buf, ks)                                                                                   \
+    do {                                                                                                             \
+        const lds_double_t* Ab_ = a_frag_base + (buf) * (BM * LDA) + (ks) * 4;                                       \
+        const volatile lds_double_t* Bb_ = b_frag_base + (buf) * (BK * LDB) + (ks) * 4 * LDB;                        \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a) af[a] = Ab_[a * 16 * LDA];                                     \
+        _Pragma("unroll") for (int b = 0; b < 4; ++b) bf[b] = Bb_[b * 16];                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#define SHG_MFMA16(af, bf)                                                                                           \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+    // 16 MFMAs with `nloads` operand loads (issued in front of them in the source) dealt between them, two MFMAs per load: a
+    // wave issues in order, and 24 loads in a row keep it away from the MFMA pipe for ~1800 cycles (the address unit takes one
+    // load per ~16 cycles and serves eight waves)
+#define SHG_MFMA16_LOADS(af, bf, nloads)                                                                             \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < (SHG_GEMM_INTERLEAVE ? (nloads) : 0); ++i) {                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, (nloads) > 8 ? 1 : ((nloads) > 4 ? 2 : 4), 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                       \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+    // k-steps 0 .. 2 of the tile in `buf` (set 0 holds the fragments of k-step 0); leaves k-step 3 in set 1.  BUF: the A operand
+    // of the next tile (at knext) is requested under k-steps 0 and 1
+#define SHG_TILE_HEAD(buf, knext, prefetch) \
+    do {                                    \
+        SHG_FRAGS(af1, bf1, buf, 1);        \
+        if (prefetch) {                     \
+            fetch_part(knext, 0);           \
+            SHG_MFMA16_LOADS(af0, bf0, NLOAD0); \
+        } else {                            \
+            SHG_MFMA16(af0, bf0);           \
+        }                                   \
+        SHG_FRAGS(af0, bf0, buf, 2);        \
+        if ((prefetch) && NLOAD1 > 0) {     \
+            fetch_part(knext, 1);           \
+            SHG_MFMA16_LOADS(af1, bf1, NLOAD1); \
+        } else {                            \
+            SHG_MFMA16(af1, bf1);           \
+        }                                   \
+        SHG_FRAGS(af1, bf1, buf, 3);        \
+        if ((prefetch) && NLOAD2 > 0) {     \
+            fetch_part(knext, 2);           \
+            SHG_MFMA16_LOADS(af0, bf0, NLOAD2); \
+        } else {                            \
+            SHG_MFMA16(af0, bf0);           \
+        }                                   \
+    } while (0)
 
     const int nfull = Keff / BK;
     const bool has_tail = (Keff % BK) != 0;
     const int tdiag = n0 / BK;                         // SYM: first K tile of the diagonal block
+    auto double_accumulators = [&]() {                 // SYM: all rows above the diagonal block are accumulated: they count twice
+        // The MFMAs of the previous k-step were issued just before (rotated loop) and hipcc does not separate a VALU read from the
+        // last passes of an MFMA across the loop back edge: without the explicit wait the fourth row quad of the last accumulators
+        // is read before it is written (observed: sigma = NaN in rows 60-63 of the wave tiles; 32 idle cycles are not enough).
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] *= 2.0;
+    };
+#ifdef SHG_TIMELINE
+    unsigned long long tl_sum[4] = {0, 0, 0, 0};
+    const unsigned long long tl_start = __builtin_readcyclecounter(), tl_wall = wall_clock64();
+    unsigned long long tl_prev = tl_start;
+#endif
     if (nfull > 0)
         fetch_full(0);
     else
         fetch_tail(0);
     if (SYM && tdiag == 0) weight_diagonal(0);
     stage(0);
+    // (scalar loads return out of order: while one is in flight every wait for LDS data degrades to lgkmcnt(0).  The ranks of
+    //  the tile after next are therefore requested right in front of the barrier, which waits for lgkmcnt(0) anyway.)
+    if (MODE != MODE_PLAIN) {
+        load_ranks(BK);
+        load_offsets(BK);
+    }
     __syncthreads();
+    SHG_FRAGS(af0, bf0, 0, 0);
+    if (BUF) {                                         // tile 1: Sigma and the first half of A
+        fetch_B(BK);
+        fetch_A(BK, 0, 4);
+    }
     // branch-free steady state, two K tiles per trip so that the LDS buffer of every access is a literal
-    auto step = [&](int t, int buf) {
-        fetch_full((t + 1) * BK);
-        if (SYM && t == tdiag && t > 0) {              // all rows above the diagonal block are accumulated: they count twice
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] *= 2.0;
-        }
-        compute(buf);
-        if (SYM && t + 1 >= tdiag) weight_diagonal((t + 1) * BK);
-        stage(buf ^ 1);
-        __syncthreads();
-    };
+#define SHG_STEP(t, buf)                                                      \
+    do {                                                                      \
+        SHG_TL_MARK(0);                                                       \
+        if (SYM && (t) == tdiag && (t) > 0) double_accumulators();            \
+        SHG_TILE_HEAD(buf, ((t) + 1) * BK, !(SHG_GEMM_X & 4));               \
+        SHG_TL_MARK(1);                                                       \
+        if (SYM && (t) + 1 >= tdiag) weight_diagonal(((t) + 1) * BK);         \
+        if (SHG_GEMM_PRIO) __builtin_amdgcn_s_setprio(3);                     \
+        if (!(SHG_GEMM_X & 8)) stage((buf) ^ 1);                              \
+        if (MODE != MODE_PLAIN) {                                             \
+            load_ranks(((t) + 2) * BK);                                       \
+            load_offsets(((t) + 2) * BK);                                     \
+        }                                                                     \
+        SHG_TL_MARK(2);                                                       \
+        if (SHG_GEMM_PRIO == 1) __builtin_amdgcn_s_setprio(0);                \
+        if (!(SHG_GEMM_X & 2)) __syncthreads();                               \
+        if (SHG_GEMM_PRIO == 2) __builtin_amdgcn_s_setprio(0);                \
+        SHG_FRAGS(af0, bf0, (buf) ^ 1, 0);                                    \
+        if (BUF && !(SHG_GEMM_X & 4)) {                                       \
+            fetch_B(((t) + 2) * BK);                                          \
+            fetch_A(((t) + 2) * BK, 0, 4);                                    \
+            SHG_MFMA16_LOADS(af1, bf1, NLOADB + NLOADA);                      \
+        } else {                                                              \
+            SHG_MFMA16(af1, bf1);                                             \
+        }                                                                     \
+        if (SHG_GEMM_PRIO == 3) __builtin_amdgcn_s_setprio(0);                \
+        SHG_TL_MARK(3);                                                       \
+    } while (0)
     int t = 0;
     for (; t + 2 < nfull; t += 2) {
-        step(t, 0);
-        step(t + 1, 1);
+        SHG_STEP(t, 0);
+        SHG_STEP(t + 1, 1);
     }
-    if (t + 1 < nfull) step(t, 0);                     // t is even here
-    if (nfull > 0) {
+    if (t + 1 < nfull) SHG_STEP(t, 0);                 // t is even here
+    if (nfull > 0) {                                   // last full tile; set 0 holds its first fragments
         if (has_tail) fetch_tail(nfull * BK);
-        if (SYM && nfull - 1 == tdiag && tdiag > 0) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] *= 2.0;
+        if (SYM && nfull - 1 == tdiag && tdiag > 0) double_accumulators();
+        if ((nfull - 1) & 1) {
+            SHG_TILE_HEAD(1, 0, false);
+        } else {
+            SHG_TILE_HEAD(0, 0, false);
         }
-        compute((nfull - 1) & 1);
         if (has_tail) {
             if (SYM) weight_diagonal(nfull * BK);
             stage(nfull & 1);
+            __syncthreads();
+            if (nfull & 1) {
+                SHG_FRAGS(af0, bf0, 1, 0);
+            } else {
+                SHG_FRAGS(af0, bf0, 0, 0);
+            }
         }
-        __syncthreads();
+        SHG_MFMA16(af1, bf1);
     }
     if (has_tail) {
-        if (SYM && nfull == tdiag && tdiag > 0) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] *= 2.0;
+        if (SYM && nfull == tdiag && tdiag > 0) double_accumulators();
+        if (nfull & 1) {
+            SHG_TILE_HEAD(1, 0, false);
+        } else {
+            SHG_TILE_HEAD(0, 0, false);
         }
-        compute(nfull & 1);
+        SHG_MFMA16(af1, bf1);
     }
+#undef SHG_STEP
+#undef SHG_MFMA16_LOADS
+#undef SHG_TILE_HEAD
+#undef SHG_FRAGS
+#undef SHG_MFMA16
     __syncthreads();
 
+#ifdef SHG_TIMELINE
+    if (P.tl && lane == 0) {
+        const size_t blin = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        unsigned long long* o = P.tl + (blin * 4 + wave) * 8;
+        for (int i = 0; i < 4; ++i) o[i] = tl_sum[i];
+        o[4] = __builtin_readcyclecounter() - tl_start;
+        o[5] = wall_clock64() - tl_wall;
+        o[6] = tl_wall;
+        o[7] = (unsigned long long)nfull;
+    }
+#endif
     // ---- epilogue.  C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
     if (MODE != MODE_COVPROP) {
 #pragma unroll
@@ -390,9 +619,10 @@ __global__ void covprop_reduce_kernel(int M, int nparts, const double* __restric
     sigma[r] = sqrt(s);                                     // grates/grid.py:837-839
 }
 
-// PKD[i][p] = PK[(m, n)][i] rearranged to the degree-wise index p (min_degree 0); rslot[p] = rank inside the degree
-__global__ void covprop_pkd_kernel(int N, int nlat, int ldlat, const double* __restrict__ pk, double* __restrict__ pkd,
-                                   int* __restrict__ rslot) {
+// PKD[i][p] = PK[(m, n)][i] rearranged to the degree-wise index p (min_degree 0); rslot[p] = rank r inside the degree,
+// csoff[p] = r * nlon * 8 = byte offset of the cos/sin table row of that rank
+__global__ void covprop_pkd_kernel(int N, int nlat, int ldlat, int nlon, const double* __restrict__ pk, double* __restrict__ pkd,
+                                   int* __restrict__ rslot, unsigned* __restrict__ csoff) {
     const int P = (N + 1) * (N + 1);
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= (long long)nlat * P) return;
@@ -403,7 +633,10 @@ __global__ void covprop_pkd_kernel(int N, int nlat, int ldlat, const double* __r
     const int r = p - n * n;
     const int m = (r + 1) >> 1;
     pkd[tid] = pk[(size_t)(order_offset(N, m) + n - m) * ldlat + i];
-    if (i == 0) rslot[p] = r;
+    if (i == 0) {
+        rslot[p] = r;
+        csoff[p] = (unsigned)r * (unsigned)nlon * 8u;
+    }
 }
 
 // CSR[r][j]: r = 0 -> 1, r = 2m-1 -> cos(m lon_j), r = 2m -> sin(m lon_j)
@@ -493,8 +726,10 @@ int synth_generic(const double* pkd, int ldp, const double* csr, int ldcs, const
 // sigma[r] = sqrt(a_r^T Sigma a_r) for M rows whose A entries are products of two table entries
 int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
                     long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
-                    hipStream_t stream, bool symmetric, bool transposed_table) {
+                    hipStream_t stream, bool symmetric, bool transposed_table, const unsigned* csoff, int pk_rows) {
     GemmParams G = {};
+    G.csoff = csoff;
+    if (!transposed_table && !csoff) return fail(SHG_ERR_INVALID, "covprop_generic: the regular-grid kernel needs the cos/sin offset table");
     G.pkt = transposed_table ? 1 : 0;
     G.M = M;
     G.N = Pn;
@@ -503,6 +738,7 @@ int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, con
     G.ldb = Pn;
     G.pkd = pkd;
     G.ldp = ldp;
+    G.pk_rows = pk_rows;
     G.csr = csr;
     G.ldcs = ldcs;
     G.rslot = rslot;
@@ -511,6 +747,9 @@ int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, con
     G.p_off = p_off;
     G.row0 = row0;
     G.partial = partial;
+#ifdef SHG_TIMELINE
+    G.tl = getenv("SHG_TIMELINE_PTR") ? (unsigned long long*)strtoull(getenv("SHG_TIMELINE_PTR"), nullptr, 0) : nullptr;
+#endif
     {
         ProfileScope ps(prof, 3, stream);
         int rc = launch_gemm(MODE_COVPROP, G, stream, symmetric);
@@ -634,11 +873,13 @@ static int covprop_diag_impl(shg_plan* p, const double* cov, int nmin, int lat0,
     rc = covprop_build_cs_table(p, stream);
     if (rc) return rc;
     if (!p->pk_deg) {
-        if (hipMalloc((void**)&p->pk_deg, (size_t)p->nlat * Pfull * sizeof(double)) != hipSuccess ||
-            hipMalloc((void**)&p->rslot, (size_t)Pfull * sizeof(int)) != hipSuccess)
+        if (hipMalloc((void**)&p->pk_deg, ((size_t)p->nlat * Pfull + 64) * sizeof(double)) != hipSuccess ||      // + padding: scalar loads run a tile ahead
+            hipMalloc((void**)&p->rslot, ((size_t)2 * Pfull + 48) * sizeof(int)) != hipSuccess)      // ranks | cos/sin row offsets + 48 entries of padding
             return fail(SHG_ERR_NOMEM, "covariance propagation tables: allocation failed");
+        SHG_HIP(hipMemsetAsync(p->rslot, 0, ((size_t)2 * Pfull + 48) * sizeof(int), stream));
+        SHG_HIP(hipMemsetAsync(p->pk_deg + (size_t)p->nlat * Pfull, 0, 64 * sizeof(double), stream));
         hipLaunchKernelGGL(covprop_pkd_kernel, dim3((unsigned)ceil_div64((long long)p->nlat * Pfull, 256)), dim3(256), 0, stream, p->N,
-                           p->nlat, p->ldlat, p->pk, p->pk_deg, p->rslot);
+                           p->nlat, p->ldlat, p->nlon, p->pk, p->pk_deg, p->rslot, reinterpret_cast<unsigned*>(p->rslot + Pfull));
         SHG_HIP(hipGetLastError());
     }
     const int ncolblocks = std::max(1, ceil_div(Pn, BN));
@@ -668,5 +909,5 @@ static int covprop_diag_impl(shg_plan* p, const double* cov, int nmin, int lat0,
         return SHG_OK;
     }
     return covprop_generic(p->pk_deg, Pfull, p->cs_slot, p->nlon, p->rslot, p->nlon, p->nlon, (long long)lat0 * p->nlon, (int)M, cov, Pn,
-                           nmin * nmin, p->cov_partial, sigma, p, stream, symmetric, false);
+                           nmin * nmin, p->cov_partial, sigma, p, stream, symmetric, false, reinterpret_cast<const unsigned*>(p->rslot + Pfull), p->nlat);
 }
