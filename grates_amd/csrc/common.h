@@ -116,6 +116,8 @@ struct shg_plan {
     int* rslot = nullptr;       // [Pfull] rank inside its degree of every degree-wise index
     double* cov_partial = nullptr;   // [column blocks][band rows] partial row sums of the covariance kernel
     size_t cov_partial_size = 0;
+    double* cov_pad = nullptr;       // covariance matrix copied to rows of even length (16-byte aligned rows for the LDS copy of the kernel)
+    size_t cov_pad_size = 0;
     // workspace
     double* cpk = nullptr;      // [packed][2][chunk_pad] repacked coefficients of one pass
     double* F = nullptr;        // [chunk][K][ldlat] output of the Legendre stage

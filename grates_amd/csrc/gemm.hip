@@ -93,6 +93,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     // (not the symmetric variant: with its weighting code hipcc runs out of registers, spills the prefetched operands inside the
     //  loop and the result of the spilled build is wrong in the last row quad of every wave tile; it keeps the global-load form)
     constexpr bool BUF = (MODE == MODE_COVPROP) && !PKT && !SYM;
+    // ... and with 16-byte aligned Sigma rows (VEC) the Sigma tile does not pass through registers at all: every wave copies four
+    // tile rows (1 KB each) straight into LDS with buffer loads that write to LDS, right behind the barrier that frees the buffer
+    constexpr bool DMA = BUF && VEC;
     // PLAIN: column block fastest.  COVPROP: row block fastest -- the blocks resident at one time then walk the same
     // 33 MB column panel of Sigma together and it is fetched from HBM once instead of once per row block.
     const int m0 = (MODE == MODE_PLAIN ? blockIdx.y : blockIdx.x) * BM;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
         }
         cs_voff = (unsigned)((R % P.jmod) * 8);
     }
-    const unsigned b_voff0 = (unsigned)((VEC ? min(n0 + b_col, P.N - 2) : min(n0 + b_col, P.N - 1)) * 8);
+    const unsigned b_voff0 = (unsigned)((VEC ? min(n0 + b_col, (P.N + 1) / 2 * 2 - 2) : min(n0 + b_col, P.N - 1)) * 8);
     const unsigned b_voff1 = (unsigned)(min(n0 + b_col + 1, P.N - 1) * 8);
 
     // COVPROP: ranks (inside their degree) of the eight degree-wise indices a thread generates in the K tile it fetches next,
@@ -219,14 +222,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     };
     const unsigned b_row_bytes = (unsigned)P.ldb * 8u;
     const int b_rows_cap = (int)(0xffffffffu / max(b_row_bytes, 1u));        // rows that fit the 32-bit range of a descriptor
-    auto fetch_B = [&](int k0) {
+    typedef void __attribute__((address_space(3))) lds_void_t;
+    auto fetch_B = [&](int k0, int buf) {
         const int left = max(P.K - k0, 0);                           // uniform: rows from k0 to the end of Sigma (32-bit scalar arithmetic)
         const unsigned records = left > b_rows_cap ? 0xffffffffu : (unsigned)left * b_row_bytes;
         const __amdgpu_buffer_rsrc_t rs_b =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.B + (size_t)min(k0, P.K) * P.ldb), 0, records, 0x00020000);
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            if (VEC) {
+            if (DMA) {
+                // lane l delivers columns 2 l, 2 l + 1 of tile row b_k + 4 h to the LDS row base + 16 l
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_t*)(Bs[buf] + (b_k + 4 * h) * LDB), 16, b_voff0, brow_soff[h], 0, 0);
+            } else if (VEC) {
                 const uint4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff0, brow_soff[h], 0);
                 breg[h] = __builtin_bit_cast(double2, v);
             } else {
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
         fetch_part(k0, 2);
         if (BUF) {
             fetch_A(k0, 0, 4);
-            fetch_B(k0);
+            fetch_B(k0, 0);
         }
     };
     // last partial K tile: same addresses with k clamped, entries beyond K zeroed
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
                 creg[h] = at(P.csr + (size_t)reinterpret_cast<const crank_t*>(reinterpret_cast<unsigned long long>(P.rslot))[kc + P.p_off] * P.ldcs, cs_voff);
             }
         }
+        if (DMA) return;                          // the Sigma rows of the partial tile are in LDS already (rows beyond K read as zero)
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int gk = k0 + b_k + 4 * h;
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
 #pragma unroll
             for (int h = 0; h < 8; ++h) a_stage_base[buf * (BM * LDA) + 2 * h] = (SHG_GEMM_X & 1) ? areg[h] : ((SHG_GEMM_X & 64) ? creg[h] : areg[h] * creg[h]);
         }
-        if (SHG_GEMM_X & 16) return;
+        if ((SHG_GEMM_X & 16) || DMA) return;
 #pragma unroll
         for (int h = 0; h < 4; ++h) *(lds_store2_t*)(b_stage_base + buf * (BK * LDB) + 4 * h * LDB) = (dbl2_v){breg[h].x, breg[h].y};
     };
@@ -455,10 +463,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     const unsigned long long tl_start = __builtin_readcyclecounter(), tl_wall = wall_clock64();
     unsigned long long tl_prev = tl_start;
 #endif
-    if (nfull > 0)
+    if (nfull > 0) {
         fetch_full(0);
-    else
+    } else {
         fetch_tail(0);
+        if (DMA) fetch_B(0, 0);
+    }
     if (SYM && tdiag == 0) weight_diagonal(0);
     stage(0);
     // (scalar loads return out of order: while one is in flight every wait for LDS data degrades to lgkmcnt(0).  The ranks of
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     __syncthreads();
     SHG_FRAGS(af0, bf0, 0, 0);
     if (BUF) {                                         // tile 1: Sigma and the first half of A
-        fetch_B(BK);
+        fetch_B(BK, 1);
         fetch_A(BK, 0, 4);
     }
     // branch-free steady state, two K tiles per trip so that the LDS buffer of every access is a literal
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
         if (SHG_GEMM_PRIO == 2) __builtin_amdgcn_s_setprio(0);                \
         SHG_FRAGS(af0, bf0, (buf) ^ 1, 0);                                    \
         if (BUF && !(SHG_GEMM_X & 4)) {                                       \
-            fetch_B(((t) + 2) * BK);                                          \
+            fetch_B(((t) + 2) * BK, buf);                                     \
             fetch_A(((t) + 2) * BK, 0, 4);                                    \
             SHG_MFMA16_LOADS(af1, bf1, NLOADB + NLOADA);                      \
         } else {                                                              \
@@ -662,7 +672,9 @@ static int launch_gemm(int mode, const GemmParams& P, hipStream_t stream, bool s
     const dim3 grid = mode == MODE_PLAIN ? dim3(ceil_div(P.N, BN), ceil_div(P.M, BM)) : dim3(ceil_div(P.M, BM), ceil_div(P.N, BN));
     const size_t lds = (size_t)(2 * BM * LDA + 2 * BK * LDB) * sizeof(double);      // 71.7 KB: two blocks per CU
     // 16-byte operand loads need even leading dimensions / sizes and 16-byte aligned bases
-    const bool vec = (P.ldb % 2 == 0) && (P.N % 2 == 0) && ((uintptr_t)P.B % 16 == 0) &&
+    // (an odd N is fine as long as the rows are even: the pair that starts at the last column reads one element of padding,
+    //  which only reaches an accumulator column that is never stored)
+    const bool vec = (P.ldb % 2 == 0) && (P.N % 2 == 0 || P.ldb > P.N) && ((uintptr_t)P.B % 16 == 0) &&
                      (mode != MODE_PLAIN || ((P.lda % 2 == 0) && (P.K % 2 == 0) && ((uintptr_t)P.A % 16 == 0)));
 #define SHG_GEMM_LAUNCH(M_, V_)                                                                                                \
     do {                                                                                                                        \
@@ -726,7 +738,7 @@ int synth_generic(const double* pkd, int ldp, const double* csr, int ldcs, const
 // sigma[r] = sqrt(a_r^T Sigma a_r) for M rows whose A entries are products of two table entries
 int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
                     long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
-                    hipStream_t stream, bool symmetric, bool transposed_table, const unsigned* csoff, int pk_rows) {
+                    hipStream_t stream, bool symmetric, bool transposed_table, const unsigned* csoff, int pk_rows, int ldcov) {
     GemmParams G = {};
     G.csoff = csoff;
     if (!transposed_table && !csoff) return fail(SHG_ERR_INVALID, "covprop_generic: the regular-grid kernel needs the cos/sin offset table");
@@ -735,7 +747,7 @@ int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, con
     G.N = Pn;
     G.K = Pn;
     G.B = cov;
-    G.ldb = Pn;
+    G.ldb = ldcov > 0 ? ldcov : Pn;
     G.pkd = pkd;
     G.ldp = ldp;
     G.pk_rows = pk_rows;
@@ -908,6 +920,33 @@ static int covprop_diag_impl(shg_plan* p, const double* cov, int nmin, int lat0,
         SHG_HIP(hipGetLastError());
         return SHG_OK;
     }
-    return covprop_generic(p->pk_deg, Pfull, p->cs_slot, p->nlon, p->rslot, p->nlon, p->nlon, (long long)lat0 * p->nlon, (int)M, cov, Pn,
-                           nmin * nmin, p->cov_partial, sigma, p, stream, symmetric, false, reinterpret_cast<const unsigned*>(p->rslot + Pfull), p->nlat);
+    // The general kernel copies Sigma tiles straight into LDS when the rows of Sigma are 16-byte aligned.  An odd dimension
+    // (d/o 180: 32761) or an odd base address gets a copy with rows of even length first: 2 x 8.6 GB of traffic, ~3 ms, against
+    // seconds of MFMA work; below ~2 TFLOP of work the copy does not pay and the register path reads the matrix as it is.
+    const double* sigma_in = cov;
+    int ld_in = Pn;
+    const bool aligned = (Pn % 2 == 0) && ((uintptr_t)cov % 16 == 0);
+    if (!symmetric && !aligned && (double)M * Pn * Pn > 1e12) {
+        const int ld_pad = Pn + (Pn & 1) + ((Pn + (Pn & 1)) % 512 == 0 ? 2 : 0);        // even, not a multiple of 4 KB
+        const size_t need_pad = (size_t)Pn * ld_pad;
+        if (need_pad > p->cov_pad_size) {
+            if (p->cov_pad) {
+                SHG_HIP(hipStreamSynchronize(stream));
+                (void)hipFree(p->cov_pad);
+                p->cov_pad = nullptr;
+                p->cov_pad_size = 0;
+            }
+            if (hipMalloc((void**)&p->cov_pad, need_pad * sizeof(double)) == hipSuccess) p->cov_pad_size = need_pad;
+            else (void)hipGetLastError();                                                // no room for the copy: register path
+        }
+        if (p->cov_pad) {
+            SHG_HIP(hipMemcpy2DAsync(p->cov_pad, (size_t)ld_pad * sizeof(double), cov, (size_t)Pn * sizeof(double), (size_t)Pn * sizeof(double), Pn,
+                                     hipMemcpyDeviceToDevice, stream));
+            sigma_in = p->cov_pad;
+            ld_in = ld_pad;
+        }
+    }
+    return covprop_generic(p->pk_deg, Pfull, p->cs_slot, p->nlon, p->rslot, p->nlon, p->nlon, (long long)lat0 * p->nlon, (int)M, sigma_in, Pn,
+                           nmin * nmin, p->cov_partial, sigma, p, stream, symmetric, false, reinterpret_cast<const unsigned*>(p->rslot + Pfull), p->nlat,
+                           ld_in);
 }

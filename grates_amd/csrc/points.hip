@@ -172,7 +172,7 @@ int synth_generic(const double* pkd, int ldp, const double* csr, int ldcs, const
 
 int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, const int* rslot, long long idiv, long long jmod,
                     long long row0, int M, const double* cov, int Pn, int p_off, double* partial, double* sigma, shg_plan* prof,
-                    hipStream_t stream, bool symmetric, bool transposed_table, const unsigned* csoff = nullptr, int pk_rows = 0);
+                    hipStream_t stream, bool symmetric, bool transposed_table, const unsigned* csoff = nullptr, int pk_rows = 0, int ldcov = 0);
 
 }  // namespace shg
 

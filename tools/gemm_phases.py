@@ -4,7 +4,7 @@ build (`make -C grates_amd/csrc timeline`) sums, per wave and on the scalar unit
 marks of every K tile -- loads issued | 64 MFMAs issued | next tile staged to LDS | barrier passed -- and the shader clock
 against the 100 MHz wall clock.
 
-    python3 tools/gemm_phases.py [parallels]         (on a GPU box)
+    python3 tools/gemm_phases.py [parallels [max_degree]]         (on a GPU box)
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ import numpy as np, torch
 import grates_amd as ga
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-N = 180
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 180
 grid = ga.grid.GeographicGrid(0.5, 0.5)
 GM, R = 3.9860044150e+14, 6.3781363000e+06
 colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel('ewh'), N, grid.parallels, GM, R, grid.semimajor_axis, grid.flattening)
@@ -36,7 +36,7 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 flop = 2.0 * M * P * P + 2.0 * M * P
-print('band of %d parallels: %.2f ms, %.2f TFLOP/s' % (nb, ms, flop / ms / 1e9))
+print('d/o %d, band of %d parallels: %.2f ms, %.2f TFLOP/s' % (N, nb, ms, flop / ms / 1e9))
 t = tl.cpu().numpy().astype(np.float64)
 tiles = t[:, :, 7]
 ok = tiles > 0
