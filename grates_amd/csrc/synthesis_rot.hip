@@ -98,20 +98,23 @@ struct RotParams {
 #endif
 
 // LDS-DMA of one 1 KB piece: lane l copies 16 bytes from gbase + lane_off to LDS address lds_addr + 16 l.
-// M0 is saved and restored (the compiler reserves it); s_nop 4 covers a scalar write of the base just before the statement.
+// M0 is overwritten and not restored: hipcc treats it as a reserved register that it loads right in front of every use of
+// its own (it refuses it in a clobber list for that reason), and gfx9 LDS instructions do not read it -- saving and restoring it
+// around every piece cost three scalar instructions and five idle cycles per k-step.  The s_nop covers the scalar write of M0
+// in front of its use by the vector memory instruction.
 __device__ __forceinline__ void glds16(const double* gbase, unsigned lane_off, unsigned lds_addr) {
-    unsigned keep;
     asm volatile(
-        "s_nop 4\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, %1"
+        :
         : "v"(lane_off), "s"(gbase), "s"(lds_addr)
         : "memory");
 }
+
+#ifndef SHG_ROT_X
+#define SHG_ROT_X 0          // experiment switches (timing only): 1 no issue-side stream bookkeeping, 2 no consumer-side bookkeeping
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -201,6 +204,9 @@ __device__ __forceinline__ void rot_stream_init(RotStream& S, const RotParams& P
 
 __device__ __forceinline__ void rot_issue_piece(RotStream& S, const RotParams& P, unsigned lane_off) {
     glds16(S.iptr, lane_off, S.im0);
+#if defined(SHG_ROT_X) && (SHG_ROT_X & 1)
+    return;                                        // experiment: no stream bookkeeping (timing only, wrong results)
+#endif
     S.im0 = S.im0 + 1024 == S.ring_lds + kRingSlots * 1024 ? S.ring_lds : S.im0 + 1024;
     const bool more = S.irem > 1;
     const double* nbase = S.ibase == S.ilast ? S.ifirst : S.ibase + 2 * P.npieces * 128;
@@ -244,9 +250,9 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
         rot_issue_piece(S, P, lane_off);                                                                  \
         wait_vmcnt<kRingDepth>();                                                                         \
         T_ = ringp[S.cslot * 64];                                                                         \
-        S.cslot = S.cslot + 1 == kRingSlots ? 0 : S.cslot + 1;                                            \
+        if (!(SHG_ROT_X & 2)) S.cslot = S.cslot + 1 == kRingSlots ? 0 : S.cslot + 1;                      \
         AB_ = prow[S.pf * 256];                                                                           \
-        S.pf = S.pf + 1 == P.npieces ? 0 : S.pf + 1;                                                      \
+        if (!(SHG_ROT_X & 2)) S.pf = S.pf + 1 == P.npieces ? 0 : S.pf + 1;                                \
         __builtin_amdgcn_sched_barrier(0);                                                                \
     } while (0)
 #ifdef SHG_ROT_SETPRIO
@@ -268,12 +274,39 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
     acc[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, acc[A0 + 2], 0, 0, 0);                \
     acc[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, acc[A0 + 3], 0, 0, 0);                \
     ROT_PRIO(0)
+    // first k-step of a class: the accumulators start from the constant 0 operand of the MFMA instead of being cleared with
+    // eight VALU moves each (96 per unit; a VALU instruction costs the fp64 MFMA stream ~10 cycles).  Accumulator 0 (CA of
+    // class 0) starts from the order-0 values, which are loaded into it beforehand.
+#define ROT_MFMA2_FIRST(A0, T_, AB_)                                                                      \
+    acc[A0] = (A0) == 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, acc[A0], 0, 0, 0)              \
+                        : __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, kZero4, 0, 0, 0);             \
+    acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, kZero4, 0, 0, 0)
+#define ROT_MFMA4_FIRST(A0, T_, AB_)                                                                      \
+    acc[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, kZero4, 0, 0, 0);                         \
+    acc[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.y, kZero4, 0, 0, 0);                     \
+    acc[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, kZero4, 0, 0, 0);                     \
+    acc[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, kZero4, 0, 0, 0)
     // one class: k-steps in pairs on the register sets (tx, abx) / (ty, aby); the current fragments are in (tx, abx) on entry
     // and on exit, the fragments of the next k-step are fetched before the MFMAs of the current one are issued
-#define ROT_CLASS(C, MF, A0)                                                                              \
+#define ROT_CLASS(C, MF, A0, NACC)                                                                        \
     {                                                                                                     \
         const int nk_ = P.cls_nk[C];                                                                      \
         int i_ = 0;                                                                                       \
+        if (nk_ >= 2) {                                                                                   \
+            ROT_FETCH(ty, aby);                                                                           \
+            MF##_FIRST(A0, tx, abx);                                                                      \
+            ROT_FETCH(tx, abx);                                                                           \
+            MF(A0, ty, aby);                                                                              \
+            i_ = 2;                                                                                       \
+        } else if (nk_ == 1) {                                                                            \
+            ROT_FETCH(ty, aby);                                                                           \
+            MF##_FIRST(A0, tx, abx);                                                                      \
+            tx = ty;                                                                                      \
+            abx = aby;                                                                                    \
+            i_ = 1;                                                                                       \
+        } else {                                                                                          \
+            _Pragma("unroll") for (int z_ = ((A0) == 0 ? 1 : 0); z_ < (NACC); ++z_) acc[(A0) + z_] = kZero4; \
+        }                                                                                                 \
         for (; i_ + 2 <= nk_; i_ += 2) {                                                                  \
             ROT_FETCH(ty, aby);                                                                           \
             MF(A0, tx, abx);                                                                              \
@@ -287,13 +320,12 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
             abx = aby;                                                                                    \
         }                                                                                                 \
     }
+    const double4_t kZero4 = {0.0, 0.0, 0.0, 0.0};
     double2_t tx = S.tx, abx = S.abx, ty = {0.0, 0.0}, aby = {0.0, 0.0};
     const int ct0 = wave >> 2;
     for (int ct = ct0, q = 0; ct < P.nct; ct += 2, ++q) {
         (void)q;
         double4_t acc[T::kAcc];
-#pragma unroll
-        for (int a = 0; a < T::kAcc; ++a) acc[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
         {
             // order 0 does not depend on the longitude: start value of CA_0 (C/D layout: row = fk + 4 reg, all columns)
             const double2_t* z = panel + P.nslot * 64 + rt * 16 + fk;
@@ -303,17 +335,17 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
 #pragma unroll
         for (int c = 0; c < T::kClasses; ++c) {
             if (c < T::kTwo) {
-                ROT_CLASS(c, ROT_MFMA2, 2 * c)
+                ROT_CLASS(c, ROT_MFMA2, 2 * c, 2)
             } else {
-                ROT_CLASS(c, ROT_MFMA4, 2 * T::kTwo + 4 * (c - T::kTwo))
+                ROT_CLASS(c, ROT_MFMA4, 2 * T::kTwo + 4 * (c - T::kTwo), 4)
             }
         }
         ROT_STAMP(3 + 2 * min(q, 3));
 
         // ---- epilogue: the 2 R images of every column, in place
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (!(P.dbg & 128)) rot_images<R>(acc, r);
+        for (int r = 0; r < 4; ++r) rot_images<R>(acc, r);      // (unconditional: a run-time switch around an in-place update of the
+                                                                //  accumulator vectors makes hipcc copy every vector, ~60 moves per row)
         const int b = bt * 4 + rt;
         const bool epoch_ok = b < P.B && !(P.dbg & 1);
         double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
@@ -336,11 +368,9 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
                 int w = n2 + k * nR - (ascending ? 0 : P.nd);
                 w = w >= P.nlon ? w - P.nlon : w;
                 const int soff = (ascending ? w + 16 * ct : w + P.nd - 16 * ct - 16) * 8;
-                double a_lo = acc[t][0], a_hi = acc[t][2], b_lo = acc[t][1], b_hi = acc[t][3];
-                if (!(P.dbg & 256)) {
-                    pair_exchange(acc[t][0], acc[t][2], 0xAAAAAAAAAAAAAAAAull, a_lo, a_hi);
-                    pair_exchange(acc[t][1], acc[t][3], 0xAAAAAAAAAAAAAAAAull, b_lo, b_hi);
-                }
+                double a_lo, a_hi, b_lo, b_hi;
+                pair_exchange(acc[t][0], acc[t][2], 0xAAAAAAAAAAAAAAAAull, a_lo, a_hi);
+                pair_exchange(acc[t][1], acc[t][3], 0xAAAAAAAAAAAAAAAAull, b_lo, b_hi);
                 const double2_t va = ascending ? (double2_t){a_lo, a_hi} : (double2_t){a_hi, a_lo};
                 const double2_t vb = ascending ? (double2_t){b_lo, b_hi} : (double2_t){b_hi, b_lo};
                 // The wave-uniform part goes into the vector offset, not into the scalar offset operand of the store: with a
@@ -359,6 +389,8 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
 #undef ROT_CLASS
 #undef ROT_MFMA2
 #undef ROT_MFMA4
+#undef ROT_MFMA2_FIRST
+#undef ROT_MFMA4_FIRST
 #undef ROT_FETCH
 }
 
@@ -398,33 +430,63 @@ __global__ __launch_bounds__(512) void synthesis_rot_kernel(RotParams P) {
     // ---- phase 1: Legendre stage (see synthesis_fused.hip).  Orders are distributed over the 8 waves; the result of order m
     //      is written as one 16-byte pair (A_m, B'_m) per panel row.
     if (!(P.dbg & 2)) {
+        // Everything that is the same for all lanes stays on the scalar unit: the work-item records come through scalar loads
+        // (constant address space), every operand load is "scalar base + lane offset fixed for the kernel", the flags of a record
+        // steer uniform branches, and the two accumulators of an order start from the MFMA's constant-zero operand instead of
+        // being cleared with 16 VALU moves.  Measured before: ~9 VALU instructions per MFMA in this stage (64-bit vector address
+        // arithmetic from records that sat in vector registers, flag tests, selects, clears); VALU instructions share the issue
+        // pipe with the fp64 MFMAs, so the stage was bound by their sum (2 x (6.5 k + 9 k) cycles per SIMD and tile = the 14 us
+        // it took), not by the L2 -> L1 rate it had been attributed to.
         constexpr int ASTRIDE = NS ? 128 : 64;
+        typedef int int4_v __attribute__((ext_vector_type(4)));
+        typedef const int4_v __attribute__((address_space(4))) crec_t;
+        typedef double gdouble2_v __attribute__((ext_vector_type(2)));
+        typedef const gdouble2_v __attribute__((address_space(1))) gdouble2_t;
+        typedef const char __attribute__((address_space(1))) gbyte_t;
+        auto ld16 = [](const double* ubase, unsigned voff) {            // 16 bytes at (uniform base) + (lane offset)
+            unsigned long long b = reinterpret_cast<unsigned long long>(ubase);
+            asm volatile("" : "+s"(b));
+            asm volatile("" : "+v"(voff));
+            const gdouble2_v v = *reinterpret_cast<gdouble2_t*>(reinterpret_cast<gbyte_t*>(b) + voff);
+            return make_double2(v.x, v.y);
+        };
         const int bad = NS ? P.badmap[it] : -1;
-        const double* pkb = P.pkf + ((size_t)it * P.Qtot * 64 + lane) * 2;
+        const double* pku = P.pkf + (size_t)it * P.Qtot * 128;                                   // uniform bases
+        const double* cfu = NS ? P.cpk4 + (size_t)bt * P.Qtot * 128 : P.cpk4 + (size_t)bt * P.Qtot * 64;
+        const unsigned pk_voff = (unsigned)lane * 16u;
+        const unsigned cf_voff = NS ? (unsigned)lane * 16u : (unsigned)(fk * 8 + (fr & 7)) * 16u;
         int mode = NS && bad >= 0 ? 1 : 0;
         int prow = lane;
-        const double* cf = NS ? P.cpk4 + ((size_t)bt * P.Qtot * 64 + lane) * 2
-                              : P.cpk4 + ((size_t)bt * P.Qtot * 32 + fk * 8 + (fr & 7)) * 2;
         const bool arow = NS || fr < 8;
         double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+        bool fresh = true;                                              // uniform: the next MFMA pair opens an order
 
 #define ROT_P1_ISSUE(rec, ALO, AHI, BLO, BHI)                                                \
     do {                                                                                     \
-        ALO = *reinterpret_cast<const double2*>(cf + (size_t)(rec).x * ASTRIDE);             \
-        BLO = *reinterpret_cast<const double2*>(pkb + (size_t)(rec).x * 128);                \
-        AHI = *reinterpret_cast<const double2*>(cf + (size_t)(rec).y * ASTRIDE);             \
-        BHI = *reinterpret_cast<const double2*>(pkb + (size_t)(rec).y * 128);                \
+        ALO = ld16(cfu + (size_t)(rec).x * ASTRIDE, cf_voff);                                \
+        BLO = ld16(pku + (size_t)(rec).x * 128, pk_voff);                                    \
+        AHI = ld16(cfu + (size_t)(rec).y * ASTRIDE, cf_voff);                                \
+        BHI = ld16(pku + (size_t)(rec).y * 128, pk_voff);                                    \
     } while (0)
 
 #define ROT_P1_CONSUME(rec, ALO, AHI, BLO, BHI)                                                                     \
     do {                                                                                                            \
-        const bool lo_ = arow && ((rec).w & 1);                                                                     \
-        const bool hi_ = arow && ((rec).w & 2);                                                                     \
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.x : 0.0, BLO.x, acc0, 0, 0, 0);                       \
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.y : 0.0, BLO.y, acc1, 0, 0, 0);                       \
+        if ((rec).w & 1) {                                                                                          \
+            const double ax_ = NS ? ALO.x : (arow ? ALO.x : 0.0), ay_ = NS ? ALO.y : (arow ? ALO.y : 0.0);          \
+            if (fresh) {                                                                                            \
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BLO.x, zero4, 0, 0, 0);                            \
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BLO.y, zero4, 0, 0, 0);                            \
+            } else {                                                                                                \
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BLO.x, acc0, 0, 0, 0);                             \
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BLO.y, acc1, 0, 0, 0);                             \
+            }                                                                                                       \
+            fresh = false;                                                                                          \
+        }                                                                                                           \
         if ((rec).w & 2) {                                                                                          \
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.x : 0.0, BHI.x, acc0, 0, 0, 0);                   \
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.y : 0.0, BHI.y, acc1, 0, 0, 0);                   \
+            const double ax_ = NS ? AHI.x : (arow ? AHI.x : 0.0), ay_ = NS ? AHI.y : (arow ? AHI.y : 0.0);          \
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BHI.x, acc0, 0, 0, 0);                                 \
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BHI.y, acc1, 0, 0, 0);                                 \
         }                                                                                                           \
         if ((rec).w & 4) {                                  /* last item of an order: see synthesis_fused.hip */     \
             double vc_ = acc0[0] + acc1[0], vs_ = acc0[1] + acc1[1];                                                \
@@ -435,8 +497,7 @@ __global__ __launch_bounds__(512) void synthesis_rot_kernel(RotParams P) {
                 vs_ = (mode == 0 && fr >= 8) ? rs_ - os_ : vs_ + rs_;                                               \
             }                                                                                                       \
             if (!NS || mode == 0 || fr < 8) panel[(rec).z * 64 + prow] = (double2_t){vc_, vs_};                     \
-            acc0 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
-            acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
+            fresh = true;                                                                                           \
         }                                                                                                           \
     } while (0)
 
@@ -444,21 +505,21 @@ __global__ __launch_bounds__(512) void synthesis_rot_kernel(RotParams P) {
         double2 yal = {0, 0}, yah = {0, 0}, ybl = {0, 0}, ybh = {0, 0};
         double2 zal = {0, 0}, zah = {0, 0}, zbl = {0, 0}, zbh = {0, 0};
         double2 wal = {0, 0}, wah = {0, 0}, wbl = {0, 0}, wbh = {0, 0};
-        const int4* recs = P.itemtab + (size_t)wave * P.nrec;
+        crec_t* recs = reinterpret_cast<crec_t*>(reinterpret_cast<unsigned long long>(P.itemtab + (size_t)wave * P.nrec));
         for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
             if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
                 mode = 2;
                 prow = lane + 8;
-                pkb = P.pkf + ((size_t)(P.nit + bad) * P.Qtot * 64 + lane) * 2;
+                pku = P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128;
             }
-            int4 c0 = recs[0], c1 = recs[1], c2 = recs[2];
-            int4 n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
+            int4_v c0 = recs[0], c1 = recs[1], c2 = recs[2];
+            int4_v n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
             ROT_P1_ISSUE(c0, xal, xah, xbl, xbh);
             ROT_P1_ISSUE(c1, yal, yah, ybl, ybh);
             ROT_P1_ISSUE(c2, zal, zah, zbl, zbh);
             for (int trip = 0; trip < P.ntrip; ++trip) {
-                const int4 a3 = n0, a4 = n1, a5 = n2, a6 = n3;
-                const int4* nr = recs + 4 * trip + 7;
+                const int4_v a3 = n0, a4 = n1, a5 = n2, a6 = n3;
+                crec_t* nr = recs + 4 * trip + 7;
                 n0 = nr[0];
                 n1 = nr[1];
                 n2 = nr[2];
