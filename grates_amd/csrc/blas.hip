@@ -122,10 +122,18 @@ __global__ __launch_bounds__(256, T == 128 ? 2 : 3) void gemm_ex_kernel(GemmExPa
             }
         }
     };
-    auto fetch_full = [&](int k0) {
+    auto fetch_a = [&](int k0) {
         if (!TA) fetch_r(areg, a_base, ar_off, k0); else fetch_k(areg, a_base, P.lda, ak_off0, ak_off1, k0);
+    };
+    auto fetch_b = [&](int k0) {
         if (TB) fetch_r(breg, b_base, br_off, k0); else fetch_k(breg, b_base, P.ldb, bk_off0, bk_off1, k0);
     };
+    auto fetch_full = [&](int k0) {
+        fetch_a(k0);
+        fetch_b(k0);
+    };
+    constexpr int NLOAD_A = !TA ? 2 * F : (T == 128 ? 8 : 4);       // load instructions of a thread per operand and K tile
+    constexpr int NLOAD_B = TB ? 2 * F : (T == 128 ? 8 : 4);
     // last partial K tile (runs once, plain per-lane addresses): k clamped, entries beyond K zeroed
     auto lane_ptr = [](const double* base, unsigned byte_off) { return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off); };
     auto tail_r = [&](double* reg, const double* base, const unsigned* off, int k0) {
@@ -185,35 +193,58 @@ __global__ __launch_bounds__(256, T == 128 ? 2 : 3) void gemm_ex_kernel(GemmExPa
 #pragma unroll
         for (int b = 0; b < F; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    // fragments of k-step ks + 1 are read from LDS while the 16 MFMAs of k-step ks run (two named fragment sets; the
-    // sched_barriers keep hipcc from regrouping the reads in front of the MFMAs that hide them)
-    auto compute = [&](int buf) {
-        const double* As = As0 + buf * XBUF;
-        const double* Bs = Bs0 + buf * XBUF;
-        double af0[F], bf0[F], af1[F], bf1[F];
-#define SHG_FRAGS(af, bf, ks)                                                                                                  \
-    _Pragma("unroll") for (int a = 0; a < F; ++a)                                                                             \
-        af[a] = TA ? As[((ks) * 4 + fk) * XLK + wr * HALF + a * 16 + fr] : As[(wr * HALF + a * 16 + fr) * XLR + (ks) * 4 + fk];  \
-    _Pragma("unroll") for (int b = 0; b < F; ++b)                                                                             \
-        bf[b] = TB ? Bs[(wc * HALF + b * 16 + fr) * XLR + (ks) * 4 + fk] : Bs[((ks) * 4 + fk) * XLK + wc * HALF + b * 16 + fr]
-#define SHG_MFMA16(af, bf)                                                                                                     \
-    _Pragma("unroll") for (int a = 0; a < F; ++a)                                                                             \
-        _Pragma("unroll") for (int b = 0; b < F; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0)
-        SHG_FRAGS(af0, bf0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        SHG_FRAGS(af1, bf1, 1);
-        SHG_MFMA16(af0, bf0);
-        __builtin_amdgcn_sched_barrier(0);
-        SHG_FRAGS(af0, bf0, 2);
-        SHG_MFMA16(af1, bf1);
-        __builtin_amdgcn_sched_barrier(0);
-        SHG_FRAGS(af1, bf1, 3);
-        SHG_MFMA16(af0, bf0);
-        __builtin_amdgcn_sched_barrier(0);
-        SHG_MFMA16(af1, bf1);
-#undef SHG_FRAGS
-#undef SHG_MFMA16
-    };
+    // K tile = 4 k-steps of F x F MFMAs, organised like the K loop of gemm.hip (see there for the measurements): the fragments
+    // of k-step ks + 1 are requested from LDS BEFORE the MFMAs of k-step ks are issued (two fragment sets, the scheduling
+    // barriers pin the order), the loop is rotated so that the last k-step of a tile is issued behind the barrier that
+    // publishes the next tile (after the request for that tile's first fragments), and the operand loads of the next tile
+    // are dealt between the MFMAs of k-steps 0 and 1 instead of being issued in a row in front of them.
+    double af0[F], bf0[F], af1[F], bf1[F];
+#define SHG_FRAGS(af, bf, buf, ks)                                                                                             \
+    do {                                                                                                                       \
+        const double* As = As0 + (buf) * XBUF;                                                                                 \
+        const double* Bs = Bs0 + (buf) * XBUF;                                                                                 \
+        _Pragma("unroll") for (int a = 0; a < F; ++a)                                                                         \
+            af[a] = TA ? As[((ks) * 4 + fk) * XLK + wr * HALF + a * 16 + fr] : As[(wr * HALF + a * 16 + fr) * XLR + (ks) * 4 + fk]; \
+        _Pragma("unroll") for (int b = 0; b < F; ++b)                                                                         \
+            bf[b] = TB ? Bs[(wc * HALF + b * 16 + fr) * XLR + (ks) * 4 + fk] : Bs[((ks) * 4 + fk) * XLK + wc * HALF + b * 16 + fr]; \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    } while (0)
+#define SHG_MFMAS(af, bf)                                                                                                      \
+    do {                                                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < F; ++a)                                                                         \
+            _Pragma("unroll") for (int b = 0; b < F; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    } while (0)
+#define SHG_MFMAS_LOADS(af, bf, nloads)                                                                                        \
+    do {                                                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < F; ++a)                                                                         \
+            _Pragma("unroll") for (int b = 0; b < F; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < (nloads); ++i) {                                                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, (F * F) / (nloads) > 0 ? (F * F) / (nloads) : 1, 0);                   \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                                 \
+        }                                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    } while (0)
+    // k-steps 0 .. 2 of the tile in `buf` (set 0 holds the fragments of k-step 0); leaves k-step 3 in set 1
+#define SHG_TILE_HEAD(buf, knext, prefetch)             \
+    do {                                                \
+        SHG_FRAGS(af1, bf1, buf, 1);                    \
+        if (prefetch) {                                 \
+            fetch_a(knext);                             \
+            SHG_MFMAS_LOADS(af0, bf0, NLOAD_A);         \
+        } else {                                        \
+            SHG_MFMAS(af0, bf0);                        \
+        }                                               \
+        SHG_FRAGS(af0, bf0, buf, 2);                    \
+        if (prefetch) {                                 \
+            fetch_b(knext);                             \
+            SHG_MFMAS_LOADS(af1, bf1, NLOAD_B);         \
+        } else {                                        \
+            SHG_MFMAS(af1, bf1);                        \
+        }                                               \
+        SHG_FRAGS(af1, bf1, buf, 3);                    \
+        SHG_MFMAS(af0, bf0);                            \
+    } while (0)
 
     const int nfull = Kz / XK;
     const bool has_tail = (Kz % XK) != 0;
@@ -223,26 +254,53 @@ __global__ __launch_bounds__(256, T == 128 ? 2 : 3) void gemm_ex_kernel(GemmExPa
         fetch_tail(0);
     stage(0);
     __syncthreads();
+    SHG_FRAGS(af0, bf0, 0, 0);
     // branch-free steady state, two K tiles per trip so that the LDS buffer of every access is a literal
-    auto step = [&](int t, int buf) {
-        fetch_full((t + 1) * XK);
-        compute(buf);
-        stage(buf ^ 1);
-        __syncthreads();
-    };
+#define SHG_STEP(t, buf)                                \
+    do {                                                \
+        SHG_TILE_HEAD(buf, ((t) + 1) * XK, true);       \
+        stage((buf) ^ 1);                               \
+        __syncthreads();                                \
+        SHG_FRAGS(af0, bf0, (buf) ^ 1, 0);              \
+        SHG_MFMAS(af1, bf1);                            \
+    } while (0)
     int t = 0;
     for (; t + 2 < nfull; t += 2) {
-        step(t, 0);
-        step(t + 1, 1);
+        SHG_STEP(t, 0);
+        SHG_STEP(t + 1, 1);
     }
-    if (t + 1 < nfull) step(t, 0);                     // t is even here
-    if (nfull > 0) {
+    if (t + 1 < nfull) SHG_STEP(t, 0);                 // t is even here
+    if (nfull > 0) {                                   // last full tile; set 0 holds its first fragments
         if (has_tail) fetch_tail(nfull * XK);
-        compute((nfull - 1) & 1);
-        if (has_tail) stage(nfull & 1);
-        __syncthreads();
+        if ((nfull - 1) & 1) {
+            SHG_TILE_HEAD(1, 0, false);
+        } else {
+            SHG_TILE_HEAD(0, 0, false);
+        }
+        if (has_tail) {
+            stage(nfull & 1);
+            __syncthreads();
+            if (nfull & 1) {
+                SHG_FRAGS(af0, bf0, 1, 0);
+            } else {
+                SHG_FRAGS(af0, bf0, 0, 0);
+            }
+        }
+        SHG_MFMAS(af1, bf1);
     }
-    if (has_tail) compute(nfull & 1);
+    if (has_tail) {
+        if (nfull & 1) {
+            SHG_TILE_HEAD(1, 0, false);
+        } else {
+            SHG_TILE_HEAD(0, 0, false);
+        }
+        SHG_MFMAS(af1, bf1);
+    }
+#undef SHG_STEP
+#undef SHG_TILE_HEAD
+#undef SHG_MFMAS_LOADS
+#undef SHG_MFMAS
+#undef SHG_FRAGS
 
     // epilogue.  C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
