@@ -504,57 +504,96 @@ __device__ __forceinline__ void leaf_factor_group(double (&u)[4][8], double (*ro
     }
 }
 
-// the 32 back-substitution steps k = 32 KI + 31 .. 32 KI of the inversion (registers hold X, Ul the factor), two per barrier
-// like the factorisation: the owner of row k publishes it scaled, the owner of row k - 1 as it is; every thread forms the
-// final row k - 1 for its columns with the operations its owner would have used (bit-identical results)
-template <int KI>
-__device__ __forceinline__ void leaf_invert_group(double (&x)[4][8], double (*rowbuf)[2][LEAF], const double* dg, const double* Ul, int ty, int tx) {
-    for (int kr = 31; kr >= 1; kr -= 2) {
-        const int k = KI * 32 + kr, buf = ((31 - kr) >> 1) & 1;
-        if (ty == kr) {
-            const double r = dg[k];
+// X = U^-1 of the 128 x 128 factor held in LDS (Ul, row-major, row length LLD) by recursive doubling on the MFMA:
+//   the eight 16 x 16 diagonal blocks are inverted by one wave each (back substitution, one column per lane, 16 dependent
+//   steps), then three levels s = 16, 32, 64 of  X12 = -X11 (U12 X22)  with 16 x 16 MFMA tiles dealt to the 8 waves.
+// 16 dependent steps + 6 small products replace the 128 dependent substitution steps of a row-by-row inversion (36 us -> ~12).
+// Storage: X is upper triangular like U, so X^T lives in the strictly LOWER triangle of the same LDS array (X[i][j], j > i,
+// at Ul[j][i]) and its diagonal in dg[]; U's upper triangle stays intact.  The temporary T = U12 X22 of a level sits in the
+// slots of the X12 block it is about to become.
+__device__ __forceinline__ double leaf_x_at(const double* Ul, const double* dg, int i, int j) {
+    const double off = Ul[(j > i ? j : i) * LLD + i];                 // (a valid address for every lane)
+    return j > i ? off : (j == i ? dg[i] : 0.0);
+}
+
+__device__ __forceinline__ void leaf_invert_doubling(double* Ul, double* dg, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    // ---- diagonal blocks: wave w inverts block w, lane c < 16 column c
+    if (lane < 16) {
+        const int b0 = wave * 16, c = lane;
+        double x[16];
 #pragma unroll
-            for (int cc = 2 * KI; cc < 8; ++cc) {
-                x[KI][cc] *= r;
-                rowbuf[buf][0][tx + 16 * cc] = x[KI][cc];
-            }
-        }
-        if (ty == kr - 1) {
+        for (int i = 15; i >= 0; --i) {
+            double sum = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int cc = 2 * KI; cc < 8; ++cc) rowbuf[buf][1][tx + 16 * cc] = x[KI][cc];
-        }
-        __syncthreads();
-        const double* xk = rowbuf[buf][0];
-        const double* raw = rowbuf[buf][1];
-        const double m01 = Ul[(k - 1) * LLD + k];                        // U[k-1][k]
-        const double r1 = dg[k - 1];
-        double c0[8], c1[8];                                             // rows k and k - 1 of X (final) at this thread's columns
-#pragma unroll
-        for (int cc = 2 * KI; cc < 8; ++cc) {
-            const int c = tx + 16 * cc;
-            c0[cc] = xk[c];
-            const double t = (cc >= 2 * KI + 2 || c >= k) ? fma(-m01, c0[cc], raw[c]) : raw[c];
-            c1[cc] = t * r1;
-        }
-        if (ty == kr - 1) {
-#pragma unroll
-            for (int cc = 2 * KI; cc < 8; ++cc) x[KI][cc] = c1[cc];
+            for (int j = i + 1; j < 16; ++j) sum = fma(-Ul[(b0 + i) * LLD + b0 + j], x[j], sum);      // x[j] = 0 for j > c
+            x[i] = (i <= c) ? sum * dg[b0 + i] : 0.0;
         }
 #pragma unroll
-        for (int ii = 0; ii <= KI; ++ii) {
-            if (ii < KI || ty < kr - 1) {        // row i < k - 1
-                const double m0 = Ul[(ty + 32 * ii) * LLD + k];
-                const double m1 = Ul[(ty + 32 * ii) * LLD + k - 1];
+        for (int i = 0; i < 15; ++i)
+            if (i < c) Ul[(b0 + c) * LLD + b0 + i] = x[i];
+    }
+    __syncthreads();
+    // ---- doubling levels
 #pragma unroll
-                for (int cc = 2 * KI; cc < 8; ++cc) {
-                    const int c = tx + 16 * cc;
-                    double v = x[ii][cc];
-                    if (cc >= 2 * KI + 2 || c >= k) v = fma(-m0, c0[cc], v);
-                    if (cc >= 2 * KI + 2 || c >= k - 1) v = fma(-m1, c1[cc], v);
-                    x[ii][cc] = v;
+    for (int s = 16; s <= 64; s *= 2) {
+        const int tps = s / 16;                         // tiles per block side
+        const int ntiles = (LEAF / (2 * s)) * tps * tps;   // 4, 8, 16
+        double4_t acc[2];
+        // T = U12 X22, tile (ti, tj) of pair q -> the slots of X12
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int tau = wave + 8 * rep;
+            acc[rep] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            if (tau < ntiles) {
+                const int q = tau / (tps * tps), ti = (tau / tps) % tps, tj = tau % tps;
+                const int r0 = q * 2 * s, c1 = r0 + s;
+                for (int k4 = 0; k4 < s / 4; ++k4) {
+                    const double a = Ul[(r0 + ti * 16 + fr) * LLD + c1 + k4 * 4 + fk];
+                    const double b = leaf_x_at(Ul, dg, c1 + k4 * 4 + fk, c1 + tj * 16 + fr);
+                    acc[rep] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[rep], 0, 0, 0);
                 }
             }
         }
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {                  // (nothing reads the X12 slots before they hold T: no barrier)
+            const int tau = wave + 8 * rep;
+            if (tau < ntiles) {
+                const int q = tau / (tps * tps), ti = (tau / tps) % tps, tj = tau % tps;
+                const int r0 = q * 2 * s, c1 = r0 + s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ul[(c1 + tj * 16 + fr) * LLD + r0 + ti * 16 + fk + 4 * r] = acc[rep][r];      // T[i][j] at the slot of X12[i][j]
+            }
+        }
+        __syncthreads();
+        // X12 = -X11 T
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int tau = wave + 8 * rep;
+            acc[rep] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            if (tau < ntiles) {
+                const int q = tau / (tps * tps), ti = (tau / tps) % tps, tj = tau % tps;
+                const int r0 = q * 2 * s, c1 = r0 + s;
+                for (int k4 = 0; k4 < s / 4; ++k4) {
+                    const double a = leaf_x_at(Ul, dg, r0 + ti * 16 + fr, r0 + k4 * 4 + fk);
+                    const double b = Ul[(c1 + tj * 16 + fr) * LLD + r0 + k4 * 4 + fk];               // T[k][j]
+                    acc[rep] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[rep], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                // all reads of T done
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int tau = wave + 8 * rep;
+            if (tau < ntiles) {
+                const int q = tau / (tps * tps), ti = (tau / tps) % tps, tj = tau % tps;
+                const int r0 = q * 2 * s, c1 = r0 + s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ul[(c1 + tj * 16 + fr) * LLD + r0 + ti * 16 + fk + 4 * r] = -acc[rep][r];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -612,29 +651,24 @@ __global__ __launch_bounds__(512) void leaf_kernel(int n, double* __restrict__ A
         }
     }
     if (mode & 2) {
-        // X = U^-1 by right-looking back substitution on the identity: for k = 127 .. 0
-        //   X[k][:] /= U[k][k];   X[i][c] -= U[i][k] X[k][c]   (i < k <= c)
+        // X = U^-1 by recursive doubling in LDS (leaf_invert_doubling)
         __syncthreads();                                 // dg is rewritten below
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) {
                 const int i = ty + 32 * ii, c = tx + 16 * cc;
-                Ul[i * LLD + c] = u[ii][cc];
+                if (c >= i) Ul[i * LLD + c] = u[ii][cc];
                 if (i == c) dg[i] = 1.0 / u[ii][cc];
-                u[ii][cc] = i == c ? 1.0 : 0.0;          // from here on the registers hold X
             }
         __syncthreads();
-        leaf_invert_group<3>(u, rowpair, dg, Ul, ty, tx);
-        leaf_invert_group<2>(u, rowpair, dg, Ul, ty, tx);
-        leaf_invert_group<1>(u, rowpair, dg, Ul, ty, tx);
-        leaf_invert_group<0>(u, rowpair, dg, Ul, ty, tx);
+        leaf_invert_doubling(Ul, dg, tid);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) {
                 const int i = ty + 32 * ii, c = tx + 16 * cc;
-                if (i < n && c < n) X[(size_t)i * ldx + c] = c >= i ? u[ii][cc] : 0.0;
+                if (i < n && c < n) X[(size_t)i * ldx + c] = c > i ? Ul[c * LLD + i] : (c == i ? dg[i] : 0.0);
             }
     }
 }
