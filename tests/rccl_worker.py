@@ -47,8 +47,9 @@ def main(result_dir):
     np.save(os.path.join(result_dir, 'x_{0}.npy'.format(rank)), x.cpu().numpy())
     np.save(os.path.join(result_dir, 'zd_{0}.npy'.format(rank)), np.stack([b.cpu().numpy() for b in Zd]))
     np.save(os.path.join(result_dir, 'zu_{0}.npy'.format(rank)), np.stack([b.cpu().numpy() for b in Zu]))
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':
