@@ -543,6 +543,7 @@ int build_pk_table(shg_plan* p, hipStream_t stream) {
 
 // fragment-ordered table of the fused kernel (and the octet offsets both fragment-ordered tables share)
 static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, int rotR, hipStream_t stream);
+int rot_kernel_waves();          // synthesis_rot.hip: waves per workgroup of the rotation-folded kernel
 
 // rotR != 0: the work items carry the panel slots of the rotation-folded kernel (synthesis_rot.hip) instead of those of the 4-fold one
 int build_pkf_table(shg_plan* p, bool ns, int rotR, hipStream_t stream) {
@@ -587,7 +588,7 @@ int build_pkf_table(shg_plan* p, bool ns, int rotR, hipStream_t stream) {
     return SHG_OK;
 }
 
-// Work items of the Legendre stage per wave (8 waves; the orders are dealt to the waves longest first, each to the wave
+// Work items of the Legendre stage per wave (8 waves, 12 in the rotation-folded kernel; the orders are dealt to the waves longest first, each to the wave
 // with the fewest items so far): records
 //   x, y = first / second octet of the item in the fragment-ordered tables (y = x when the order has no second octet left)
 //   z    = panel slot of the cosine part | (panel slot of the sine part + 1) << 16   (0 in the upper half: order 0)
@@ -600,12 +601,13 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, i
         int nk[4], cn[4];
         rot_layout(rotR, N, nk, cn, &slot16);
     }
-    std::vector<std::vector<int>> rec(8);
+    const int nw = rotR ? rot_kernel_waves() : 8;        // waves that share the orders of a tile
+    std::vector<std::vector<int>> rec(nw);
     size_t longest = 0;
     for (int m = 0; m <= N; ++m) {                       // orders by decreasing length, each to the wave with the fewest items so far
         {
             int w = 0;
-            for (int v = 1; v < 8; ++v)
+            for (int v = 1; v < nw; ++v)
                 if (rec[v].size() < rec[w].size()) w = v;
             const int cnt = N + 1 - m, q = (cnt + od - 1) / od;
             // panel slots (+1 for the sine part, 0 = none).  With order 0 folded out of the K loop (fold0) it sits behind the groups.
@@ -621,7 +623,7 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, i
             }
         }
     }
-    for (int w = 0; w < 8; ++w) longest = std::max(longest, rec[w].size() / 4);
+    for (int w = 0; w < nw; ++w) longest = std::max(longest, rec[w].size() / 4);
     // octet -> (order, octet inside the order) for the gather repack
     std::vector<int> octinfo((size_t)qoff[N + 1], 0);
     for (int m = 0; m <= N; ++m)
@@ -634,8 +636,8 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, i
     if (hipMalloc((void**)&p->octinfo_d, std::max<size_t>(octinfo.size(), 1) * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "octet table allocation failed");
     SHG_HIP(hipMemcpy(p->octinfo_d, octinfo.data(), octinfo.size() * sizeof(int), hipMemcpyHostToDevice));
     const int ntrip = (int)((longest + 3) / 4), nrec = 4 * ntrip + 8;
-    std::vector<int> table((size_t)8 * nrec * 4, 0);
-    for (int w = 0; w < 8; ++w) {
+    std::vector<int> table((size_t)nw * nrec * 4, 0);
+    for (int w = 0; w < nw; ++w) {
         const int pad = rec[w].empty() ? 0 : rec[w][0];              // a valid octet for the padding records
         for (int t = 0; t < nrec; ++t)
             for (int c = 0; c < 4; ++c) {

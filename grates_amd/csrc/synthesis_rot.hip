@@ -43,12 +43,17 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
+#ifndef SHG_ROT_WAVES
+#define SHG_ROT_WAVES 8          // waves per workgroup.  12 (three per SIMD; the kernel needs 143 registers, no spill at 168; ring
+#endif                           // depth 3 to fit the LDS) measured the same 0.525 ms: the fp64 issue pipe is the bound, not occupancy
 #ifndef SHG_RING_DEPTH
-#define SHG_RING_DEPTH 5
+#define SHG_RING_DEPTH (SHG_ROT_WAVES > 8 ? 3 : 5)
 #endif
+constexpr int kWaves = SHG_ROT_WAVES;
+constexpr int kColStride = kWaves / 4;              // column tiles of a wave: wave >> 2, + kColStride, ...
 constexpr int kRingDepth = SHG_RING_DEPTH;         // trig pieces in flight per wave
 constexpr int kRingSlots = kRingDepth + 1;          // ring slots (1 KB each) per wave
-constexpr int kRingDoubles = 8 * kRingSlots * 128;  // the rings of the 8 waves sit at the start of the LDS (DMA offsets < 64 KB)
+constexpr int kRingDoubles = kWaves * kRingSlots * 128;  // the rings of the waves sit at the start of the LDS (DMA offsets < 64 KB)
 constexpr int kMaxClasses = 4;
 
 // class layout for R rotations: position of class r in the K sequence (two-sum classes first), and whether it has four sums
@@ -91,7 +96,7 @@ struct RotParams {
 #ifdef SHG_TIMELINE
 #define ROT_STAMP(ev)                                                                                         \
     do {                                                                                                      \
-        if (P.tl && lane == 0) P.tl[((size_t)blockIdx.x * 8 + wave) * 16 + (ev)] = wall_clock64();            \
+        if (P.tl && lane == 0) P.tl[((size_t)blockIdx.x * kWaves + wave) * 16 + (ev)] = wall_clock64();            \
     } while (0)
 #else
 #define ROT_STAMP(ev)
@@ -190,9 +195,9 @@ __device__ __forceinline__ void rot_stream_init(RotStream& S, const RotParams& P
     S.ring_lds = lds0 + (unsigned)wave * (kRingSlots * 1024);
     S.im0 = S.ring_lds;
     const int ct0 = min(wave >> 2, P.nct - 1);
-    const int nq = (P.nct - ct0 + 1) >> 1;                          // column tiles of this wave
+    const int nq = (P.nct - ct0 + kColStride - 1) / kColStride;     // column tiles of this wave
     S.ifirst = P.trig + (size_t)ct0 * P.npieces * 128;
-    S.ilast = S.ifirst + (size_t)(nq - 1) * 2 * P.npieces * 128;
+    S.ilast = S.ifirst + (size_t)(nq - 1) * kColStride * P.npieces * 128;
     S.ibase = S.ifirst;
     S.iptr = S.ifirst;
     S.irem = P.npieces;
@@ -209,14 +214,14 @@ __device__ __forceinline__ void rot_issue_piece(RotStream& S, const RotParams& P
 #endif
     S.im0 = S.im0 + 1024 == S.ring_lds + kRingSlots * 1024 ? S.ring_lds : S.im0 + 1024;
     const bool more = S.irem > 1;
-    const double* nbase = S.ibase == S.ilast ? S.ifirst : S.ibase + 2 * P.npieces * 128;
+    const double* nbase = S.ibase == S.ilast ? S.ifirst : S.ibase + kColStride * P.npieces * 128;
     S.ibase = more ? S.ibase : nbase;
     S.iptr = more ? S.iptr + 128 : nbase;
     S.irem = more ? S.irem - 1 : P.npieces;
 }
 
 // Longitude stage + epilogue of one wave for the tile (bt, it).  A unit = (row tile wave & 3, column tile ct), ct = wave >> 2,
-// (wave >> 2) + 2, ...  (Taking the column tiles of a row tile from a common counter, so that the older wave of a SIMD, which
+// (wave >> 2) + kColStride, ...  (Taking the column tiles of a row tile from a common counter, so that the older wave of a SIMD, which
 // wins every MFMA issue slot and runs ~1.3 times faster, takes more of them, measured 16 % slower: the four waves that work
 // on the same column tile then drift apart and no longer share the trig pieces in the L1.)
 // On entry (S.tx, S.abx) hold the fragments of the first k-step; on exit those of the first k-step of column tile wave >> 2
@@ -235,7 +240,7 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
     const int grid_bytes = P.nlat * P.nlon * 8;        // one epoch's grid; < 2^31 (checked on the host)
     const int n2 = P.nlon >> 1, nR = P.nlon / R;
     const double2_t* const ringp = reinterpret_cast<const double2_t*>(As) + wave * (kRingSlots * 64) + lane;   // + slot * 64
-    // all units of a wave lie in the same row tile: (wave + 8 q) & 3 = wave & 3
+    // all units of a wave lie in the same row tile wave & 3
     const int rt = wave & 3;
     const double2_t* const prow = panel + rt * 16 + fr + fk * 64;        // + 256 p: k-step p of the flat class sequence
     // Fragments of the next k-step of the flat (unit, k-step) sequence -> (T_, AB_): one more trig piece issued, the piece of
@@ -323,7 +328,7 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
     const double4_t kZero4 = {0.0, 0.0, 0.0, 0.0};
     double2_t tx = S.tx, abx = S.abx, ty = {0.0, 0.0}, aby = {0.0, 0.0};
     const int ct0 = wave >> 2;
-    for (int ct = ct0, q = 0; ct < P.nct; ct += 2, ++q) {
+    for (int ct = ct0, q = 0; ct < P.nct; ct += kColStride, ++q) {
         (void)q;
         double4_t acc[T::kAcc];
         {
@@ -395,7 +400,7 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
 }
 
 template <bool NS, int R>
-__global__ __launch_bounds__(512) void synthesis_rot_kernel(RotParams P) {
+__global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P) {
     using T = RotTraits<R>;
     extern __shared__ __attribute__((aligned(16))) double As[];   // rings [8][kRingSlots][64][2], then panel [nslot + 1][64 rows][2]
 
@@ -630,6 +635,8 @@ int rot_layout(int R, int N, int nk[kMaxClasses], int cnt[kMaxClasses], std::vec
     return s;
 }
 
+int rot_kernel_waves() { return kWaves; }
+
 static size_t rot_lds_bytes(int nslot) { return (size_t)kRingDoubles * 8 + (size_t)(nslot + 1) * 1024; }      // rings, panel
 
 int rot_applicable(const shg_plan* p) {
@@ -671,10 +678,10 @@ template <int R>
 static int launch_rot(shg_plan* p, bool ns, const RotParams& P, size_t lds, dim3 grid_dim, hipStream_t stream) {
     if (ns) {
         SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((synthesis_rot_kernel<true, R>), grid_dim, dim3(512), lds, stream, P);
+        hipLaunchKernelGGL((synthesis_rot_kernel<true, R>), grid_dim, dim3(64 * kWaves), lds, stream, P);
     } else {
         SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((synthesis_rot_kernel<false, R>), grid_dim, dim3(512), lds, stream, P);
+        hipLaunchKernelGGL((synthesis_rot_kernel<false, R>), grid_dim, dim3(64 * kWaves), lds, stream, P);
     }
     return SHG_OK;
 }

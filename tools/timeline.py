@@ -21,7 +21,7 @@ plan = ga.engine.Plan(96, colat, kn, grid.meridians)
 batch = torch.from_numpy(np.random.default_rng(0).standard_normal((240, 97, 97)) * 1e-10).cuda()
 out = torch.empty((240, 720, 1440), dtype=torch.float64, device='cuda')
 ntiles = 60 * 45
-tl = torch.zeros((ntiles, 8, 16), dtype=torch.int64, device='cuda')
+tl = torch.zeros((ntiles, 8, 16), dtype=torch.int64, device='cuda')      # 8 waves per workgroup (synthesis_rot.hip: SHG_ROT_WAVES)
 for _ in range(5): plan.synthesis(batch, out=out)
 torch.cuda.synchronize()
 os.environ['SHG_TIMELINE_PTR'] = str(tl.data_ptr())
