@@ -147,10 +147,10 @@ __device__ __forceinline__ void rot_images<6>(double4_t* acc, int r) {
         const double x0 = sgn ? ca0 - sb0 : ca0 + sb0, x3 = sgn ? ca3 - sb3 : ca3 + sb3;
         const double x1 = sgn ? ca1 - sb1 : ca1 + sb1, y1 = sgn ? cb1 + sa1 : cb1 - sa1;
         const double x2 = sgn ? ca2 - sb2 : ca2 + sb2, y2 = sgn ? cb2 + sa2 : cb2 - sa2;
-        const double t = fma(-0.5, x2, x0), q = g * y2;
-        const double e0 = x0 + x2, e1 = t + q, e2 = t - q;
-        const double u = fma(0.5, x1, -x3), v = g * y1;
-        const double o0 = x1 + x3, o1 = u + v, o2 = v - u;
+        const double t = fma(-0.5, x2, x0);
+        const double e0 = x0 + x2, e1 = fma(g, y2, t), e2 = fma(-g, y2, t);
+        const double u = fma(0.5, x1, -x3);
+        const double o0 = x1 + x3, o1 = fma(g, y1, u), o2 = fma(g, y1, -u);
         acc[6 * sgn + 0][r] = e0 + o0;
         acc[6 * sgn + 3][r] = e0 - o0;
         acc[6 * sgn + 1][r] = e1 + o1;
@@ -170,10 +170,10 @@ __device__ __forceinline__ void rot_images<3>(double4_t* acc, int r) {
     for (int sgn = 0; sgn < 2; ++sgn) {
         const double x0 = sgn ? ca0 - sb0 : ca0 + sb0;
         const double x1 = sgn ? ca1 - sb1 : ca1 + sb1, y1 = sgn ? cb1 + sa1 : cb1 - sa1;
-        const double t = fma(-0.5, x1, x0), q = g * y1;
+        const double t = fma(-0.5, x1, x0);
         acc[3 * sgn + 0][r] = x0 + x1;
-        acc[3 * sgn + 1][r] = t + q;
-        acc[3 * sgn + 2][r] = t - q;
+        acc[3 * sgn + 1][r] = fma(g, y1, t);
+        acc[3 * sgn + 2][r] = fma(-g, y1, t);
     }
 }
 
