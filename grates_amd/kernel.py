@@ -42,20 +42,14 @@ class IsotropicKernel(metaclass=abc.ABCMeta):
     def coefficients(self, min_degree, max_degree, r=6378136.3, colat=0):
         """Kernel coefficients (m, max_degree + 1 - min_degree) for radius / colatitude of m points.
         Scalars broadcast against arrays; arrays must have equal shapes (grates/kernel.py:110-124)."""
-        r_scalar, c_scalar = np.isscalar(r), np.isscalar(colat)
-        r_array, c_array = isinstance(r, np.ndarray), isinstance(colat, np.ndarray)
-        if r_scalar and c_scalar:
-            radius, colatitude = r, colat
-        elif r_scalar and c_array:
-            radius, colatitude = np.full(colat.shape, r), colat
-        elif r_array and c_scalar:
-            radius, colatitude = r, np.full(r.shape, colat)
-        elif r_array and c_array:
-            if r.shape != colat.shape:
-                raise ValueError('shape mismatch in radius and colatitude: objects cannot be broadcast to a single shape')
-            radius, colatitude = r, colat
-        else:
+        kinds = tuple('scalar' if np.isscalar(v) else ('array' if isinstance(v, np.ndarray) else None) for v in (r, colat))
+        if None in kinds:
             raise ValueError('input must be either numeric scalar or ndarrays of matching or broadcastable dimensions')
+        if kinds == ('array', 'array') and r.shape != colat.shape:
+            raise ValueError('shape mismatch in radius and colatitude: objects cannot be broadcast to a single shape')
+        # a scalar next to an array is expanded to the array's shape; two scalars stay scalars
+        radius = np.full(colat.shape, r) if kinds == ('scalar', 'array') else r
+        colatitude = np.full(r.shape, colat) if kinds == ('array', 'scalar') else colat
         return self._coefficients(min_degree, max_degree, radius, colatitude)
 
     def coefficient(self, n, r=6378136.3, colat=0):
