@@ -303,6 +303,8 @@ def test_full_size_config5_chain():
               'epochs_per_s': round(T / (t_solve + t_inv), 1), 'residual': residual, 'monte_carlo_quadratic_form_defect': quad_defect,
               'covariance_asymmetry_max': worst_sym, 'identity_defect_max': worst_id}
     print(json.dumps(record))
+    del bm, ne, x, xs, bs, rhs, eye, Z, acc, D, R, Nx, own
+    torch.cuda.empty_cache()                              # 250 GB go back to the driver: the library allocates outside torch's cache
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     try:
         os.makedirs(out_dir, exist_ok=True)
