@@ -276,33 +276,59 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     if (!(P.dbg & 2)) {
         // plain layout: octet = 8 degrees, A rows 8-15 are zero (not stored);  NS layout: octet = 16 degrees, all 16 rows used
         constexpr int ASTRIDE = NS ? 128 : 64;                        // doubles per octet of the coefficient table
+        // Bookkeeping on the scalar unit, as in synthesis_rot.hip (see there for the measurement): records through scalar loads,
+        // operand loads "scalar base + fixed lane offset", uniform branches on the record flags, the accumulators of an order
+        // started from the MFMA's constant-zero operand.
+        typedef int int4_v __attribute__((ext_vector_type(4)));
+        typedef const int4_v __attribute__((address_space(4))) crec_t;
+        typedef double gdouble2_v __attribute__((ext_vector_type(2)));
+        typedef const gdouble2_v __attribute__((address_space(1))) gdouble2_t;
+        typedef const char __attribute__((address_space(1))) gbyte_t;
+        auto ld16 = [](const double* ubase, unsigned voff) {            // 16 bytes at (uniform base) + (lane offset)
+            unsigned long long b_ = reinterpret_cast<unsigned long long>(ubase);
+            asm volatile("" : "+s"(b_));
+            asm volatile("" : "+v"(voff));
+            const gdouble2_v v = *reinterpret_cast<gdouble2_t*>(reinterpret_cast<gbyte_t*>(b_) + voff);
+            return make_double2(v.x, v.y);
+        };
         const int bad = NS ? P.badmap[it] : -1;                       // block-uniform
-        const double* pkb = P.pkf + ((size_t)it * P.Qtot * 64 + lane) * 2;                       // + octet * 128
+        const double* pku = P.pkf + (size_t)it * P.Qtot * 128;                                   // uniform bases: + octet * 128
+        const double* cfu = NS ? P.cpk4 + (size_t)bt * P.Qtot * 128 : P.cpk4 + (size_t)bt * P.Qtot * 64;     // + octet * ASTRIDE
+        const unsigned pk_voff = (unsigned)lane * 16u;
+        const unsigned cf_voff = NS ? (unsigned)lane * 16u : (unsigned)(fk * 8 + (fr & 7)) * 16u;
         int mode = NS && bad >= 0 ? 1 : 0;
         int prow = lane;                                              // panel row written by this lane
-        const double* cf = NS ? P.cpk4 + ((size_t)bt * P.Qtot * 64 + lane) * 2
-                              : P.cpk4 + ((size_t)bt * P.Qtot * 32 + fk * 8 + (fr & 7)) * 2;     // + octet * ASTRIDE
         const bool arow = NS || fr < 8;
         double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+        bool fresh = true;                                            // uniform: the next MFMA pair opens an order
 
         // 16-byte fragment loads: A and B of two k-steps per load, 1 KB (B) / 512 B or 1 KB (A) contiguous per wave
 #define SHG_P1_ISSUE(rec, ALO, AHI, BLO, BHI)                                                \
     do {                                                                                     \
-        ALO = *reinterpret_cast<const double2*>(cf + (size_t)(rec).x * ASTRIDE);             \
-        BLO = *reinterpret_cast<const double2*>(pkb + (size_t)(rec).x * 128);                \
-        AHI = *reinterpret_cast<const double2*>(cf + (size_t)(rec).y * ASTRIDE);             \
-        BHI = *reinterpret_cast<const double2*>(pkb + (size_t)(rec).y * 128);                \
+        ALO = ld16(cfu + (size_t)(rec).x * ASTRIDE, cf_voff);                                \
+        BLO = ld16(pku + (size_t)(rec).x * 128, pk_voff);                                    \
+        AHI = ld16(cfu + (size_t)(rec).y * ASTRIDE, cf_voff);                                \
+        BHI = ld16(pku + (size_t)(rec).y * 128, pk_voff);                                    \
     } while (0)
 
 #define SHG_P1_CONSUME(rec, ALO, AHI, BLO, BHI)                                                                     \
     do {                                                                                                            \
-        const bool lo_ = arow && ((rec).w & 1);                                                                     \
-        const bool hi_ = arow && ((rec).w & 2);                                                                     \
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.x : 0.0, BLO.x, acc0, 0, 0, 0);                       \
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo_ ? ALO.y : 0.0, BLO.y, acc1, 0, 0, 0);                       \
+        if ((rec).w & 1) {                                  /* item valid (uniform) */                              \
+            const double ax_ = NS ? ALO.x : (arow ? ALO.x : 0.0), ay_ = NS ? ALO.y : (arow ? ALO.y : 0.0);          \
+            if (fresh) {                                                                                            \
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BLO.x, zero4, 0, 0, 0);                            \
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BLO.y, zero4, 0, 0, 0);                            \
+            } else {                                                                                                \
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BLO.x, acc0, 0, 0, 0);                             \
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BLO.y, acc1, 0, 0, 0);                             \
+            }                                                                                                       \
+            fresh = false;                                                                                          \
+        }                                                                                                           \
         if ((rec).w & 2) {                                  /* second octet present (uniform) */                    \
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.x : 0.0, BHI.x, acc0, 0, 0, 0);                   \
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi_ ? AHI.y : 0.0, BHI.y, acc1, 0, 0, 0);                   \
+            const double ax_ = NS ? AHI.x : (arow ? AHI.x : 0.0), ay_ = NS ? AHI.y : (arow ? AHI.y : 0.0);          \
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BHI.x, acc0, 0, 0, 0);                                 \
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BHI.y, acc1, 0, 0, 0);                                 \
         }                                                                                                           \
         if ((rec).w & 4) {                                  /* last item of an order */                             \
             /* C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15: reg 0 = cosine part of epoch (lane >> 4),  */ \
@@ -323,8 +349,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
                 As[((rec).z & 0xFFFF) * kPanelStride + prow] = vc_;                   /* cosine slot */            \
                 if ((rec).z >> 16) As[(((rec).z >> 16) - 1) * kPanelStride + prow] = vs_;   /* sine slot (m >= 1) */ \
             }                                                                                                       \
-            acc0 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
-            acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};                                                                 \
+            fresh = true;                                                                                           \
         }                                                                                                           \
     } while (0)
 
@@ -341,21 +366,21 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         // per trip with scalar loads one trip ahead.  Counted loop, four items per trip, three items in flight; exhausted
         // sequences are padded with records that re-read a valid octet with all flags clear (zero A operand): no branch
         // around loads and a single loop exit keep the compiler's vmcnt bookkeeping exact.
-        const int4* recs = P.itemtab + (size_t)wave * P.nrec;
+        crec_t* recs = reinterpret_cast<crec_t*>(reinterpret_cast<unsigned long long>(P.itemtab + (size_t)wave * P.nrec));
         for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
             if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
                 mode = 2;
                 prow = lane + 8;
-                pkb = P.pkf + ((size_t)(P.nit + bad) * P.Qtot * 64 + lane) * 2;
+                pku = P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128;
             }
-            int4 c0 = recs[0], c1 = recs[1], c2 = recs[2];
-            int4 n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
+            int4_v c0 = recs[0], c1 = recs[1], c2 = recs[2];
+            int4_v n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
             SHG_P1_ISSUE(c0, xal, xah, xbl, xbh);
             SHG_P1_ISSUE(c1, yal, yah, ybl, ybh);
             SHG_P1_ISSUE(c2, zal, zah, zbl, zbh);
             for (int trip = 0; trip < P.ntrip; ++trip) {
-                const int4 a3 = n0, a4 = n1, a5 = n2, a6 = n3;
-                const int4* nr = recs + 4 * trip + 7;
+                const int4_v a3 = n0, a4 = n1, a5 = n2, a6 = n3;
+                crec_t* nr = recs + 4 * trip + 7;
                 n0 = nr[0];
                 n1 = nr[1];
                 n2 = nr[2];
