@@ -26,7 +26,10 @@ constexpr int BM = 128, BN = 128, BK = 16;
 #ifndef SHG_GEMM_INTERLEAVE
 #define SHG_GEMM_INTERLEAVE 1           // operand loads dealt between the MFMAs (0: experiment switch, loads in a row)
 #endif
-constexpr int LDA = 18;     // As[row][k], 18-double rows: the 16 rows x 2 k a half wave reads in one LDS cycle fall into 32 distinct bank pairs
+#ifndef SHG_LDA
+#define SHG_LDA 17
+#endif
+constexpr int LDA = SHG_LDA;     // As[row][k], 17-double rows: neither the fragment reads (16 rows x 2 k per half wave) nor the staging writes (32 consecutive rows per half wave) have a bank conflict; 18 made the writes 2-way (+0.7 %)
 constexpr int LDB = 144;    // Bs[k][col], 128 + 16 pad
 
 enum { MODE_PLAIN = 0, MODE_COVPROP = 1, MODE_SYNTH = 2 };      // SYNTH: A generated like COVPROP, C stored like PLAIN
