@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     constexpr bool BUF = (MODE == MODE_COVPROP) && !PKT && !SYM;
     // ... and with 16-byte aligned Sigma rows (VEC) the Sigma tile does not pass through registers at all: every wave copies four
     // tile rows (1 KB each) straight into LDS with buffer loads that write to LDS, right behind the barrier that frees the buffer
-    constexpr bool DMA = BUF && VEC;
+    // (the same for the B operand of a plain product: PDMA)
+    constexpr bool PDMA = (MODE == MODE_PLAIN) && VEC;
+    constexpr bool DMA = (BUF && VEC) || PDMA;
     // PLAIN: column block fastest.  COVPROP: row block fastest -- the blocks resident at one time then walk the same
     // 33 MB column panel of Sigma together and it is fetched from HBM once instead of once per row block.
     const int m0 = (MODE == MODE_PLAIN ? blockIdx.y : blockIdx.x) * BM;
@@ -208,11 +210,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     const unsigned pk_bytes = BUF ? (unsigned)(((long long)P.pk_rows * P.ldp - (pk_base - P.pkd)) * 8) : 0u;
     const __amdgpu_buffer_rsrc_t rs_pk = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pk_base), 0, pk_bytes, 0x00020000);
     unsigned brow_soff[4] = {0, 0, 0, 0};
-    if (BUF) {
+    if (BUF || PDMA) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) brow_soff[h] = (unsigned)((size_t)(b_k + 4 * h) * P.ldb * 8);
-        load_offsets(0);
     }
+    if (BUF) load_offsets(0);
     // (BUF) rows h0 .. h1-1 of the generated A operand of the K tile at k0, and its Sigma rows.  The Sigma descriptor ends with
     // the matrix: rows beyond K read as zero, so a tile may be requested speculatively (the loop asks one tile ahead of need)
     auto fetch_A = [&](int k0, int h0, int h1) {
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
     //   BUF            behind the barrier, under the last k-step of the previous tile: Sigma and A rows 0-3; part 0: A rows 4-7
     constexpr int NLOAD0 = MODE == MODE_PLAIN ? (VEC ? 4 : 8) : 8;
     constexpr int NLOADA = 8;                                        // BUF: loads of A rows 0-3
-    constexpr int NLOAD1 = MODE == MODE_PLAIN ? (VEC ? 4 : 8) : (BUF ? 0 : 8);
+    constexpr int NLOAD1 = MODE == MODE_PLAIN ? (VEC ? 0 : 8) : (BUF ? 0 : 8);      // (plain product with 16-byte loads: B goes straight to LDS)
     constexpr int NLOAD2 = (MODE == MODE_PLAIN || BUF) ? 0 : (VEC ? 4 : 8);
     constexpr int NLOADB = VEC ? 4 : 8;
     auto fetch_old_B = [&](int k0) {
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
                         areg[2 * h + 1] = at(ak + 1, off);
                     }
                 }
-            } else if (part == 1) {
+            } else if (part == 1 && !PDMA) {
                 fetch_old_B(k0);
             }
         } else if (BUF) {
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
             fetch_A(k0, 0, 4);
             fetch_B(k0, 0);
         }
+        if (PDMA) fetch_B(k0, 0);
     };
     // last partial K tile: same addresses with k clamped, entries beyond K zeroed
     auto fetch_tail = [&](int k0) {
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
         fetch_B(BK, 1);
         fetch_A(BK, 0, 4);
     }
+    if (PDMA) fetch_B(BK, 1);
     // branch-free steady state, two K tiles per trip so that the LDS buffer of every access is a literal
 #define SHG_STEP(t, buf)                                                      \
     do {                                                                      \
@@ -509,6 +513,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams P) {      /
             fetch_B(((t) + 2) * BK, buf);                                     \
             fetch_A(((t) + 2) * BK, 0, 4);                                    \
             SHG_MFMA16_LOADS(af1, bf1, NLOADB + NLOADA);                      \
+        } else if (PDMA && !(SHG_GEMM_X & 4)) {                               \
+            fetch_B(((t) + 2) * BK, buf);                                     \
+            SHG_MFMA16_LOADS(af1, bf1, NLOADB);                               \
         } else {                                                              \
             SHG_MFMA16(af1, bf1);                                             \
         }                                                                     \
