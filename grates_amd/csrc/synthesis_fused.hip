@@ -511,7 +511,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
                 // lanes (2q, 2q+1) hold adjacent columns: swap halves so that every lane owns two rows x two
                 // adjacent columns and stores 16 bytes; one store instruction then writes 8 rows x one full 128-byte line
                 // (a transposed product with 4 adjacent columns per lane needs no exchange but writes 16 rows x 64 bytes per
-                // instruction and measured 12 % slower: tools/experiments/synthesis_fused_v4_transposed_epilogue.hip.txt).
+                // instruction and measured 12 % slower in round 1).
                 // Branch-free buffer stores: lanes outside the grid carry an offset beyond the buffer and are dropped.
                 const __amdgpu_buffer_rsrc_t rsrc =
                     __builtin_amdgcn_make_buffer_rsrc(P.G + (size_t)b * P.nlat * P.nlon, 0, grid_bytes, 0x00020000);
