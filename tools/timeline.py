@@ -42,7 +42,7 @@ bar = us[:, :, 2] - us[:, :, 1]
 print('phase1 per wave: mean %.2f  p10 %.2f p90 %.2f max %.2f' % (np.nanmean(ph1), np.nanpercentile(ph1, 10), np.nanpercentile(ph1, 90), np.nanmax(ph1)))
 print('barrier wait: mean %.2f max %.2f;  phase1 incl barrier (tile level): mean %.2f' % (np.nanmean(bar), np.nanmax(bar), np.nanmean(us[:, :, 2].max(1) - us[:, :, 0].min(1))))
 prev = us[:, :, 2]
-for c in range(3):
+for c in range(4):             # units of a wave (rotation-folded kernel: 4 column tiles per wave at 0.25 degree)
     M = us[:, :, 3 + 2 * c] - prev
     E = us[:, :, 4 + 2 * c] - us[:, :, 3 + 2 * c]
     print('cb %d: M mean %.2f p10 %.2f p90 %.2f | E mean %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f' % (c, np.nanmean(M), np.nanpercentile(M, 10), np.nanpercentile(M, 90),
@@ -53,7 +53,7 @@ print('tile total: mean %.2f p10 %.2f p90 %.2f' % (tile_t.mean(), np.percentile(
 T = np.arange(0, np.nanmax(us), 4.0)
 def count(a, b):
     return [(np.nan_to_num(a, nan=1e30) <= x).sum() - (np.nan_to_num(b, nan=1e30) <= x).sum() for x in T]
-inE = sum(np.array(count(us[:, :, 3 + 2 * c], us[:, :, 4 + 2 * c])) for c in range(3))
+inE = sum(np.array(count(us[:, :, 3 + 2 * c], us[:, :, 4 + 2 * c])) for c in range(4))
 inP1 = np.array(count(us[:, :, 0], us[:, :, 2]))
 print('t(us)   waves in epilogue   waves in phase1 (of 2048)')
 for x, a, b in list(zip(T, inE, inP1))[::3]:
