@@ -146,3 +146,21 @@ def test_bare_multi_gpu_invocation_launches_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main(['--gpus', '2'])
     assert 'WORLD_SIZE' in str(e.value.code) and len(calls) == 1
+
+
+def test_block_table_compressed_rows():
+    """engine.BlockTable: the stored upper blocks of a block matrix in the compressed row form of the shg_block_* calls
+    (include/shg.h): rows ascending, columns ascending from the diagonal, blocks below the diagonal left out."""
+    from grates_amd import engine
+    bounds = [0, 3, 5, 9, 10]
+    shape = lambda i, j: (bounds[i + 1] - bounds[i], bounds[j + 1] - bounds[j])          # noqa: E731
+    keys = [(2, 3), (0, 0), (1, 1), (0, 2), (3, 3), (2, 2), (1, 0), (0, 1)]                # (1, 0) lies below the diagonal
+    blocks = {k: torch.zeros(shape(*k), dtype=torch.float64) for k in keys}
+    table = engine.BlockTable(bounds, blocks)
+    assert table.nb == 4 and table.bounds.dtype == np.int32 and table.bounds.tolist() == bounds
+    assert table.rowptr.tolist() == [0, 3, 4, 6, 7]
+    assert table.colidx.tolist() == [0, 1, 2, 1, 2, 3, 3]
+    expect = [(0, 0), (0, 1), (0, 2), (1, 1), (2, 2), (2, 3), (3, 3)]
+    assert table.address.tolist() == [blocks[k].data_ptr() for k in expect]
+    nb, pb, pr, pc, pa = table.args()
+    assert nb == 4 and all(isinstance(p, type(pb)) for p in (pr, pc, pa))
