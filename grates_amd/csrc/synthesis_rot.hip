@@ -559,8 +559,14 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
         S.abx = panel[(wave & 3) * 16 + fr + fk * 64];
         S.pf = P.npieces > 1 ? 1 : 0;
         rot_phase2<NS, R>(P, As, panel, S, wave, lane, bt, it);
+        // The prefetched pieces of the stream must have landed before the LDS is released -- but not the stores: the 4 R stores of
+        // the last unit are the youngest operations of the wave (its last LDS-DMA was issued in the last k-step, before them), and
+        // the counter runs in order, so "at most 4 R outstanding" means every DMA is done.  The wave ends with its stores in flight
+        // instead of waiting for HBM to acknowledge them.
+        wait_vmcnt<4 * R>();
+    } else {
+        wait_vmcnt<0>();
     }
-    wait_vmcnt<0>();          // the prefetched pieces of the stream must have landed before the LDS is released
     ROT_STAMP(12);
 }
 
