@@ -399,6 +399,123 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
 #undef ROT_FETCH
 }
 
+// Phase 1: Legendre stage of tile (bt, it) (see synthesis_fused.hip).  The orders of the tile are dealt to the waves that call this
+// (work-item records `recs`, one list per wave); the result of order m is one 16-byte pair (A_m, B'_m) per panel row, written to
+// `panel` -- the LDS panel of the tile, or (persistent kernel) the image of the NEXT tile's panel in global memory.
+template <bool NS, typename PanelPtr>
+__device__ __forceinline__ void rot_phase1(const RotParams& P, PanelPtr panel, const int4* recs_wave, int bt, int it, int lane) {
+    const int fr = lane & 15, fk = lane >> 4;
+    // Everything that is the same for all lanes stays on the scalar unit: the work-item records come through scalar loads
+    // (constant address space), every operand load is "scalar base + lane offset fixed for the kernel", the flags of a record
+    // steer uniform branches, and the two accumulators of an order start from the MFMA's constant-zero operand instead of
+    // being cleared with 16 VALU moves.  Measured before: ~9 VALU instructions per MFMA in this stage (64-bit vector address
+    // arithmetic from records that sat in vector registers, flag tests, selects, clears); VALU instructions share the issue
+    // pipe with the fp64 MFMAs, so the stage was bound by their sum (2 x (6.5 k + 9 k) cycles per SIMD and tile = the 14 us
+    // it took), not by the L2 -> L1 rate it had been attributed to.
+    constexpr int ASTRIDE = NS ? 128 : 64;
+    typedef int int4_v __attribute__((ext_vector_type(4)));
+    typedef const int4_v __attribute__((address_space(4))) crec_t;
+    typedef double gdouble2_v __attribute__((ext_vector_type(2)));
+    typedef const gdouble2_v __attribute__((address_space(1))) gdouble2_t;
+    typedef const char __attribute__((address_space(1))) gbyte_t;
+    auto ld16 = [](const double* ubase, unsigned voff) {            // 16 bytes at (uniform base) + (lane offset)
+        unsigned long long b = reinterpret_cast<unsigned long long>(ubase);
+        asm volatile("" : "+s"(b));
+        asm volatile("" : "+v"(voff));
+        const gdouble2_v v = *reinterpret_cast<gdouble2_t*>(reinterpret_cast<gbyte_t*>(b) + voff);
+        return make_double2(v.x, v.y);
+    };
+    const int bad = NS ? P.badmap[it] : -1;
+    const double* pku = P.pkf + (size_t)it * P.Qtot * 128;                                   // uniform bases
+    const double* cfu = NS ? P.cpk4 + (size_t)bt * P.Qtot * 128 : P.cpk4 + (size_t)bt * P.Qtot * 64;
+    const unsigned pk_voff = (unsigned)lane * 16u;
+    const unsigned cf_voff = NS ? (unsigned)lane * 16u : (unsigned)(fk * 8 + (fr & 7)) * 16u;
+    int mode = NS && bad >= 0 ? 1 : 0;
+    int prow = lane;
+    const bool arow = NS || fr < 8;
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+    bool fresh = true;                                              // uniform: the next MFMA pair opens an order
+
+#define ROT_P1_ISSUE(rec, ALO, AHI, BLO, BHI)                                                \
+do {                                                                                     \
+    ALO = ld16(cfu + (size_t)(rec).x * ASTRIDE, cf_voff);                                \
+    BLO = ld16(pku + (size_t)(rec).x * 128, pk_voff);                                    \
+    AHI = ld16(cfu + (size_t)(rec).y * ASTRIDE, cf_voff);                                \
+    BHI = ld16(pku + (size_t)(rec).y * 128, pk_voff);                                    \
+} while (0)
+
+#define ROT_P1_CONSUME(rec, ALO, AHI, BLO, BHI)                                                                     \
+do {                                                                                                            \
+    if ((rec).w & 1) {                                                                                          \
+        const double ax_ = NS ? ALO.x : (arow ? ALO.x : 0.0), ay_ = NS ? ALO.y : (arow ? ALO.y : 0.0);          \
+        if (fresh) {                                                                                            \
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BLO.x, zero4, 0, 0, 0);                            \
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BLO.y, zero4, 0, 0, 0);                            \
+        } else {                                                                                                \
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BLO.x, acc0, 0, 0, 0);                             \
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BLO.y, acc1, 0, 0, 0);                             \
+        }                                                                                                       \
+        fresh = false;                                                                                          \
+    }                                                                                                           \
+    if ((rec).w & 2) {                                                                                          \
+        const double ax_ = NS ? AHI.x : (arow ? AHI.x : 0.0), ay_ = NS ? AHI.y : (arow ? AHI.y : 0.0);          \
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BHI.x, acc0, 0, 0, 0);                                 \
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BHI.y, acc1, 0, 0, 0);                                 \
+    }                                                                                                           \
+    if ((rec).w & 4) {                                  /* last item of an order: see synthesis_fused.hip */     \
+        double vc_ = acc0[0] + acc1[0], vs_ = acc0[1] + acc1[1];                                                \
+        if (NS) {                                                                                               \
+            const double oc_ = acc0[2] + acc1[2], os_ = acc0[3] + acc1[3];                                      \
+            const double rc_ = swap_half_row(fr < 8 ? vc_ : oc_), rs_ = swap_half_row(fr < 8 ? vs_ : os_);      \
+            vc_ = (mode == 0 && fr >= 8) ? rc_ - oc_ : vc_ + rc_;                                               \
+            vs_ = (mode == 0 && fr >= 8) ? rs_ - os_ : vs_ + rs_;                                               \
+        }                                                                                                       \
+        if (!NS || mode == 0 || fr < 8) panel[(rec).z * 64 + prow] = (double2_t){vc_, vs_};                     \
+        fresh = true;                                                                                           \
+    }                                                                                                           \
+} while (0)
+
+    double2 xal = {0, 0}, xah = {0, 0}, xbl = {0, 0}, xbh = {0, 0};
+    double2 yal = {0, 0}, yah = {0, 0}, ybl = {0, 0}, ybh = {0, 0};
+    double2 zal = {0, 0}, zah = {0, 0}, zbl = {0, 0}, zbh = {0, 0};
+    double2 wal = {0, 0}, wah = {0, 0}, wbl = {0, 0}, wbh = {0, 0};
+    crec_t* recs = reinterpret_cast<crec_t*>(reinterpret_cast<unsigned long long>(recs_wave));
+    for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
+        if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
+            mode = 2;
+            prow = lane + 8;
+            pku = P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128;
+        }
+        int4_v c0 = recs[0], c1 = recs[1], c2 = recs[2];
+        int4_v n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
+        ROT_P1_ISSUE(c0, xal, xah, xbl, xbh);
+        ROT_P1_ISSUE(c1, yal, yah, ybl, ybh);
+        ROT_P1_ISSUE(c2, zal, zah, zbl, zbh);
+        for (int trip = 0; trip < P.ntrip; ++trip) {
+            const int4_v a3 = n0, a4 = n1, a5 = n2, a6 = n3;
+            crec_t* nr = recs + 4 * trip + 7;
+            n0 = nr[0];
+            n1 = nr[1];
+            n2 = nr[2];
+            n3 = nr[3];
+            ROT_P1_ISSUE(a3, wal, wah, wbl, wbh);
+            ROT_P1_CONSUME(c0, xal, xah, xbl, xbh);
+            ROT_P1_ISSUE(a4, xal, xah, xbl, xbh);
+            ROT_P1_CONSUME(c1, yal, yah, ybl, ybh);
+            ROT_P1_ISSUE(a5, yal, yah, ybl, ybh);
+            ROT_P1_CONSUME(c2, zal, zah, zbl, zbh);
+            ROT_P1_ISSUE(a6, zal, zah, zbl, zbh);
+            ROT_P1_CONSUME(a3, wal, wah, wbl, wbh);
+            c0 = a4;
+            c1 = a5;
+            c2 = a6;
+        }
+    }
+#undef ROT_P1_ISSUE
+#undef ROT_P1_CONSUME
+}
+
 template <bool NS, int R>
 __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P) {
     using T = RotTraits<R>;
@@ -432,119 +549,8 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
 #pragma unroll
     for (int d = 0; d < kRingDepth; ++d) rot_issue_piece(S, P, (unsigned)lane * 16u);
 
-    // ---- phase 1: Legendre stage (see synthesis_fused.hip).  Orders are distributed over the 8 waves; the result of order m
-    //      is written as one 16-byte pair (A_m, B'_m) per panel row.
-    if (!(P.dbg & 2)) {
-        // Everything that is the same for all lanes stays on the scalar unit: the work-item records come through scalar loads
-        // (constant address space), every operand load is "scalar base + lane offset fixed for the kernel", the flags of a record
-        // steer uniform branches, and the two accumulators of an order start from the MFMA's constant-zero operand instead of
-        // being cleared with 16 VALU moves.  Measured before: ~9 VALU instructions per MFMA in this stage (64-bit vector address
-        // arithmetic from records that sat in vector registers, flag tests, selects, clears); VALU instructions share the issue
-        // pipe with the fp64 MFMAs, so the stage was bound by their sum (2 x (6.5 k + 9 k) cycles per SIMD and tile = the 14 us
-        // it took), not by the L2 -> L1 rate it had been attributed to.
-        constexpr int ASTRIDE = NS ? 128 : 64;
-        typedef int int4_v __attribute__((ext_vector_type(4)));
-        typedef const int4_v __attribute__((address_space(4))) crec_t;
-        typedef double gdouble2_v __attribute__((ext_vector_type(2)));
-        typedef const gdouble2_v __attribute__((address_space(1))) gdouble2_t;
-        typedef const char __attribute__((address_space(1))) gbyte_t;
-        auto ld16 = [](const double* ubase, unsigned voff) {            // 16 bytes at (uniform base) + (lane offset)
-            unsigned long long b = reinterpret_cast<unsigned long long>(ubase);
-            asm volatile("" : "+s"(b));
-            asm volatile("" : "+v"(voff));
-            const gdouble2_v v = *reinterpret_cast<gdouble2_t*>(reinterpret_cast<gbyte_t*>(b) + voff);
-            return make_double2(v.x, v.y);
-        };
-        const int bad = NS ? P.badmap[it] : -1;
-        const double* pku = P.pkf + (size_t)it * P.Qtot * 128;                                   // uniform bases
-        const double* cfu = NS ? P.cpk4 + (size_t)bt * P.Qtot * 128 : P.cpk4 + (size_t)bt * P.Qtot * 64;
-        const unsigned pk_voff = (unsigned)lane * 16u;
-        const unsigned cf_voff = NS ? (unsigned)lane * 16u : (unsigned)(fk * 8 + (fr & 7)) * 16u;
-        int mode = NS && bad >= 0 ? 1 : 0;
-        int prow = lane;
-        const bool arow = NS || fr < 8;
-        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-        bool fresh = true;                                              // uniform: the next MFMA pair opens an order
-
-#define ROT_P1_ISSUE(rec, ALO, AHI, BLO, BHI)                                                \
-    do {                                                                                     \
-        ALO = ld16(cfu + (size_t)(rec).x * ASTRIDE, cf_voff);                                \
-        BLO = ld16(pku + (size_t)(rec).x * 128, pk_voff);                                    \
-        AHI = ld16(cfu + (size_t)(rec).y * ASTRIDE, cf_voff);                                \
-        BHI = ld16(pku + (size_t)(rec).y * 128, pk_voff);                                    \
-    } while (0)
-
-#define ROT_P1_CONSUME(rec, ALO, AHI, BLO, BHI)                                                                     \
-    do {                                                                                                            \
-        if ((rec).w & 1) {                                                                                          \
-            const double ax_ = NS ? ALO.x : (arow ? ALO.x : 0.0), ay_ = NS ? ALO.y : (arow ? ALO.y : 0.0);          \
-            if (fresh) {                                                                                            \
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BLO.x, zero4, 0, 0, 0);                            \
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BLO.y, zero4, 0, 0, 0);                            \
-            } else {                                                                                                \
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BLO.x, acc0, 0, 0, 0);                             \
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BLO.y, acc1, 0, 0, 0);                             \
-            }                                                                                                       \
-            fresh = false;                                                                                          \
-        }                                                                                                           \
-        if ((rec).w & 2) {                                                                                          \
-            const double ax_ = NS ? AHI.x : (arow ? AHI.x : 0.0), ay_ = NS ? AHI.y : (arow ? AHI.y : 0.0);          \
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, BHI.x, acc0, 0, 0, 0);                                 \
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, BHI.y, acc1, 0, 0, 0);                                 \
-        }                                                                                                           \
-        if ((rec).w & 4) {                                  /* last item of an order: see synthesis_fused.hip */     \
-            double vc_ = acc0[0] + acc1[0], vs_ = acc0[1] + acc1[1];                                                \
-            if (NS) {                                                                                               \
-                const double oc_ = acc0[2] + acc1[2], os_ = acc0[3] + acc1[3];                                      \
-                const double rc_ = swap_half_row(fr < 8 ? vc_ : oc_), rs_ = swap_half_row(fr < 8 ? vs_ : os_);      \
-                vc_ = (mode == 0 && fr >= 8) ? rc_ - oc_ : vc_ + rc_;                                               \
-                vs_ = (mode == 0 && fr >= 8) ? rs_ - os_ : vs_ + rs_;                                               \
-            }                                                                                                       \
-            if (!NS || mode == 0 || fr < 8) panel[(rec).z * 64 + prow] = (double2_t){vc_, vs_};                     \
-            fresh = true;                                                                                           \
-        }                                                                                                           \
-    } while (0)
-
-        double2 xal = {0, 0}, xah = {0, 0}, xbl = {0, 0}, xbh = {0, 0};
-        double2 yal = {0, 0}, yah = {0, 0}, ybl = {0, 0}, ybh = {0, 0};
-        double2 zal = {0, 0}, zah = {0, 0}, zbl = {0, 0}, zbh = {0, 0};
-        double2 wal = {0, 0}, wah = {0, 0}, wbl = {0, 0}, wbh = {0, 0};
-        crec_t* recs = reinterpret_cast<crec_t*>(reinterpret_cast<unsigned long long>(P.itemtab + (size_t)wave * P.nrec));
-        for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
-            if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
-                mode = 2;
-                prow = lane + 8;
-                pku = P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128;
-            }
-            int4_v c0 = recs[0], c1 = recs[1], c2 = recs[2];
-            int4_v n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
-            ROT_P1_ISSUE(c0, xal, xah, xbl, xbh);
-            ROT_P1_ISSUE(c1, yal, yah, ybl, ybh);
-            ROT_P1_ISSUE(c2, zal, zah, zbl, zbh);
-            for (int trip = 0; trip < P.ntrip; ++trip) {
-                const int4_v a3 = n0, a4 = n1, a5 = n2, a6 = n3;
-                crec_t* nr = recs + 4 * trip + 7;
-                n0 = nr[0];
-                n1 = nr[1];
-                n2 = nr[2];
-                n3 = nr[3];
-                ROT_P1_ISSUE(a3, wal, wah, wbl, wbh);
-                ROT_P1_CONSUME(c0, xal, xah, xbl, xbh);
-                ROT_P1_ISSUE(a4, xal, xah, xbl, xbh);
-                ROT_P1_CONSUME(c1, yal, yah, ybl, ybh);
-                ROT_P1_ISSUE(a5, yal, yah, ybl, ybh);
-                ROT_P1_CONSUME(c2, zal, zah, zbl, zbh);
-                ROT_P1_ISSUE(a6, zal, zah, zbl, zbh);
-                ROT_P1_CONSUME(a3, wal, wah, wbl, wbh);
-                c0 = a4;
-                c1 = a5;
-                c2 = a6;
-            }
-        }
-#undef ROT_P1_ISSUE
-#undef ROT_P1_CONSUME
-    }
+    // ---- phase 1: Legendre stage.  Orders are distributed over the waves of the workgroup.
+    if (!(P.dbg & 2)) rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
     ROT_STAMP(1);
     __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
     ROT_STAMP(2);
