@@ -281,19 +281,13 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         // started from the MFMA's constant-zero operand.
         typedef int int4_v __attribute__((ext_vector_type(4)));
         typedef const int4_v __attribute__((address_space(4))) crec_t;
-        typedef double gdouble2_v __attribute__((ext_vector_type(2)));
-        typedef const gdouble2_v __attribute__((address_space(1))) gdouble2_t;
-        typedef const char __attribute__((address_space(1))) gbyte_t;
-        auto ld16 = [](const double* ubase, unsigned voff) {            // 16 bytes at (uniform base) + (lane offset)
-            unsigned long long b_ = reinterpret_cast<unsigned long long>(ubase);
-            asm volatile("" : "+s"(b_));
-            asm volatile("" : "+v"(voff));
-            const gdouble2_v v = *reinterpret_cast<gdouble2_t*>(reinterpret_cast<gbyte_t*>(b_) + voff);
-            return make_double2(v.x, v.y);
+        auto ld16 = [](__amdgpu_buffer_rsrc_t table, unsigned voff, unsigned soff) {      // descriptor (scalar) + lane offset + octet offset (scalar)
+            return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(table, voff, soff, 0));
         };
         const int bad = NS ? P.badmap[it] : -1;                       // block-uniform
-        const double* pku = P.pkf + (size_t)it * P.Qtot * 128;                                   // uniform bases: + octet * 128
-        const double* cfu = NS ? P.cpk4 + (size_t)bt * P.Qtot * 128 : P.cpk4 + (size_t)bt * P.Qtot * 64;     // + octet * ASTRIDE
+        __amdgpu_buffer_rsrc_t pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)it * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
+        const __amdgpu_buffer_rsrc_t cfu =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(NS ? P.cpk4 + (size_t)bt * P.Qtot * 128 : P.cpk4 + (size_t)bt * P.Qtot * 64), 0, 0xffffffffu, 0x00020000);
         const unsigned pk_voff = (unsigned)lane * 16u;
         const unsigned cf_voff = NS ? (unsigned)lane * 16u : (unsigned)(fk * 8 + (fr & 7)) * 16u;
         int mode = NS && bad >= 0 ? 1 : 0;
@@ -306,10 +300,10 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         // 16-byte fragment loads: A and B of two k-steps per load, 1 KB (B) / 512 B or 1 KB (A) contiguous per wave
 #define SHG_P1_ISSUE(rec, ALO, AHI, BLO, BHI)                                                \
     do {                                                                                     \
-        ALO = ld16(cfu + (size_t)(rec).x * ASTRIDE, cf_voff);                                \
-        BLO = ld16(pku + (size_t)(rec).x * 128, pk_voff);                                    \
-        AHI = ld16(cfu + (size_t)(rec).y * ASTRIDE, cf_voff);                                \
-        BHI = ld16(pku + (size_t)(rec).y * 128, pk_voff);                                    \
+        ALO = ld16(cfu, cf_voff, (unsigned)(rec).x * (ASTRIDE * 8u));                        \
+        BLO = ld16(pku, pk_voff, (unsigned)(rec).x * 1024u);                                 \
+        AHI = ld16(cfu, cf_voff, (unsigned)(rec).y * (ASTRIDE * 8u));                        \
+        BHI = ld16(pku, pk_voff, (unsigned)(rec).y * 1024u);                                 \
     } while (0)
 
 #define SHG_P1_CONSUME(rec, ALO, AHI, BLO, BHI)                                                                     \
@@ -371,7 +365,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
             if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
                 mode = 2;
                 prow = lane + 8;
-                pku = P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128;
+                pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
             }
             int4_v c0 = recs[0], c1 = recs[1], c2 = recs[2];
             int4_v n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
