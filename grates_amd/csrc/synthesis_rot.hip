@@ -432,6 +432,7 @@ __device__ __forceinline__ void rot_phase1(const RotParams& P, PanelPtr panel, c
     const bool arow = NS || fr < 8;
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+    double sgm = (mode == 0 && fr >= 8) ? -1.0 : 1.0;                 // sign of the lane's own part in the north / south combination
     bool fresh = true;                                              // uniform: the next MFMA pair opens an order
 
 #define ROT_P1_ISSUE(rec, ALO, AHI, BLO, BHI)                                                \
@@ -464,9 +465,12 @@ do {                                                                            
         double vc_ = acc0[0] + acc1[0], vs_ = acc0[1] + acc1[1];                                                \
         if (NS) {                                                                                               \
             const double oc_ = acc0[2] + acc1[2], os_ = acc0[3] + acc1[3];                                      \
-            const double rc_ = swap_half_row(fr < 8 ? vc_ : oc_), rs_ = swap_half_row(fr < 8 ? vs_ : os_);      \
-            vc_ = (mode == 0 && fr >= 8) ? rc_ - oc_ : vc_ + rc_;                                               \
-            vs_ = (mode == 0 && fr >= 8) ? rs_ - os_ : vs_ + rs_;                                               \
+            /* a lane sends x = (E of slots 0-7 | O of slots 8-15) and receives the other part r: E + O = r + x on */ \
+            /* the northern slots, E - O = r - x on the mirrored ones: one exact fma with the lane's sign           */ \
+            const double xc_ = fr < 8 ? vc_ : oc_, xs_ = fr < 8 ? vs_ : os_;                                   \
+            const double rc_ = swap_half_row(xc_), rs_ = swap_half_row(xs_);                                   \
+            vc_ = fma(sgm, xc_, rc_);                                                                           \
+            vs_ = fma(sgm, xs_, rs_);                                                                           \
         }                                                                                                       \
         if (!NS || mode == 0 || fr < 8) panel[(rec).z * 64 + prow] = (double2_t){vc_, vs_};                     \
         fresh = true;                                                                                           \
@@ -481,6 +485,7 @@ do {                                                                            
     for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
         if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
             mode = 2;
+            sgm = 1.0;
             prow = lane + 8;
             pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
         }
