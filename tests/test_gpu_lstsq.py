@@ -312,3 +312,32 @@ def test_full_size_config5_chain():
             f.write(json.dumps(record) + '\n')
     except OSError:
         pass
+
+
+def test_block_table_validation():
+    """The shg_block_* calls check the compressed-row table before they touch memory: missing diagonal block, columns out of
+    order or out of range and NULL blocks are reported as errors (no fault, nothing launched)."""
+    import torch
+    eng = ga.engine
+    bounds = [0, 4, 9, 12]
+    blocks = {(i, j): torch.eye(bounds[i + 1] - bounds[i], bounds[j + 1] - bounds[j], dtype=torch.float64, device='cuda') * (4.0 if i == j else 0.5)
+              for i, j in ((0, 0), (0, 1), (1, 1), (1, 2), (2, 2))}
+    keep = [torch.zeros((s, s), dtype=torch.float64, device='cuda') for s in (4, 5, 3)]
+    inverses = np.array([k.data_ptr() for k in keep], dtype=np.uint64)
+    good = eng.BlockTable(bounds, blocks)
+    assert eng.block_potrf(good, inverses) == 0                                   # SPD: factors
+    for mutate in ('swap_columns', 'no_diagonal', 'column_range', 'null_block'):
+        table = eng.BlockTable(bounds, {k: v.clone() for k, v in blocks.items()})
+        if mutate == 'swap_columns':
+            table.colidx[0], table.colidx[1] = table.colidx[1], table.colidx[0]
+        elif mutate == 'no_diagonal':
+            table.colidx[2] = 2                                                   # row 1 starts with column 2
+        elif mutate == 'column_range':
+            table.colidx[3] = 7
+        else:
+            table.address[1] = 0
+        with pytest.raises(Exception):
+            eng.block_potrf(table, inverses)
+    x = torch.ones((12, 2), dtype=torch.float64, device='cuda')
+    with pytest.raises(Exception):
+        eng.block_solve(good, np.array([0, 0, 0], dtype=np.uint64), False, x)      # no scratch for the inverses
