@@ -8,6 +8,7 @@
 // Stages (all on the device, batched over epochs):
 //   1. weight_transpose   WVt[j][(b, i)] = area[i][j] v[b][i][j]
 //   2. fp64 MFMA GEMM     Gt[s][(b, i)] = sum_j T_s(lon_j) WVt[j][(b, i)]          (gemm.hip)
+//      (grids with the four-fold meridian symmetry: weight_fold + GEMMs over a quarter of the meridians, see below)
 //   3. weight_squares     w2[s][i]
 //   4. analysis_solve     one workgroup per slot s = (m, cos|sin): normal matrix, Cholesky, right-hand sides of all
 //                         epochs, forward / backward substitution, scatter into anm.
@@ -38,6 +39,49 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(int nb, int nlat,
         const int j = j0 + k;
         const long long r = r0 + tx;
         if (j < nlon && r < rows) wvt[(size_t)j * rows + r] = tile[tx][k];
+    }
+}
+
+// Longitude fold for grids with the four-fold meridian symmetry (plan flag sym4).  With mu_c = lon[nlon/2 + c] in (0, pi/2)
+// the four meridians  j1 = nlon/2 + c (mu),  j2 = nlon/2 - 1 - c (-mu),  j3 = c (mu - pi),  j4 = nlon - 1 - c (pi - mu)  carry
+//   cos m lon = cos m mu * (1, 1, (-1)^m, (-1)^m),      sin m lon = sin m mu * (1, -1, (-1)^m, -(-1)^m),
+// so the longitude transform needs only the quarter domain once the weighted values w = area * v are folded:
+//   F[0] = (w1 + w2) - (w3 + w4)   cos, odd m          F[1] = (w1 - w2) - (w3 - w4)   sin, odd m
+//   F[2] = (w1 + w2) + (w3 + w4)   cos, even m         F[3] = (w1 - w2) + (w3 - w4)   sin, even m
+// each stored [nlon/4][(b, i)]: a quarter of the multiply-adds of the plain transform, the same bytes read.
+__global__ __launch_bounds__(256) void weight_fold_kernel(int nb, int nlat, int nlon, const double* __restrict__ v,
+                                                          const double* __restrict__ area, double* __restrict__ F) {
+    __shared__ double tile[4][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const int nq = nlon / 4, h = nlon / 2;
+    const int c0 = blockIdx.x * 32;
+    const long long r0 = (long long)blockIdx.y * 32;              // flat (b, i) row
+    const long long rows = (long long)nb * nlat;
+    for (int k = ty; k < 32; k += 8) {
+        const long long r = r0 + k;
+        const int c = c0 + tx;
+        double w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0;
+        if (r < rows && c < nq) {
+            const double* vr = v + r * nlon;
+            const double* ar = area + (size_t)(r % nlat) * nlon;
+            w1 = vr[h + c] * ar[h + c];
+            w2 = vr[h - 1 - c] * ar[h - 1 - c];
+            w3 = vr[c] * ar[c];
+            w4 = vr[nlon - 1 - c] * ar[nlon - 1 - c];
+        }
+        const double p12 = w1 + w2, p34 = w3 + w4, q12 = w1 - w2, q34 = w3 - w4;
+        tile[0][k][tx] = p12 - p34;
+        tile[1][k][tx] = q12 - q34;
+        tile[2][k][tx] = p12 + p34;
+        tile[3][k][tx] = q12 + q34;
+    }
+    __syncthreads();
+    const size_t plane = (size_t)nq * rows;
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k;
+        const long long r = r0 + tx;
+        if (c < nq && r < rows)
+            for (int g = 0; g < 4; ++g) F[g * plane + (size_t)c * rows + r] = tile[g][tx][k];
     }
 }
 
@@ -195,42 +239,55 @@ static int build_analysis_operator(shg_plan* p, const double* w2, int nmin, hipS
 
 using namespace shg;
 
-// The cached operator H (p->ana_H) for these area weights and this minimum degree; rebuilt when either differs from what it
-// was built for.  The weights are compared entry by entry on the device with the copy kept beside the operator.
-static int ensure_analysis_operator(shg_plan* p, const double* area, int nmin, hipStream_t stream) {
+// The cached operator H (p->ana_H) belongs to one set of area weights and one minimum degree.  The weights are compared
+// entry by entry on the device with the copy kept beside the operator; the operator is rebuilt when they differ.
+static int analysis_tables(shg_plan* p, hipStream_t stream) {
+    const int rc = build_pk_table(p, stream);
+    return rc ? rc : covprop_build_cs_table(p, stream);
+}
+
+static bool analysis_operator_cached(const shg_plan* p, int nmin) { return p->ana_H && p->ana_area && p->ana_nmin == nmin; }
+
+static int rebuild_analysis_operator(shg_plan* p, const double* area, int nmin, hipStream_t stream) {
     const int N = p->N, S = 2 * N + 1, nlat = p->nlat, nlon = p->nlon;
     const size_t na = (size_t)nlat * nlon;
-    int rc = build_pk_table(p, stream);
-    if (rc) return rc;
-    rc = covprop_build_cs_table(p, stream);
-    if (rc) return rc;
-    bool valid = p->ana_H && p->ana_area && p->ana_nmin == nmin;
-    if (valid) {
-        int* diff = nullptr;
-        if (workspace_alloc((void**)&diff, sizeof(int), stream) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
-        int host = 0;
-        hipError_t e = hipMemsetAsync(diff, 0, sizeof(int), stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(analysis_compare_kernel, dim3(256), dim3(256), 0, stream, (long long)na, area, p->ana_area, diff);
-            e = hipMemcpyAsync(&host, diff, sizeof(int), hipMemcpyDeviceToHost, stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFreeAsync(diff, stream);
-        if (e != hipSuccess) return fail(SHG_ERR_HIP, "shg_analysis: weight comparison failed: %s", hipGetErrorString(e));
-        valid = host == 0;
-    }
-    if (valid) return SHG_OK;
     p->ana_nmin = -1;
     if (!p->ana_area && hipMalloc((void**)&p->ana_area, na * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "analysis weight copy allocation failed");
     double* w2 = nullptr;
     if (workspace_alloc((void**)&w2, (size_t)S * nlat * sizeof(double), stream) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
     hipLaunchKernelGGL(weight_squares_kernel, dim3(nlat), dim3(256), 0, stream, S, nlat, nlon, area, p->cs_slot, w2);
-    rc = build_analysis_operator(p, w2, nmin, stream);
+    const int rc = build_analysis_operator(p, w2, nmin, stream);
     (void)hipFreeAsync(w2, stream);
     if (rc) return rc;
     SHG_HIP(hipMemcpyAsync(p->ana_area, area, na * sizeof(double), hipMemcpyDeviceToDevice, stream));
     p->ana_nmin = nmin;
     return SHG_OK;
+}
+
+// *diff (device, zeroed here) becomes non-zero when `area` is not the set of weights the cached operator was built for
+static int launch_weight_compare(shg_plan* p, const double* area, int* diff, hipStream_t stream) {
+    SHG_HIP(hipMemsetAsync(diff, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(analysis_compare_kernel, dim3(256), dim3(256), 0, stream, (long long)p->nlat * p->nlon, area, p->ana_area, diff);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+static int ensure_analysis_operator(shg_plan* p, const double* area, int nmin, hipStream_t stream) {
+    int rc = analysis_tables(p, stream);
+    if (rc) return rc;
+    if (analysis_operator_cached(p, nmin)) {
+        int* diff = nullptr;
+        if (workspace_alloc((void**)&diff, sizeof(int), stream) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
+        int host = 0;
+        rc = launch_weight_compare(p, area, diff, stream);
+        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(&host, diff, sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (!rc && e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFreeAsync(diff, stream);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(SHG_ERR_HIP, "shg_analysis: weight comparison failed: %s", hipGetErrorString(e));
+        if (host == 0) return SHG_OK;
+    }
+    return rebuild_analysis_operator(p, area, nmin, stream);
 }
 
 extern "C" int shg_analysis_matrix(shg_plan* p, const double* area, int nmin, double* F, void* stream_) {
@@ -248,48 +305,95 @@ extern "C" int shg_analysis_matrix(shg_plan* p, const double* area, int nmin, do
     return SHG_OK;
 }
 
+// one pass over all epochs with the operator in p->ana_H (workspaces sized for `chunk` epochs)
+static int analysis_pass(shg_plan* p, const double* grid, const double* area, int nmin, int B, int chunk, bool folded, double* wvt, double* gt,
+                         double* X, double* anm, hipStream_t stream) {
+    const int N = p->N, S = 2 * N + 1, nlat = p->nlat, nlon = p->nlon, R = N + 1;
+    SHG_HIP(hipMemsetAsync(anm, 0, (size_t)B * R * R * sizeof(double), stream));
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        const long long rows = (long long)nb * nlat;
+        int rc;
+        if (folded) {
+            // slots in gt: 0 = order 0, 2m-1 = cos m, 2m = sin m.  Per parity and cos | sin the slots are 4 apart, so each
+            // group is a GEMM on strided rows of the trig table (columns nlon/2 ... of cs_slot = the quarter domain) whose
+            // output rows land in slot order; the two groups of a parity differ by one slot and form one batched call.
+            const int nq = nlon / 4;
+            const long long plane = (long long)nq * rows;
+            hipLaunchKernelGGL(weight_fold_kernel, dim3(ceil_div(nq, 32), (unsigned)ceil_div64(rows, 32)), dim3(256), 0, stream, nb, nlat,
+                               nlon, grid + (size_t)b0 * nlat * nlon, area, wvt);
+            ProfileScope ps(p, 4, stream);
+            const double* quarter = p->cs_slot + nlon / 2;
+            rc = gemm_ex(false, false, 1, (int)rows, nq, 1.0, quarter, nlon, 0, wvt + 2 * plane, (int)rows, 0, 0.0, gt, (int)rows, 0, 1, false, stream);
+            const int odd = (N + 1) / 2, even = N / 2;            // orders 1, 3, ... / 2, 4, ...
+            if (!rc && odd)
+                rc = gemm_ex(false, false, odd, (int)rows, nq, 1.0, quarter + (size_t)nlon, 4 * nlon, nlon, wvt, (int)rows, plane, 0.0,
+                             gt + rows, 4 * (int)rows, rows, 2, false, stream);
+            if (!rc && even)
+                rc = gemm_ex(false, false, even, (int)rows, nq, 1.0, quarter + (size_t)3 * nlon, 4 * nlon, nlon, wvt + 2 * plane, (int)rows,
+                             plane, 0.0, gt + 3 * rows, 4 * (int)rows, rows, 2, false, stream);
+        } else {
+            hipLaunchKernelGGL(weight_transpose_kernel, dim3(ceil_div(nlon, 32), (unsigned)ceil_div64(rows, 32)), dim3(256), 0, stream, nb,
+                               nlat, nlon, grid + (size_t)b0 * nlat * nlon, area, wvt);
+            ProfileScope ps(p, 4, stream);
+            rc = shg_dgemm(S, (int)rows, nlon, p->cs_slot, nlon, wvt, (int)rows, gt, (int)rows, stream);
+        }
+        if (rc) return rc;
+        ProfileScope ps(p, 5, stream);
+        // X_s [R][nb] = H_s [R][nlat] gt_s^T   (gt_s is [nb][nlat])
+        rc = gemm_ex(false, true, R, nb, nlat, 1.0, p->ana_H, nlat, (long long)R * nlat, gt, nlat, rows, 0.0, X, nb, (long long)R * nb, S, false, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(analysis_scatter_kernel, dim3(ceil_div(nb, 64), R, S), dim3(64), 0, stream, N, nmin, nb, b0, X, anm);
+    }
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
 extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area, int nmin, int B, double* anm, void* stream_) {
     SHG_REQUIRE(p != nullptr, "shg_analysis: NULL plan");
     SHG_REQUIRE(B >= 0 && nmin >= 0, "shg_analysis: negative size");
     if (B == 0) return SHG_OK;
     SHG_REQUIRE(grid && area && anm, "shg_analysis: NULL pointer");
+    SHG_REQUIRE(nmin <= p->N, "shg_analysis: min_degree %d out of range", nmin);
     hipStream_t stream = (hipStream_t)stream_;
     PlanGuard guard(p, stream);
     const int N = p->N, S = 2 * N + 1, nlat = p->nlat, nlon = p->nlon;
-    int rc = ensure_analysis_operator(p, area, nmin, stream);
+    int rc = analysis_tables(p, stream);
     if (rc) return rc;
-    SHG_HIP(hipMemsetAsync(anm, 0, (size_t)B * (N + 1) * (N + 1) * sizeof(double), stream));
+    // With a cached operator the pass is queued at once and the comparison of the weights with the ones the operator was
+    // built for rides along on the stream: its verdict is read after the pass (the host never waits in the middle of the
+    // call), and only weights that did change cost a rebuild and a second pass.
+    const bool optimistic = analysis_operator_cached(p, nmin);
+    if (!optimistic && (rc = rebuild_analysis_operator(p, area, nmin, stream)) != SHG_OK) return rc;
 
     const int chunk = std::min(B, kAnaEpochChunk);
     const int R = N + 1;
+    const bool folded = p->sym4 && 4LL * chunk * nlat < (1LL << 29);     // ldc = 4 * rows as int
     double *wvt = nullptr, *gt = nullptr, *X = nullptr;
+    int* diff = nullptr;
     if (workspace_alloc((void**)&wvt, (size_t)nlon * chunk * nlat * sizeof(double), stream) != hipSuccess ||
         workspace_alloc((void**)&gt, (size_t)S * chunk * nlat * sizeof(double), stream) != hipSuccess ||
-        workspace_alloc((void**)&X, (size_t)S * R * chunk * sizeof(double), stream) != hipSuccess) {
-        for (void* q : {(void*)wvt, (void*)gt, (void*)X})
+        workspace_alloc((void**)&X, (size_t)S * R * chunk * sizeof(double), stream) != hipSuccess ||
+        workspace_alloc((void**)&diff, sizeof(int), stream) != hipSuccess) {
+        for (void* q : {(void*)wvt, (void*)gt, (void*)X, (void*)diff})
             if (q) (void)hipFreeAsync(q, stream);
         return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
     }
-    for (int b0 = 0; b0 < B && rc == SHG_OK; b0 += chunk) {
-        const int nb = std::min(chunk, B - b0);
-        const long long rows = (long long)nb * nlat;
-        hipLaunchKernelGGL(weight_transpose_kernel, dim3(ceil_div(nlon, 32), (unsigned)ceil_div64(rows, 32)), dim3(256), 0, stream, nb,
-                           nlat, nlon, grid + (size_t)b0 * nlat * nlon, area, wvt);
-        {
-            ProfileScope ps(p, 4, stream);
-            rc = shg_dgemm(S, (int)rows, nlon, p->cs_slot, nlon, wvt, (int)rows, gt, (int)rows, stream);
+    if (optimistic) rc = launch_weight_compare(p, area, diff, stream);
+    if (!rc) rc = analysis_pass(p, grid, area, nmin, B, chunk, folded, wvt, gt, X, anm, stream);
+    if (!rc && optimistic) {
+        int changed = 0;
+        hipError_t e = hipMemcpyAsync(&changed, diff, sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = fail(SHG_ERR_HIP, "shg_analysis: weight comparison failed: %s", hipGetErrorString(e));
+        if (!rc && changed) {
+            rc = rebuild_analysis_operator(p, area, nmin, stream);
+            if (!rc) rc = analysis_pass(p, grid, area, nmin, B, chunk, folded, wvt, gt, X, anm, stream);
         }
-        if (rc) break;
-        ProfileScope ps(p, 5, stream);
-        // X_s [R][nb] = H_s [R][nlat] gt_s^T   (gt_s is [nb][nlat])
-        rc = gemm_ex(false, true, R, nb, nlat, 1.0, p->ana_H, nlat, (long long)R * nlat, gt, nlat, rows, 0.0, X, nb, (long long)R * nb, S, false, stream);
-        if (rc) break;
-        hipLaunchKernelGGL(analysis_scatter_kernel, dim3(ceil_div(nb, 64), R, S), dim3(64), 0, stream, N, nmin, nb, b0, X, anm);
     }
     (void)hipFreeAsync(wvt, stream);
     (void)hipFreeAsync(gt, stream);
     (void)hipFreeAsync(X, stream);
-    if (rc) return rc;
-    SHG_HIP(hipGetLastError());
-    return SHG_OK;
+    (void)hipFreeAsync(diff, stream);
+    return rc;
 }

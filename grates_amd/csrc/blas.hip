@@ -372,7 +372,9 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
     //  operand: 128-row tiles only)
     const long long tiles64 = (long long)ceil_div(N, 64) * ceil_div(M, 64) * batch;
     const bool split_candidate = batch == 1 && !upper_only && K >= 512 && tiles64 < 256;
-    const bool small_tiles = work_tiles < 200 && !split_candidate && (const double*)C != A && (const double*)C != B;
+    // (and products of at most 64 rows with many column tiles: a 128-row tile would be more than half empty)
+    const bool narrow = M <= 64 && !upper_only && tiles64 >= 512;
+    const bool small_tiles = (work_tiles < 200 || narrow) && !split_candidate && (const double*)C != A && (const double*)C != B;
     const int XT = small_tiles ? 64 : 128;
     dim3 grid(ceil_div(N, XT), ceil_div(M, XT), batch);
     const size_t lds = (size_t)4 * (small_tiles ? GemmExTile<64>::BUF : GemmExTile<128>::BUF) * sizeof(double);   // 73.7 KB (two workgroups per CU) / 41 KB

@@ -174,7 +174,7 @@ class Plan:
             g = g.unsqueeze(0)
         a = to_device(area, self.device).reshape(self.nlat, self.nlon)
         n1 = self.max_degree + 1
-        out = torch.zeros((g.shape[0], n1, n1), dtype=torch.float64, device=self.device)
+        out = torch.empty((g.shape[0], n1, n1), dtype=torch.float64, device=self.device)    # zeroed by the library
         with torch.cuda.device(self.device):
             _lib.call('shg_analysis', self._handle, _ptr(g), _ptr(a), int(min_degree), g.shape[0], _ptr(out), _stream())
         return out[0] if single else out

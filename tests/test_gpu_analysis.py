@@ -80,6 +80,29 @@ def test_against_oracle_batched(N, nmin, dlon, dlat):
         assert relerr(out[e], ref) < TOL
 
 
+def test_operator_follows_weights_and_meridians():
+    """The cached operator is rebuilt when the area weights change between calls (same plan, same min_degree), and grids
+    without the four-fold meridian symmetry (here: shifted meridians, odd count) take the unfolded longitude transform."""
+    N, nmin = 10, 1
+    grid = ga.grid.GeographicGrid(9.0, 6.0)
+    ker = orc.KernelTable('potential')
+    rng = np.random.default_rng(404)
+    for meridians in (grid.meridians, grid.meridians + 0.05, np.linspace(-np.pi, np.pi, 35, endpoint=False) + 0.01):
+        vals = rng.standard_normal((3, grid.parallels.size, meridians.size))
+        area = rng.uniform(0.5, 1.5, grid.parallels.size * meridians.size)
+        colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel('potential'), N, grid.parallels, 3.9860044150e+14, 6.3781363000e+06,
+                                                       grid.semimajor_axis, grid.flattening)
+        plan = ga.engine.Plan(N, colat, kn, meridians)
+        first = ga.engine.to_host(plan.analysis(vals, area, nmin))
+        other = area * rng.uniform(0.8, 1.2, area.size)
+        second = ga.engine.to_host(plan.analysis(vals, other, nmin))            # optimistic pass, verdict "changed", second pass
+        again = ga.engine.to_host(plan.analysis(vals, area, nmin))
+        for e in range(3):
+            assert relerr(first[e], orc.analysis_regular(vals[e].ravel(), area, nmin, N, meridians, grid.parallels, ker)) < TOL
+            assert relerr(second[e], orc.analysis_regular(vals[e].ravel(), other, nmin, N, meridians, grid.parallels, ker)) < TOL
+        assert np.array_equal(first, again)
+
+
 def test_irregular_grid_analysis():
     lon, lat = inputs.scattered_points(77, 400)
     grid = ga.grid.IrregularGrid(lon, lat)
