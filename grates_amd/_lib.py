@@ -60,6 +60,7 @@ PROTOTYPES = {
     'shg_synthesis_matrix': [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_analysis_matrix': [c_plan_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_block_potrf': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [c_double_p, ctypes.c_void_p],
+    'shg_block_potrf_rows': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_block_solve': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     'shg_block_sparse_inverse': [ctypes.c_int] + [ctypes.c_void_p] * 6,
     'shg_block_inverse': [ctypes.c_int] + [ctypes.c_void_p] * 6,

@@ -388,7 +388,7 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
         if (slices > 1) {
             const int chunk = round_up(ceil_div(K, slices), XK);
             slices = ceil_div(K, chunk);
-            if (slices > 1 && workspace_alloc((void**)&partial, (size_t)slices * M * N * sizeof(double), stream) == hipSuccess) {
+            if (slices > 1 && (partial = (double*)stream_scratch(stream, 0, (size_t)slices * M * N * sizeof(double))) != nullptr) {
                 P.K = chunk;
                 P.Ktotal = K;
                 P.strideA = ta ? (long long)chunk * lda : chunk;
@@ -423,7 +423,6 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
 #undef SHG_GEMM_EX
     if (partial) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(N, 256), M), dim3(256), 0, stream, M, N, slices, alpha, partial, beta, C, ldc);
-        (void)hipFreeAsync(partial, stream);
     }
     SHG_HIP(hipGetLastError());
     return SHG_OK;

@@ -103,11 +103,17 @@ using namespace shg;
 
 // A = W^T W in place (upper blocks); inv[r] <- U_rr^-1.  *info (device int, may be NULL): 1-based index of the first
 // non-positive pivot (counted over the whole matrix), 0 on success.
-extern "C" int shg_block_potrf(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int* info,
-                               void* stream_) {
+// Only the block rows first <= r < last are eliminated: the rows before `first` count as factored already (their updates have
+// been applied), the rows from `last` on receive the updates and are left as the Schur complement of what has been
+// eliminated.  Two chains that meet in a common last block (the two halves of a block-tridiagonal system, each walked from
+// its free end) are factored this way on two streams at once; the caller adds the two complements and finishes with the
+// last row.
+extern "C" int shg_block_potrf_rows(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
+                                    int first, int last, int* info, void* stream_) {
     const BlockView V{nb, bounds, rowptr, colidx, blk};
     int rc = check(V, inv, "shg_block_potrf");
     if (rc) return rc;
+    SHG_REQUIRE(first >= 0 && first <= last && last <= nb, "shg_block_potrf_rows: rows %d .. %d outside 0 .. %d", first, last, nb);
     hipStream_t stream = (hipStream_t)stream_;
     Scratch scratch(stream);
     const int dmax = V.max_size();
@@ -116,7 +122,7 @@ extern "C" int shg_block_potrf(int nb, const int* bounds, const int* rowptr, con
     int* info_blk = (int*)scratch.get(1);
     SHG_REQUIRE(work && panel && info_blk, "shg_block_potrf: workspace allocation failed");
     if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
-    for (int r = 0; r < nb; ++r) {
+    for (int r = first; r < last; ++r) {
         const int dr = V.size(r);
         const int e0 = V.begin(r), e1 = V.end(r);
         double* Arr = blk[e0];
@@ -145,6 +151,11 @@ extern "C" int shg_block_potrf(int nb, const int* bounds, const int* rowptr, con
     }
     SHG_HIP(hipGetLastError());
     return SHG_OK;
+}
+
+extern "C" int shg_block_potrf(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int* info,
+                               void* stream) {
+    return shg_block_potrf_rows(nb, bounds, rowptr, colidx, blk, inv, 0, nb, info, stream);
 }
 
 // Solve W x = b (transpose == 0) or W^T x = b (transpose != 0) with the block factor; B [n][k] row-major with leading

@@ -14,6 +14,7 @@
 namespace shg {
 
 int fail(int code, const char* fmt, ...);
+void* stream_scratch(hipStream_t stream, int slot, size_t bytes);              // grow-only scratch of a stream (plan.hip), never freed by the user
 hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream);    // hipMallocAsync from a pool that keeps freed memory cached
 
 #define SHG_HIP(call)                                                                              \

@@ -5,6 +5,10 @@
 #include <cstring>
 #include <string>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 namespace shg {
@@ -36,6 +40,34 @@ hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream) {
         prepared_device = dev;
     }
     return hipMallocAsync(ptr, bytes, stream);
+}
+
+// Scratch that lives as long as its stream is in use: one grow-only buffer per (stream, slot), handed to successive
+// operations of that stream (which the stream orders, so they may share it).  For workspaces inside chains of thousands of
+// small operations: on ROCm 7.2 hipFreeAsync keeps the calling thread until the stream has caught up (0.2 - 1.4 ms per call
+// in the factorisation of a d = 1681 block), which makes the host the pace-maker of such a chain.
+void* stream_scratch(hipStream_t stream, int slot, size_t bytes) {
+    struct Entry {
+        void* ptr = nullptr;
+        size_t size = 0;
+    };
+    static std::mutex mtx;
+    static std::map<std::pair<hipStream_t, int>, Entry> table;
+    std::lock_guard<std::mutex> lock(mtx);
+    Entry& e = table[std::make_pair(stream, slot)];
+    if (e.size < bytes) {
+        if (e.ptr) (void)hipFree(e.ptr);             // waits for the device: whatever still used the old buffer is done
+        e.ptr = nullptr;
+        e.size = 0;
+        const size_t want = std::max(bytes + bytes / 4, (size_t)1 << 20);
+        if (hipMalloc(&e.ptr, want) != hipSuccess) {
+            e.ptr = nullptr;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        e.size = want;
+    }
+    return e.ptr;
 }
 
 // a_nm / b_nm of  P_nm = (a_nm t) P_(n-1)m - b_nm P_(n-2)m   in packed order-major layout.

@@ -252,9 +252,9 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
 #define ROT_FETCH(T_, AB_)                                                                                \
     do {                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        rot_issue_piece(S, P, lane_off);                                                                  \
-        wait_vmcnt<kRingDepth>();                                                                         \
-        T_ = ringp[S.cslot * 64];                                                                         \
+        if (!(SHG_ROT_X & 8)) rot_issue_piece(S, P, lane_off);                                            \
+        if (!(SHG_ROT_X & 8)) wait_vmcnt<kRingDepth>();                                                   \
+        if (!(SHG_ROT_X & 4)) T_ = ringp[S.cslot * 64];                                                   \
         if (!(SHG_ROT_X & 2)) S.cslot = S.cslot + 1 == kRingSlots ? 0 : S.cslot + 1;                      \
         AB_ = prow[S.pf * 256];                                                                           \
         if (!(SHG_ROT_X & 2)) S.pf = S.pf + 1 == P.npieces ? 0 : S.pf + 1;                                \

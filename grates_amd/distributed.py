@@ -136,6 +136,154 @@ def _gather_blocks(tensors, group=None):
     return out
 
 
+class _Chain:
+    """A symmetric positive definite block-tridiagonal matrix (diag[t] = N[t, t], upper[t] = N[t, t+1], device tensors) behind the
+    three operations the partitioned smoother needs.  The blocks are copied unless `consume` is set: then the chain works in
+    the caller's tensors (which end up holding factor / covariance blocks), as a chain of BASELINE config 5's size must."""
+
+    def __init__(self, diag, upper, consume=False):
+        from .lstsq import BlockMatrix
+        self.n = len(diag)
+        self.matrix = _chain_matrix(BlockMatrix, diag, upper, not consume)
+
+    def factor(self):
+        self.matrix.cholesky()
+
+    def solve(self, b):
+        """N^-1 b for b [n, k]"""
+        return self.matrix.solve_triangular(self.matrix.solve_triangular(b, transpose=True))
+
+    def sparse_inverse(self):
+        """(Zdiag, Zupper): the block-tridiagonal part of N^-1"""
+        self.matrix.sparse_inverse()
+        block = self.matrix.device_block
+        return [block(t, t) for t in range(self.n)], [block(t, t + 1) for t in range(self.n - 1)]
+
+
+def _chain_matrix(BlockMatrix, blocks_d, blocks_u, copy=True):
+    index = np.concatenate(([0], np.cumsum([int(b.shape[0]) for b in blocks_d])))
+    bm = BlockMatrix(index, index)
+    for i, b in enumerate(blocks_d):
+        bm._set_device(i, i, b.clone() if copy else b)
+    for i, b in enumerate(blocks_u):
+        bm._set_device(i, i + 1, b.clone() if copy else b)
+    return bm
+
+
+def _transposed(block, in_place):
+    """block^T as a contiguous tensor; a square block can be transposed in its own storage"""
+    if in_place and block.shape[0] == block.shape[1] and block.is_contiguous():
+        block.copy_(block.t().clone())
+        return block
+    return block.t().contiguous()
+
+
+class _TwistedChain:
+    """
+    The same chain eliminated from both ends at once ("twisted" factorisation: elimination order 0, 1, ..., m-1 and n-1, n-2, ...,
+    m+1, then the middle epoch m).  A block-tridiagonal system has no fill-in in this order either, the two half chains share
+    nothing but the Schur complement of block m, and each is a plain chain in its own order -- so the top half [0 .. m] and the
+    bottom half [n-1 .. m] (reversed, coupling blocks transposed) are two BlockMatrix objects that are factored, swept and
+    inverted by two host threads on two HIP streams (shg_block_potrf_rows leaves the common last block as Schur complement;
+    the two complements are added and the last row is finished in both).  The epoch-by-epoch factorisation of a d = 1681 block
+    keeps a handful of CUs busy (its critical path is a chain of one-workgroup leaf factorisations), so two chains at once take
+    about the time of one.  The factor differs from the one of the natural order; solutions and covariance blocks do not
+    (up to rounding).
+    """
+
+    def __init__(self, diag, upper, consume=False):
+        import torch
+        from .lstsq import BlockMatrix
+        self.torch = torch
+        self.n = n = len(diag)
+        self.m = m = n // 2
+        self.sizes = [int(b.shape[0]) for b in diag]
+        self.bounds = np.concatenate(([0], np.cumsum(self.sizes)))
+        self.middle = diag[m].clone()                                          # both halves update a copy of their own
+        self.top = _chain_matrix(BlockMatrix, diag[:m + 1], upper[:m], not consume)
+        # position p of the bottom chain = epoch n - 1 - p; its coupling (p, p + 1) = N[n-1-p, n-2-p] = upper[n-2-p]^T
+        self.bottom = _chain_matrix(BlockMatrix, [diag[t] for t in range(n - 1, m, -1)] + [self.middle.clone()],
+                                    [_transposed(upper[t - 1], consume) for t in range(n - 1, m, -1)], not consume)
+        self.nt, self.nbot = m + 1, n - m
+        self.device = diag[0].device
+        self.streams = _side_streams(self.device)
+
+    def _both(self, top_job, bottom_job):
+        """run the two jobs on two threads / streams; both streams are drained when this returns"""
+        from concurrent.futures import ThreadPoolExecutor
+        torch = self.torch
+        main = torch.cuda.current_stream(self.device)
+
+        def run(job, stream):
+            torch.cuda.set_device(self.device)
+            stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                out = job()
+            stream.synchronize()
+            return out
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            futures = [pool.submit(run, job, stream) for job, stream in zip((top_job, bottom_job), self.streams)]
+            return [f.result() for f in futures]
+
+    def factor(self):
+        from . import engine
+        nt, nbot = self.nt, self.nbot
+        self._both(lambda: self.top._cholesky_rows(0, nt - 1), lambda: self.bottom._cholesky_rows(0, nbot - 1))
+        # Schur complement of the middle block: N_mm minus the contributions of both halves
+        st, sb = self.top.device_block(nt - 1, nt - 1), self.bottom.device_block(nbot - 1, nbot - 1)
+        engine.axpby(1.0, sb, 1.0, st)
+        engine.axpby(-1.0, self.middle, 1.0, st)
+        sb.copy_(st)
+        self._both(lambda: self.top._cholesky_rows(nt - 1, nt), lambda: self.bottom._cholesky_rows(nbot - 1, nbot))
+
+    def _rows(self, t):
+        return slice(int(self.bounds[t]), int(self.bounds[t + 1]))
+
+    def solve(self, b):
+        torch = self.torch
+        n, m, k = self.n, self.m, b.shape[1]
+        dm = self.sizes[m]
+        b_top = b[:int(self.bounds[m + 1])].clone()
+        b_bot = torch.cat([b[self._rows(t)] for t in range(n - 1, m, -1)] + [torch.zeros((dm, k), dtype=b.dtype, device=b.device)], dim=0)
+        y_top, y_bot = self._both(lambda: self.top.solve_triangular(b_top, transpose=True), lambda: self.bottom.solve_triangular(b_bot, transpose=True))
+        # W^T y = b: the middle rows collect the contributions of both halves (the bottom half started from zero there)
+        y_top[-dm:] += y_bot[-dm:]
+        y_bot[-dm:] = y_top[-dm:]
+        x_top, x_bot = self._both(lambda: self.top.solve_triangular(y_top), lambda: self.bottom.solve_triangular(y_bot))
+        pos = np.concatenate(([0], np.cumsum([self.sizes[t] for t in range(n - 1, m - 1, -1)])))     # row offsets of the bottom chain
+        return torch.cat([x_top] + [x_bot[int(pos[n - 1 - t]):int(pos[n - t])] for t in range(m + 1, n)], dim=0)
+
+    def sparse_inverse(self):
+        n, m = self.n, self.m
+        top, bot = self.top.device_block, self.bottom.device_block
+
+        def bottom_job():
+            # (N^-1)[t, t+1] for t >= m is the transpose of the bottom chain's block (n-2-t, n-1-t): transposed in its own storage
+            self.bottom.sparse_inverse()
+            return [_transposed(bot(n - 2 - t, n - 1 - t), True) for t in range(m, n - 1)]
+        _, lower = self._both(self.top.sparse_inverse, bottom_job)
+        zdiag = [top(t, t) for t in range(m + 1)] + [bot(n - 1 - t, n - 1 - t) for t in range(m + 1, n)]
+        return zdiag, [top(t, t + 1) for t in range(m)] + lower
+
+
+_side_stream_cache = {}
+
+
+def _side_streams(device):
+    import torch
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _side_stream_cache:
+        _side_stream_cache[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _side_stream_cache[key]
+
+
+def _make_chain(diag, upper, consume=False):
+    """two-ended elimination for chains long enough to gain from it (GRATES_AMD_TWISTED=0: natural order throughout)"""
+    if len(diag) >= 8 and os.environ.get('GRATES_AMD_TWISTED', '1') != '0':
+        return _TwistedChain(diag, upper, consume)
+    return _Chain(diag, upper, consume)
+
+
 class _PartitionedChain:
     """
     Nested dissection of a symmetric positive definite block-tridiagonal matrix whose block rows (epochs) are distributed over
@@ -145,7 +293,7 @@ class _PartitionedChain:
     vectors) per rank.  A second, small all_gather beforehand hands every rank the coupling block to its left separator.
     """
 
-    def __init__(self, diag, upper, rhs, group):
+    def __init__(self, diag, upper, rhs, group, consume=False):
         import torch
         import torch.distributed as dist
         from . import engine
@@ -166,20 +314,11 @@ class _PartitionedChain:
             return torch.zeros((r, c), dtype=torch.float64, device=device)
         self.zeros = zeros
 
-        def chain(blocks_d, blocks_u):
-            index = np.concatenate(([0], np.cumsum([int(b.shape[0]) for b in blocks_d])))
-            bm = BlockMatrix(index, index)
-            for i, b in enumerate(blocks_d):
-                bm._set_device(i, i, b.clone())
-            for i, b in enumerate(blocks_u):
-                bm._set_device(i, i + 1, b.clone())
-            return bm
-
         self.ni = ni = n_loc if (last or world == 1) else n_loc - 1         # interior epochs
         self.n_int = n_int = int(bounds[ni])
         if world == 1:
-            self.interior = chain(diag, upper[:n_loc - 1])
-            self.interior.cholesky()
+            self.interior = _make_chain(diag, upper[:n_loc - 1], consume)
+            self.interior.factor()
             return
 
         # coupling to the left separator: N[s_(g-1), t0] lives on the previous rank
@@ -191,8 +330,8 @@ class _PartitionedChain:
         self.left = left = boundaries[rank - 1][0] if rank > 0 else None      # [d_sep_left, d_first]
         self.right = upper[ni - 1] if not last else None                      # N[t1-2, t1-1]
 
-        self.interior = interior = chain(diag[:ni], upper[:ni - 1])
-        interior.cholesky()
+        self.interior = interior = _make_chain(diag[:ni], upper[:ni - 1], consume)
+        interior.factor()
         columns = [rhs[:n_int]] if k else []
         if left is not None:                                                # C_left = left^T in the first interior block rows
             cl = zeros(n_int, left.shape[0])
@@ -204,7 +343,7 @@ class _PartitionedChain:
             columns.append(cr)
         W = torch.cat(columns, dim=1).contiguous()
         del columns
-        Z = interior.solve_triangular(interior.solve_triangular(W, transpose=True))
+        Z = interior.solve(W)
         del W
         self.zb = Z[:, :k]
         pos = k
@@ -254,7 +393,7 @@ class _PartitionedChain:
         reduced.cholesky()
 
 
-def solve_block_tridiagonal_partitioned(diag, upper, rhs, group=None):
+def solve_block_tridiagonal_partitioned(diag, upper, rhs, group=None, consume=False):
     """
     Solve the symmetric positive definite block-tridiagonal system N x = b whose block rows (epochs) are distributed over the
     ranks in contiguous ranges: the fixed-interval smoother of grates.lstsq (NormalEquations.solve on a VAR(1)-constrained
@@ -270,10 +409,17 @@ def solve_block_tridiagonal_partitioned(diag, upper, rhs, group=None):
     its interior chain with the block Cholesky of grates_amd.lstsq.BlockMatrix (sequential in epochs, all ranks concurrently)
     and solves it for the right-hand side and for its two coupling blocks; ONE all_gather (RCCL) collects the separator blocks
     and the Schur complement pieces, every rank solves the small separator system redundantly and back-substitutes.
+    Interior chains of eight epochs and more are eliminated from both ends at once (_TwistedChain).
+
+    consume=True lets the factorisation work in the caller's blocks instead of copies of them (they are overwritten): a chain
+    of BASELINE config 5's size (3650 epochs x 2 x 22.6 MB plus the inverses of the diagonal factor blocks) fits the card only once.
     """
-    pc = _PartitionedChain(diag, upper, rhs, group)
+    return _partitioned_solution(_PartitionedChain(diag, upper, rhs, group, consume), rhs)
+
+
+def _partitioned_solution(pc, rhs):
     if pc.world == 1:
-        return pc.interior.solve_triangular(pc.interior.solve_triangular(rhs, transpose=True))
+        return pc.interior.solve(rhs)
     engine, d, rank = pc.engine, pc.d, pc.rank
     x_sep = pc.reduced.solve_triangular(pc.reduced.solve_triangular(pc.red_rhs, transpose=True))
     # back substitution of the interior chain
@@ -286,7 +432,7 @@ def solve_block_tridiagonal_partitioned(diag, upper, rhs, group=None):
     return x_int
 
 
-def sparse_inverse_block_tridiagonal_partitioned(diag, upper, group=None):
+def sparse_inverse_block_tridiagonal_partitioned(diag, upper, group=None, consume=False):
     """
     Block-tridiagonal part of N^-1 (the covariance blocks NormalEquations.compute_covariance(sparse=True) leaves in the matrix,
     grates/lstsq.py:823-846, 1026-1042) for a chain whose epochs are distributed over the ranks like in
@@ -303,12 +449,24 @@ def sparse_inverse_block_tridiagonal_partitioned(diag, upper, group=None):
     The only collectives are the two all_gathers of the factorisation and one more of a single d x d block per rank (the
     covariance block that couples a separator to the first epoch of the next rank is computed by that next rank).
     """
-    pc = _PartitionedChain(diag, upper, None, group)
+    return _partitioned_covariance(_PartitionedChain(diag, upper, None, group, consume))
+
+
+def smooth_block_tridiagonal_partitioned(diag, upper, rhs, group=None, consume=False):
+    """Solution and covariance blocks from ONE factorisation: (x, Zdiag, Zupper) as returned by solve_block_tridiagonal_partitioned
+    and sparse_inverse_block_tridiagonal_partitioned (NormalEquations.solve followed by compute_covariance(sparse=True),
+    grates/lstsq.py:950-968, 1026-1042)."""
+    pc = _PartitionedChain(diag, upper, rhs, group, consume)
+    x = _partitioned_solution(pc, rhs)
+    zdiag, zupper = _partitioned_covariance(pc)
+    return x, zdiag, zupper
+
+
+def _partitioned_covariance(pc):
     torch, engine = pc.torch, pc.engine
     ni, bounds = pc.ni, pc.bounds
     if pc.world == 1:
-        pc.interior.sparse_inverse()
-        return ([pc.interior.device_block(t, t) for t in range(ni)], [pc.interior.device_block(t, t + 1) for t in range(ni - 1)])
+        return pc.interior.sparse_inverse()
     d, rank, last = pc.d, pc.rank, pc.last
     pc.reduced.sparse_inverse()
     sep = pc.reduced.device_block
@@ -324,17 +482,12 @@ def sparse_inverse_block_tridiagonal_partitioned(diag, upper, group=None):
     dl = d if pc.left is not None else 0
     Y = pc.Y.contiguous()
     P = engine.gemm(Y, M)                                                   # [n_int, dl + dr] = Y Z_SS
-    pc.interior.sparse_inverse()
+    Zdiag, Zupper = pc.interior.sparse_inverse()
     rows = lambda t: slice(int(bounds[t]), int(bounds[t + 1]))          # noqa: E731
-    Zdiag, Zupper = [], []
     for t in range(ni):
-        block = pc.interior.device_block(t, t)
-        engine.gemm(P[rows(t)], Y[rows(t)], transb=True, beta=1.0, out=block)
-        Zdiag.append(block)
+        engine.gemm(P[rows(t)], Y[rows(t)], transb=True, beta=1.0, out=Zdiag[t])
         if t + 1 < ni:
-            block = pc.interior.device_block(t, t + 1)
-            engine.gemm(P[rows(t)], Y[rows(t + 1)], transb=True, beta=1.0, out=block)
-            Zupper.append(block)
+            engine.gemm(P[rows(t)], Y[rows(t + 1)], transb=True, beta=1.0, out=Zupper[t])
     # blocks next to the separators: Z[t, r] = -(Y Z_SS)[t, r],  Z[l, t] = -(Y Z_SS)[t, l]^T
     to_left = (-P[rows(0), :dl]).t().contiguous() if pc.left is not None else pc.zeros(d, pc.sizes[0])
     from_right = _gather_blocks([to_left], pc.group)

@@ -308,12 +308,13 @@ class BlockTable:
         return self.nb, as_ptr(self.bounds), as_ptr(self.rowptr), as_ptr(self.colidx), as_ptr(self.address)
 
 
-def block_potrf(table, inverses):
-    """In-place block Cholesky; returns 0 or the 1-based index of the first non-positive pivot."""
+def block_potrf(table, inverses, first=0, last=None):
+    """In-place block Cholesky of the block rows first <= r < last (default: all; later rows are left as the Schur complement);
+    returns 0 or the 1-based index of the first non-positive pivot."""
     torch = require_gpu()
     inverses, pi = _table(inverses)
     info = torch.zeros(1, dtype=torch.int32, device=device())
-    _lib.call('shg_block_potrf', *table.args(), pi, _ptr(info), _stream())
+    _lib.call('shg_block_potrf_rows', *table.args(), pi, int(first), int(table.nb if last is None else last), _ptr(info), _stream())
     return int(info.item())
 
 

@@ -395,6 +395,17 @@ class BlockMatrix:
         if pivot:
             raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(pivot))
 
+    def _cholesky_rows(self, first, last):
+        """Eliminate the block rows first <= r < last only (shg_block_potrf_rows): the rows from `last` on are left as the Schur
+        complement.  A sequence of calls that covers all rows in ascending order equals cholesky()."""
+        self.__square_bounds()
+        if first == 0:
+            self.__allocate_fill()
+            self.__inverse_factor.clear()
+        pivot = engine.block_potrf(self.__block_table(), self.__inverse_table(), first, last)
+        if pivot:
+            raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(pivot))
+
     def __vector(self, b):
         v = _dev(b)
         return v.reshape(1, -1) if v.dim() == 1 else v

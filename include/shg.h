@@ -205,12 +205,16 @@ int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream)
  * diagonal, blk[e] = device address of block (i, colidx[e]) (row-major [rows_i][cols_j]);
  * inv[i] = scratch [rows_i][rows_i] holding U_ii^-1 (written by shg_block_potrf, read by the others).
  *   shg_block_potrf           N = W^T W in place, fill-in allocated by the caller       (grates/lstsq.py:698-717)
+ *   shg_block_potrf_rows      the same for the block rows first <= r < last only: earlier rows count as factored, later rows are
+ *                             left as the Schur complement (two half chains of a tridiagonal system on two streams)
  *   shg_block_solve           W x = b / W^T x = b for B [n][k] in place                 (grates/lstsq.py:778-821, 950-968)
  *   shg_block_sparse_inverse  (W^T W)^-1 on the pattern of W (Takahashi), in place      (grates/lstsq.py:823-846, 1026-1042)
  *   shg_block_inverse         full inverse, upper blocks, in place                      (grates/lstsq.py:848-882)
  *   shg_block_multiply        V = W B (mode 0), the reference's W^T B (1), N B for a symmetric N (2)   (grates/lstsq.py:719-776)
  * ------------------------------------------------------------------------------------------------ */
 int shg_block_potrf(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int* info, void* stream);
+int shg_block_potrf_rows(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int first, int last,
+                         int* info, void* stream);
 int shg_block_solve(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int transpose, double* B,
                     int k, int ldb, void* stream);
 int shg_block_sparse_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, void* stream);

@@ -54,7 +54,7 @@ def _worker(rank, world, port, epochs, dim, columns, result_dir):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,epochs,dim', [(2, 7, 40), (3, 8, 130), (3, 6, 257)])
+@pytest.mark.parametrize('world,epochs,dim', [(2, 7, 40), (3, 8, 130), (3, 6, 257), (2, 21, 48)])
 def test_partitioned_smoother_solve(world, epochs, dim, tmp_path):
     columns = 3
     mp.spawn(_worker, args=(world, _free_port(), epochs, dim, columns, str(tmp_path)), nprocs=world, join=True)
@@ -86,6 +86,139 @@ def test_partitioned_smoother_solve(world, epochs, dim, tmp_path):
             assert np.abs(zu[t] - Zref[t * dim:(t + 1) * dim, (t + 1) * dim:(t + 2) * dim]).max() < 1e-10 * scale
     Zd1, Zu1 = gd.sparse_inverse_block_tridiagonal_partitioned([dev(b) for b in diag], [dev(b) for b in upper])
     assert relerr(np.stack([b.cpu().numpy() for b in Zd1]), zd) < 1e-10 and relerr(np.stack([b.cpu().numpy() for b in Zu1]), zu) < 1e-10
+
+
+@pytest.mark.parametrize('sizes', [[5, 9, 130, 7, 64, 3, 17, 40], [33] * 11, [140, 20, 1, 75, 16, 16, 90, 12, 129]])
+def test_two_ended_chain_matches_natural_order(sizes):
+    """_TwistedChain (both halves of the chain eliminated at once on two streams) against the natural-order chain and the
+    dense inverse, ragged block sizes, even and odd epoch counts."""
+    from grates_amd import distributed as gd
+    rng = np.random.default_rng(len(sizes))
+    n = len(sizes)
+    bounds = np.concatenate(([0], np.cumsum(sizes)))
+    diag = [rng.standard_normal((d, d + 4)) for d in sizes]
+    diag = [G @ G.T / G.shape[0] + 3.0 * np.eye(G.shape[0]) for G in diag]
+    upper = [rng.standard_normal((sizes[t], sizes[t + 1])) * (0.4 / np.sqrt(max(sizes[t], sizes[t + 1]))) for t in range(n - 1)]
+    N = np.zeros((bounds[-1], bounds[-1]))
+    for t in range(n):
+        N[bounds[t]:bounds[t + 1], bounds[t]:bounds[t + 1]] = diag[t]
+        if t + 1 < n:
+            N[bounds[t]:bounds[t + 1], bounds[t + 1]:bounds[t + 2]] = upper[t]
+            N[bounds[t + 1]:bounds[t + 2], bounds[t]:bounds[t + 1]] = upper[t].T
+    rhs = rng.standard_normal((bounds[-1], 4))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dd, du, db = [dev(b) for b in diag], [dev(b) for b in upper], dev(rhs)
+    keep = [b.clone() for b in dd + du]
+    results = []
+    for cls in (gd._TwistedChain, gd._Chain):
+        chain = cls(dd, du)
+        chain.factor()
+        x = chain.solve(db).cpu().numpy()
+        zd, zu = chain.sparse_inverse()
+        results.append((x, [b.cpu().numpy() for b in zd], [b.cpu().numpy() for b in zu]))
+    assert all(torch.equal(a, b) for a, b in zip(keep, dd + du))               # the caller's blocks are not touched
+    Z = np.linalg.inv(N)
+    scale = np.abs(Z).max()
+    for x, zd, zu in results:
+        assert relerr(x, np.linalg.solve(N, rhs)) < 1e-11
+        assert len(zd) == n and len(zu) == n - 1
+        for t in range(n):
+            assert np.abs(zd[t] - Z[bounds[t]:bounds[t + 1], bounds[t]:bounds[t + 1]]).max() < 1e-11 * scale
+            if t + 1 < n:
+                assert np.abs(zu[t] - Z[bounds[t]:bounds[t + 1], bounds[t + 1]:bounds[t + 2]]).max() < 1e-11 * scale
+    assert relerr(results[0][0], results[1][0]) < 1e-12
+
+
+def test_two_ended_chain_reports_indefinite_blocks():
+    from grates_amd import distributed as gd
+    d = [torch.eye(4, dtype=torch.float64, device='cuda') * (1.0 if t != 6 else -1.0) for t in range(9)]
+    u = [torch.zeros((4, 4), dtype=torch.float64, device='cuda') for _ in range(8)]
+    with pytest.raises(np.linalg.LinAlgError):
+        gd._TwistedChain(d, u).factor()
+
+
+def test_full_size_config5_product_path():
+    """BASELINE config 5 at its stated size through the product entry point: 3650 daily epochs of a d/o-40 state (d = 1681),
+    solution and covariance blocks from ONE factorisation (smooth_block_tridiagonal_partitioned, world size 1: the chain is
+    eliminated from both ends at once on two streams).  The factorisation works in the caller's blocks (consume=True; 3 x 82.5 GB
+    with the inverses of the diagonal factor blocks; a card with less free memory gets a shorter chain, never below 64 epochs).
+    Checked through properties that need no reference run, with the blocks regenerated from their seeds: the residual of the
+    solution, symmetry of the covariance blocks and (N N^-1)_tt = I at sample epochs including the ones around the meeting point."""
+    import json
+    import time
+    from grates_amd import distributed as gd
+    from test_gpu_lstsq import _config5_blocks
+    d, T = 1681, 3650
+    free, _ = torch.cuda.mem_get_info()
+    T = min(T, int((free - 30e9) // (3 * d * d * 8)))
+    assert T >= 64, 'not enough free device memory for a 64-epoch chain'
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(49_999)
+    rhs = torch.randn((T * d, 1), dtype=torch.float64, device='cuda', generator=gen)
+    # two runs: the first one maps 82.5 GB of fresh device memory for the inverses of the diagonal factor blocks (21 us per MB
+    # on this system), the second finds them in the allocator's cache like every later pass of an iterated adjustment does
+    seconds = []
+    x = zd = zu = None
+    for run in range(2):
+        x = zd = zu = None                                # the blocks of the first run go back to the allocator before the second set is built
+        diag, upper = [], []
+        for t in range(T):
+            D, R = _config5_blocks(t, d, gen, torch)
+            diag.append(D)
+            if t + 1 < T:
+                upper.append(R)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x, zd, zu = gd.smooth_block_tridiagonal_partitioned(diag, upper, rhs, consume=True)
+        torch.cuda.synchronize()
+        seconds.append(time.perf_counter() - t0)
+        del diag, upper
+    elapsed = seconds[1]
+    assert len(zd) == T and len(zu) == T - 1
+
+    num = torch.zeros((), dtype=torch.float64, device='cuda')
+    prev = None
+    for t in range(T):
+        D, R = _config5_blocks(t, d, gen, torch)
+        Nx = D @ x[t * d:(t + 1) * d]
+        if t + 1 < T:
+            Nx += R @ x[(t + 1) * d:(t + 2) * d]
+        if prev is not None:
+            Nx += prev.t() @ x[(t - 1) * d:t * d]
+        num += ((Nx - rhs[t * d:(t + 1) * d]) ** 2).sum()
+        prev = R
+    residual = float(torch.sqrt(num) / rhs.norm())
+    assert residual < 1e-13, residual
+
+    eye = torch.eye(d, dtype=torch.float64, device='cuda')
+    worst_sym = worst_id = 0.0
+    m = T // 2
+    for t in sorted({0, 1, T // 3, m - 1, m, m + 1, T - 2, T - 1}):
+        Z = zd[t]
+        worst_sym = max(worst_sym, float((Z - Z.t()).abs().max() / Z.abs().max()))
+        assert float(Z.diagonal().min()) > 0.0
+        D, R = _config5_blocks(t, d, gen, torch)
+        acc = D @ Z
+        if t + 1 < T:
+            acc += R @ zu[t].t()
+        if t > 0:
+            acc += _config5_blocks(t - 1, d, gen, torch)[1].t() @ zu[t - 1]
+        worst_id = max(worst_id, float((acc - eye).abs().max()))
+    assert worst_sym < 1e-13 and worst_id < 1e-12, (worst_sym, worst_id)
+    record = {'path': 'config5 full size: smooth_block_tridiagonal_partitioned, one rank, two-ended elimination', 'epochs': T, 'dim': d,
+              'right_hand_sides': 1, 'first_call_s': round(seconds[0], 3), 'factor_solve_sparse_inverse_s': round(elapsed, 3),
+              'epochs_per_s': round(T / elapsed, 1),
+              'residual': residual, 'covariance_asymmetry_max': worst_sym, 'identity_defect_max': worst_id}
+    print(json.dumps(record))
+    del x, zd, zu, Z, acc, D, R, Nx, prev, eye
+    torch.cuda.empty_cache()
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'config5_two_ended.json'), 'w') as f:
+            f.write(json.dumps(record) + '\n')
+    except OSError:
+        pass
 
 
 def test_partitioned_smoother_single_process_single_epoch():
