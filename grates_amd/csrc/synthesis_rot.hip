@@ -42,6 +42,7 @@ namespace shg {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 
 #ifndef SHG_ROT_WAVES
 #define SHG_ROT_WAVES 8          // waves per workgroup.  12 (three per SIMD; the kernel needs 143 registers, no spill at 168; ring
@@ -117,6 +118,9 @@ __device__ __forceinline__ void glds16(const double* gbase, unsigned lane_off, u
         : "memory");
 }
 
+#ifndef SHG_ROT_STORE8
+#define SHG_ROT_STORE8 0     // 1: 8-byte stores straight from the accumulator layout (no lane exchange)
+#endif
 #ifndef SHG_ROT_X
 #define SHG_ROT_X 0          // experiment switches (timing only): 1 no issue-side stream bookkeeping, 2 no consumer-side bookkeeping
 #endif
@@ -354,6 +358,33 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
         const int b = bt * 4 + rt;
         const bool epoch_ok = b < P.B && !(P.dbg & 1);
         double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
+#if SHG_ROT_STORE8
+        {
+            // C layout as it is: lane (fr, fk) holds rows fk + 4 r of column fr, so one 8-byte store instruction writes four rows of
+            // 16 adjacent columns = four whole 128-byte lines, and the column exchange between neighbouring lanes is not needed.
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Gb, 0, grid_bytes, 0x00020000);
+            const bool col_ok = epoch_ok && ct * 16 + fr < P.nd;
+            unsigned row[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                row[r] = col_ok && slot_valid(fk + 4 * r) ? (unsigned)grid_row(fk + 4 * r) * (unsigned)P.nlon * 8u : 0x80000000u;
+            const unsigned asc = (unsigned)fr * 8u, desc = (unsigned)(15 - fr) * 8u;
+#pragma unroll
+            for (int t = 0; t < kImages; ++t) {
+                const int k = t < R ? t : t - R;
+                const bool ascending = t < R;
+                int w = n2 + k * nR - (ascending ? 0 : P.nd);
+                w = w >= P.nlon ? w - P.nlon : w;
+                const int soff = (ascending ? w + 16 * ct : w + P.nd - 16 * ct - 16) * 8;
+                const unsigned lane_col = (ascending ? asc : desc) + (unsigned)soff;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double value = acc[t][r];      // (a bit_cast of the vector element itself reads element 0 for every r)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, value), rsrc, row[r] + lane_col, 0, SHG_STORE_AUX);
+                }
+            }
+        }
+#else
         {
             // lanes (2 q, 2 q + 1) hold adjacent columns: after the exchange every lane owns two rows x two adjacent columns and
             // stores 16 bytes.  Byte offset = lane part (row, column inside the tile) + wave-uniform part (image, column tile);
@@ -387,6 +418,7 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, vb), rsrc, row_b + lane_col, 0, SHG_STORE_AUX);
             }
         }
+#endif
         ROT_STAMP(4 + 2 * min(q, 3));
     }
     S.tx = tx;
