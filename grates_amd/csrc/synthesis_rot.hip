@@ -42,7 +42,6 @@ namespace shg {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 
 #ifndef SHG_ROT_WAVES
 #define SHG_ROT_WAVES 8          // waves per workgroup.  12 (three per SIMD; the kernel needs 143 registers, no spill at 168; ring
@@ -118,12 +117,6 @@ __device__ __forceinline__ void glds16(const double* gbase, unsigned lane_off, u
         : "memory");
 }
 
-#ifndef SHG_ROT_P1_BLOCKS
-#define SHG_ROT_P1_BLOCKS 1  // Legendre stage of north-south symmetric grids on the four-block MFMA (rot_phase1_blocks); 0: 16 x 16 x 4
-#endif
-#ifndef SHG_ROT_STORE8
-#define SHG_ROT_STORE8 0     // 1: 8-byte stores straight from the accumulator layout (no lane exchange)
-#endif
 #ifndef SHG_ROT_X
 #define SHG_ROT_X 0          // experiment switches (timing only): 1 no issue-side stream bookkeeping, 2 no consumer-side bookkeeping
 #endif
@@ -361,33 +354,6 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
         const int b = bt * 4 + rt;
         const bool epoch_ok = b < P.B && !(P.dbg & 1);
         double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
-#if SHG_ROT_STORE8
-        {
-            // C layout as it is: lane (fr, fk) holds rows fk + 4 r of column fr, so one 8-byte store instruction writes four rows of
-            // 16 adjacent columns = four whole 128-byte lines, and the column exchange between neighbouring lanes is not needed.
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Gb, 0, grid_bytes, 0x00020000);
-            const bool col_ok = epoch_ok && ct * 16 + fr < P.nd;
-            unsigned row[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                row[r] = col_ok && slot_valid(fk + 4 * r) ? (unsigned)grid_row(fk + 4 * r) * (unsigned)P.nlon * 8u : 0x80000000u;
-            const unsigned asc = (unsigned)fr * 8u, desc = (unsigned)(15 - fr) * 8u;
-#pragma unroll
-            for (int t = 0; t < kImages; ++t) {
-                const int k = t < R ? t : t - R;
-                const bool ascending = t < R;
-                int w = n2 + k * nR - (ascending ? 0 : P.nd);
-                w = w >= P.nlon ? w - P.nlon : w;
-                const int soff = (ascending ? w + 16 * ct : w + P.nd - 16 * ct - 16) * 8;
-                const unsigned lane_col = (ascending ? asc : desc) + (unsigned)soff;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double value = acc[t][r];      // (a bit_cast of the vector element itself reads element 0 for every r)
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, value), rsrc, row[r] + lane_col, 0, SHG_STORE_AUX);
-                }
-            }
-        }
-#else
         {
             // lanes (2 q, 2 q + 1) hold adjacent columns: after the exchange every lane owns two rows x two adjacent columns and
             // stores 16 bytes.  Byte offset = lane part (row, column inside the tile) + wave-uniform part (image, column tile);
@@ -421,7 +387,6 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, vb), rsrc, row_b + lane_col, 0, SHG_STORE_AUX);
             }
         }
-#endif
         ROT_STAMP(4 + 2 * min(q, 3));
     }
     S.tx = tx;
@@ -553,124 +518,6 @@ do {                                                                            
 #undef ROT_P1_CONSUME
 }
 
-// Phase 1 for grids with the north-south symmetry on the four-block fp64 MFMA (v_mfma_f64_4x4x4_4b_f64: the four diagonal
-// 4 x 4 blocks of a 16 x 16 x 4 product in 17 instead of 64 cycles, same operand lanes: A lane 16 k + row, B lane 16 k + column,
-// result lane 16 i + 4 block + j = row 4 block + i, column 4 block + j; tools/scratch probe, rate 15 of the 16 multiply-adds per
-// cycle of the big instruction).  In the 16 x 16 formulation above the rows are (epoch, C | S, even | odd part) and the columns
-// (even | odd part, parallel): the even rows times odd columns and vice versa -- half of every MFMA -- are computed and thrown
-// away.  Here a k-step is two four-block instructions, one for the even and one for the odd part, each
-//     block (rg, cg):  rows (C | S = rg, epoch i)  x  columns (parallel 4 cg + j),
-// so nothing is wasted, and the even and odd sums of one (epoch, C | S, parallel) meet in the same lane: north = E + O and
-// south = E - O are two additions (no exchange between lanes, no selects) and go to the panel as two 8-byte LDS writes.
-// The operands are gathered from the same fragment tables with per-lane offsets that are fixed for the kernel.
-template <typename PanelPtr>
-__device__ __forceinline__ void rot_phase1_blocks(const RotParams& P, PanelPtr panel, const int4* recs_wave, int bt, int it, int lane) {
-    typedef int int4_v __attribute__((ext_vector_type(4)));
-    typedef const int4_v __attribute__((address_space(4))) crec_t;
-    auto ld16 = [](__amdgpu_buffer_rsrc_t table, unsigned voff, unsigned soff) {
-        return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(table, voff, soff, 0));
-    };
-    const int k = lane >> 4, blk = (lane >> 2) & 3, in = lane & 3;
-    const int rg = blk >> 1, cg = blk & 1;
-    // table rows of the 16 x 16 layout: 4 (C even, S even, C odd, S odd) + epoch; table columns: parallel (even part), 8 + parallel (odd part)
-    const unsigned a_even = (unsigned)(16 * k + 4 * rg + in) * 16u, a_odd = a_even + 128u;
-    const unsigned b_even = (unsigned)(16 * k + 4 * cg + in) * 16u, b_odd = b_even + 128u;
-    // this lane's result: row i = lane >> 4 of its block = epoch, component rg
-    const int di = lane >> 4;
-    const int pnorth = (di * 16 + 4 * cg + in) * 2 + rg;                               // double index inside a panel slot: (row, C | S)
-    double* const pd = reinterpret_cast<double*>(panel);
-    const int bad = P.badmap[it];
-    __amdgpu_buffer_rsrc_t pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)it * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
-    const __amdgpu_buffer_rsrc_t cfu = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.cpk4 + (size_t)bt * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
-    int mode = bad >= 0 ? 1 : 0;
-    double e0 = 0.0, e1 = 0.0, o0 = 0.0, o1 = 0.0;
-    bool fresh = true;
-
-#define ROT_B_ISSUE(rec, F)                                                                   \
-do {                                                                                      \
-    F[0] = ld16(cfu, a_even, (unsigned)(rec).x * 1024u);                                  \
-    F[1] = ld16(pku, b_even, (unsigned)(rec).x * 1024u);                                  \
-    F[2] = ld16(cfu, a_odd, (unsigned)(rec).x * 1024u);                                   \
-    F[3] = ld16(pku, b_odd, (unsigned)(rec).x * 1024u);                                   \
-    F[4] = ld16(cfu, a_even, (unsigned)(rec).y * 1024u);                                  \
-    F[5] = ld16(pku, b_even, (unsigned)(rec).y * 1024u);                                  \
-    F[6] = ld16(cfu, a_odd, (unsigned)(rec).y * 1024u);                                   \
-    F[7] = ld16(pku, b_odd, (unsigned)(rec).y * 1024u);                                   \
-} while (0)
-
-#define ROT_B_CONSUME(rec, F)                                                                                    \
-do {                                                                                                         \
-    if ((rec).w & 1) {                                                                                       \
-        if (fresh) {                                                                                         \
-            e0 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[0].x, F[1].x, 0.0, 0, 0, 0);                           \
-            o0 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[2].x, F[3].x, 0.0, 0, 0, 0);                           \
-            e1 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[0].y, F[1].y, 0.0, 0, 0, 0);                           \
-            o1 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[2].y, F[3].y, 0.0, 0, 0, 0);                           \
-        } else {                                                                                             \
-            e0 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[0].x, F[1].x, e0, 0, 0, 0);                            \
-            o0 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[2].x, F[3].x, o0, 0, 0, 0);                            \
-            e1 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[0].y, F[1].y, e1, 0, 0, 0);                            \
-            o1 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[2].y, F[3].y, o1, 0, 0, 0);                            \
-        }                                                                                                    \
-        fresh = false;                                                                                       \
-    }                                                                                                        \
-    if ((rec).w & 2) {                                                                                       \
-        e0 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[4].x, F[5].x, e0, 0, 0, 0);                                \
-        o0 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[6].x, F[7].x, o0, 0, 0, 0);                                \
-        e1 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[4].y, F[5].y, e1, 0, 0, 0);                                \
-        o1 = __builtin_amdgcn_mfma_f64_4x4x4f64(F[6].y, F[7].y, o1, 0, 0, 0);                                \
-    }                                                                                                        \
-    if ((rec).w & 4) {                                  /* last item of an order */                           \
-        const double even_ = e0 + e1, odd_ = o0 + o1;                                                        \
-        double* slot_ = pd + (rec).z * 128 + pnorth;                                                         \
-        if (mode == 0) {                                                                                     \
-            slot_[0] = even_ + odd_;                                                                         \
-            slot_[16] = even_ - odd_;                   /* mirrored parallel: 8 rows on */                    \
-        } else if (mode == 1) {                                                                              \
-            slot_[0] = even_ + odd_;                                                                         \
-        } else {                                                                                             \
-            slot_[16] = even_ + odd_;                   /* polar block: the mirrored parallels from their own table */ \
-        }                                                                                                    \
-        fresh = true;                                                                                        \
-    }                                                                                                        \
-} while (0)
-
-    double2 fx[8], fy[8], fz[8], fw[8];
-    crec_t* recs = reinterpret_cast<crec_t*>(reinterpret_cast<unsigned long long>(recs_wave));
-    for (int pass = 0; pass < (bad >= 0 ? 2 : 1); ++pass) {
-        if (pass == 1) {
-            mode = 2;
-            pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
-        }
-        int4_v c0 = recs[0], c1 = recs[1], c2 = recs[2];
-        int4_v n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
-        ROT_B_ISSUE(c0, fx);
-        ROT_B_ISSUE(c1, fy);
-        ROT_B_ISSUE(c2, fz);
-        for (int trip = 0; trip < P.ntrip; ++trip) {
-            const int4_v a3 = n0, a4 = n1, a5 = n2, a6 = n3;
-            crec_t* nr = recs + 4 * trip + 7;
-            n0 = nr[0];
-            n1 = nr[1];
-            n2 = nr[2];
-            n3 = nr[3];
-            ROT_B_ISSUE(a3, fw);
-            ROT_B_CONSUME(c0, fx);
-            ROT_B_ISSUE(a4, fx);
-            ROT_B_CONSUME(c1, fy);
-            ROT_B_ISSUE(a5, fy);
-            ROT_B_CONSUME(c2, fz);
-            ROT_B_ISSUE(a6, fz);
-            ROT_B_CONSUME(a3, fw);
-            c0 = a4;
-            c1 = a5;
-            c2 = a6;
-        }
-    }
-#undef ROT_B_ISSUE
-#undef ROT_B_CONSUME
-}
-
 template <bool NS, int R>
 __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P) {
     using T = RotTraits<R>;
@@ -705,12 +552,7 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
     for (int d = 0; d < kRingDepth; ++d) rot_issue_piece(S, P, (unsigned)lane * 16u);
 
     // ---- phase 1: Legendre stage.  Orders are distributed over the waves of the workgroup.
-    if (!(P.dbg & 2)) {
-        if (NS && SHG_ROT_P1_BLOCKS)
-            rot_phase1_blocks(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
-        else
-            rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
-    }
+    if (!(P.dbg & 2)) rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
     ROT_STAMP(1);
     __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
     ROT_STAMP(2);
