@@ -59,6 +59,7 @@ PROTOTYPES = {
     'shg_analysis': [c_plan_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_synthesis_matrix': [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_analysis_matrix': [c_plan_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_scratch_release': [],
     'shg_block_potrf': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [c_double_p, ctypes.c_void_p],
     'shg_block_potrf_rows': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_block_solve': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],

@@ -388,7 +388,7 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
         if (slices > 1) {
             const int chunk = round_up(ceil_div(K, slices), XK);
             slices = ceil_div(K, chunk);
-            if (slices > 1 && (partial = (double*)stream_scratch(stream, 0, (size_t)slices * M * N * sizeof(double))) != nullptr) {
+            if (slices > 1 && (partial = (double*)stream_scratch(stream, kScratchSplitK, (size_t)slices * M * N * sizeof(double))) != nullptr) {
                 P.K = chunk;
                 P.Ktotal = K;
                 P.strideA = ta ? (long long)chunk * lda : chunk;

@@ -14,7 +14,10 @@
 namespace shg {
 
 int fail(int code, const char* fmt, ...);
-void* stream_scratch(hipStream_t stream, int slot, size_t bytes);              // grow-only scratch of a stream (plan.hip), never freed by the user
+// grow-only scratch of a stream (plan.hip), kept until shg_scratch_release(); one slot per buffer that is live at the same time
+enum ScratchSlot { kScratchSplitK = 0, kScratchAnaFold = 1, kScratchAnaTransform = 2, kScratchAnaSolution = 3, kScratchAnaFlag = 4 };
+void* stream_scratch(hipStream_t stream, int slot, size_t bytes);
+void stream_scratch_release();
 hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream);    // hipMallocAsync from a pool that keeps freed memory cached
 
 #define SHG_HIP(call)                                                                              \

@@ -45,16 +45,20 @@ hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream) {
 // Scratch that lives as long as its stream is in use: one grow-only buffer per (stream, slot), handed to successive
 // operations of that stream (which the stream orders, so they may share it).  For workspaces inside chains of thousands of
 // small operations: on ROCm 7.2 hipFreeAsync keeps the calling thread until the stream has caught up (0.2 - 1.4 ms per call
-// in the factorisation of a d = 1681 block), which makes the host the pace-maker of such a chain.
+// in the factorisation of a d = 1681 block; 0.2 ms for a 0.5 GB buffer even on an idle stream), which makes the host the
+// pace-maker of such a chain.  shg_scratch_release() gives the buffers back.
+namespace {
+struct ScratchEntry {
+    void* ptr = nullptr;
+    size_t size = 0;
+};
+std::mutex g_scratch_mutex;
+std::map<std::pair<hipStream_t, int>, ScratchEntry> g_scratch;
+}  // namespace
+
 void* stream_scratch(hipStream_t stream, int slot, size_t bytes) {
-    struct Entry {
-        void* ptr = nullptr;
-        size_t size = 0;
-    };
-    static std::mutex mtx;
-    static std::map<std::pair<hipStream_t, int>, Entry> table;
-    std::lock_guard<std::mutex> lock(mtx);
-    Entry& e = table[std::make_pair(stream, slot)];
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    ScratchEntry& e = g_scratch[std::make_pair(stream, slot)];
     if (e.size < bytes) {
         if (e.ptr) (void)hipFree(e.ptr);             // waits for the device: whatever still used the old buffer is done
         e.ptr = nullptr;
@@ -68,6 +72,13 @@ void* stream_scratch(hipStream_t stream, int slot, size_t bytes) {
         e.size = want;
     }
     return e.ptr;
+}
+
+void stream_scratch_release() {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    for (auto& kv : g_scratch)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    g_scratch.clear();
 }
 
 // a_nm / b_nm of  P_nm = (a_nm t) P_(n-1)m - b_nm P_(n-2)m   in packed order-major layout.
@@ -213,6 +224,12 @@ extern "C" int shg_plan_profile_read(shg_plan* p, double ms[SHG_PROFILE_KINDS], 
 }
 
 extern "C" const char* shg_last_error(void) { return g_last_error.c_str(); }
+extern "C" int shg_scratch_release(void) {
+    SHG_HIP(hipDeviceSynchronize());
+    shg::stream_scratch_release();
+    return SHG_OK;
+}
+
 extern "C" const char* shg_version(void) { return "libshg 0.1 (gfx950)"; }
 
 extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* colat_h, const double* kn_h,

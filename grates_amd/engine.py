@@ -191,6 +191,13 @@ class Plan:
         return out
 
 
+def release_scratch():
+    """Give the per-stream scratch buffers the library keeps between calls (shg_analysis, split-K block products) back to
+    the driver; waits for the device."""
+    require_gpu()
+    _lib.call('shg_scratch_release')
+
+
 _plan_cache = {}
 _PLAN_CACHE_LIMIT = 8
 

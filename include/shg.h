@@ -245,6 +245,10 @@ int shg_synthesis_matrix(int N, int nmin, const double* colat, const double* lon
 int shg_analysis_matrix(shg_plan* plan, const double* area, int nmin, double* F, void* stream);
 int shg_congruence(int n, int k, const double* W, int ldw, const double* S, int lds, double* C, int ldc, double* work, void* stream);
 
+/* Some operations keep their scratch buffers per stream between calls (the split-K workspace of the block products, the
+ * buffers of shg_analysis: freeing stream-ordered memory costs more than these calls take).  This gives them back; it waits
+ * for the device first. */
+int shg_scratch_release(void);
 const char* shg_last_error(void);
 const char* shg_version(void);
 

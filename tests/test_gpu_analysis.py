@@ -101,6 +101,8 @@ def test_operator_follows_weights_and_meridians():
             assert relerr(first[e], orc.analysis_regular(vals[e].ravel(), area, nmin, N, meridians, grid.parallels, ker)) < TOL
             assert relerr(second[e], orc.analysis_regular(vals[e].ravel(), other, nmin, N, meridians, grid.parallels, ker)) < TOL
         assert np.array_equal(first, again)
+        ga.engine.release_scratch()                                              # the scratch kept between calls comes back on demand
+        assert np.array_equal(first, ga.engine.to_host(plan.analysis(vals, area, nmin)))
 
 
 def test_irregular_grid_analysis():
