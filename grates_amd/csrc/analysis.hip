@@ -85,6 +85,137 @@ __global__ __launch_bounds__(256) void weight_fold_kernel(int nb, int nlat, int 
     }
 }
 
+// Fold and longitude transform in one kernel (degrees up to 126): gt[slot][(b, i)] = sum_c T_slot(mu_c) F_group(slot)[c][(b, i)]
+// without the folded planes ever reaching memory -- the values are read once (with their area weights), folded in registers
+// and multiplied from LDS.  A workgroup owns 64 rows (b, i) and ALL slots: wave w the rows 16 w .. 16 w + 15 with 4 x MT
+// accumulator tiles (group g = cos even | cos odd | sin even | sin odd, 16 orders per tile).  The quarter domain is walked in
+// chunks of 8 columns through two LDS stages; per chunk every thread loads two columns of one row in their four images (and
+// the weights), folds them, and one row of the trig chunk.  Operand fragments: A = T[order][c] (LDS [c][order]), B = F[c][row]
+// (LDS [group][c][row]), D row = order fk + 4 reg, column = row fr.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+#ifndef SHG_ANA_X
+#define SHG_ANA_X 0    // experiment switches (timing only): 1 no MFMAs, 2 no global loads after the first chunk
+#endif
+constexpr int kAtKC = 8, kAtRows = 64, kAtFP = kAtRows + 2;
+
+__device__ __forceinline__ int analysis_slot(int g, int k) { return g == 0 ? (k == 0 ? 0 : 4 * k - 1) : (g == 1 ? 4 * k + 1 : (g == 2 ? 4 * k + 4 : 4 * k + 2)); }
+
+template <int MT>
+__global__ __launch_bounds__(256) void analysis_transform_kernel(int nb, int nlat, int nlon, int N, const double* __restrict__ v,
+                                                                 const double* __restrict__ area, const double* __restrict__ cs,
+                                                                 double* __restrict__ gt) {
+    constexpr int TR = 4 * MT * 16;                     // rows of the trig chunk: group g, tile t, order 16 t + m
+    constexpr int TP = TR + 2;
+    __shared__ double TL[2][kAtKC][TP];
+    __shared__ double FL[2][4][kAtKC][kAtFP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int nq = nlon / 4, h = nlon / 2;
+    const long long rows = (long long)nb * nlat;
+    const long long r0 = (long long)blockIdx.x * kAtRows;
+    const int count[4] = {N / 2 + 1, (N + 1) / 2, N / 2, (N + 1) / 2};
+    // loader role: row lrow, columns c0 + 2 cp, c0 + 2 cp + 1
+    const int lrow = tid >> 2, cp = tid & 3;
+    const long long lr = r0 + lrow;
+    const bool row_ok = lr < rows;
+    const double* vrow = v + (row_ok ? lr : rows - 1) * nlon;
+    const double* arow = area + (size_t)((row_ok ? lr : rows - 1) % nlat) * nlon;
+    // trig role: table row tid (group tg, order index tk)
+    const int tg = tid / (MT * 16), tk = tid % (MT * 16);
+    const bool trig_ok = tid < TR && tk < count[tg < 4 ? tg : 0];
+    const double* trow = cs + (size_t)(trig_ok ? analysis_slot(tg, tk) : 0) * nlon + h;
+
+    double2_t x1, x2, x3, x4, w1, w2, w3, w4;           // the four images of two columns (x2, x4: descending) and their weights
+    double2_t tq[4];
+    // Columns come in aligned pairs (c even; nlon is a multiple of 4, so every image of a pair is a 16-byte load inside the
+    // row); a pair that starts beyond the quarter domain is not loaded, a column beyond it is zeroed when it is staged.
+    auto fetch = [&](int c0) {
+        const int c = c0 + 2 * cp;
+        const int cc = c < nq ? c : 0;
+        x1 = *reinterpret_cast<const double2_t*>(vrow + h + cc);
+        x2 = *reinterpret_cast<const double2_t*>(vrow + h - 2 - cc);
+        x3 = *reinterpret_cast<const double2_t*>(vrow + cc);
+        x4 = *reinterpret_cast<const double2_t*>(vrow + nlon - 2 - cc);
+        w1 = *reinterpret_cast<const double2_t*>(arow + h + cc);
+        w2 = *reinterpret_cast<const double2_t*>(arow + h - 2 - cc);
+        w3 = *reinterpret_cast<const double2_t*>(arow + cc);
+        w4 = *reinterpret_cast<const double2_t*>(arow + nlon - 2 - cc);
+        if (tid < TR) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ct = c0 + 2 * q;
+                tq[q] = *reinterpret_cast<const double2_t*>(trow + (ct < nq ? ct : 0));
+            }
+        }
+    };
+    auto stage = [&](int c0, int buf) {
+        const int c = c0 + 2 * cp;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = row_ok && c + j < nq;
+            // ascending images hold column c + j in component j, descending ones in component 1 - j
+            const double a1 = j ? x1.y * w1.y : x1.x * w1.x, a2 = j ? x2.x * w2.x : x2.y * w2.y;
+            const double a3 = j ? x3.y * w3.y : x3.x * w3.x, a4 = j ? x4.x * w4.x : x4.y * w4.y;
+            const double p12 = a1 + a2, p34 = a3 + a4, q12 = a1 - a2, q34 = a3 - a4;
+            FL[buf][0][2 * cp + j][lrow] = ok ? p12 + p34 : 0.0;       // cos, even orders
+            FL[buf][1][2 * cp + j][lrow] = ok ? p12 - p34 : 0.0;       // cos, odd
+            FL[buf][2][2 * cp + j][lrow] = ok ? q12 + q34 : 0.0;       // sin, even
+            FL[buf][3][2 * cp + j][lrow] = ok ? q12 - q34 : 0.0;       // sin, odd
+        }
+        if (tid < TR) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ct = c0 + 2 * q;
+                TL[buf][2 * q][tid] = trig_ok && ct < nq ? tq[q].x : 0.0;
+                TL[buf][2 * q + 1][tid] = trig_ok && ct + 1 < nq ? tq[q].y : 0.0;
+            }
+        }
+    };
+
+    double4_t acc[4][MT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[g][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    int ntile[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ntile[g] = (count[g] + 15) / 16;
+
+    const int nchunk = (nq + kAtKC - 1) / kAtKC;
+    fetch(0);
+    stage(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk && !(SHG_ANA_X & 2)) fetch((ch + 1) * kAtKC);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double b = FL[buf][g][4 * ks + fk][16 * wave + fr];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    if (t < ntile[g] && !(SHG_ANA_X & 1)) acc[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(TL[buf][4 * ks + fk][(g * MT + t) * 16 + fr], b, acc[g][t], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunk) stage((ch + 1) * kAtKC, buf ^ 1);
+        __syncthreads();
+    }
+    const long long r = r0 + 16 * wave + fr;
+    if (r < rows) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int k = 16 * t + fk + 4 * reg;
+                    if (k < count[g]) gt[(size_t)analysis_slot(g, k) * rows + r] = acc[g][t][reg];
+                }
+    }
+}
+
 // w2[s][i] = sum_j area[i][j] cs[s][j]^2 : one workgroup per parallel
 __global__ __launch_bounds__(256) void weight_squares_kernel(int S, int nlat, int nlon, const double* __restrict__ area,
                                                              const double* __restrict__ cs, double* __restrict__ w2) {
@@ -305,6 +436,31 @@ extern "C" int shg_analysis_matrix(shg_plan* p, const double* area, int nmin, do
     return SHG_OK;
 }
 
+// fold kernel + one batched GEMM per parity (degrees above 126: the fused kernel's accumulators do not fit)
+static int folded_transform(shg_plan* p, const double* grid, const double* area, int nb, double* wvt, double* gt, hipStream_t stream) {
+    const int N = p->N, nlat = p->nlat, nlon = p->nlon;
+    const long long rows = (long long)nb * nlat;
+    // slots in gt: 0 = order 0, 2m-1 = cos m, 2m = sin m.  Per parity and cos | sin the slots are 4 apart, so each
+    // group is a GEMM on strided rows of the trig table (columns nlon/2 ... of cs_slot = the quarter domain) whose
+    // output rows land in slot order; the two groups of a parity differ by one slot and form one batched call.
+    const int nq = nlon / 4;
+    const long long plane = (long long)nq * rows;
+    hipLaunchKernelGGL(weight_fold_kernel, dim3(ceil_div(nq, 32), (unsigned)ceil_div64(rows, 32)), dim3(256), 0, stream, nb, nlat,
+               nlon, grid, area, wvt);
+    ProfileScope ps(p, 4, stream);
+    int rc;
+    const double* quarter = p->cs_slot + nlon / 2;
+    rc = gemm_ex(false, false, 1, (int)rows, nq, 1.0, quarter, nlon, 0, wvt + 2 * plane, (int)rows, 0, 0.0, gt, (int)rows, 0, 1, false, stream);
+    const int odd = (N + 1) / 2, even = N / 2;    // orders 1, 3, ... / 2, 4, ...
+    if (!rc && odd)
+        rc = gemm_ex(false, false, odd, (int)rows, nq, 1.0, quarter + (size_t)nlon, 4 * nlon, nlon, wvt, (int)rows, plane, 0.0,
+             gt + rows, 4 * (int)rows, rows, 2, false, stream);
+    if (!rc && even)
+        rc = gemm_ex(false, false, even, (int)rows, nq, 1.0, quarter + (size_t)3 * nlon, 4 * nlon, nlon, wvt + 2 * plane, (int)rows,
+             plane, 0.0, gt + 3 * rows, 4 * (int)rows, rows, 2, false, stream);
+    return rc;
+}
+
 // one pass over all epochs with the operator in p->ana_H (workspaces sized for `chunk` epochs)
 static int analysis_pass(shg_plan* p, const double* grid, const double* area, int nmin, int B, int chunk, bool folded, double* wvt, double* gt,
                          double* X, double* anm, hipStream_t stream) {
@@ -318,20 +474,19 @@ static int analysis_pass(shg_plan* p, const double* grid, const double* area, in
             // slots in gt: 0 = order 0, 2m-1 = cos m, 2m = sin m.  Per parity and cos | sin the slots are 4 apart, so each
             // group is a GEMM on strided rows of the trig table (columns nlon/2 ... of cs_slot = the quarter domain) whose
             // output rows land in slot order; the two groups of a parity differ by one slot and form one batched call.
-            const int nq = nlon / 4;
-            const long long plane = (long long)nq * rows;
-            hipLaunchKernelGGL(weight_fold_kernel, dim3(ceil_div(nq, 32), (unsigned)ceil_div64(rows, 32)), dim3(256), 0, stream, nb, nlat,
-                               nlon, grid + (size_t)b0 * nlat * nlon, area, wvt);
-            ProfileScope ps(p, 4, stream);
-            const double* quarter = p->cs_slot + nlon / 2;
-            rc = gemm_ex(false, false, 1, (int)rows, nq, 1.0, quarter, nlon, 0, wvt + 2 * plane, (int)rows, 0, 0.0, gt, (int)rows, 0, 1, false, stream);
-            const int odd = (N + 1) / 2, even = N / 2;            // orders 1, 3, ... / 2, 4, ...
-            if (!rc && odd)
-                rc = gemm_ex(false, false, odd, (int)rows, nq, 1.0, quarter + (size_t)nlon, 4 * nlon, nlon, wvt, (int)rows, plane, 0.0,
-                             gt + rows, 4 * (int)rows, rows, 2, false, stream);
-            if (!rc && even)
-                rc = gemm_ex(false, false, even, (int)rows, nq, 1.0, quarter + (size_t)3 * nlon, 4 * nlon, nlon, wvt + 2 * plane, (int)rows,
-                             plane, 0.0, gt + 3 * rows, 4 * (int)rows, rows, 2, false, stream);
+            if (N <= 126) {
+                ProfileScope ps(p, 4, stream);
+                const unsigned blocks = (unsigned)ceil_div64(rows, kAtRows);
+                if (N <= 62)
+                    hipLaunchKernelGGL(analysis_transform_kernel<2>, dim3(blocks), dim3(256), 0, stream, nb, nlat, nlon, N, grid + (size_t)b0 * nlat * nlon,
+                                       area, p->cs_slot, gt);
+                else
+                    hipLaunchKernelGGL(analysis_transform_kernel<4>, dim3(blocks), dim3(256), 0, stream, nb, nlat, nlon, N, grid + (size_t)b0 * nlat * nlon,
+                                       area, p->cs_slot, gt);
+                rc = SHG_OK;
+            } else {
+                rc = folded_transform(p, grid + (size_t)b0 * nlat * nlon, area, nb, wvt, gt, stream);
+            }
         } else {
             hipLaunchKernelGGL(weight_transpose_kernel, dim3(ceil_div(nlon, 32), (unsigned)ceil_div64(rows, 32)), dim3(256), 0, stream, nb,
                                nlat, nlon, grid + (size_t)b0 * nlat * nlon, area, wvt);
