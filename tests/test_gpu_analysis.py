@@ -64,7 +64,8 @@ def test_round_trip_d60_one_degree(golden):
     assert relerr(out.anm, anm) < TOL                                         # band-limited field is recovered
 
 
-@pytest.mark.parametrize('N,nmin,dlon,dlat', [(0, 0, 30, 30), (5, 0, 15, 10), (12, 3, 7.5, 6), (40, 2, 2, 2)])
+@pytest.mark.parametrize('N,nmin,dlon,dlat', [(0, 0, 30, 30), (5, 0, 15, 10), (12, 3, 7.5, 6), (40, 2, 2, 2), (63, 0, 2.5, 2.5),
+                                              (127, 4, 1.25, 1.25)])      # 127: beyond the fused transform kernel (fold kernel + GEMMs)
 def test_against_oracle_batched(N, nmin, dlon, dlat):
     grid = ga.grid.GeographicGrid(dlon, dlat)
     rng = np.random.default_rng(N + 7)
