@@ -126,17 +126,28 @@ __global__ __launch_bounds__(256) void analysis_transform_kernel(int nb, int nla
     const bool trig_ok = tid < TR && tk < count[tg < 4 ? tg : 0];
     const double* trow = cs + (size_t)(trig_ok ? analysis_slot(tg, tk) : 0) * nlon + h;
 
-    double2_t x1, x2, x3, x4, w1, w2, w3, w4;           // the four images of two columns (x2, x4: descending) and their weights
+    // The values come from HBM, the weights and the trig rows from L2: the values of a chunk are requested two chunks ahead
+    // (two register sets, used alternately), weights and trig rows one chunk ahead -- and in that order of age, because the
+    // memory counter retires in order: what is waited for must be older than what may stay in flight.
+    struct Images {
+        double2_t x1, x2, x3, x4;                         // the four images of two columns (x2, x4: descending)
+    };
+    Images va, vb;
+    double2_t w1, w2, w3, w4;
     double2_t tq[4];
     // Columns come in aligned pairs (c even; nlon is a multiple of 4, so every image of a pair is a 16-byte load inside the
     // row); a pair that starts beyond the quarter domain is not loaded, a column beyond it is zeroed when it is staged.
-    auto fetch = [&](int c0) {
+    auto fetch_values = [&](Images& x, int c0) {
         const int c = c0 + 2 * cp;
         const int cc = c < nq ? c : 0;
-        x1 = *reinterpret_cast<const double2_t*>(vrow + h + cc);
-        x2 = *reinterpret_cast<const double2_t*>(vrow + h - 2 - cc);
-        x3 = *reinterpret_cast<const double2_t*>(vrow + cc);
-        x4 = *reinterpret_cast<const double2_t*>(vrow + nlon - 2 - cc);
+        x.x1 = *reinterpret_cast<const double2_t*>(vrow + h + cc);
+        x.x2 = *reinterpret_cast<const double2_t*>(vrow + h - 2 - cc);
+        x.x3 = *reinterpret_cast<const double2_t*>(vrow + cc);
+        x.x4 = *reinterpret_cast<const double2_t*>(vrow + nlon - 2 - cc);
+    };
+    auto fetch_weights = [&](int c0) {
+        const int c = c0 + 2 * cp;
+        const int cc = c < nq ? c : 0;
         w1 = *reinterpret_cast<const double2_t*>(arow + h + cc);
         w2 = *reinterpret_cast<const double2_t*>(arow + h - 2 - cc);
         w3 = *reinterpret_cast<const double2_t*>(arow + cc);
@@ -149,14 +160,14 @@ __global__ __launch_bounds__(256) void analysis_transform_kernel(int nb, int nla
             }
         }
     };
-    auto stage = [&](int c0, int buf) {
+    auto stage = [&](const Images& x, int c0, int buf) {
         const int c = c0 + 2 * cp;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool ok = row_ok && c + j < nq;
             // ascending images hold column c + j in component j, descending ones in component 1 - j
-            const double a1 = j ? x1.y * w1.y : x1.x * w1.x, a2 = j ? x2.x * w2.x : x2.y * w2.y;
-            const double a3 = j ? x3.y * w3.y : x3.x * w3.x, a4 = j ? x4.x * w4.x : x4.y * w4.y;
+            const double a1 = j ? x.x1.y * w1.y : x.x1.x * w1.x, a2 = j ? x.x2.x * w2.x : x.x2.y * w2.y;
+            const double a3 = j ? x.x3.y * w3.y : x.x3.x * w3.x, a4 = j ? x.x4.x * w4.x : x.x4.y * w4.y;
             const double p12 = a1 + a2, p34 = a3 + a4, q12 = a1 - a2, q34 = a3 - a4;
             FL[buf][0][2 * cp + j][lrow] = ok ? p12 + p34 : 0.0;       // cos, even orders
             FL[buf][1][2 * cp + j][lrow] = ok ? p12 - p34 : 0.0;       // cos, odd
@@ -183,24 +194,45 @@ __global__ __launch_bounds__(256) void analysis_transform_kernel(int nb, int nla
     for (int g = 0; g < 4; ++g) ntile[g] = (count[g] + 15) / 16;
 
     const int nchunk = (nq + kAtKC - 1) / kAtKC;
-    fetch(0);
-    stage(0, 0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunk && !(SHG_ANA_X & 2)) fetch((ch + 1) * kAtKC);
+    // products of one chunk: 8 (k-step, group) items of one B fragment and up to MT A fragments; the fragments of item q + 1
+    // are read while the MFMAs of item q run (hipcc otherwise puts every read right in front of its MFMA and waits for it)
+    auto products = [&](int buf) {
+        double fa[2][MT], fb[2];
+        auto read_item = [&](int q, int set) {
+            const int ks = q >> 2, g = q & 3;
+            fb[set] = FL[buf][g][4 * ks + fk][16 * wave + fr];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int t = 0; t < MT; ++t) fa[set][t] = TL[buf][4 * ks + fk][(g * MT + t) * 16 + fr];      // (unconditional: exact lgkmcnt counts)
+        };
+        read_item(0, 0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const double b = FL[buf][g][4 * ks + fk][16 * wave + fr];
+        for (int q = 0; q < 8; ++q) {
+            if (q + 1 < 8) read_item(q + 1, (q + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int g = q & 3;
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    if (t < ntile[g] && !(SHG_ANA_X & 1)) acc[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(TL[buf][4 * ks + fk][(g * MT + t) * 16 + fr], b, acc[g][t], 0, 0, 0);
-            }
+            for (int t = 0; t < MT; ++t)
+                if (t < ntile[g] && !(SHG_ANA_X & 1)) acc[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q & 1][t], fb[q & 1], acc[g][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (ch + 1 < nchunk) stage((ch + 1) * kAtKC, buf ^ 1);
+    };
+    // one step: weights of chunk ch + 1 and values of chunk ch + 2 requested, products of chunk ch, chunk ch + 1 staged
+    auto step = [&](int ch, Images& next, Images& after) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk && !(SHG_ANA_X & 2)) fetch_weights((ch + 1) * kAtKC);
+        if (ch + 2 < nchunk && !(SHG_ANA_X & 2)) fetch_values(after, (ch + 2) * kAtKC);
+        products(buf);
+        if (ch + 1 < nchunk) stage(next, (ch + 1) * kAtKC, buf ^ 1);
         __syncthreads();
+    };
+    fetch_values(va, 0);
+    fetch_weights(0);
+    if (nchunk > 1) fetch_values(vb, kAtKC);
+    stage(va, 0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        step(ch, vb, va);                         // chunk ch + 1 sits in vb, chunk ch + 2 goes to va
+        if (ch + 1 < nchunk) step(ch + 1, va, vb);
     }
     const long long r = r0 + 16 * wave + fr;
     if (r < rows) {
