@@ -557,11 +557,12 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     const int R = N + 1;
     const bool folded = p->sym4 && 4LL * chunk * nlat < (1LL << 29);     // ldc = 4 * rows as int
     // per-stream scratch kept between calls (stream_scratch): a hipFreeAsync of the 0.5 GB fold buffer alone costs 0.2 ms
-    double* wvt = (double*)stream_scratch(stream, kScratchAnaFold, (size_t)nlon * chunk * nlat * sizeof(double));
-    double* gt = (double*)stream_scratch(stream, kScratchAnaTransform, (size_t)S * chunk * nlat * sizeof(double));
-    double* X = (double*)stream_scratch(stream, kScratchAnaSolution, (size_t)S * R * chunk * sizeof(double));
-    int* diff = (int*)stream_scratch(stream, kScratchAnaFlag, sizeof(int));
-    if (!wvt || !gt || !X || !diff) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
+    ScratchLease lease(stream);
+    double* wvt = folded && N <= 126 ? nullptr : (double*)lease.get(kScratchAnaFold, (size_t)nlon * chunk * nlat * sizeof(double));
+    double* gt = (double*)lease.get(kScratchAnaTransform, (size_t)S * chunk * nlat * sizeof(double));
+    double* X = (double*)lease.get(kScratchAnaSolution, (size_t)S * R * chunk * sizeof(double));
+    int* diff = (int*)lease.get(kScratchAnaFlag, sizeof(int));
+    if ((!wvt && !(folded && N <= 126)) || !gt || !X || !diff) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
     if (optimistic) rc = launch_weight_compare(p, area, diff, stream);
     if (!rc) rc = analysis_pass(p, grid, area, nmin, B, chunk, folded, wvt, gt, X, anm, stream);
     if (!rc && optimistic) {

@@ -8,6 +8,8 @@
 //
 // Blocked right-looking Cholesky, nb = 128: leaf factorisation + leaf inverse in LDS (one workgroup), row panel
 // U12 = U11^-T A12 and trailing update A22 -= U12^T U12 as MFMA GEMMs (upper tiles only).
+#include <memory>
+
 #include "common.h"
 
 namespace shg {
@@ -383,12 +385,17 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
     const int tiles = (int)(grid.x * grid.y);
     double* partial = nullptr;
     int slices = 1;
+    std::unique_ptr<ScratchLease> lease;            // held until the kernel that sums the partial products is enqueued
     if (!small_tiles && batch == 1 && !upper_only && tiles < 384 && K >= 512) {                 // fewer than 1.5 workgroups per CU
         slices = std::min(std::min(16, K / 256), std::max(1, 512 / tiles));
         if (slices > 1) {
             const int chunk = round_up(ceil_div(K, slices), XK);
             slices = ceil_div(K, chunk);
-            if (slices > 1 && (partial = (double*)stream_scratch(stream, kScratchSplitK, (size_t)slices * M * N * sizeof(double))) != nullptr) {
+            if (slices > 1) {
+                lease.reset(new ScratchLease(stream));
+                partial = (double*)lease->get(kScratchSplitK, (size_t)slices * M * N * sizeof(double));
+            }
+            if (slices > 1 && partial != nullptr) {
                 P.K = chunk;
                 P.Ktotal = K;
                 P.strideA = ta ? (long long)chunk * lda : chunk;

@@ -16,7 +16,16 @@ namespace shg {
 int fail(int code, const char* fmt, ...);
 // grow-only scratch of a stream (plan.hip), kept until shg_scratch_release(); one slot per buffer that is live at the same time
 enum ScratchSlot { kScratchSplitK = 0, kScratchAnaFold = 1, kScratchAnaTransform = 2, kScratchAnaSolution = 3, kScratchAnaFlag = 4 };
-void* stream_scratch(hipStream_t stream, int slot, size_t bytes);
+class ScratchLease {          // the scratch buffers of one stream, held while the operations that use them are enqueued (plan.hip)
+public:
+    explicit ScratchLease(hipStream_t stream);
+    ~ScratchLease();
+    ScratchLease(const ScratchLease&) = delete;
+    ScratchLease& operator=(const ScratchLease&) = delete;
+    void* get(int slot, size_t bytes);
+private:
+    void* owner_;
+};
 void stream_scratch_release();
 hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream);    // hipMallocAsync from a pool that keeps freed memory cached
 

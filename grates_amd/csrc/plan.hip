@@ -6,6 +6,7 @@
 #include <string>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <utility>
 
@@ -42,23 +43,40 @@ hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream) {
     return hipMallocAsync(ptr, bytes, stream);
 }
 
-// Scratch that lives as long as its stream is in use: one grow-only buffer per (stream, slot), handed to successive
-// operations of that stream (which the stream orders, so they may share it).  For workspaces inside chains of thousands of
+// Scratch that lives as long as its stream is in use: grow-only buffers per (stream, slot), handed to successive
+// operations of that stream (which the stream orders, so they may share them).  For workspaces inside chains of thousands of
 // small operations: on ROCm 7.2 hipFreeAsync keeps the calling thread until the stream has caught up (0.2 - 1.4 ms per call
 // in the factorisation of a d = 1681 block; 0.2 ms for a 0.5 GB buffer even on an idle stream), which makes the host the
-// pace-maker of such a chain.  shg_scratch_release() gives the buffers back.
+// pace-maker of such a chain.  A ScratchLease holds the stream's buffers exclusively while the operations that use them are
+// being enqueued, so that two threads that feed the same stream cannot interleave their use of one buffer; leases nest
+// inside a thread (shg_analysis holds one while gemm_ex takes its own).  shg_scratch_release() gives the buffers back.
 namespace {
-struct ScratchEntry {
+struct ScratchBuffer {
     void* ptr = nullptr;
     size_t size = 0;
 };
+struct StreamScratch {
+    std::recursive_mutex mtx;
+    std::map<int, ScratchBuffer> slots;
+};
 std::mutex g_scratch_mutex;
-std::map<std::pair<hipStream_t, int>, ScratchEntry> g_scratch;
+std::map<hipStream_t, std::unique_ptr<StreamScratch>> g_scratch;
 }  // namespace
 
-void* stream_scratch(hipStream_t stream, int slot, size_t bytes) {
-    std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    ScratchEntry& e = g_scratch[std::make_pair(stream, slot)];
+ScratchLease::ScratchLease(hipStream_t stream) {
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        std::unique_ptr<StreamScratch>& e = g_scratch[stream];
+        if (!e) e.reset(new StreamScratch);
+        owner_ = e.get();
+    }
+    static_cast<StreamScratch*>(owner_)->mtx.lock();
+}
+
+ScratchLease::~ScratchLease() { static_cast<StreamScratch*>(owner_)->mtx.unlock(); }
+
+void* ScratchLease::get(int slot, size_t bytes) {
+    ScratchBuffer& e = static_cast<StreamScratch*>(owner_)->slots[slot];
     if (e.size < bytes) {
         if (e.ptr) (void)hipFree(e.ptr);             // waits for the device: whatever still used the old buffer is done
         e.ptr = nullptr;
@@ -76,9 +94,12 @@ void* stream_scratch(hipStream_t stream, int slot, size_t bytes) {
 
 void stream_scratch_release() {
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    for (auto& kv : g_scratch)
-        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-    g_scratch.clear();
+    for (auto& kv : g_scratch) {
+        std::lock_guard<std::recursive_mutex> hold(kv.second->mtx);
+        for (auto& b : kv.second->slots)
+            if (b.second.ptr) (void)hipFree(b.second.ptr);
+        kv.second->slots.clear();
+    }
 }
 
 // a_nm / b_nm of  P_nm = (a_nm t) P_(n-1)m - b_nm P_(n-2)m   in packed order-major layout.
