@@ -321,6 +321,105 @@ __global__ void analysis_scatter_kernel(int N, int nmin, int nb, int b0, const d
     out[sine ? (size_t)(m - 1) * (N + 1) + n : (size_t)n * (N + 1) + m] = X[((size_t)s * (N + 1) + a) * nb + b];
 }
 
+// x_s = H_s g_s for all slots and epochs, written straight into anm (degrees up to 127, even parallel count).  A slot of order m
+// has only d_s = N + 1 - max(m, nmin) rows: a batched GEMM on the padded [N+1][nlat] operators computes (N+1)(2N+1) rows
+// where (N+1)^2 - nmin^2 are wanted, and rounds N + 1 = 97 up to a 128-row tile on top.  Here a workgroup takes one slot and
+// 64 epochs: ceil(d_s / 16) row tiles of 16, wave w the epochs 16 w .. 16 w + 15; operands through two LDS stages of 16
+// parallels ([k][row] and [k][epoch], so that the fragment reads are conflict free), results scattered into
+// anm[b][n][m] / anm[b][m-1][n] by the lanes that hold them (the scatter kernel's pattern, without the round trip through X).
+constexpr int kOpKC = 16, kOpCols = 64, kOpRows = 128;
+
+__global__ __launch_bounds__(256) void analysis_operator_kernel(int N, int nmin, int nlat, int nb, int b0, const double* __restrict__ H,
+                                                                const double* __restrict__ gt, double* __restrict__ anm) {
+    __shared__ double AL[2][kOpKC][kOpRows + 2];
+    __shared__ double BL[2][kOpKC][kOpCols + 2];
+    const int s = blockIdx.x, cb = blockIdx.y * kOpCols;
+    const int m = (s + 1) >> 1;
+    const bool sine = s > 0 && (s & 1) == 0;
+    const int n0 = max(m, nmin), R = N + 1;
+    const int d = R - n0;
+    if (d <= 0) return;
+    const int ntile = (d + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const double* Hs = H + (size_t)s * R * nlat;
+    const double* gs = gt + (size_t)s * nb * nlat;                 // [nb][nlat]
+    const int kp = tid & 7, lrow = tid >> 3;                       // loader: 16-byte piece kp of row lrow (+ 32 per pass)
+    double2_t ra[4], rb[2];
+    auto fetch = [&](int k0) {
+        const int k = k0 + 2 * kp;
+        const bool kok = k < nlat;                                 // nlat is even: a pair is inside or outside
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = lrow + 32 * p;
+            ra[p] = (kok && row < d) ? *reinterpret_cast<const double2_t*>(Hs + (size_t)row * nlat + k) : (double2_t){0.0, 0.0};
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int col = cb + lrow + 32 * p;
+            rb[p] = (kok && col < nb) ? *reinterpret_cast<const double2_t*>(gs + (size_t)col * nlat + k) : (double2_t){0.0, 0.0};
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (lrow + 32 * p < 16 * ntile) {
+                AL[buf][2 * kp][lrow + 32 * p] = ra[p].x;
+                AL[buf][2 * kp + 1][lrow + 32 * p] = ra[p].y;
+            }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            BL[buf][2 * kp][lrow + 32 * p] = rb[p].x;
+            BL[buf][2 * kp + 1][lrow + 32 * p] = rb[p].y;
+        }
+    };
+    double4_t acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int nchunk = (nlat + kOpKC - 1) / kOpKC;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) fetch((ch + 1) * kOpKC);
+        double fa[2][8], fb[2];
+        auto read_step = [&](int kk, int set) {
+            fb[set] = BL[buf][4 * kk + fk][16 * wave + fr];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) fa[set][t] = AL[buf][4 * kk + fk][(t < ntile ? 16 * t : 0) + fr];
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk + 1 < 4) read_step(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][t], fb[kk & 1], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ch + 1 < nchunk) stage(buf ^ 1);
+        __syncthreads();
+    }
+    const int b = cb + 16 * wave + fr;
+    if (b < nb) {
+        double* out = anm + (size_t)(b0 + b) * R * R;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < ntile) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int a = 16 * t + fk + 4 * reg;
+                    if (a < d) {
+                        const int n = n0 + a;
+                        out[sine ? (size_t)(m - 1) * R + n : (size_t)n * R + m] = acc[t][reg];
+                    }
+                }
+            }
+    }
+}
+
 // number of entries in which the area weights differ from the ones the cached operator was built for (bitwise compare)
 __global__ __launch_bounds__(256) void analysis_compare_kernel(long long n, const double* __restrict__ a, const double* __restrict__ b,
                                                                int* __restrict__ diff) {
@@ -527,10 +626,14 @@ static int analysis_pass(shg_plan* p, const double* grid, const double* area, in
         }
         if (rc) return rc;
         ProfileScope ps(p, 5, stream);
-        // X_s [R][nb] = H_s [R][nlat] gt_s^T   (gt_s is [nb][nlat])
-        rc = gemm_ex(false, true, R, nb, nlat, 1.0, p->ana_H, nlat, (long long)R * nlat, gt, nlat, rows, 0.0, X, nb, (long long)R * nb, S, false, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(analysis_scatter_kernel, dim3(ceil_div(nb, 64), R, S), dim3(64), 0, stream, N, nmin, nb, b0, X, anm);
+        if (R <= kOpRows && nlat % 2 == 0) {
+            hipLaunchKernelGGL(analysis_operator_kernel, dim3(S, ceil_div(nb, kOpCols)), dim3(256), 0, stream, N, nmin, nlat, nb, b0, p->ana_H, gt, anm);
+        } else {
+            // X_s [R][nb] = H_s [R][nlat] gt_s^T   (gt_s is [nb][nlat])
+            rc = gemm_ex(false, true, R, nb, nlat, 1.0, p->ana_H, nlat, (long long)R * nlat, gt, nlat, rows, 0.0, X, nb, (long long)R * nb, S, false, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(analysis_scatter_kernel, dim3(ceil_div(nb, 64), R, S), dim3(64), 0, stream, N, nmin, nb, b0, X, anm);
+        }
     }
     SHG_HIP(hipGetLastError());
     return SHG_OK;
