@@ -87,44 +87,64 @@ __global__ __launch_bounds__(256) void weight_fold_kernel(int nb, int nlat, int 
 
 // Fold and longitude transform in one kernel (degrees up to 126): gt[slot][(b, i)] = sum_c T_slot(mu_c) F_group(slot)[c][(b, i)]
 // without the folded planes ever reaching memory -- the values are read once (with their area weights), folded in registers
-// and multiplied from LDS.  A workgroup owns 64 rows (b, i) and ALL slots: wave w the rows 16 w .. 16 w + 15 with 4 x MT
-// accumulator tiles (group g = cos even | cos odd | sin even | sin odd, 16 orders per tile).  The quarter domain is walked in
+// and multiplied from LDS.  A workgroup owns 64 rows (b, i) and ALL slots: wave g the group g = cos even | cos odd | sin even |
+// sin odd with MT tiles of 16 orders x 4 tiles of 16 rows (every trig fragment serves four row tiles, every value fragment MT
+// order tiles: 7 LDS reads per 12 MFMAs at d/o 96).  Order 0 needs no trig: its sum over the columns is kept by the loader
+// threads and reduced at the end, which leaves the four groups with N/2 or (N+1)/2 orders each.  The quarter domain is walked in
 // chunks of 8 columns through two LDS stages; per chunk every thread loads two columns of one row in their four images (and
 // the weights), folds them, and one row of the trig chunk.  Operand fragments: A = T[order][c] (LDS [c][order]), B = F[c][row]
 // (LDS [group][c][row]), D row = order fk + 4 reg, column = row fr.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 #ifndef SHG_ANA_X
-#define SHG_ANA_X 0    // experiment switches (timing only): 1 no MFMAs, 2 no global loads after the first chunk
+#define SHG_ANA_X 0    // experiment switches (timing only): 1 no MFMAs, 2 no global loads after the first chunk, 4 / 8 / 16 no weight / trig / value loads
 #endif
 constexpr int kAtKC = 8, kAtRows = 64, kAtFP = kAtRows + 2;
 
-__device__ __forceinline__ int analysis_slot(int g, int k) { return g == 0 ? (k == 0 ? 0 : 4 * k - 1) : (g == 1 ? 4 * k + 1 : (g == 2 ? 4 * k + 4 : 4 * k + 2)); }
+// slot of order index k of group g: cos 2 (k + 1) | cos 2 k + 1 | sin 2 (k + 1) | sin 2 k + 1
+__device__ __forceinline__ int analysis_slot(int g, int k) { return g == 0 ? 4 * k + 3 : (g == 1 ? 4 * k + 1 : (g == 2 ? 4 * k + 4 : 4 * k + 2)); }
 
-template <int MT>
+// trig table in the order the kernel stages it: T[chunk][k][row], row = (group g, order index), T = cos | sin (order * mu_c),
+// zero beyond the quarter domain and beyond a group's orders (built once per plan and degree)
+__global__ void analysis_trig_kernel(int N, int nlon, int mt, const double* __restrict__ cs, double* __restrict__ T) {
+    const int TR = 4 * mt * 16;
+    const int nq = nlon / 4;
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;                                // column of the padded quarter domain
+    if (row >= TR) return;
+    const int g = row / (mt * 16), k = row % (mt * 16);
+    const int count = (g & 1) ? (N + 1) / 2 : N / 2;
+    double value = 0.0;
+    if (c < nq && k < count) {
+        const int slot = g == 0 ? 4 * k + 3 : (g == 1 ? 4 * k + 1 : (g == 2 ? 4 * k + 4 : 4 * k + 2));
+        value = cs[(size_t)slot * nlon + nlon / 2 + c];
+    }
+    T[((size_t)(c / kAtKC) * kAtKC + c % kAtKC) * TR + row] = value;
+}
+
+template <int MT, bool ROWW>
 __global__ __launch_bounds__(256) void analysis_transform_kernel(int nb, int nlat, int nlon, int N, const double* __restrict__ v,
-                                                                 const double* __restrict__ area, const double* __restrict__ cs,
+                                                                 const double* __restrict__ area, const double* __restrict__ trig,
                                                                  double* __restrict__ gt) {
     constexpr int TR = 4 * MT * 16;                     // rows of the trig chunk: group g, tile t, order 16 t + m
     constexpr int TP = TR + 2;
-    __shared__ double TL[2][kAtKC][TP];
+    __shared__ __attribute__((aligned(16))) double TL[2][kAtKC][TP];
     __shared__ double FL[2][4][kAtKC][kAtFP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     const int nq = nlon / 4, h = nlon / 2;
     const long long rows = (long long)nb * nlat;
     const long long r0 = (long long)blockIdx.x * kAtRows;
-    const int count[4] = {N / 2 + 1, (N + 1) / 2, N / 2, (N + 1) / 2};
+    const int count[4] = {N / 2, (N + 1) / 2, N / 2, (N + 1) / 2};
     // loader role: row lrow, columns c0 + 2 cp, c0 + 2 cp + 1
     const int lrow = tid >> 2, cp = tid & 3;
     const long long lr = r0 + lrow;
     const bool row_ok = lr < rows;
     const double* vrow = v + (row_ok ? lr : rows - 1) * nlon;
     const double* arow = area + (size_t)((row_ok ? lr : rows - 1) % nlat) * nlon;
-    // trig role: table row tid (group tg, order index tk)
-    const int tg = tid / (MT * 16), tk = tid % (MT * 16);
-    const bool trig_ok = tid < TR && tk < count[tg < 4 ? tg : 0];
-    const double* trow = cs + (size_t)(trig_ok ? analysis_slot(tg, tk) : 0) * nlon + h;
+    // trig role: MT 16-byte pieces of the chunk's [8][TR] block, lane-contiguous in memory; piece q covers rows 2 pr, 2 pr + 1 of
+    // column pk
+    const double wrow = ROWW ? arow[0] : 0.0;               // weights constant along the parallel: one value per thread
 
     // The values come from HBM, the weights and the trig rows from L2: the values of a chunk are requested two chunks ahead
     // (two register sets, used alternately), weights and trig rows one chunk ahead -- and in that order of age, because the
@@ -133,13 +153,15 @@ __global__ __launch_bounds__(256) void analysis_transform_kernel(int nb, int nla
         double2_t x1, x2, x3, x4;                         // the four images of two columns (x2, x4: descending)
     };
     Images va, vb;
+    double order0 = 0.0;                                  // sum of this thread's columns of its row: the order-0 transform
     double2_t w1, w2, w3, w4;
-    double2_t tq[4];
+    double2_t tq[MT];
     // Columns come in aligned pairs (c even; nlon is a multiple of 4, so every image of a pair is a 16-byte load inside the
     // row); a pair that starts beyond the quarter domain is not loaded, a column beyond it is zeroed when it is staged.
     auto fetch_values = [&](Images& x, int c0) {
         const int c = c0 + 2 * cp;
         const int cc = c < nq ? c : 0;
+        if (SHG_ANA_X & 16) return;
         x.x1 = *reinterpret_cast<const double2_t*>(vrow + h + cc);
         x.x2 = *reinterpret_cast<const double2_t*>(vrow + h - 2 - cc);
         x.x3 = *reinterpret_cast<const double2_t*>(vrow + cc);
@@ -148,71 +170,75 @@ __global__ __launch_bounds__(256) void analysis_transform_kernel(int nb, int nla
     auto fetch_weights = [&](int c0) {
         const int c = c0 + 2 * cp;
         const int cc = c < nq ? c : 0;
-        w1 = *reinterpret_cast<const double2_t*>(arow + h + cc);
-        w2 = *reinterpret_cast<const double2_t*>(arow + h - 2 - cc);
-        w3 = *reinterpret_cast<const double2_t*>(arow + cc);
-        w4 = *reinterpret_cast<const double2_t*>(arow + nlon - 2 - cc);
-        if (tid < TR) {
+        if (!ROWW && !(SHG_ANA_X & 4)) {
+            w1 = *reinterpret_cast<const double2_t*>(arow + h + cc);
+            w2 = *reinterpret_cast<const double2_t*>(arow + h - 2 - cc);
+            w3 = *reinterpret_cast<const double2_t*>(arow + cc);
+            w4 = *reinterpret_cast<const double2_t*>(arow + nlon - 2 - cc);
+        }
+        if (!(SHG_ANA_X & 8)) {
+            const double* block = trig + (size_t)(c0 / kAtKC) * (kAtKC * TR);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ct = c0 + 2 * q;
-                tq[q] = *reinterpret_cast<const double2_t*>(trow + (ct < nq ? ct : 0));
-            }
+            for (int q = 0; q < MT; ++q) tq[q] = *reinterpret_cast<const double2_t*>(block + 2 * (q * 256 + tid));
         }
     };
+    // Rows beyond the batch may hold anything -- they only reach accumulator columns that the epilogue does not store; the
+    // trig table is zero beyond the quarter domain.
     auto stage = [&](const Images& x, int c0, int buf) {
-        const int c = c0 + 2 * cp;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const bool ok = row_ok && c + j < nq;
             // ascending images hold column c + j in component j, descending ones in component 1 - j
-            const double a1 = j ? x.x1.y * w1.y : x.x1.x * w1.x, a2 = j ? x.x2.x * w2.x : x.x2.y * w2.y;
-            const double a3 = j ? x.x3.y * w3.y : x.x3.x * w3.x, a4 = j ? x.x4.x * w4.x : x.x4.y * w4.y;
-            const double p12 = a1 + a2, p34 = a3 + a4, q12 = a1 - a2, q34 = a3 - a4;
-            FL[buf][0][2 * cp + j][lrow] = ok ? p12 + p34 : 0.0;       // cos, even orders
-            FL[buf][1][2 * cp + j][lrow] = ok ? p12 - p34 : 0.0;       // cos, odd
-            FL[buf][2][2 * cp + j][lrow] = ok ? q12 + q34 : 0.0;       // sin, even
-            FL[buf][3][2 * cp + j][lrow] = ok ? q12 - q34 : 0.0;       // sin, odd
-        }
-        if (tid < TR) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ct = c0 + 2 * q;
-                TL[buf][2 * q][tid] = trig_ok && ct < nq ? tq[q].x : 0.0;
-                TL[buf][2 * q + 1][tid] = trig_ok && ct + 1 < nq ? tq[q].y : 0.0;
+            double a1, a2, a3, a4;
+            if (ROWW) {
+                a1 = (j ? x.x1.y : x.x1.x) * wrow, a2 = (j ? x.x2.x : x.x2.y) * wrow;
+                a3 = (j ? x.x3.y : x.x3.x) * wrow, a4 = (j ? x.x4.x : x.x4.y) * wrow;
+            } else {
+                a1 = j ? x.x1.y * w1.y : x.x1.x * w1.x, a2 = j ? x.x2.x * w2.x : x.x2.y * w2.y;
+                a3 = j ? x.x3.y * w3.y : x.x3.x * w3.x, a4 = j ? x.x4.x * w4.x : x.x4.y * w4.y;
             }
+            const double p12 = a1 + a2, p34 = a3 + a4, q12 = a1 - a2, q34 = a3 - a4;
+            order0 += (c0 + 2 * cp + j < nq) ? p12 + p34 : 0.0;
+            FL[buf][0][2 * cp + j][lrow] = p12 + p34;       // cos, even orders
+            FL[buf][1][2 * cp + j][lrow] = p12 - p34;       // cos, odd
+            FL[buf][2][2 * cp + j][lrow] = q12 + q34;       // sin, even
+            FL[buf][3][2 * cp + j][lrow] = q12 - q34;       // sin, odd
+        }
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            const int piece = q * 256 + tid;                // piece of two rows: column piece / (TR / 2), rows 2 (piece % (TR / 2))
+            *reinterpret_cast<double2_t*>(&TL[buf][piece / (TR / 2)][2 * (piece % (TR / 2))]) = tq[q];
         }
     };
 
-    double4_t acc[4][MT];
+    double4_t acc[MT][4];                               // [order tile][row tile] of this wave's group
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int t = 0; t < MT; ++t) acc[g][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    int ntile[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) ntile[g] = (count[g] + 15) / 16;
+        for (int nt = 0; nt < 4; ++nt) acc[t][nt] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int g = wave;
+    const int ntile = (count[g] + 15) / 16;
 
     const int nchunk = (nq + kAtKC - 1) / kAtKC;
-    // products of one chunk: 8 (k-step, group) items of one B fragment and up to MT A fragments; the fragments of item q + 1
-    // are read while the MFMAs of item q run (hipcc otherwise puts every read right in front of its MFMA and waits for it)
+    // products of one chunk: per k-step MT trig fragments and four value fragments, read one k-step ahead of their MFMAs
     auto products = [&](int buf) {
-        double fa[2][MT], fb[2];
-        auto read_item = [&](int q, int set) {
-            const int ks = q >> 2, g = q & 3;
-            fb[set] = FL[buf][g][4 * ks + fk][16 * wave + fr];
+        double fa[2][MT], fb[2][4];
+        auto read_step = [&](int ks, int set) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) fa[set][t] = TL[buf][4 * ks + fk][(g * MT + t) * 16 + fr];      // (unconditional: exact lgkmcnt counts)
+            for (int t = 0; t < MT; ++t) fa[set][t] = TL[buf][4 * ks + fk][(g * MT + t) * 16 + fr];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fb[set][nt] = FL[buf][g][4 * ks + fk][16 * nt + fr];
         };
-        read_item(0, 0);
+        read_step(0, 0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (q + 1 < 8) read_item(q + 1, (q + 1) & 1);
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks + 1 < 2) read_step(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            const int g = q & 3;
 #pragma unroll
             for (int t = 0; t < MT; ++t)
-                if (t < ntile[g] && !(SHG_ANA_X & 1)) acc[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q & 1][t], fb[q & 1], acc[g][t], 0, 0, 0);
+                if (t < ntile && !(SHG_ANA_X & 1)) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks & 1][t], fb[ks & 1][nt], acc[t][nt], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -234,18 +260,23 @@ __global__ __launch_bounds__(256) void analysis_transform_kernel(int nb, int nla
         step(ch, vb, va);                         // chunk ch + 1 sits in vb, chunk ch + 2 goes to va
         if (ch + 1 < nchunk) step(ch + 1, va, vb);
     }
-    const long long r = r0 + 16 * wave + fr;
-    if (r < rows) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+    for (int nt = 0; nt < 4; ++nt) {
+        const long long r = r0 + 16 * nt + fr;
+        if (r < rows) {
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int k = 16 * t + fk + 4 * reg;
-                    if (k < count[g]) gt[(size_t)analysis_slot(g, k) * rows + r] = acc[g][t][reg];
+                    if (k < count[g]) gt[(size_t)analysis_slot(g, k) * rows + r] = acc[t][nt][reg];
                 }
+        }
     }
+    // order 0: the four loader threads of a row sit in adjacent lanes
+    order0 += __shfl_xor(order0, 1);
+    order0 += __shfl_xor(order0, 2);
+    if (cp == 0 && row_ok) gt[lr] = order0;
 }
 
 // w2[s][i] = sum_j area[i][j] cs[s][j]^2 : one workgroup per parallel
@@ -420,6 +451,14 @@ __global__ __launch_bounds__(256) void analysis_operator_kernel(int N, int nmin,
     }
 }
 
+// *varies becomes non-zero when the weights are not constant along every parallel
+__global__ __launch_bounds__(256) void analysis_rowconst_kernel(int nlat, int nlon, const double* __restrict__ area, int* __restrict__ varies) {
+    int d = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)nlat * nlon; e += (long long)gridDim.x * 256)
+        d |= __builtin_bit_cast(long long, area[e]) != __builtin_bit_cast(long long, area[(e / nlon) * nlon]) ? 1 : 0;
+    if (d) atomicOr(varies, 1);
+}
+
 // number of entries in which the area weights differ from the ones the cached operator was built for (bitwise compare)
 __global__ __launch_bounds__(256) void analysis_compare_kernel(long long n, const double* __restrict__ a, const double* __restrict__ b,
                                                                int* __restrict__ diff) {
@@ -518,10 +557,21 @@ static int rebuild_analysis_operator(shg_plan* p, const double* area, int nmin, 
     double* w2 = nullptr;
     if (workspace_alloc((void**)&w2, (size_t)S * nlat * sizeof(double), stream) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
     hipLaunchKernelGGL(weight_squares_kernel, dim3(nlat), dim3(256), 0, stream, S, nlat, nlon, area, p->cs_slot, w2);
-    const int rc = build_analysis_operator(p, w2, nmin, stream);
+    int rc = build_analysis_operator(p, w2, nmin, stream);
     (void)hipFreeAsync(w2, stream);
     if (rc) return rc;
     SHG_HIP(hipMemcpyAsync(p->ana_area, area, na * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    {   // weights that are constant along every parallel (geographic and Gauss grids) need not be streamed by the transform kernel
+        ScratchLease lease(stream);
+        int* varies = (int*)lease.get(kScratchAnaFlag, sizeof(int));
+        if (!varies) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
+        int host = 1;
+        SHG_HIP(hipMemsetAsync(varies, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(analysis_rowconst_kernel, dim3(256), dim3(256), 0, stream, nlat, nlon, area, varies);
+        SHG_HIP(hipMemcpyAsync(&host, varies, sizeof(int), hipMemcpyDeviceToHost, stream));
+        SHG_HIP(hipStreamSynchronize(stream));
+        p->ana_rowconst = host == 0;
+    }
     p->ana_nmin = nmin;
     return SHG_OK;
 }
@@ -567,6 +617,23 @@ extern "C" int shg_analysis_matrix(shg_plan* p, const double* area, int nmin, do
     return SHG_OK;
 }
 
+// the fused transform kernel's trig table for mt order tiles per group (built once per plan)
+static int ensure_transform_table(shg_plan* p, int mt, hipStream_t stream) {
+    if (p->ana_trig && p->ana_trig_mt == mt) return SHG_OK;
+    const int TR = 4 * mt * 16;
+    const int ncol = ceil_div(p->nlon / 4, kAtKC) * kAtKC;
+    if (p->ana_trig) {
+        SHG_HIP(hipStreamSynchronize(stream));
+        (void)hipFree(p->ana_trig);
+        p->ana_trig = nullptr;
+    }
+    if (hipMalloc((void**)&p->ana_trig, (size_t)ncol * TR * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "analysis trig table allocation failed");
+    hipLaunchKernelGGL(analysis_trig_kernel, dim3(ceil_div(TR, 128), ncol), dim3(128), 0, stream, p->N, p->nlon, mt, p->cs_slot, p->ana_trig);
+    SHG_HIP(hipGetLastError());
+    p->ana_trig_mt = mt;
+    return SHG_OK;
+}
+
 // fold kernel + one batched GEMM per parity (degrees above 126: the fused kernel's accumulators do not fit)
 static int folded_transform(shg_plan* p, const double* grid, const double* area, int nb, double* wvt, double* gt, hipStream_t stream) {
     const int N = p->N, nlat = p->nlat, nlon = p->nlon;
@@ -608,12 +675,18 @@ static int analysis_pass(shg_plan* p, const double* grid, const double* area, in
             if (N <= 126) {
                 ProfileScope ps(p, 4, stream);
                 const unsigned blocks = (unsigned)ceil_div64(rows, kAtRows);
-                if (N <= 62)
-                    hipLaunchKernelGGL(analysis_transform_kernel<2>, dim3(blocks), dim3(256), 0, stream, nb, nlat, nlon, N, grid + (size_t)b0 * nlat * nlon,
-                                       area, p->cs_slot, gt);
-                else
-                    hipLaunchKernelGGL(analysis_transform_kernel<4>, dim3(blocks), dim3(256), 0, stream, nb, nlat, nlon, N, grid + (size_t)b0 * nlat * nlon,
-                                       area, p->cs_slot, gt);
+                const double* values = grid + (size_t)b0 * nlat * nlon;
+                const int mt = N <= 64 ? 2 : (N <= 96 ? 3 : 4);           // (N + 1) / 2 orders per group at most: 32 | 48 | 64
+                rc = ensure_transform_table(p, mt, stream);
+                if (rc) return rc;
+#define SHG_ANA_LAUNCH(MT_, RW_)                                                                                                       \
+    hipLaunchKernelGGL((analysis_transform_kernel<MT_, RW_>), dim3(blocks), dim3(256), 0, stream, nb, nlat, nlon, N, values, area, p->ana_trig, gt)
+                if (p->ana_rowconst) {
+                    if (mt == 2) SHG_ANA_LAUNCH(2, true); else if (mt == 3) SHG_ANA_LAUNCH(3, true); else SHG_ANA_LAUNCH(4, true);
+                } else {
+                    if (mt == 2) SHG_ANA_LAUNCH(2, false); else if (mt == 3) SHG_ANA_LAUNCH(3, false); else SHG_ANA_LAUNCH(4, false);
+                }
+#undef SHG_ANA_LAUNCH
                 rc = SHG_OK;
             } else {
                 rc = folded_transform(p, grid + (size_t)b0 * nlat * nlon, area, nb, wvt, gt, stream);
@@ -663,9 +736,10 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     ScratchLease lease(stream);
     double* wvt = folded && N <= 126 ? nullptr : (double*)lease.get(kScratchAnaFold, (size_t)nlon * chunk * nlat * sizeof(double));
     double* gt = (double*)lease.get(kScratchAnaTransform, (size_t)S * chunk * nlat * sizeof(double));
-    double* X = (double*)lease.get(kScratchAnaSolution, (size_t)S * R * chunk * sizeof(double));
+    const bool direct = R <= kOpRows && nlat % 2 == 0;          // operator kernel writes anm itself
+    double* X = direct ? nullptr : (double*)lease.get(kScratchAnaSolution, (size_t)S * R * chunk * sizeof(double));
     int* diff = (int*)lease.get(kScratchAnaFlag, sizeof(int));
-    if ((!wvt && !(folded && N <= 126)) || !gt || !X || !diff) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
+    if ((!wvt && !(folded && N <= 126)) || !gt || (!X && !direct) || !diff) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
     if (optimistic) rc = launch_weight_compare(p, area, diff, stream);
     if (!rc) rc = analysis_pass(p, grid, area, nmin, B, chunk, folded, wvt, gt, X, anm, stream);
     if (!rc && optimistic) {
