@@ -121,11 +121,20 @@ extern "C" int shg_block_potrf_rows(int nb, const int* bounds, const int* rowptr
     double* panel = scratch.get((size_t)dmax * dmax);
     int* info_blk = (int*)scratch.get(1);
     SHG_REQUIRE(work && panel && info_blk, "shg_block_potrf: workspace allocation failed");
+    // inv[r] == blk[diagonal r]: the caller keeps U_rr^-1 INSTEAD of U_rr (nothing but shg_block_multiply needs the diagonal
+    // factor blocks once their inverses exist): the block is factored in a scratch copy and its inverse goes where it was
+    double* diag_copy = nullptr;
     if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
     for (int r = first; r < last; ++r) {
         const int dr = V.size(r);
         const int e0 = V.begin(r), e1 = V.end(r);
         double* Arr = blk[e0];
+        if (inv[r] == Arr) {
+            if (!diag_copy) diag_copy = scratch.get((size_t)dmax * dmax);
+            SHG_REQUIRE(diag_copy != nullptr, "shg_block_potrf: workspace allocation failed");
+            SHG_HIP(hipMemcpyAsync(diag_copy, Arr, (size_t)dr * dr * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            Arr = diag_copy;
+        }
         SHG_HIP(hipMemsetAsync(info_blk, 0, sizeof(int), stream));
         rc = potrf_inverse_upper(dr, Arr, dr, inv[r], dr, work, info_blk, stream);      // factor and inverse in one recursive sweep
         if (rc) return rc;
@@ -218,7 +227,8 @@ extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, const int* ro
     // T_rk = U_rr^-1 W_rk of the current block row: as many scratch blocks as the densest row has off-diagonal blocks
     int most = 0;
     for (int r = 0; r < nb; ++r) most = std::max(most, V.end(r) - V.begin(r) - 1);
-    double* tbuf = scratch.get((size_t)std::max(most, 1) * dmax * dmax);
+    const int most_slot = std::max(most, 1);                                      // one more scratch block behind the T blocks
+    double* tbuf = scratch.get((size_t)(most_slot + 1) * dmax * dmax);
     SHG_REQUIRE(tbuf != nullptr, "shg_block_sparse_inverse: workspace allocation failed");
     auto T = [&](int e, int r) { return tbuf + (size_t)(e - V.begin(r) - 1) * dmax * dmax; };       // scratch of entry e of row r
     for (int r = nb - 1; r >= 0; --r) {
@@ -230,7 +240,14 @@ extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, const int* ro
             if (rc) return rc;
             SHG_HIP(hipMemsetAsync(blk[e], 0, (size_t)dr * dk * sizeof(double), stream));
         }
-        rc = gemm(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, blk[e0], dr, false, stream);               // Z_rr = U^-1 U^-T ...
+        if (inv[r] == blk[e0]) {                                                                                       // (inverse kept in the diagonal block itself)
+            double* zrr = T(e0 + 1 + most_slot, r);
+            rc = gemm(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, zrr, dr, false, stream);
+            if (rc) return rc;
+            SHG_HIP(hipMemcpyAsync(blk[e0], zrr, (size_t)dr * dr * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        } else {
+            rc = gemm(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, blk[e0], dr, false, stream);           // Z_rr = U^-1 U^-T ...
+        }
         if (rc) return rc;
         for (int f = e1 - 1; f >= e0; --f) {                                                                           // ... and the row, last block first
             const int j = colidx[f];
@@ -258,6 +275,7 @@ extern "C" int shg_block_inverse(int nb, const int* bounds, const int* rowptr, c
     const BlockView V{nb, bounds, rowptr, colidx, blk};
     int rc = check(V, inv, "shg_block_inverse");
     if (rc) return rc;
+    for (int i = 0; i < nb; ++i) SHG_REQUIRE(inv[i] != blk[rowptr[i]], "shg_block_inverse: needs the diagonal factor blocks (inverse kept in their place)");
     for (int i = 0; i < nb; ++i)                        // ascending columns from the diagonal: a full row has exactly nb - i entries
         SHG_REQUIRE(V.end(i) - V.begin(i) == nb - i, "shg_block_inverse: block row %d is not fully allocated", i);
     hipStream_t stream = (hipStream_t)stream_;

@@ -229,6 +229,7 @@ class BlockMatrix:
         self.__column_index = column_index
         self.__data = {}
         self.__inverse_factor = {}      # diagonal index -> inverse of the upper triangular factor block
+        self._inverse_in_place = False  # the factorisation keeps U_ii^-1 in the diagonal blocks instead of U_ii (distributed chains)
 
     def copy(self):
         """Deep copy of BlockMatrix"""
@@ -358,7 +359,7 @@ class BlockMatrix:
         for i in range(nb):
             if i not in self.__inverse_factor:
                 size = self.__block_shape(i, i)[0]
-                self.__inverse_factor[i] = _zeros((size, size))
+                self.__inverse_factor[i] = self.__data[(i, i)] if self._inverse_in_place else _zeros((size, size))
             table[i] = self.__inverse_factor[i].data_ptr()
         return table
 
@@ -444,6 +445,7 @@ class BlockMatrix:
         self.__ensure_factor_inverses()
         engine.block_sparse_inverse(self.__block_table(), self.__inverse_table())
         self.__inverse_factor.clear()
+        self._inverse_in_place = False
 
     def inverse(self):
         """

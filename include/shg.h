@@ -203,7 +203,9 @@ int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream)
  * HBM, the call walks them on the device (csrc/blockchol.hip).  nb block rows / columns with boundaries bounds[0..nb]; the
  * stored blocks (j >= i) in compressed row form: entries rowptr[i] .. rowptr[i+1]-1 of row i, colidx[e] ascending from the
  * diagonal, blk[e] = device address of block (i, colidx[e]) (row-major [rows_i][cols_j]);
- * inv[i] = scratch [rows_i][rows_i] holding U_ii^-1 (written by shg_block_potrf, read by the others).
+ * inv[i] = scratch [rows_i][rows_i] holding U_ii^-1 (written by shg_block_potrf, read by the others).  inv[i] may be the
+ * diagonal block itself: then U_ii^-1 is kept INSTEAD of U_ii (solve and sparse inverse need nothing else; a third less
+ * memory for a long chain), and shg_block_multiply / shg_block_inverse, which read U_ii, must not be used on that factor.
  *   shg_block_potrf           N = W^T W in place, fill-in allocated by the caller       (grates/lstsq.py:698-717)
  *   shg_block_potrf_rows      the same for the block rows first <= r < last only: earlier rows count as factored, later rows are
  *                             left as the Schur complement (two half chains of a tridiagonal system on two streams)
