@@ -40,6 +40,7 @@ struct GemmExParams {
     double alpha, beta;
     int upper_only;           // skip output tiles that lie entirely below the diagonal
     int Ktotal;               // > 0: split-K launch, slice z covers k in [z K, min(Ktotal, (z + 1) K))
+    int tri;                  // triangular operands (square, M = K resp. K = N): 1 op(A) upper, 2 op(A) lower, 4 op(B) upper, 8 op(B) lower
 };
 
 // TA: A is stored [K][M] (op(A) = A^T);  TB: B is stored [N][K] (op(B) = B^T).  Row-major everywhere.
@@ -58,10 +59,24 @@ __global__ __launch_bounds__(256, T == 128 ? 2 : 3) void gemm_ex_kernel(GemmExPa
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, fk = lane >> 4;
     // split-K launches (Ktotal > 0) give every z slice its own K range of at most P.K (= Kz here) entries
-    const int Kz = P.Ktotal > 0 ? min(P.K, P.Ktotal - (int)blockIdx.z * P.K) : P.K;
+    int Kz = P.Ktotal > 0 ? min(P.K, P.Ktotal - (int)blockIdx.z * P.K) : P.K;
     const double* A = P.A + (size_t)blockIdx.z * P.strideA;
     const double* B = P.B + (size_t)blockIdx.z * P.strideB;
     double* C = P.C + (size_t)blockIdx.z * P.strideC;
+    // Triangular operands: the K range of this tile shrinks to where neither operand is structurally zero (the inverse of a
+    // Cholesky factor times a block: half of the K tiles on average; U^-1 U^-T: a third).  The skipped entries are never read.
+    if (P.tri) {
+        int kb = 0, ke = Kz;
+        if (P.tri & 1) kb = max(kb, m0);                 // op(A)[i][k] = 0 for k < i
+        if (P.tri & 2) ke = min(ke, m0 + XM);            // op(A)[i][k] = 0 for k > i
+        if (P.tri & 4) ke = min(ke, n0 + XN);            // op(B)[k][j] = 0 for k > j
+        if (P.tri & 8) kb = max(kb, n0);                 // op(B)[k][j] = 0 for k < j
+        kb &= ~(XK - 1);
+        kb = min(kb, max(ke, 0));
+        A += TA ? (size_t)kb * P.lda : (size_t)kb;
+        B += TB ? (size_t)kb : (size_t)kb * P.ldb;
+        Kz = max(ke - kb, 0);
+    }
 
     // staging roles of a thread
     //   k-contiguous operand  ([row][k] in memory):  piece h: row = (tid >> 3) + 32 h, k = (tid & 7) * 2, 2 elements
@@ -248,6 +263,7 @@ __global__ __launch_bounds__(256, T == 128 ? 2 : 3) void gemm_ex_kernel(GemmExPa
         SHG_MFMAS(af0, bf0);                            \
     } while (0)
 
+    if (Kz > 0) {
     const int nfull = Kz / XK;
     const bool has_tail = (Kz % XK) != 0;
     if (nfull > 0)
@@ -298,6 +314,7 @@ __global__ __launch_bounds__(256, T == 128 ? 2 : 3) void gemm_ex_kernel(GemmExPa
         }
         SHG_MFMAS(af1, bf1);
     }
+    }   // Kz > 0
 #undef SHG_STEP
 #undef SHG_TILE_HEAD
 #undef SHG_MFMAS_LOADS
@@ -340,10 +357,20 @@ __global__ void splitk_reduce_kernel(int M, int N, int slices, double alpha, con
     *out = beta == 0.0 ? alpha * s : fma(beta, *out, alpha * s);
 }
 
+int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
+                long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, int tri, hipStream_t stream);
+
 int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
             long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, hipStream_t stream) {
+    return gemm_ex_tri(ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, upper_only, 0, stream);
+}
+
+// tri: triangular structure of the operands (see GemmExParams::tri); entries on the zero side are not read
+int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
+                long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, int tri, hipStream_t stream) {
     if (M <= 0 || N <= 0 || batch <= 0) return SHG_OK;
     GemmExParams P;
+    P.tri = tri;
     P.M = M;
     P.N = N;
     P.K = K;
@@ -405,6 +432,7 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
                 P.strideC = (long long)M * N;
                 P.alpha = 1.0;
                 P.beta = 0.0;
+                P.tri = 0;                              // (K slices and triangular K ranges are not combined)
                 grid.z = slices;
             } else {
                 slices = 1;
@@ -798,15 +826,15 @@ static int potrf_inverse_rec(int n, double* A, int lda, double* X, int ldx, doub
     // U12 = X11^T A12: A12 is staged in the (still unused) X12 region, the product goes back into A12
     SHG_HIP(hipMemcpy2DAsync(X12, (size_t)ldx * sizeof(double), A12, (size_t)lda * sizeof(double), (size_t)n2 * sizeof(double), n1,
                              hipMemcpyDeviceToDevice, stream));
-    rc = gemm_ex(true, false, n1, n2, n1, 1.0, X, ldx, 0, X12, ldx, 0, 0.0, A12, lda, 0, 1, false, stream);
+    rc = gemm_ex_tri(true, false, n1, n2, n1, 1.0, X, ldx, 0, X12, ldx, 0, 0.0, A12, lda, 0, 1, false, 2, stream);       // X11^T is lower triangular
     if (rc) return rc;
     rc = gemm_ex(true, false, n2, n2, n1, -1.0, A12, lda, 0, A12, lda, 0, 1.0, A22, lda, 0, 1, true, stream);
     if (rc) return rc;
     rc = potrf_inverse_rec(n2, A22, lda, X22, ldx, work, info, info_base + n1, stream);
     if (rc) return rc;
-    rc = gemm_ex(false, false, n1, n2, n2, 1.0, A12, lda, 0, X22, ldx, 0, 0.0, work, n2, 0, 1, false, stream);
+    rc = gemm_ex_tri(false, false, n1, n2, n2, 1.0, A12, lda, 0, X22, ldx, 0, 0.0, work, n2, 0, 1, false, 4, stream);    // X22 is upper triangular
     if (rc) return rc;
-    return gemm_ex(false, false, n1, n2, n1, -1.0, X, ldx, 0, work, n2, 0, 0.0, X12, ldx, 0, 1, false, stream);
+    return gemm_ex_tri(false, false, n1, n2, n1, -1.0, X, ldx, 0, work, n2, 0, 0.0, X12, ldx, 0, 1, false, 1, stream);   // X11 is upper triangular
 }
 
 size_t potrf_inverse_work(int n) { return (size_t)(n / 2 + LEAF) * (n / 2 + LEAF); }

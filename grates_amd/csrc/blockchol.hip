@@ -28,6 +28,8 @@ namespace shg {
 
 int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
             long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, hipStream_t stream);
+int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
+                long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, int tri, hipStream_t stream);
 int potrf_inverse_upper(int n, double* A, int lda, double* X, int ldx, double* work, int* info, hipStream_t stream);
 size_t potrf_inverse_work(int n);
 
@@ -60,6 +62,13 @@ struct BlockView {
 inline int gemm(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb, double beta, double* C,
                 int ldc, bool upper, hipStream_t s) {
     return gemm_ex(ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, upper, s);
+}
+
+// the same with a triangular operand: the inverse of a diagonal factor block is upper triangular, so op(A) = U^-1 is upper (1),
+// op(A) = U^-T lower (2), op(B) = U^-T lower (8) -- the products skip the K tiles that are structurally zero
+inline int gemm_tri(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb, double beta, double* C,
+                    int ldc, int tri, hipStream_t s) {
+    return gemm_ex_tri(ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, false, tri, s);
 }
 
 struct Scratch {                       // stream-ordered scratch, released when the call returns
@@ -142,7 +151,7 @@ extern "C" int shg_block_potrf_rows(int nb, const int* bounds, const int* rowptr
         // W_rc = U_rr^-T A_rc, through the panel scratch (the product cannot overwrite its own operand)
         for (int e = e0 + 1; e < e1; ++e) {
             const int dc = V.size(colidx[e]);
-            rc = gemm(true, false, dr, dc, dr, 1.0, inv[r], dr, blk[e], dc, 0.0, panel, dc, false, stream);
+            rc = gemm_tri(true, false, dr, dc, dr, 1.0, inv[r], dr, blk[e], dc, 0.0, panel, dc, 2, stream);
             if (rc) return rc;
             SHG_HIP(hipMemcpyAsync(blk[e], panel, (size_t)dr * dc * sizeof(double), hipMemcpyDeviceToDevice, stream));
         }
@@ -185,7 +194,7 @@ extern "C" int shg_block_solve(int nb, const int* bounds, const int* rowptr, con
     if (transpose) {
         for (int r = 0; r < nb; ++r) {
             const int dr = V.size(r);
-            rc = gemm(true, false, dr, k, dr, 1.0, inv[r], dr, rows(r), ldb, 0.0, tmp, k, false, stream);           // x_r = U_rr^-T b_r
+            rc = gemm_tri(true, false, dr, k, dr, 1.0, inv[r], dr, rows(r), ldb, 0.0, tmp, k, 2, stream);             // x_r = U_rr^-T b_r
             if (rc) return rc;
             SHG_HIP(hipMemcpy2DAsync(rows(r), (size_t)ldb * sizeof(double), tmp, (size_t)k * sizeof(double), (size_t)k * sizeof(double), dr,
                                      hipMemcpyDeviceToDevice, stream));
@@ -205,7 +214,7 @@ extern "C" int shg_block_solve(int nb, const int* bounds, const int* rowptr, con
                 rc = gemm(false, false, dr, k, V.size(c), -1.0, Wrc, V.size(c), rows(c), ldb, 1.0, rows(r), ldb, false, stream);  // b_r -= W_rc x_c
                 if (rc) return rc;
             }
-            rc = gemm(false, false, dr, k, dr, 1.0, inv[r], dr, rows(r), ldb, 0.0, tmp, k, false, stream);           // x_r = U_rr^-1 b_r
+            rc = gemm_tri(false, false, dr, k, dr, 1.0, inv[r], dr, rows(r), ldb, 0.0, tmp, k, 1, stream);             // x_r = U_rr^-1 b_r
             if (rc) return rc;
             SHG_HIP(hipMemcpy2DAsync(rows(r), (size_t)ldb * sizeof(double), tmp, (size_t)k * sizeof(double), (size_t)k * sizeof(double), dr,
                                      hipMemcpyDeviceToDevice, stream));
@@ -236,17 +245,17 @@ extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, const int* ro
         const int e0 = V.begin(r), e1 = V.end(r);
         for (int e = e0 + 1; e < e1; ++e) {
             const int dk = V.size(colidx[e]);
-            rc = gemm(false, false, dr, dk, dr, 1.0, inv[r], dr, blk[e], dk, 0.0, T(e, r), dk, false, stream);
+            rc = gemm_tri(false, false, dr, dk, dr, 1.0, inv[r], dr, blk[e], dk, 0.0, T(e, r), dk, 1, stream);
             if (rc) return rc;
             SHG_HIP(hipMemsetAsync(blk[e], 0, (size_t)dr * dk * sizeof(double), stream));
         }
         if (inv[r] == blk[e0]) {                                                                                       // (inverse kept in the diagonal block itself)
             double* zrr = T(e0 + 1 + most_slot, r);
-            rc = gemm(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, zrr, dr, false, stream);
+            rc = gemm_tri(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, zrr, dr, 9, stream);
             if (rc) return rc;
             SHG_HIP(hipMemcpyAsync(blk[e0], zrr, (size_t)dr * dr * sizeof(double), hipMemcpyDeviceToDevice, stream));
         } else {
-            rc = gemm(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, blk[e0], dr, false, stream);           // Z_rr = U^-1 U^-T ...
+            rc = gemm_tri(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, blk[e0], dr, 9, stream);            // Z_rr = U^-1 U^-T ...
         }
         if (rc) return rc;
         for (int f = e1 - 1; f >= e0; --f) {                                                                           // ... and the row, last block first
