@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('SHG_LIBRARY', os.path.join(_HERE, 'lib', 'libshg.so'))      # override: A/B timing of two builds
+LIB_PATH = os.path.join(_HERE, 'lib', 'libshg.so')      # the one library the package loads; no environment override
 
 c_double_p = ctypes.c_void_p     # device or host pointer passed as integer address
 c_plan_p = ctypes.c_void_p
@@ -71,6 +71,16 @@ PROTOTYPES = {
 STRING_GETTERS = ('shg_last_error', 'shg_version')
 
 _lib = None
+
+
+def use_library(path):
+    """Profiling tools only (tools/timeline.py, tools/gemm_phases.py): load an instrumented build (`make timeline`) instead of
+    libshg.so.  Must be called before the first library call of the process; the product never calls it and no environment
+    variable selects a library."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError('libshg is already loaded from ' + LIB_PATH)
+    LIB_PATH = os.path.abspath(path)
 
 
 def load():

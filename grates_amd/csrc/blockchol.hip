@@ -89,13 +89,15 @@ struct Scratch {                       // stream-ordered scratch, released when 
 int check(const BlockView& V, double* const* inv, const char* who) {
     SHG_REQUIRE(V.nb >= 0 && V.bounds && V.rowptr && (V.nb == 0 || (V.colidx && V.blk)), "%s: NULL block table", who);
     SHG_REQUIRE(V.nb == 0 || V.rowptr[0] == 0, "%s: rowptr must start at 0", who);
+    SHG_REQUIRE(V.nb == 0 || inv != nullptr, "%s: NULL table of scratch matrices for the inverses of the diagonal factor blocks", who);
+    SHG_REQUIRE(V.nb == 0 || inv != nullptr, "%s: NULL table of scratch matrices for the inverses of the diagonal factor blocks", who);
     for (int i = 0; i < V.nb; ++i) {
         SHG_REQUIRE(V.size(i) > 0, "%s: empty block row %d", who, i);
         SHG_REQUIRE(V.end(i) > V.begin(i) && V.colidx[V.begin(i)] == i && V.blk[V.begin(i)] != nullptr, "%s: diagonal block %d is missing", who, i);
         for (int e = V.begin(i) + 1; e < V.end(i); ++e)
             SHG_REQUIRE(V.colidx[e] > V.colidx[e - 1] && V.colidx[e] < V.nb && V.blk[e] != nullptr,
                         "%s: block row %d: columns must ascend from the diagonal, inside the matrix, with non-NULL blocks", who, i);
-        SHG_REQUIRE(!inv || inv[i] != nullptr, "%s: scratch for the inverse of diagonal block %d is missing", who, i);
+        SHG_REQUIRE(inv[i] != nullptr, "%s: scratch for the inverse of diagonal block %d is missing", who, i);
     }
     return SHG_OK;
 }

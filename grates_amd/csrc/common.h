@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -41,6 +42,21 @@ hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream);    // 
     do {                                                                                           \
         if (!(cond)) return shg::fail(SHG_ERR_INVALID, __VA_ARGS__);                               \
     } while (0)
+
+// Knock-out switches for timing experiments (results are wrong with any of them on) exist in -DSHG_EXPERIMENT builds only
+// (`make timeline` -> libshg_timeline.so, never loaded by the package): the shipping library reads no environment variable.
+#ifdef SHG_EXPERIMENT
+#define SHG_DBG(P, bits) ((P).dbg & (bits))
+inline int experiment_switches() {
+    const char* e = getenv("SHG_DEBUG");
+    return e ? atoi(e) : 0;
+}
+#else
+#define SHG_DBG(P, bits) 0
+#if (defined(SHG_ROT_X) && SHG_ROT_X) || (defined(SHG_GEMM_X) && SHG_GEMM_X) || (defined(SHG_ANA_X) && SHG_ANA_X)
+#error "SHG_ROT_X / SHG_GEMM_X / SHG_ANA_X are timing experiments: build with -DSHG_EXPERIMENT (make timeline)"
+#endif
+#endif
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

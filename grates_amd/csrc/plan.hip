@@ -57,17 +57,27 @@ struct ScratchBuffer {
 };
 struct StreamScratch {
     std::recursive_mutex mtx;
+    int device = 0;
     std::map<int, ScratchBuffer> slots;
 };
+// Keyed by (device, stream): the default stream is the null handle on every device, and a buffer allocated on one device must
+// never be handed to a kernel of another.  Entries are created once and never erased, so a pointer to one stays valid.
+// Lock order: g_scratch_mutex is only ever held for the map lookup itself and never while a stream mutex is taken -- a nested
+// lease (shg_analysis -> gemm_ex) and a concurrent shg_scratch_release() can then not wait for each other in a cycle.
 std::mutex g_scratch_mutex;
-std::map<hipStream_t, std::unique_ptr<StreamScratch>> g_scratch;
+std::map<std::pair<int, hipStream_t>, std::unique_ptr<StreamScratch>> g_scratch;
 }  // namespace
 
 ScratchLease::ScratchLease(hipStream_t stream) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     {
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
-        std::unique_ptr<StreamScratch>& e = g_scratch[stream];
-        if (!e) e.reset(new StreamScratch);
+        std::unique_ptr<StreamScratch>& e = g_scratch[std::make_pair(dev, stream)];
+        if (!e) {
+            e.reset(new StreamScratch);
+            e->device = dev;
+        }
         owner_ = e.get();
     }
     static_cast<StreamScratch*>(owner_)->mtx.lock();
@@ -93,13 +103,22 @@ void* ScratchLease::get(int slot, size_t bytes) {
 }
 
 void stream_scratch_release() {
-    std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    for (auto& kv : g_scratch) {
-        std::lock_guard<std::recursive_mutex> hold(kv.second->mtx);
-        for (auto& b : kv.second->slots)
-            if (b.second.ptr) (void)hipFree(b.second.ptr);
-        kv.second->slots.clear();
+    std::vector<StreamScratch*> entries;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        for (auto& kv : g_scratch) entries.push_back(kv.second.get());
     }
+    int current = 0;
+    (void)hipGetDevice(&current);
+    for (StreamScratch* e : entries) {
+        std::lock_guard<std::recursive_mutex> hold(e->mtx);
+        if (e->slots.empty()) continue;
+        (void)hipSetDevice(e->device);
+        for (auto& b : e->slots)
+            if (b.second.ptr) (void)hipFree(b.second.ptr);
+        e->slots.clear();
+    }
+    (void)hipSetDevice(current);
 }
 
 // a_nm / b_nm of  P_nm = (a_nm t) P_(n-1)m - b_nm P_(n-2)m   in packed order-major layout.

@@ -178,6 +178,12 @@ int covprop_generic(const double* pkd, int ldp, const double* csr, int ldcs, con
 
 using namespace shg;
 
+// points per pass: 2 GB of Legendre table, and at most 65535 point tiles of 32 (grid.y of the generation and transpose kernels)
+static int point_chunk(int npts, int Pfull) {
+    const long long by_memory = std::max<long long>(128, ((1LL << 31) / 8 / Pfull) / 128 * 128);
+    return (int)std::min<long long>(std::min<long long>(npts, 65535LL * 32), by_memory);
+}
+
 extern "C" int shg_synthesis_points(int N, const double* colat, const double* lon, const double* kn, int npts, const double* anm,
                                     int B, double* values, void* stream_) {
     SHG_REQUIRE(N >= 0 && npts >= 0 && B >= 0, "shg_synthesis_points: negative size");
@@ -202,7 +208,7 @@ extern "C" int shg_synthesis_points(int N, const double* colat, const double* lo
     // recursion runs once per point instead of once per point and group of 16 epochs.
     if (B >= 48) {
         const int Pfull = (N + 1) * (N + 1);
-        const int chunk = (int)std::min<long long>(npts, std::max<long long>(128, ((1LL << 31) / 8 / Pfull) / 128 * 128));    // 2 GB of Legendre table
+        const int chunk = point_chunk(npts, Pfull);
         double *X = nullptr, *xr = nullptr, *pkT = nullptr, *csr = nullptr, *Cc = nullptr;
         int* rslot = nullptr;
         int rc = SHG_OK;
@@ -290,7 +296,7 @@ extern "C" int shg_synthesis_matrix(int N, int nmin, const double* colat, const 
     hipStream_t stream = (hipStream_t)stream_;
     std::vector<double> a, b;
     recursion_tables(N, a, b);
-    const int chunk = (int)std::min<long long>(npts, std::max<long long>(128, ((1LL << 31) / 8 / Pfull) / 128 * 128));    // 2 GB of Legendre table
+    const int chunk = point_chunk(npts, Pfull);
     double *pkT = nullptr, *csr = nullptr, *knT = nullptr, *tab = nullptr;
     int* rslot = nullptr;
     int rc = SHG_OK;

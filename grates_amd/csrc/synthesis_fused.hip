@@ -202,7 +202,9 @@ struct FusedParams {
     int gcount[4];            // used slots per group (the rest up to goff[g+1] is zero padding)
     int ns, nh;               // north-south symmetric variant: blocks of 8 northern parallels + mirrors; nh = nlat / 2
     int slot0;                // panel slot of order 0 when it is folded out of the K loop (start value of the accumulators), or -1
+#ifdef SHG_EXPERIMENT
     int dbg;                  // experiment switches (SHG_DEBUG): 1 no stores, 2 no Legendre phase, 4 no longitude phase, 8 no longitude MFMAs
+#endif
     int Qtot;                 // row octets of the fragment-ordered tables
     const int* qoff;          // [N+2]
     const double* cpk4;       // [nbt][Qtot][32][2]
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
 
     // ---- phase 1: Legendre stage.  Orders are distributed over the 8 waves; items of 4 k-steps are double
     //      buffered in two named register sets so that the fragments of item t+1 are in flight while item t runs.
-    if (!(P.dbg & 2)) {
+    if (!SHG_DBG(P, 2)) {
         // plain layout: octet = 8 degrees, A rows 8-15 are zero (not stored);  NS layout: octet = 16 degrees, all 16 rows used
         constexpr int ASTRIDE = NS ? 128 : 64;                        // doubles per octet of the coefficient table
         // Bookkeeping on the scalar unit, as in synthesis_rot.hip (see there for the measurement): records through scalar loads,
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
     const int grid_bytes = P.nlat * P.nlon * 8;        // one epoch's grid; < 2^31 (checked on the host)
     const int par = fr & 1;
     const size_t cb_stride = (size_t)8 * P.K * 16;
-    for (int ccb = 0; ccb < P.ncb && !(P.dbg & 4); ++ccb) {
+    for (int ccb = 0; ccb < P.ncb && !SHG_DBG(P, 4); ++ccb) {
         double4_t acc[4][4];
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg)
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
         }
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
-            for (int body = P.goff[gg] >> 4; body < (P.goff[gg + 1] >> 4) && !(P.dbg & 8); ++body) {
+            for (int body = P.goff[gg] >> 4; body < (P.goff[gg + 1] >> 4) && !SHG_DBG(P, 8); ++body) {
                 // next body of the flat (column block, body) sequence; clamped at the very end
                 int nb_ = body + 1, ncb_ = ccb;
                 if (nb_ == nbody) {
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(512) void synthesis_fused_kernel(FusedParams P) {
                 img[2][r] = s2 - d2;
                 img[3][r] = s2 + d2;
             }
-            if (P.dbg & 1) {
+            if (SHG_DBG(P, 1)) {
                 if (img[0][0] != 1.2345e-300) continue;
             }
             if (pair_stores) {
@@ -786,8 +788,9 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     const int N = p->N;
     const int cnt[4] = {N / 2 + (fold ? 0 : 1), (N + 1) / 2, N / 2, (N + 1) / 2};
     for (int g = 0; g < 4; ++g) P.gcount[g] = cnt[g];
-    const char* dbg_env = getenv("SHG_DEBUG");
-    P.dbg = dbg_env ? atoi(dbg_env) : 0;
+#ifdef SHG_EXPERIMENT
+    P.dbg = experiment_switches();
+#endif
     P.Qtot = p->Qtot;
     P.qoff = p->qoff;
     P.cpk4 = p->cpk4;
@@ -797,7 +800,7 @@ int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStre
     P.nrec = p->itemtab_nrec;
     P.ntrip = p->itemtab_ntrip;
     P.blockmap = nullptr;
-    if (!(P.dbg & 2048)) {                             // SHG_DEBUG bit 11: plain block order (experiment switch)
+    if (!SHG_DBG(P, 2048)) {                             // SHG_DEBUG bit 11: plain block order (experiment switch)
         rc = build_blockmap(p, nbt, nit, stream);
         if (rc) return rc;
         P.blockmap = p->blockmap_d;

@@ -58,7 +58,9 @@ struct Fused32Params {
     int N, nlat, nlon, K, ncol, B, nit, ncb, nh, Qtot;
     int goff[5];
     int gcount[4];
+#ifdef SHG_EXPERIMENT
     int dbg;
+#endif
     const int* qoff;
     const int* badmap;        // [nit]
     const double* cpk4;       // [nbt][Qtot][64][2]  (pack_coefficients4_ns_kernel)
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void synthesis_fused32_kernel(Fused32Params
 
     // ---- phase 1: Legendre stage (see synthesis_fused.hip; NS layout, 4 parallels per block: columns 0-3 / 8-11 of the
     //      MFMA tile carry the even / odd degree sums of the 4 northern parallels)
-    if (!(P.dbg & 2)) {
+    if (!SHG_DBG(P, 2)) {
         const int bad = P.badmap[it];
         const double* pkb = P.pkf + ((size_t)it * P.Qtot * 64 + lane) * 2;
         const double* cf = P.cpk4 + ((size_t)bt * P.Qtot * 64 + lane) * 2;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void synthesis_fused32_kernel(Fused32Params
     rb1 = tbase[ct_stride + 64];
     rb2 = tbase[ct_stride + 128];
     rb3 = tbase[ct_stride + 192];
-    for (int ccb = 0; ccb < P.ncb && !(P.dbg & 4); ++ccb) {
+    for (int ccb = 0; ccb < P.ncb && !SHG_DBG(P, 4); ++ccb) {
         double4_t acc[4][2][2];                        // [group][column tile][row tile]
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg)
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void synthesis_fused32_kernel(Fused32Params
                 for (int rt = 0; rt < 2; ++rt) acc[gg][ct][rt] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
-            for (int body = P.goff[gg] >> 4; body < (P.goff[gg + 1] >> 4) && !(P.dbg & 8); ++body) {
+            for (int body = P.goff[gg] >> 4; body < (P.goff[gg + 1] >> 4) && !SHG_DBG(P, 8); ++body) {
                 int nb_ = body + 1, ncb_ = ccb;        // next body of the flat (column block, body) sequence; clamped at the very end
                 if (nb_ == nbody) {
                     nb_ = 0;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void synthesis_fused32_kernel(Fused32Params
                     img[2][r] = s2 - d2;
                     img[3][r] = s2 + d2;
                 }
-                if (P.dbg & 1) {
+                if (SHG_DBG(P, 1)) {
                     if (img[0][0] != 1.2345e-300) continue;
                 }
                 const bool rowok = i0n + fk < P.nh;
@@ -403,8 +405,9 @@ int synthesis_fused32(shg_plan* p, const double* anm, int B, double* grid, hipSt
     for (int g = 0; g < 5; ++g) P.goff[g] = p->goff[g];
     const int cnt[4] = {N / 2 + 1, (N + 1) / 2, N / 2, (N + 1) / 2};
     for (int g = 0; g < 4; ++g) P.gcount[g] = cnt[g];
-    const char* dbg_env = getenv("SHG_DEBUG");
-    P.dbg = dbg_env ? atoi(dbg_env) : 0;
+#ifdef SHG_EXPERIMENT
+    P.dbg = experiment_switches();
+#endif
     P.qoff = p->qoff32;
     P.badmap = p->badmap32_d;
     P.cpk4 = p->cpk4;

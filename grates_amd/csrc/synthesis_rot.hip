@@ -78,7 +78,9 @@ struct RotParams {
     int cls_nk[kMaxClasses];  // k-steps (4 orders each) of the classes in K order; their panel slots follow each other: class c starts at 4 * (nk[0] + .. + nk[c-1])
     int cls_cnt[kMaxClasses]; // orders in each class (the slots up to 4 * cls_nk are zero padding)
     int nslot;                // panel slots of the orders >= 1 = 4 * npieces; order 0 sits in slot nslot
+#ifdef SHG_EXPERIMENT
     int dbg;                  // experiment switches (SHG_DEBUG): 1 no stores, 2 no Legendre stage, 4 no longitude stage
+#endif
     int Qtot;
     const double* cpk4;       // repacked coefficients (see synthesis_fused.hip), S_nm negated where s_m = -1
     const double* pkf;
@@ -352,7 +354,7 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
         for (int r = 0; r < 4; ++r) rot_images<R>(acc, r);      // (unconditional: a run-time switch around an in-place update of the
                                                                 //  accumulator vectors makes hipcc copy every vector, ~60 moves per row)
         const int b = bt * 4 + rt;
-        const bool epoch_ok = b < P.B && !(P.dbg & 1);
+        const bool epoch_ok = b < P.B && !SHG_DBG(P, 1);
         double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
         {
             // lanes (2 q, 2 q + 1) hold adjacent columns: after the exchange every lane owns two rows x two adjacent columns and
@@ -552,13 +554,13 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
     for (int d = 0; d < kRingDepth; ++d) rot_issue_piece(S, P, (unsigned)lane * 16u);
 
     // ---- phase 1: Legendre stage.  Orders are distributed over the waves of the workgroup.
-    if (!(P.dbg & 2)) rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
+    if (!SHG_DBG(P, 2)) rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
     ROT_STAMP(1);
     __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
     ROT_STAMP(2);
 
     // ---- phase 2: longitude stage
-    if ((wave >> 2) < P.nct && !(P.dbg & 4)) {
+    if ((wave >> 2) < P.nct && !SHG_DBG(P, 4)) {
         const double2_t* const ringp = reinterpret_cast<const double2_t*>(As) + wave * (kRingSlots * 64) + lane;
         rot_issue_piece(S, P, (unsigned)lane * 16u);       // fragments of the first k-step
         wait_vmcnt<kRingDepth>();
@@ -721,8 +723,9 @@ int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream
     P.nct = ceil_div(P.nd, 16);
     P.nslot = rot_layout(R, p->N, P.cls_nk, P.cls_cnt, nullptr);
     P.npieces = P.nslot / 4;
-    const char* dbg_env = getenv("SHG_DEBUG");
-    P.dbg = dbg_env ? atoi(dbg_env) : 0;
+#ifdef SHG_EXPERIMENT
+    P.dbg = experiment_switches();
+#endif
     P.Qtot = p->Qtot;
     P.cpk4 = p->cpk4;
     P.pkf = p->pkf;
@@ -731,7 +734,7 @@ int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream
     P.ntrip = p->itemtab_ntrip;
     P.badmap = p->badmap_d;
     P.blockmap = nullptr;
-    if (!(P.dbg & 2048)) {
+    if (!SHG_DBG(P, 2048)) {
         rc = build_blockmap(p, nbt, nit, stream);
         if (rc) return rc;
         P.blockmap = p->blockmap_d;

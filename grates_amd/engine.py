@@ -302,6 +302,9 @@ class BlockTable:
         self.bounds = np.ascontiguousarray(bounds, dtype=np.int32)
         nb = self.bounds.size - 1
         keys = sorted(k for k in blocks if k[1] >= k[0])
+        for k in keys:                   # csrc/blockchol.hip reads every block as dense row-major with ld = columns
+            if not blocks[k].is_contiguous():
+                raise ValueError('block {0} is not a contiguous row-major tensor (strides {1})'.format(k, tuple(blocks[k].stride())))
         self.rowptr = np.zeros(nb + 1, dtype=np.int32)
         for i, _ in keys:
             self.rowptr[i + 1] += 1
@@ -313,6 +316,12 @@ class BlockTable:
     def args(self):
         as_ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
         return self.nb, as_ptr(self.bounds), as_ptr(self.rowptr), as_ptr(self.colidx), as_ptr(self.address)
+
+
+def _require_row_major(B, name):
+    if B.dim() != 2 or (B.shape[1] > 1 and B.stride(1) != 1):
+        raise ValueError('{0}: a two-dimensional tensor with a contiguous last dimension is expected (shape {1}, strides {2})'.format(
+            name, tuple(B.shape), tuple(B.stride())))
 
 
 def block_potrf(table, inverses, first=0, last=None):
@@ -327,6 +336,7 @@ def block_potrf(table, inverses, first=0, last=None):
 
 def block_solve(table, inverses, transpose, B):
     """B [n, k] <- W^-1 B or W^-T B in place (device tensor, contiguous last dimension)."""
+    _require_row_major(B, 'block_solve')
     inverses, pi = _table(inverses)
     _lib.call('shg_block_solve', *table.args(), pi, 1 if transpose else 0, _ptr(B), B.shape[1], max(B.stride(0), 1), _stream())
     return B
@@ -345,7 +355,8 @@ def block_inverse(table, inverses):
 def block_multiply(table, mode, B):
     """mode 0: W B, 1: the reference's W^T B (assigning form), 2: N B with the upper blocks of a symmetric N."""
     torch = require_gpu()
-    out = torch.empty_like(B)
+    _require_row_major(B, 'block_multiply')
+    out = torch.empty((B.shape[0], B.shape[1]), dtype=B.dtype, device=B.device)
     _lib.call('shg_block_multiply', *table.args(), int(mode), _ptr(B), B.shape[1], max(B.stride(0), 1), _ptr(out), max(out.stride(0), 1), _stream())
     return out
 

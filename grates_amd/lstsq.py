@@ -30,7 +30,7 @@ def _dev(x):
     """fp64 device tensor (copy) of an ndarray / tensor"""
     torch = engine.require_gpu()
     if torch.is_tensor(x):
-        return x.to(device=engine.device(), dtype=torch.float64).clone()
+        return x.to(device=engine.device(), dtype=torch.float64).clone(memory_format=torch.contiguous_format)   # dense row-major, whatever the strides of x
     return engine.to_device(np.asarray(x, dtype=np.float64))
 
 
@@ -230,13 +230,23 @@ class BlockMatrix:
         self.__data = {}
         self.__inverse_factor = {}      # diagonal index -> inverse of the upper triangular factor block
         self._inverse_in_place = False  # the factorisation keeps U_ii^-1 in the diagonal blocks instead of U_ii (distributed chains)
+        self._holds_factor_inverses = False   # ... and has done so: the diagonal blocks currently hold U_ii^-1
 
     def copy(self):
         """Deep copy of BlockMatrix"""
         output = BlockMatrix(self.__row_index, self.__column_index)
         for key, block in self.__data.items():
             output.__data[key] = block.clone()
+        output._inverse_in_place = self._inverse_in_place
+        output._holds_factor_inverses = self._holds_factor_inverses
         return output
+
+    def __require_plain_factor(self, operation):
+        """A chain factored with `_inverse_in_place` keeps U_ii^-1 where the reference's class keeps U_ii: only the solves and the
+        sparse inverse understand that state."""
+        if self._holds_factor_inverses:
+            raise ValueError('{0}: the diagonal blocks hold the inverses of the factor blocks (in-place factorisation of '
+                             'grates_amd.distributed); only solve_triangular and sparse_inverse are defined in this state'.format(operation))
 
     @staticmethod
     def compute_block_index(array_shape, block_size):
@@ -301,8 +311,8 @@ class BlockMatrix:
         self._set_device(key[0], key[1], _dev(value))
 
     def _set_device(self, i, j, tensor):
-        """store a device tensor as block (i, j) without copying it"""
-        self.__data[(int(i), int(j))] = tensor
+        """store a device tensor as block (i, j); no copy when it is dense row-major (what csrc/blockchol.hip assumes of every block)"""
+        self.__data[(int(i), int(j))] = tensor if tensor.is_contiguous() else tensor.contiguous()
         if i == j:
             self.__inverse_factor.pop(int(i), None)
 
@@ -393,6 +403,7 @@ class BlockMatrix:
         self.__allocate_fill()
         self.__inverse_factor.clear()
         pivot = engine.block_potrf(self.__block_table(), self.__inverse_table())
+        self._holds_factor_inverses = self._inverse_in_place
         if pivot:
             raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(pivot))
 
@@ -404,6 +415,7 @@ class BlockMatrix:
             self.__allocate_fill()
             self.__inverse_factor.clear()
         pivot = engine.block_potrf(self.__block_table(), self.__inverse_table(), first, last)
+        self._holds_factor_inverses = self._inverse_in_place
         if pivot:
             raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(pivot))
 
@@ -414,6 +426,7 @@ class BlockMatrix:
     def multiply_triangular(self, b, transpose=False):
         """v = W b or v = W^T b with the upper triangular factor (grates/lstsq.py:719-750).  As upstream, the transposed
         branch assigns instead of accumulating (lstsq.py:743)."""
+        self.__require_plain_factor('multiply_triangular')
         bd = self.__vector(b)
         v = engine.block_multiply(self.__block_table(), 1 if transpose else 0, bd)
         return _like_input(v, b)
@@ -435,7 +448,7 @@ class BlockMatrix:
         by cholesky(): grates/lstsq.py:807, 817 invert / solve with the diagonal blocks on the fly)"""
         for i in range(self.shape[0]):
             if i not in self.__inverse_factor:
-                self.__inverse_factor[i] = engine.trtri(self.__data[(i, i)])
+                self.__inverse_factor[i] = self.__data[(i, i)] if self._holds_factor_inverses else engine.trtri(self.__data[(i, i)])
 
     def sparse_inverse(self):
         """
@@ -446,12 +459,14 @@ class BlockMatrix:
         engine.block_sparse_inverse(self.__block_table(), self.__inverse_table())
         self.__inverse_factor.clear()
         self._inverse_in_place = False
+        self._holds_factor_inverses = False
 
     def inverse(self):
         """
         Full inverse N^-1 = W^-1 W^-T from the Cholesky factor W held by the matrix, in place, upper triangle
         (grates/lstsq.py:848-882).
         """
+        self.__require_plain_factor('inverse')
         nb = self.shape[0]
         for i in range(nb):
             for j in range(i, nb):
@@ -462,12 +477,15 @@ class BlockMatrix:
 
     def _scale(self, value):
         """Scale whole matrix with a factor."""
+        self.__require_plain_factor('_scale')
         for block in self.__data.values():
             engine.axpby(value, block, 0.0, block)
         self.__inverse_factor.clear()
 
     def _axpy(self, factor, other):
         """Perform self += factor * other."""
+        self.__require_plain_factor('_axpy')
+        other.__require_plain_factor('_axpy')
         for key, block in other.__data.items():
             if key in self.__data:
                 engine.axpby(factor, block, 1.0, self.__data[key])

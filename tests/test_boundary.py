@@ -88,3 +88,43 @@ def test_header_is_plain_c(tmp_path):
     src = tmp_path / 'use_shg.c'
     src.write_text('#include "shg.h"\nint main(void) { shg_plan* p = 0; return shg_plan_destroy(p) + (int)sizeof(shg_status) * 0; }\n')
     subprocess.run([gcc, '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)], check=True)
+
+
+def test_shipping_library_has_no_experiment_switches(monkeypatch):
+    """The timing knock-outs of the profiling builds (SHG_DEBUG, SHG_ROT_X, SHG_GEMM_X, SHG_ANA_X) are compiled out of
+    libshg.so: it reads no environment variable at all, and the package loads exactly one library whatever SHG_LIBRARY says."""
+    import subprocess
+    from grates_amd import _lib
+    undefined = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert 'getenv' not in undefined
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    for name in (b'SHG_DEBUG', b'SHG_TIMELINE_PTR', b'SHG_LIBRARY'):
+        assert name not in blob, name
+    monkeypatch.setenv('SHG_LIBRARY', '/nonexistent/libother.so')
+    import importlib
+    fresh = importlib.reload(_lib)
+    try:
+        assert fresh.LIB_PATH == os.path.join(ROOT, 'grates_amd', 'lib', 'libshg.so')
+    finally:
+        monkeypatch.delenv('SHG_LIBRARY')
+        importlib.reload(_lib)
+    for fn in os.listdir(os.path.join(ROOT, 'grates_amd', 'csrc')):
+        if fn.endswith(('.hip', '.h')):
+            text = open(os.path.join(ROOT, 'grates_amd', 'csrc', fn)).read()
+            for m in re.finditer(r'getenv\(', text):
+                guard = text.rfind('#ifdef SHG_', 0, m.start())
+                assert guard >= 0 and text[guard:m.start()].count('#endif') == 0, fn + ' calls getenv outside an experiment / timeline build'
+
+
+def test_block_calls_reject_null_inverse_table():
+    """A NULL table of inverse scratch matrices is an argument error, not a segfault (checked before any HIP call)."""
+    from grates_amd import _lib
+    lib = _lib.load()
+    bounds = (ctypes.c_int * 2)(0, 3)
+    rowptr = (ctypes.c_int * 2)(0, 1)
+    colidx = (ctypes.c_int * 1)(0)
+    blocks = (ctypes.c_uint64 * 1)(0x1000)
+    as_p = lambda a: ctypes.cast(a, ctypes.c_void_p)      # noqa: E731
+    for name, tail in (('shg_block_solve', (0, None, 1, 1, None)), ('shg_block_sparse_inverse', (None,)), ('shg_block_inverse', (None,))):
+        status = getattr(lib, name)(1, as_p(bounds), as_p(rowptr), as_p(colidx), as_p(blocks), None, *tail)
+        assert status == -1 and b'inverses' in lib.shg_last_error(), name

@@ -141,8 +141,8 @@ def test_full_size_config5_product_path():
     """BASELINE config 5 at its stated size through the product entry point: 3650 daily epochs of a d/o-40 state (d = 1681),
     solution and covariance blocks from ONE factorisation (smooth_block_tridiagonal_partitioned, world size 1: the chain is
     eliminated from both ends at once on two streams).  The factorisation works in the caller's blocks (consume=True) and keeps
-    the inverses of the diagonal factor blocks in those blocks' own storage: 2 x 82.5 GB (a card with less free memory gets a
-    shorter chain, never below 64 epochs).
+    the inverses of the diagonal factor blocks in those blocks' own storage: 2 x 82.5 GB (skipped, never shortened, on a card
+    with less free memory).
     Checked through properties that need no reference run, with the blocks regenerated from their seeds: the residual of the
     solution, symmetry of the covariance blocks and (N N^-1)_tt = I at sample epochs including the ones around the meeting point."""
     import json
@@ -151,8 +151,9 @@ def test_full_size_config5_product_path():
     from test_gpu_lstsq import _config5_blocks
     d, T = 1681, 3650
     free, _ = torch.cuda.mem_get_info()
-    T = min(T, int((free - 30e9) // (2 * d * d * 8)))
-    assert T >= 64, 'not enough free device memory for a 64-epoch chain'
+    if int((free - 30e9) // (2 * d * d * 8)) < T:
+        pytest.skip('config 5 at its stated size needs {0:.0f} GB of free device memory, {1:.0f} GB are free'.format(
+            (2 * T * d * d * 8 + 30e9) / 1e9, free / 1e9))
     gen = torch.Generator(device='cuda')
     gen.manual_seed(49_999)
     rhs = torch.randn((T * d, 1), dtype=torch.float64, device='cuda', generator=gen)

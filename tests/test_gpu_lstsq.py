@@ -226,7 +226,7 @@ def test_full_size_config5_chain():
     """BASELINE config 5 at its stated size: 3650 daily epochs of a d/o-40 state (d = 1681), VAR(1) coupling, solved with the
     1 + 100 right-hand sides of NormalEquations.solve and followed by the sparse inverse (grates/lstsq.py:950-968, 1026-1042).
     The chain is built on the device from per-epoch seeds (3 x 82.5 GB: matrix, coupling blocks, inverses of the diagonal factor
-    blocks; on a card with less free memory the chain is shortened, never below 64 epochs) and checked through properties that
+    blocks; the test is skipped, never shortened, when that does not fit) and checked through properties that
     need no reference run: the residual ||N x - n|| / ||n|| with N regenerated from the seeds, symmetry of the covariance
     blocks and the identity (N N^-1)_tt = I, which for a block-tridiagonal N only involves blocks of the sparse inverse."""
     import json
@@ -236,8 +236,9 @@ def test_full_size_config5_chain():
     d, T = 1681, 3650
     free, _ = torch.cuda.mem_get_info()
     fit = int((free - 30e9) // (3 * d * d * 8))          # 30 GB for the right-hand sides, the scratch and the checks
-    T = min(T, fit)
-    assert T >= 64, 'not enough free device memory for a 64-epoch chain'
+    if fit < T:
+        pytest.skip('config 5 at its stated size needs {0:.0f} GB of free device memory, {1:.0f} GB are free'.format(
+            (3 * T * d * d * 8 + 30e9) / 1e9, free / 1e9))
     gen = torch.Generator(device='cuda')
     idx = np.arange(0, (T + 1) * d, d)
     bm = ls.BlockMatrix(idx, idx)
@@ -341,3 +342,47 @@ def test_block_table_validation():
     x = torch.ones((12, 2), dtype=torch.float64, device='cuda')
     with pytest.raises(Exception):
         eng.block_solve(good, np.array([0, 0, 0], dtype=np.uint64), False, x)      # no scratch for the inverses
+
+
+def test_blocks_with_foreign_strides_and_in_place_factor_state():
+    """csrc/blockchol.hip reads every block as dense row-major.  Blocks assigned as transposed views (tensor or ndarray) are
+    stored contiguously, a table built from a non-contiguous tensor is refused, right-hand sides need a contiguous last
+    dimension, and a chain that keeps U_ii^-1 in place of U_ii refuses the operations that would read those blocks as U_ii."""
+    import torch
+    eng = ga.engine
+    rng = np.random.default_rng(5)
+    d = 37
+    G = rng.standard_normal((2 * d, 2 * d + 3))
+    N = G @ G.T / d + 2.0 * np.eye(2 * d)
+    idx = np.array([0, d, 2 * d])
+    bm = ls.BlockMatrix(idx, idx)
+    bm[0, 0] = N[:d, :d]
+    bm._set_device(0, 1, torch.from_numpy(np.ascontiguousarray(N[d:, :d])).cuda().t())       # a transposed view of N[1, 0]
+    bm[1, 1] = torch.from_numpy(np.ascontiguousarray(N[d:, d:].T)).cuda().t()                # the same through __setitem__
+    assert all(bm.device_block(i, j).is_contiguous() for i, j in ((0, 0), (0, 1), (1, 1)))
+    rhs = rng.standard_normal((2 * d, 3))
+    bm.cholesky()
+    x = bm.solve_triangular(bm.solve_triangular(rhs, transpose=True))
+    assert relerr(x, np.linalg.solve(N, rhs)) < TOL
+    with pytest.raises(ValueError):
+        eng.BlockTable(idx, {(0, 0): torch.ones((d, 2 * d), dtype=torch.float64, device='cuda')[:, ::2]})
+    wide = torch.ones((2 * d, 6), dtype=torch.float64, device='cuda')
+    with pytest.raises(ValueError):
+        eng.block_solve(eng.BlockTable(idx, {(i, i): bm.device_block(i, i) for i in (0, 1)}), np.zeros(2, dtype=np.uint64), False, wide[:, ::2])
+
+    # in-place factorisation (what grates_amd.distributed uses for its chains)
+    chain = ls.BlockMatrix(idx, idx)
+    chain._inverse_in_place = True
+    chain[0, 0], chain[0, 1], chain[1, 1] = N[:d, :d], N[:d, d:], N[d:, d:]
+    chain.cholesky()
+    y = chain.solve_triangular(chain.solve_triangular(rhs, transpose=True))
+    assert relerr(y, np.linalg.solve(N, rhs)) < TOL
+    twin = chain.copy()                                                   # the copy knows what its diagonal blocks hold
+    assert relerr(twin.solve_triangular(twin.solve_triangular(rhs, transpose=True)), y) < 1e-14
+    for call in (lambda: chain.multiply_triangular(rhs), lambda: chain.inverse(), lambda: chain._scale(2.0), lambda: chain._axpy(1.0, bm)):
+        with pytest.raises(ValueError):
+            call()
+    chain.sparse_inverse()
+    Z = np.linalg.inv(N)
+    assert relerr(chain[0, 0], Z[:d, :d]) < TOL_INV and relerr(chain[0, 1], Z[:d, d:]) < TOL_INV
+    chain._scale(2.0)                                                     # an ordinary matrix again

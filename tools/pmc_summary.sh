@@ -36,5 +36,4 @@ PY
   done
 }
 run_group r02_synthesis_pmc synthesis_rot_kernel python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --cov-parallels 0 --steps 20 --warmup 5 --ramp 50
-export SHG_LIBRARY=$GRAFT_REPO_ROOT/grates_amd/lib/libshg.so
-run_group r02_covprop_pmc gemm_f64_kernel python3 $GRAFT_REPO_ROOT/tools/gemm_phases.py 8
+run_group r02_covprop_pmc gemm_f64_kernel python3 $GRAFT_REPO_ROOT/tools/gemm_phases.py --release-library 8

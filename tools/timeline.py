@@ -10,8 +10,11 @@ how many waves of the chip are in an epilogue / in the Legendre stage over time.
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault('SHG_LIBRARY', os.path.join(ROOT, 'grates_amd', 'lib', 'libshg_timeline.so'))
 sys.path.insert(0, ROOT)
+from grates_amd import _lib
+if '--release-library' not in sys.argv:
+    _lib.use_library(os.path.join(ROOT, 'grates_amd', 'lib', 'libshg_timeline.so'))      # instrumented build (make timeline)
+sys.argv = [a for a in sys.argv if a != '--release-library']
 import numpy as np, torch
 import grates_amd as ga
 GM, R = 3.9860044150e+14, 6.3781363000e+06
