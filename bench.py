@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
 """
-Benchmark of the hot path (BASELINE.json): batched synthesis of 240 monthly d/o-96 solutions to a 0.25 degree
-GeographicGrid (kernel 'ewh') on MI355X, plus the second half of the metric, the d/o-180 covariance propagation.
+Benchmark of the hot path (BASELINE.json).  Headline: batched synthesis of 240 monthly d/o-96 solutions to a 0.25 degree
+GeographicGrid (kernel 'ewh') on MI355X; beside it one leg per remaining BASELINE configuration:
 
-    python bench.py --gpus N --steps K --warmup W
+    covariance   config 4   d/o-180 covariance propagation to the 0.5 degree grid (second half of the metric), fp64 MFMA
+    analysis     (a13)      d/o 96 <- 0.5 degree grid, 240 epochs (the reference's 142 s case), HBM
+    filters      config 3   DDK5-type filter of a d/o-120 series of 240 epochs: order-wise block form (HBM) and the full
+                            normal-matrix multiply 14637^2 x 240 (fp64 MFMA)
+    smoother     config 5   3650 daily d/o-40 epochs (d = 1681), block-tridiagonal normal equations: solution and covariance
+                            blocks from one factorisation (fp64 MFMA); epochs sharded over the ranks, all_gather of separators
 
-One "step" = one pass of the hot path over one batch: 240 coefficient sets already resident in HBM ->
-240 grids in HBM (shg_synthesis through the C ABI).
+    python bench.py --gpus N --steps K --warmup W [--legs synthesis,covariance,analysis,filters,smoother]
+
+One "step" of the headline = one pass of the hot path over one batch: 240 coefficient sets already resident in HBM ->
+240 grids in HBM (shg_synthesis through the C ABI).  `value` is measured exactly as the contract says: W warm-up steps straight
+after the setup, then K timed steps between barrier + synchronize pairs, max over ranks.  `value_after_ramp` repeats the
+measurement behind `--ramp` further untimed launches (device clocks ramp up over the first ~100 ms of fp64 MFMA work).
 
 N > 1: one process per GPU.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment) the script is a
 rank; started bare (`python bench.py --gpus 4`) it launches `python -m torch.distributed.run --nproc-per-node N` on
 itself as a child process BEFORE anything touches the GPU and exits with the child's code.
-  * synthesis: epochs are independent, every rank synthesises its own 240 epochs (weak scaling, no data-path collective);
-    `value` = epochs of all ranks / max-over-ranks time;
-  * covariance: the WHOLE 360 x 720 grid, the parallels split into contiguous latitude bands
-    (grates_amd.distributed.latitude_bands), Sigma replicated, one all_gather of the per-band sigma (RCCL); the
-    checksum of the gathered grid is the same for every N.
+  * synthesis, analysis, filters: epochs are independent, every rank works on its own 240 epochs (weak scaling, no data-path
+    collective); `value` = epochs of all ranks / max-over-ranks time;
+  * covariance: the WHOLE 360 x 720 grid, the parallels split into contiguous latitude bands, Sigma replicated, one all_gather of
+    the per-band sigma (RCCL); the checksum of the gathered grid is the same for every N (strong scaling);
+  * smoother: the 3650 epochs split into contiguous ranges (strong scaling), nested dissection with all_gathers of separator
+    blocks (grates_amd.distributed.smooth_block_tridiagonal_partitioned).
 
-Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      dominant kernel against the HBM roofline, kernel time from HIP events recorded on the launching stream
-                inside the timed region
-  cpu_baseline  the CPU oracle (oracle/shg_oracle.py, same formulation as the reference) timed on a bounded sample on
-                this host (rank 0, N = 1 only)
-  covariance    the covariance leg (its own roofline and cpu_baseline objects)
+Rank 0 prints ONE JSON line with the contract fields plus, for the headline and inside every leg,
+  roofline      the leg's dominant kernel(s) against the HBM or fp64 MFMA roofline; kernel time from HIP events recorded on the
+                launching stream inside the timed region
+  cpu_baseline  the CPU oracle (oracle/, same formulation as the reference) timed on a bounded sample on this host (N = 1 only)
+  check         the TIMED OUTPUT BUFFER compared with the oracle on a sample, or a size-independent property of it
+The oracle is only the checker and the CPU baseline here; nothing under oracle/ is on the measured path.
 """
 
 import argparse
@@ -48,6 +58,11 @@ COV_DEGREE = 180
 COV_GRID_STEP = 0.5
 MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (spec); measured 77.3 TFLOP/s (profiles/r01_microbench.txt)
 GM, R_EARTH = 3.9860044150e+14, 6.3781363000e+06
+ANA_DEGREE, ANA_GRID_STEP = 96, 0.5
+DDK_DEGREE, DDK_LEVEL_SCALE = 120, 1e11          # config 3: DDK5 weights 1e11 n^4 (grates/filter.py:334-349)
+SMOOTHER_DIM, SMOOTHER_EPOCHS = 1681, 3650       # config 5: d/o 40 state, ten years of daily solutions
+LEGS = ('synthesis', 'covariance', 'analysis', 'filters', 'smoother')
+FORBIDDEN_ENVIRONMENT = ('SHG_LIBRARY', 'SHG_DEBUG', 'SHG_TIMELINE_PTR')
 
 
 def parse_args(argv=None):
@@ -55,20 +70,41 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--ramp', type=int, default=300, help='untimed launches before the warm-up steps (device clock ramp)')
+    ap.add_argument('--legs', default='all', help='comma separated subset of ' + ','.join(LEGS) + " (default: all; 'synthesis' always runs)")
+    ap.add_argument('--ramp', type=int, default=300, help='untimed launches before the second measurement of the headline (device clock ramp)')
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass of the staged path (0 = library default)')
-    ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'fused_plain', 'fused32', 'rot', 'rot_plain'],
-                    help='synthesis kernel path')
-    ap.add_argument('--cpu-sample', type=int, default=16, help='solutions timed on the CPU baseline (0 = skip)')
+    ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'fused32', 'rot'], help='synthesis kernel path')
+    ap.add_argument('--cpu-sample', type=int, default=16, help='solutions timed on the CPU baseline (0 = skip all CPU baselines)')
     ap.add_argument('--cov-parallels', type=int, default=-1,
                     help='parallels of the covariance leg over all ranks (-1 = the whole 0.5 degree grid, 360; 0 = skip the leg)')
     ap.add_argument('--cov-repeats', type=int, default=3, help='timed passes of the covariance leg')
     ap.add_argument('--cov-cpu-parallels', type=int, default=1, help='parallels of the covariance CPU baseline (0 = skip)')
     ap.add_argument('--cov-extensions', type=int, default=1, help='1: also time the symmetric and separable variants (N = 1 only)')
+    ap.add_argument('--smoother-epochs', type=int, default=SMOOTHER_EPOCHS, help='epochs of the smoother leg over all ranks (BASELINE config 5: 3650)')
+    ap.add_argument('--smoother-repeats', type=int, default=2, help='timed passes of the smoother leg (first call, repeated call)')
+    ap.add_argument('--smoother-cpu-epochs', type=int, default=12, help='epochs of the short chain the CPU oracle solves (baseline + spot check)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only to rehearse on one GPU)")
     ap.add_argument('--same-device', action='store_true', help='rehearsal: map every rank to cuda:0 (with --backend gloo)')
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    wanted = LEGS if args.legs == 'all' else tuple(x.strip() for x in args.legs.split(',') if x.strip())
+    unknown = [x for x in wanted if x not in LEGS]
+    if unknown:
+        ap.error('unknown leg(s) ' + ', '.join(unknown))
+    args.leg_set = set(wanted) | {'synthesis'}
+    if args.cov_parallels == 0:
+        args.leg_set.discard('covariance')
+    return args
+
+
+def refuse_experiment_environment(environ=None):
+    """The shipping library has no run-time switches (tests/test_boundary.py); the variables that used to select a profiling
+    build or knock parts of a kernel out must not even be present, so that a line can never stem from such a run."""
+    environ = os.environ if environ is None else environ
+    present = [v for v in FORBIDDEN_ENVIRONMENT if v in environ]
+    if present:
+        raise SystemExit('bench.py refuses to run with ' + ', '.join(present) + ' set: experiment switches / library overrides are not '
+                         'part of the product (unset them; profiling tools live in tools/).')
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -91,8 +127,40 @@ def launch_ranks(args, argv):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# workloads: the GPU one (product path through the C ABI) and a stand-in of the same shape for the CPU test of the rank
-# function (tests/test_bench_ranks.py): same sharding, barriers, gather, checksum and JSON assembly, no GPU
+# synthetic inputs, seeded per unit so that every world size works on the same data
+# ---------------------------------------------------------------------------------------------------------------------
+def coefficient_batch(first_seed, count, max_degree):
+    import numpy as np
+    return np.stack([np.random.default_rng(first_seed + e).standard_normal((max_degree + 1, max_degree + 1)) * 1e-10 for e in range(count)])
+
+
+def orderwise_normal_blocks(seed, nmax, scale=1e12):
+    """Synthetic SPD order-wise normal blocks (G G^T) * 1e12 of the reference's shapes (data/__init__.py:111-117): order 0, then
+    cosine and sine block of every order m, each indexed by degree m .. nmax."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    sizes = [nmax + 1] + [nmax + 1 - m for m in range(1, nmax + 1) for _ in (0, 1)]
+    blocks = []
+    for s in sizes:
+        G = rng.standard_normal((s, s + 4))
+        blocks.append((G @ G.T) * scale)
+    return blocks
+
+
+def smoother_blocks(t, d, gen, torch, engine):
+    """Epoch t of the seeded config-5 system: N_tt = G G^T / d + 4 I (SPD), N_t,t+1 = R / d, right-hand side n_t ~ N(0, 1)."""
+    gen.manual_seed(50_000 + t)
+    G = torch.randn((d, d + 8), dtype=torch.float64, device='cuda', generator=gen)
+    D = engine.gemm(G, G, transb=True, alpha=1.0 / d)
+    D.diagonal().add_(4.0)
+    R = torch.randn((d, d), dtype=torch.float64, device='cuda', generator=gen) / d
+    b = torch.randn((d, 1), dtype=torch.float64, device='cuda', generator=gen)
+    return D, R, b
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads: the GPU one (product path through the C ABI) and, in tests/test_bench_ranks.py, a stand-in of the same interface
+# for the CPU test of the rank function: same sharding, barriers, gathers, checksums and JSON assembly, no GPU
 # ---------------------------------------------------------------------------------------------------------------------
 class GpuWorkload:
     device = 'cuda'
@@ -102,16 +170,19 @@ class GpuWorkload:
         self.torch = torch
         self.args, self.rank, self.world = args, rank, world
         torch.cuda.set_device(local_rank)
+        import grates_amd as ga
+        self.ga = ga
 
     def synchronize(self):
         self.torch.cuda.synchronize()
 
-    # ---- synthesis
+    def oracle_kernel(self):
+        from oracle import shg_oracle as orc
+        return orc, orc.KernelTable(KERNEL, self.ga.data.load_love_numbers()[0])
+
+    # ---- synthesis (headline)
     def setup_synthesis(self):
-        import numpy as np
-        import grates_amd as ga
-        torch = self.torch
-        self.ga = ga
+        ga, torch = self.ga, self.torch
         grid = ga.grid.GeographicGrid(GRID_STEP, GRID_STEP)
         self.grid = grid
         self.nlat, self.nlon = grid.parallels.size, grid.meridians.size
@@ -124,12 +195,11 @@ class GpuWorkload:
             self.plan.set_path(self.args.path)
         B = self.args.epochs
         # synthetic monthly solutions: default_rng(1000 + e) N(0,1) * 1e-10, distinct per rank
-        self.batch_host = np.stack([np.random.default_rng(1000 + self.rank * B + e).standard_normal((MAX_DEGREE + 1, MAX_DEGREE + 1)) * 1e-10
-                                    for e in range(B)])
+        self.batch_host = coefficient_batch(1000 + self.rank * B, B, MAX_DEGREE)
         self.batch = torch.from_numpy(self.batch_host).cuda()
         self.out = torch.empty((B, self.nlat, self.nlon), dtype=torch.float64, device='cuda')
         info = self.plan.info()
-        rot = bool(info['rotation_symmetry']) and self.args.path in ('auto', 'rot', 'rot_plain')
+        rot = bool(info['rotation_symmetry']) and self.args.path in ('auto', 'rot')
         self.kernel_name = ('synthesis_rot_kernel' if rot else 'synthesis_fused_kernel') if info['fused'] else 'lon_stage_kernel<4>'
         self.config = {'fused_kernel': info['fused'], 'fourfold_symmetry': info['fourfold_symmetry'], 'rotation_folded_kernel': rot}
 
@@ -146,19 +216,29 @@ class GpuWorkload:
         del self.out, self.batch
         self.torch.cuda.empty_cache()
 
-    def cpu_baseline(self, sample_epochs):
-        """Oracle synthesis (N+1 dgemms per solution like the reference) on `sample_epochs` solutions."""
-        from oracle import shg_oracle as orc
-        ker = orc.KernelTable(KERNEL, self.ga.data.load_love_numbers()[0])
+    def synthesis_check(self, sample_epochs, timed):
+        """The oracle (N+1 dgemms per solution like the reference) on the first `sample_epochs` solutions: compared with the
+        grids the timed steps left in the output buffer, and (timed=True) the CPU baseline."""
+        import numpy as np
+        orc, ker = self.oracle_kernel()
         grid = self.grid
-        orc.synthesis_regular(self.batch_host[0], grid.meridians, grid.parallels, ker)      # warm BLAS / page in
+        if timed:
+            orc.synthesis_regular(self.batch_host[0], grid.meridians, grid.parallels, ker)      # warm BLAS / page in
+        worst = 0.0
         t0 = time.perf_counter()
-        for e in range(sample_epochs):
-            orc.synthesis_regular(self.batch_host[e], grid.meridians, grid.parallels, ker)
+        refs = [orc.synthesis_regular(self.batch_host[e], grid.meridians, grid.parallels, ker) for e in range(sample_epochs)]
         dt = time.perf_counter() - t0
-        return {'value': sample_epochs / dt, 'unit': 'solutions/s', 'cores': blas_threads(), 'kind': 'port',
-                'sample': '{0} of the {1} d/o-{2} epochs -> {3} deg grid, NumPy oracle (reference formulation), {4:.1f} s'.format(
-                    sample_epochs, self.args.epochs, MAX_DEGREE, GRID_STEP, dt)}
+        for e, ref in enumerate(refs):
+            got = self.out[e].cpu().numpy()
+            worst = max(worst, float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))))
+        check = {'max_rel_err_vs_oracle': worst, 'epochs_checked': sample_epochs, 'tolerance': 1e-12, 'ok': bool(worst < 1e-12),
+                 'what': 'grids of the timed output buffer against the NumPy oracle'}
+        baseline = None
+        if timed:
+            baseline = {'value': sample_epochs / dt, 'unit': 'solutions/s', 'cores': blas_threads(), 'kind': 'port',
+                        'sample': '{0} of the {1} d/o-{2} epochs -> {3} deg grid, NumPy oracle (reference formulation), {4:.1f} s'.format(
+                            sample_epochs, self.args.epochs, MAX_DEGREE, GRID_STEP, dt)}
+        return check, baseline
 
     # ---- covariance
     def setup_covariance(self):
@@ -189,10 +269,14 @@ class GpuWorkload:
     def cov_profile_read(self):
         return self.cov_plan.profile_read()
 
+    def release_covariance(self):
+        del self.cov, self.cov_plan
+        self.ga.engine.release_scratch()
+        self.torch.cuda.empty_cache()
+
     def covariance_cpu(self, lat0, count, sigma_gpu):
         import numpy as np
-        from oracle import shg_oracle as orc
-        ker = orc.KernelTable(KERNEL, self.ga.data.load_love_numbers()[0])
+        orc, ker = self.oracle_kernel()
         grid = self.cov_grid
         cov_host = self.cov.cpu().numpy()
         t0 = time.perf_counter()
@@ -205,9 +289,300 @@ class GpuWorkload:
                 'sample': '{0} of {1} parallels at full P (NumPy oracle, per-parallel F @ Sigma), {2:.1f} s incl. table setup'.format(count, self.cov_nlat, dt),
                 'max_rel_diff_vs_gpu': float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))}
 
+    # ---- analysis: RegularGrid.to_potential_coefficients, grates/grid.py:752-790
+    def leg_analysis(self, ctx):
+        import numpy as np
+        ga, torch, args = self.ga, self.torch, self.args
+        N, B = ANA_DEGREE, args.epochs
+        grid = ga.grid.GeographicGrid(ANA_GRID_STEP, ANA_GRID_STEP)
+        nlat, nlon = grid.parallels.size, grid.meridians.size
+        colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel(KERNEL), N, grid.parallels, GM, R_EARTH, grid.semimajor_axis, grid.flattening)
+        plan = ga.engine.Plan(N, colat, kn, grid.meridians)
+        batch_host = coefficient_batch(20_000 + self.rank * B, B, N)
+        batch = torch.from_numpy(batch_host).cuda()
+        grids = plan.synthesis(batch)                                         # band-limited input fields, resident in HBM
+        area = ga.engine.to_device(grid.area.reshape(nlat, nlon))
+        state = {}
+
+        def step():
+            state['out'] = plan.analysis(grids, area, 0)
+        step()                                                                # builds and caches the per-order operators
+        elapsed, prof, _ = ctx.timed(step, args.warmup, args.steps, plan)
+        out = state['out']
+        if ctx.rank != 0:
+            return None
+        k_lon, k_solve = prof.get('analysis_lon', (0.0, 0)), prof.get('analysis_solve', (0.0, 0))
+        per_call_ms = (k_lon[0] + k_solve[0]) / max(args.steps, 1)
+        per_epoch = 8 * (nlat * nlon + (N + 1) ** 2)                          # values read once, coefficients written once
+        achieved = per_epoch * B / (per_call_ms * 1e-3) / 1e9 if per_call_ms > 0 else None
+        # MFMA floor of the transform as built (4-fold folded: 2 nlon/4 (2N+1) flops per row) plus the operator product on the rows that exist
+        mfma_flops = 2.0 * B * nlat * (nlon / 4.0) * (2 * N + 1) + 2.0 * B * nlat * (N + 1) ** 2
+        roundtrip = float(((out - batch).abs().max() / batch.abs().max()).item())
+        leg = {
+            'metric': 'analysis d/o {0} <- {1} deg grid ({2}x{3}), area-weighted least squares per order'.format(N, ANA_GRID_STEP, nlat, nlon),
+            'value': ctx.world * B * args.steps / elapsed, 'unit': 'epochs/s', 'n_gpus': ctx.world, 'scaling': 'weak',
+            'ms_per_step': 1e3 * elapsed / args.steps, 'dtype': 'f64',
+            'config': {'workload': '{0} epochs per GPU, grids resident in HBM, kernel {1}, min_degree 0'.format(B, KERNEL), 'max_degree': N,
+                       'grid': [nlat, nlon], 'epochs_per_gpu': B},
+            'roofline': {'kernel': 'analysis_transform_kernel + analysis_operator_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,
+                         'algorithmic_bytes_per_launch': per_epoch * B, 'avg_launch_ms': per_call_ms,
+                         'kernels': {'analysis_transform_kernel': {'avg_us': 1e3 * k_lon[0] / max(k_lon[1], 1), 'launches': int(k_lon[1])},
+                                     'analysis_operator_kernel': {'avg_us': 1e3 * k_solve[0] / max(k_solve[1], 1), 'launches': int(k_solve[1])}},
+                         'mfma_floor_ms': mfma_flops / (MFMA_F64_PEAK_TFLOPS * 1e12) * 1e3},
+            'check': {'roundtrip_max_rel_err': roundtrip, 'tolerance': 1e-11, 'ok': bool(roundtrip < 1e-11),
+                      'what': 'coefficients of the timed output buffer against the band-limited input of all {0} epochs'.format(B)},
+        }
+        if ctx.world == 1 and args.cpu_sample > 0:
+            orc, ker = self.oracle_kernel()
+            orders = list(range(0, N + 1, 12))                                # 9 of the 97 independent per-order least-squares problems
+            values = grids[0].cpu().numpy().ravel()
+            t0 = time.perf_counter()
+            ref = orc.analysis_regular(values, grid.area, 0, N, grid.meridians, grid.parallels, ker, orders=orders)
+            dt = time.perf_counter() - t0
+            cost = lambda ms: sum((1 if m == 0 else 2) * (N + 1 - m) for m in ms)      # noqa: E731  columns of the design matrices built
+            full = dt * cost(range(N + 1)) / cost(orders)
+            got = out[0].cpu().numpy()
+            mask = np.zeros((N + 1, N + 1), dtype=bool)
+            for m in orders:
+                mask[m:, m] = True
+                if m:
+                    mask[m - 1, m:] = True
+            err = float(np.max(np.abs(got - ref)[mask]) / np.max(np.abs(ref)))
+            leg['check'].update({'max_rel_err_vs_oracle': err, 'orders_checked': orders, 'ok': bool(roundtrip < 1e-11 and err < 1e-11)})
+            leg['cpu_baseline'] = {'value': 1.0 / full, 'unit': 'epochs/s', 'cores': blas_threads(), 'kind': 'port',
+                                   'sample': 'orders {0} of one epoch (NumPy oracle: design matrix + weighted normal equations per order, grid.py:665-696), '
+                                             '{1:.1f} s, scaled by the design-matrix columns of all orders ({2:.0f} s per epoch)'.format(orders, dt, full)}
+        return leg
+
+    # ---- filters: OrderWiseFilter / DDK and GeneralMatrix, grates/filter.py:153-222, 456-479
+    def leg_filters(self, ctx):
+        import numpy as np
+        ga, torch, args = self.ga, self.torch, self.args
+        nmax, T = DDK_DEGREE, args.epochs
+        normals = orderwise_normal_blocks(44, nmax)
+        weights = DDK_LEVEL_SCALE * np.arange(nmax + 1, dtype=float) ** 4
+        weights[0] = 1
+        blocks = ga.engine.ddk_blocks(normals, weights)                      # (N_m + diag w)^-1 N_m on the device, grates/filter.py:334-349
+        flt = ga.filter.OrderWiseFilter(blocks)
+        batch_host = coefficient_batch(30_000 + self.rank * T, T, nmax)
+        batch_host[:, 0:2, 0:2] = 0.0                                          # GRACE-type series carry no degree 0 / 1
+        batch = torch.from_numpy(batch_host).cuda()
+        state = {}
+
+        def step_block():
+            state['block'] = flt.filter_batch(batch)
+        step_block()
+        el_block, _, ev_block = ctx.timed(step_block, args.warmup, args.steps, events=True)
+        nmin = 2
+        P = (nmax + 1) ** 2 - nmin ** 2
+        dense = ga.filter.GeneralMatrix(flt.matrix(nmin, nmax), nmin, nmax)   # 14637 x 14637 full normal-type matrix, 1.7 GB
+
+        def step_dense():
+            state['dense'] = dense.filter_batch(batch)
+        step_dense()
+        dense_steps = max(args.steps // 2, 1)
+        el_dense, _, ev_dense = ctx.timed(step_dense, max(args.warmup // 2, 1), dense_steps, events=True)
+        if ctx.rank != 0:
+            return None
+        block_bytes = 8.0 * (sum(b.size for b in blocks) + 2.0 * (nmax + 1) ** 2 * T)
+        dense_flops = 2.0 * P * P * T
+        agree = float(((state['dense'] - state['block']).abs().max() / state['block'].abs().max()).item())
+        out = {
+            'block': {
+                'metric': 'order-wise (DDK5-type) filter of a d/o-{0} series, block form'.format(nmax), 'value': ctx.world * T * args.steps / el_block,
+                'unit': 'epochs/s', 'n_gpus': ctx.world, 'scaling': 'weak', 'ms_per_step': 1e3 * el_block / args.steps, 'dtype': 'f64',
+                'config': {'workload': '{0} epochs per GPU, {1} blocks, weights 1e11 n^4'.format(T, len(blocks)), 'max_degree': nmax, 'epochs_per_gpu': T},
+                'roofline': {'kernel': 'orderwise_filter_kernel', 'bound': 'hbm', 'achieved': block_bytes / (ev_block * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                             'unit': 'GB/s', 'frac': block_bytes / (ev_block * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                             'algorithmic_bytes_per_launch': block_bytes, 'avg_launch_ms': ev_block},
+            },
+            'dense': {
+                'metric': 'the same filter as full normal-matrix multiply W X, W {0} x {0}'.format(P), 'value': ctx.world * T * dense_steps / el_dense,
+                'unit': 'epochs/s', 'n_gpus': ctx.world, 'scaling': 'weak', 'ms_per_step': 1e3 * el_dense / dense_steps, 'dtype': 'f64',
+                'GFLOPs': dense_flops * dense_steps / el_dense / 1e9,
+                'config': {'workload': '{0} epochs per GPU: ravel, W [{1} x {1}] @ X [{1} x {0}], unravel'.format(T, P), 'max_degree': nmax, 'min_degree': nmin,
+                           'epochs_per_gpu': T, 'flops_per_step': dense_flops},
+                'roofline': {'kernel': 'gemm_ex_kernel (shg_dense_filter; the step also holds the ravel / unravel kernels)', 'bound': 'mfma',
+                             'achieved': dense_flops / (ev_dense * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': dense_flops / (ev_dense * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': ev_dense},
+            },
+            'check': {'dense_vs_block_max_rel_diff': agree, 'tolerance': 1e-12, 'ok': bool(agree < 1e-12),
+                      'what': 'timed output buffers of the two forms against each other (all epochs)'},
+        }
+        if ctx.world == 1 and args.cpu_sample > 0:
+            orc, _ = self.oracle_kernel()
+            host_block = state['block'].cpu().numpy()
+            t0 = time.perf_counter()
+            refs = [orc.orderwise_filter(batch_host[e], blocks) for e in range(T)]
+            dt = time.perf_counter() - t0
+            err = max(float(np.max(np.abs(host_block[e] - refs[e])) / np.max(np.abs(refs[e]))) for e in range(T))
+            out['block']['cpu_baseline'] = {'value': T / dt, 'unit': 'epochs/s', 'cores': blas_threads(), 'kind': 'port',
+                                            'sample': 'all {0} epochs, NumPy oracle (2N+1 block mat-vecs per epoch, filter.py:182-187), {1:.2f} s'.format(T, dt)}
+            W = dense.matrix(nmin, nmax)
+            X = np.stack([orc.ravel_coefficients(batch_host[e], nmin, nmax) for e in range(T)], axis=1)
+            W @ X[:, 0:8]                                                      # warm BLAS
+            t0 = time.perf_counter()
+            Y = W @ X
+            dt = time.perf_counter() - t0
+            host_dense = state['dense'].cpu().numpy()
+            ref0 = orc.general_matrix_filter(batch_host[0], W, nmin, nmax)
+            err_dense = max(float(np.max(np.abs(host_dense[0] - ref0)) / np.max(np.abs(ref0))),
+                            float(np.max(np.abs(orc.ravel_coefficients(host_dense[T - 1], nmin, nmax) - Y[:, T - 1])) / np.max(np.abs(Y[:, T - 1]))))
+            out['dense']['cpu_baseline'] = {'value': dense_flops / dt / 1e9, 'unit': 'GFLOP/s', 'cores': blas_threads(), 'kind': 'port',
+                                            'sample': 'W @ X for all {0} epochs in one dgemm (NumPy oracle, filter.py:473-477), {1:.2f} s'.format(T, dt)}
+            out['check'].update({'block_max_rel_err_vs_oracle': err, 'dense_max_rel_err_vs_oracle': err_dense, 'epochs_checked_block': T,
+                                 'ok': bool(agree < 1e-12 and err < 1e-12 and err_dense < 1e-12)})
+        return out
+
+    # ---- smoother: NormalEquations.solve + compute_covariance(sparse=True), grates/lstsq.py:950-968, 1026-1042
+    def leg_smoother(self, ctx):
+        import numpy as np
+        from grates_amd import distributed as gd
+        ga, torch, args = self.ga, self.torch, self.args
+        d, T = SMOOTHER_DIM, args.smoother_epochs
+        t_first, t_stop = gd.shard_range(T, ctx.rank, ctx.world)
+        n_loc = t_stop - t_first
+        last = ctx.rank == ctx.world - 1
+        free, _ = torch.cuda.mem_get_info()
+        per_rank_ranks = ctx.world if args.same_device else 1
+        interior_extra = 0 if ctx.world == 1 else 2 * n_loc * d * (2 * d) * 8       # Y and Y Z_SS of the nested dissection
+        need = (2 * n_loc * d * d * 8 + interior_extra) * per_rank_ranks + 24e9
+        enough = ctx.all_ranks_agree(free >= need and n_loc >= 2)
+        if not enough:
+            return {'skipped': 'config 5 needs {0:.0f} GB of free device memory per GPU at this world size, {1:.0f} GB are free (or fewer than '
+                               'two epochs per rank)'.format(need / 1e9, free / 1e9)} if ctx.rank == 0 else None
+        gen = torch.Generator(device='cuda')
+
+        def build():
+            diag, upper, rhs = [], [], []
+            for t in range(t_first, t_stop):
+                D, R, b = smoother_blocks(t, d, gen, torch, ga.engine)
+                diag.append(D)
+                rhs.append(b)
+                if t + 1 < T:
+                    upper.append(R)                                            # upper[-1] of a rank but the last couples to the next rank's first epoch
+            return diag, upper, torch.cat(rhs, dim=0)
+
+        seconds, phases = [], []
+        x = zd = zu = None
+        for _ in range(max(args.smoother_repeats, 1)):
+            x = zd = zu = None                                                # the previous pass's blocks go back to the allocator first
+            diag, upper, rhs = build()
+            tm = {}
+            ctx.barrier()
+            t0 = time.perf_counter()
+            x, zd, zu = gd.smooth_block_tridiagonal_partitioned(diag, upper, rhs, consume=True, timings=tm)
+            ctx.barrier()
+            seconds.append(ctx.max_over_ranks(time.perf_counter() - t0))
+            phases.append({k: ctx.max_over_ranks(v) for k, v in sorted(tm.items())})
+            del diag, upper
+        elapsed = seconds[-1]
+
+        # ---- the timed output: residual of the solution over the whole chain (blocks regenerated from their seeds; the solution of the
+        # neighbouring epochs across rank boundaries comes through one small all_gather), identity (N N^-1)_tt = I at sample epochs
+        edges = ctx.gather_rows([x[:d, 0].contiguous(), x[-d:, 0].contiguous()])
+        before = edges[ctx.rank - 1][1] if ctx.rank > 0 else None
+        after = edges[ctx.rank + 1][0] if not last else None
+        num = torch.zeros((), dtype=torch.float64, device='cuda')
+        den = torch.zeros((), dtype=torch.float64, device='cuda')
+        prev = smoother_blocks(t_first - 1, d, gen, torch, ga.engine)[1] if ctx.rank > 0 else None
+        for k, t in enumerate(range(t_first, t_stop)):
+            D, R, b = smoother_blocks(t, d, gen, torch, ga.engine)
+            own = x[k * d:(k + 1) * d]
+            Nx = ga.engine.gemm(D, own)
+            if t + 1 < T:
+                nxt = x[(k + 1) * d:(k + 2) * d] if k + 1 < n_loc else after.reshape(d, 1)
+                Nx += ga.engine.gemm(R, nxt.contiguous())
+            if prev is not None:
+                prv = x[(k - 1) * d:k * d] if k > 0 else before.reshape(d, 1)
+                Nx += ga.engine.gemm(prev, prv.contiguous(), transa=True)
+            num += ((Nx - b) ** 2).sum()
+            den += (b ** 2).sum()
+            prev = R
+        sums = ctx.sum_over_ranks([float(num.item()), float(den.item()), float(x.sum().item())])
+        residual = float(np.sqrt(sums[0] / sums[1]))
+        eye = torch.eye(d, dtype=torch.float64, device='cuda')
+        worst_id = worst_sym = 0.0
+        for k in sorted({1, n_loc // 2, max(n_loc - 3, 1)}):
+            if not 1 <= k < n_loc - 1:
+                continue
+            t = t_first + k
+            Z = zd[k]
+            worst_sym = max(worst_sym, float(((Z - Z.t()).abs().max() / Z.abs().max()).item()))
+            D, R, _ = smoother_blocks(t, d, gen, torch, ga.engine)
+            acc = ga.engine.gemm(D, Z) + ga.engine.gemm(R, zu[k], transb=True)
+            acc += ga.engine.gemm(smoother_blocks(t - 1, d, gen, torch, ga.engine)[1], zu[k - 1], transa=True)
+            worst_id = max(worst_id, float((acc - eye).abs().max().item()))
+        worst_id, worst_sym = ctx.max_over_ranks(worst_id), ctx.max_over_ranks(worst_sym)
+        del x, zd, zu
+        torch.cuda.empty_cache()
+        if ctx.rank != 0:
+            return None
+        flops_factor, flops_inverse = 7.0 / 3.0 * d ** 3, 13.0 / 3.0 * d ** 3
+        flops = T * (flops_factor + flops_inverse)
+        ph = phases[-1]
+        leg = {
+            'metric': 'block-tridiagonal normal-equation smoother: solution + covariance blocks of {0} epochs x {1} parameters'.format(T, d),
+            'value': T / elapsed, 'unit': 'epochs/s', 'n_gpus': ctx.world, 'scaling': 'strong', 'dtype': 'f64',
+            'seconds': elapsed, 'seconds_all': seconds, 'phases_s': ph, 'phases_all': phases,
+            'config': {'workload': 'N_tt = G G^T / d + 4 I, N_t,t+1 = R / d seeded per epoch on the device, one right-hand side; '
+                                   'grates_amd.distributed.smooth_block_tridiagonal_partitioned(consume=True)', 'epochs': T, 'dim': d,
+                       'epochs_per_rank': ctx.all_counts, 'parallelism': 'epochs in {0} contiguous range(s), all_gather of separator blocks'.format(ctx.world),
+                       'flops_per_epoch': {'factor (potrf d^3/3 + U^-T A d^3 + Schur update d^3)': flops_factor,
+                                           'sparse inverse (U^-1 W d^3 + T Z 2 d^3 + U^-1 U^-T d^3/3 + T Z^T d^3)': flops_inverse},
+                       'flops': flops},
+            'roofline': {'kernel': 'gemm_ex_kernel + leaf_kernel (block Cholesky, sweeps and Takahashi recursion of one chain)', 'bound': 'mfma',
+                         'achieved': flops / elapsed / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': flops / elapsed / 1e12 / MFMA_F64_PEAK_TFLOPS, 'traffic': None,
+                         'factor_TFLOPs': T * flops_factor / ph['factor_s'] / 1e12 if ph.get('factor_s') else None,
+                         'factor_frac': T * flops_factor / ph['factor_s'] / 1e12 / MFMA_F64_PEAK_TFLOPS if ph.get('factor_s') else None,
+                         'sparse_inverse_TFLOPs': T * flops_inverse / ph['covariance_s'] / 1e12 if ph.get('covariance_s') else None,
+                         'note': 'algorithmic flops of the single-chain formulation; with N > 1 the nested dissection executes more'},
+            'check': {'residual': residual, 'identity_defect_max': worst_id, 'covariance_asymmetry_max': worst_sym, 'solution_checksum': sums[2],
+                      'tolerance': {'residual': 1e-13, 'identity': 1e-12}, 'ok': bool(residual < 1e-13 and worst_id < 1e-12 and worst_sym < 1e-13),
+                      'what': '||N x - n|| / ||n|| of the timed solution with N regenerated from the seeds; (N N^-1)_tt = I and symmetry of timed covariance blocks'},
+        }
+        if ctx.world == 1 and args.cpu_sample > 0 and args.smoother_cpu_epochs >= 2:
+            leg['cpu_baseline'], spot = self.smoother_cpu(min(args.smoother_cpu_epochs, T), d, gen)
+            leg['check'].update(spot)
+            leg['check']['ok'] = bool(leg['check']['ok'] and spot['short_chain_max_rel_err_vs_oracle'] < 1e-9)
+        return leg
+
+    def smoother_cpu(self, n, d, gen):
+        """The first `n` epochs of the same seeded system as a chain of their own: the oracle (block Cholesky, two sweeps, Takahashi
+        recursion in the reference formulation with LAPACK per block) is the CPU baseline, and the product path run on that short
+        chain is compared with it."""
+        import numpy as np
+        from grates_amd import distributed as gd
+        from oracle import lstsq_oracle as lo
+        ga, torch = self.ga, self.torch
+        sets = [smoother_blocks(t, d, gen, torch, ga.engine) for t in range(n)]
+        host = [(D.cpu().numpy(), R.cpu().numpy(), b.cpu().numpy()) for D, R, b in sets]
+        x, zd, zu = gd.smooth_block_tridiagonal_partitioned([s[0] for s in sets], [s[1] for s in sets[:-1]], torch.cat([s[2] for s in sets], dim=0))
+        bm = lo.block_matrix(np.arange(0, (n + 1) * d, d))
+        for t, (D, R, _) in enumerate(host):
+            bm['blocks'][(t, t)] = D.copy()
+            if t + 1 < n:
+                bm['blocks'][(t, t + 1)] = R.copy()
+        rhs = np.vstack([h[2] for h in host])
+        t0 = time.perf_counter()
+        lo.cholesky(bm)
+        ref_x = lo.solve_triangular(bm, lo.solve_triangular(bm, rhs, transpose=True))
+        lo.sparse_inverse(bm)
+        dt = time.perf_counter() - t0
+        err = float(np.max(np.abs(x.cpu().numpy() - ref_x)) / np.max(np.abs(ref_x)))
+        for t in (0, n // 2, n - 1):
+            ref = bm['blocks'][(t, t)]
+            err = max(err, float(np.max(np.abs(zd[t].cpu().numpy() - ref)) / np.max(np.abs(ref))))
+        baseline = {'value': n / dt, 'unit': 'epochs/s', 'cores': blas_threads(), 'kind': 'port',
+                    'sample': 'chain of the first {0} epochs at d = {1}: block Cholesky, forward / backward sweep and sparse inverse of the NumPy / LAPACK '
+                              'oracle (lstsq.py:698-846), {2:.1f} s'.format(n, d, dt)}
+        return baseline, {'short_chain_max_rel_err_vs_oracle': err, 'short_chain_epochs': n, 'short_chain_tolerance': 1e-9}
+
 
 def blas_threads():
-    """Threads the NumPy BLAS of the CPU baseline runs on (one convention for both legs)."""
+    """Threads the NumPy BLAS of the CPU baseline runs on (one convention for all legs)."""
     try:
         import threadpoolctl
         return int(max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1]))
@@ -218,7 +593,7 @@ def blas_threads():
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (profiles/), with its origin:
     counters cannot be collected inside a timed run."""
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             with open(path) as f:
@@ -238,11 +613,80 @@ def algorithmic_bytes_per_solution(max_degree, nlat, nlon):
 # ---------------------------------------------------------------------------------------------------------------------
 # rank function
 # ---------------------------------------------------------------------------------------------------------------------
+class RankContext:
+    """Rank, world and the collectives a leg needs: barrier, max / sum over ranks, small gathers."""
+
+    def __init__(self, args, wl, rank, world, dist, torch, reduce_device):
+        self.args, self.wl, self.rank, self.world, self.dist, self.torch, self.reduce_device = args, wl, rank, world, dist, torch, reduce_device
+        from grates_amd import distributed as gd
+        self.all_counts = [b - a for a, b in (gd.shard_range(args.smoother_epochs, r, world) for r in range(world))]
+
+    def barrier(self):
+        self.wl.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.wl.synchronize()
+
+    def _reduce(self, values, op):
+        if self.world == 1:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.reduce_device)
+        self.dist.all_reduce(t, op=op)
+        return [float(v) for v in t.tolist()]
+
+    def max_over_ranks(self, x):
+        return self._reduce([x], self.dist.ReduceOp.MAX)[0] if self.world > 1 else x
+
+    def sum_over_ranks(self, values):
+        return self._reduce(values, self.dist.ReduceOp.SUM) if self.world > 1 else list(values)
+
+    def all_ranks_agree(self, flag):
+        return self._reduce([1.0 if flag else 0.0], self.dist.ReduceOp.MIN)[0] > 0.5 if self.world > 1 else bool(flag)
+
+    def gather_rows(self, tensors):
+        """per-rank lists of the given (equally shaped, small) device tensors of every rank"""
+        if self.world == 1:
+            return [list(tensors)]
+        from grates_amd import distributed as gd
+        return gd.gather_blocks(tensors)
+
+    def timed(self, step, warmup, steps, plan=None, events=False):
+        """W warm-up steps, K timed steps between barrier + synchronize pairs, max over ranks -> (seconds, kernel profile, GPU ms per
+        step).  Kernel time comes from HIP events over exactly the timed steps, on the stream the kernels are launched on: with a
+        plan its in-library events around every kernel, with events=True one event pair around every step (torch's current stream
+        is the stream grates_amd.engine hands to every shg_* call)."""
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        if plan is not None:
+            plan.profile(True)
+            plan.profile_read()
+        pairs = []
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if events:
+                pair = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
+                pair[0].record()
+                step()
+                pair[1].record()
+                pairs.append(pair)
+            else:
+                step()
+        self.barrier()
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        prof = {}
+        if plan is not None:
+            prof = plan.profile_read()
+            plan.profile(False)
+        step_ms = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs) if pairs else None
+        return elapsed, prof, step_ms
+
+
 def run_rank(args, workload_factory=GpuWorkload, emit=print):
     """One rank of the benchmark (the whole benchmark when WORLD_SIZE is 1).  Returns the result dict on rank 0."""
     import torch
     import torch.distributed as dist
-    from grates_amd import distributed as gd
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -257,19 +701,8 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     reduce_device = wl.device if args.backend == 'nccl' else 'cpu'
-
-    def barrier():
-        wl.synchronize()
-        if world > 1:
-            dist.barrier()
-        wl.synchronize()
-
-    def max_over_ranks(x):
-        if world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=reduce_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    ctx = RankContext(args, wl, rank, world, dist, torch, reduce_device)
+    barrier, max_over_ranks = ctx.barrier, ctx.max_over_ranks
 
     def timed_steps(warmup, steps):
         for _ in range(warmup):
@@ -287,32 +720,38 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
         wl.profile(False)
         return elapsed, prof
 
-    # ---- synthesis: W warm-up steps, K timed steps between barrier + synchronize pairs, max over ranks.
-    # First as the contract states it, straight after the setup (`value_without_ramp`); then again behind `--ramp` untimed
-    # launches (`value`): after an idle period the first ~100 ms of fp64 MFMA work run at lower clocks.
+    # ---- synthesis: W warm-up steps, K timed steps between barrier + synchronize pairs, max over ranks -- straight after the
+    # setup, as the contract states it (`value`); then again behind `--ramp` untimed launches (`value_after_ramp`): after an idle
+    # period the first ~100 ms of fp64 MFMA work run at lower clocks.
     wl.setup_synthesis()
     B = args.epochs
     barrier()
-    cold_elapsed, _ = timed_steps(args.warmup, args.steps)
+    elapsed, prof = timed_steps(args.warmup, args.steps)
     for _ in range(args.ramp):
         wl.synthesis_step()
     barrier()
-    elapsed, prof = timed_steps(args.warmup, args.steps)
+    ramp_elapsed, ramp_prof = timed_steps(args.warmup, args.steps) if args.ramp > 0 else (elapsed, prof)
 
     line = None
     if rank == 0:
         per_solution = algorithmic_bytes_per_solution(MAX_DEGREE, wl.nlat, wl.nlon)
-        lon_ms, lon_launches = prof.get('lon_stage', (0.0, 0))
-        launches_per_step = lon_launches / max(args.steps, 1)
-        epochs_per_launch = B / max(launches_per_step, 1e-9)
-        lon_avg_ms = lon_ms / max(lon_launches, 1)
-        achieved = per_solution * epochs_per_launch / (lon_avg_ms * 1e-3) / 1e9 if lon_launches else None
+
+        def kernel_rate(p):
+            lon_ms, lon_launches = p.get('lon_stage', (0.0, 0))
+            launches_per_step = lon_launches / max(args.steps, 1)
+            epochs_per_launch = B / max(launches_per_step, 1e-9)
+            avg_ms = lon_ms / max(lon_launches, 1)
+            rate = per_solution * epochs_per_launch / (avg_ms * 1e-3) / 1e9 if lon_launches else None
+            return rate, avg_ms, epochs_per_launch
+        achieved, lon_avg_ms, epochs_per_launch = kernel_rate(prof)
+        ramp_achieved, ramp_avg_ms, _ = kernel_rate(ramp_prof)
         traffic, traffic_source = pmc_traffic(wl.kernel_name)
         kernels = {k: {'ms_total': round(v[0], 4), 'launches': int(v[1]), 'avg_us': round(1e3 * v[0] / max(v[1], 1), 3)} for k, v in prof.items()}
         config = {'workload': 'batch of {0} monthly solutions d/o {1} -> {2} deg GeographicGrid ({3}x{4}), kernel {5}, per GPU'.format(
             B, MAX_DEGREE, GRID_STEP, wl.nlat, wl.nlon, KERNEL),
             'max_degree': MAX_DEGREE, 'epochs_per_gpu': B, 'grid': [wl.nlat, wl.nlon],
-            'parallelism': 'epochs sharded over {0} GPU(s), no collective'.format(world), 'untimed_ramp_launches': args.ramp}
+            'parallelism': 'epochs sharded over {0} GPU(s), no collective'.format(world),
+            'legs': sorted(args.leg_set), 'ramp_launches_before_value_after_ramp': args.ramp}
         config.update(wl.config)
         line = {
             'metric': METRIC,
@@ -328,7 +767,8 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
             'dtype': 'f64',
             'data': 'synthetic',
             'config': config,
-            'value_without_ramp': world * B * args.steps / cold_elapsed,
+            'value_after_ramp': world * B * args.steps / ramp_elapsed,
+            'ms_per_step_after_ramp': 1e3 * ramp_elapsed / args.steps,
             'roofline': {
                 'kernel': wl.kernel_name, 'bound': 'hbm',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -337,16 +777,34 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
                 'algorithmic_bytes_per_launch': per_solution * epochs_per_launch,
                 'avg_launch_ms': lon_avg_ms,
                 'whole_path_GBs': per_solution * B * args.steps / elapsed / 1e9,
+                'after_ramp': {'achieved': ramp_achieved, 'frac': (ramp_achieved / HBM_PEAK_GBS) if ramp_achieved else None, 'avg_launch_ms': ramp_avg_ms,
+                               'whole_path_GBs': per_solution * B * args.steps / ramp_elapsed / 1e9},
             },
             'kernels': kernels,
         }
-        line['cpu_baseline'] = wl.cpu_baseline(min(args.cpu_sample, B)) if world == 1 and args.cpu_sample > 0 else None
+        sample = min(args.cpu_sample, B) if world == 1 else min(args.cpu_sample, 1)
+        if sample > 0:
+            line['check'], line['cpu_baseline'] = wl.synthesis_check(sample, timed=world == 1)
+        else:
+            line['check'], line['cpu_baseline'] = None, None
 
-    # ---- second half of the metric: full-covariance propagation GFLOP/s (d/o 180 -> 0.5 deg, latitude bands)
+    # ---- the other legs, each between its own barriers
     wl.release_synthesis()
-    cov = covariance_leg(args, wl, rank, world, barrier, max_over_ranks, gd) if args.cov_parallels != 0 else None
+    legs = {}
+    if 'covariance' in args.leg_set:
+        from grates_amd import distributed as gd
+        legs['covariance'] = covariance_leg(args, wl, rank, world, barrier, max_over_ranks, gd)
+        if hasattr(wl, 'release_covariance'):
+            wl.release_covariance()
+    for name in ('analysis', 'filters', 'smoother'):
+        runner = getattr(wl, 'leg_' + name, None)
+        if name in args.leg_set and runner is not None:
+            barrier()
+            legs[name] = runner(ctx)
     if rank == 0:
-        line['covariance'] = cov
+        line.update(legs)
+        checks = [line.get('check')] + [legs[k].get('check') for k in legs if isinstance(legs[k], dict)]
+        line['all_checks_ok'] = all(c.get('ok', True) for c in checks if isinstance(c, dict))
         emit(json.dumps(line))
     if world > 1:
         dist.barrier()
@@ -358,7 +816,6 @@ def covariance_leg(args, wl, rank, world, barrier, max_over_ranks, gd):
     """d/o-180 covariance propagation to the 0.5 degree grid (BASELINE config 4): sigma = sqrt(diag(A Sigma A^T)) with A
     generated on the fly, A Sigma on fp64 MFMA.  Flops = 2 M P^2 + 2 M P.  The parallels [0, total) are split into one
     contiguous band per rank, every rank holds all of Sigma, the bands are gathered with one all_gather."""
-    import torch
     wl.setup_covariance()
     nlat, nlon, P = wl.cov_nlat, wl.cov_nlon, wl.P
     total = nlat if args.cov_parallels < 0 else min(args.cov_parallels, nlat)
@@ -424,14 +881,18 @@ def covariance_leg(args, wl, rank, world, barrier, max_over_ranks, gd):
             if total == nlat:
                 out[key]['max_rel_diff_vs_general'] = float(((sep - sigma).abs().max() / sigma.abs().max()).item())
             del sep
-    if world == 1 and args.cov_cpu_parallels > 0 and hasattr(wl, 'covariance_cpu'):
+    if world == 1 and args.cov_cpu_parallels > 0 and args.cpu_sample > 0 and hasattr(wl, 'covariance_cpu'):
         out['cpu_baseline'] = wl.covariance_cpu(0, args.cov_cpu_parallels, sigma)
+        err = out['cpu_baseline']['max_rel_diff_vs_gpu']
+        out['check'] = {'max_rel_err_vs_oracle': err, 'tolerance': 1e-11, 'ok': bool(err < 1e-11),
+                        'what': 'sigma of the first {0} parallel(s) of the timed, gathered output against the NumPy oracle'.format(args.cov_cpu_parallels)}
     return out
 
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    refuse_experiment_environment()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
         raise SystemExit(launch_ranks(args, argv))
     run_rank(args)

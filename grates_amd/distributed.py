@@ -99,16 +99,46 @@ def synthesize_sharded(time_series_batch, grid, kernel='ewh', GM=3.9860044150e+1
     Epoch-sharded batched synthesis: `time_series_batch` [T, N+1, N+1] is the full batch (host array) or a callable
     start, stop -> batch slice; returns (start, stop, device tensor of this rank's grids).  No collective.
     """
-    import torch.distributed as dist
     from . import gravityfield
+    start, stop, local = _epoch_shard(time_series_batch, group)
+    return start, stop, gravityfield.synthesize(local, grid, kernel, GM, R)
+
+
+def _epoch_shard(batch, group):
+    """(start, stop, this rank's contiguous slice of the leading axis of `batch`) -- host arrays are sliced before they are uploaded"""
+    import torch.distributed as dist
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    total = time_series_batch.shape[0] if hasattr(time_series_batch, 'shape') else None
-    if total is None:
-        raise ValueError('time_series_batch must be an array [T, N+1, N+1]')
-    start, stop = shard_range(total, rank, world)
-    local = np.ascontiguousarray(time_series_batch[start:stop]) if isinstance(time_series_batch, np.ndarray) else time_series_batch[start:stop]
-    return start, stop, gravityfield.synthesize(local, grid, kernel, GM, R)
+    if not hasattr(batch, 'shape') or len(batch.shape) < 1:
+        raise ValueError('an array or tensor with the epochs along its first axis is expected')
+    start, stop = shard_range(int(batch.shape[0]), rank, world)
+    local = np.ascontiguousarray(batch[start:stop]) if isinstance(batch, np.ndarray) else batch[start:stop]
+    return start, stop, local
+
+
+def analysis_sharded(value_batch, grid, min_degree, max_degree, kernel='potential', GM=3.9860044150e+14, R=6.3781363000e+06, group=None):
+    """
+    Epoch-sharded batched analysis (RegularGrid.to_potential_coefficients, grates/grid.py:752-790, for a series of grids):
+    `value_batch` [T, nlat, nlon] is the full batch (host array or device tensor); this rank analyses its contiguous range of
+    epochs on its GPU.  Returns (start, stop, device tensor [stop - start, N+1, N+1]).  No collective: the per-order
+    operators depend on the grid only and are built redundantly by every rank.
+    """
+    start, stop, local = _epoch_shard(value_batch, group)
+    nlat, nlon = grid.parallels.size, grid.meridians.size
+    if tuple(local.shape[1:]) != (nlat, nlon):
+        raise ValueError('value_batch must have shape [T, {0}, {1}], got {2}'.format(nlat, nlon, tuple(value_batch.shape)))
+    plan = grid._plan(kernel, max_degree, GM, R)
+    return start, stop, plan.analysis(local, grid.area.reshape(nlat, nlon), min_degree)
+
+
+def filter_sharded(spatial_filter, anm_batch, group=None):
+    """
+    Epoch-sharded batched filtering: `spatial_filter` is any grates_amd.filter object with `filter_batch` (Gaussian, OrderWiseFilter /
+    DDK, GeneralMatrix / VDK; the filter itself -- blocks or the dense matrix -- is replicated on every rank), `anm_batch`
+    [T, N+1, N+1] the full series.  Returns (start, stop, device tensor of this rank's filtered epochs).  No collective.
+    """
+    start, stop, local = _epoch_shard(anm_batch, group)
+    return start, stop, spatial_filter.filter_batch(local)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -134,6 +164,11 @@ def _gather_blocks(tensors, group=None):
             pos += t.numel()
         out.append(blocks)
     return out
+
+
+def gather_blocks(tensors, group=None):
+    """all_gather of a list of equally shaped device tensors (the same shapes on every rank): per-rank lists, on every rank."""
+    return _gather_blocks(tensors, group)
 
 
 class _Chain:
@@ -453,13 +488,35 @@ def sparse_inverse_block_tridiagonal_partitioned(diag, upper, group=None, consum
     return _partitioned_covariance(_PartitionedChain(diag, upper, None, group, consume))
 
 
-def smooth_block_tridiagonal_partitioned(diag, upper, rhs, group=None, consume=False):
+def smooth_block_tridiagonal_partitioned(diag, upper, rhs, group=None, consume=False, timings=None):
     """Solution and covariance blocks from ONE factorisation: (x, Zdiag, Zupper) as returned by solve_block_tridiagonal_partitioned
     and sparse_inverse_block_tridiagonal_partitioned (NormalEquations.solve followed by compute_covariance(sparse=True),
-    grates/lstsq.py:950-968, 1026-1042)."""
+    grates/lstsq.py:950-968, 1026-1042).
+
+    timings : dict, optional
+        receives the wall-clock seconds of the three phases ('factor_s': interior chains, all_gather and separator system;
+        'solve_s': sweeps and back substitution; 'covariance_s': sparse inverse) -- the device is drained after each phase when
+        a dict is given, and not otherwise."""
+    import time
+
+    def lap(key, since):
+        """drain the device and book the phase (only when the caller asked for timings)"""
+        if timings is None:
+            return since
+        pc_torch.cuda.synchronize()
+        now = time.perf_counter()
+        timings[key] = now - since
+        return now
+    import torch as pc_torch
+    if timings is not None:
+        pc_torch.cuda.synchronize()
+    t0 = time.perf_counter()
     pc = _PartitionedChain(diag, upper, rhs, group, consume)
+    t0 = lap('factor_s', t0)
     x = _partitioned_solution(pc, rhs)
+    t0 = lap('solve_s', t0)
     zdiag, zupper = _partitioned_covariance(pc)
+    lap('covariance_s', t0)
     return x, zdiag, zupper
 
 

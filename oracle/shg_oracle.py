@@ -370,17 +370,21 @@ def synthesis_matrix(min_degree, max_degree, meridians, parallels, kernel, GM=GM
 
 
 def analysis_regular(values, area, min_degree, max_degree, meridians, parallels, kernel, GM=GM_DEFAULT, R=R_DEFAULT,
-                     a=GRS80_A, f=GRS80_F):
+                     a=GRS80_A, f=GRS80_F, orders=None):
     """Area-weighted least squares per order and per cos/sin.  grid.py:665-696, 752-790.
-    values, area: flattened [nlat*nlon].  Returns anm [N+1, N+1]."""
+    values, area: flattened [nlat*nlon].  Returns anm [N+1, N+1].
+    orders: the orders to solve (default: all, like the reference's loop grid.py:779-785); the orders are independent
+    least-squares problems, the others stay zero (bounded samples of the benchmark's CPU baseline)."""
     anm = np.zeros((max_degree + 1, max_degree + 1))
     w = area[:, np.newaxis]
+    wanted = set(range(max_degree + 1)) if orders is None else set(int(m) for m in orders)
 
     def lsq(A):
         return np.linalg.solve((A * w).T @ A, (A * w).T) @ values
 
-    anm[min_degree:, 0] = lsq(synthesis_matrix_per_order(0, min_degree, max_degree, meridians, parallels, kernel, GM, R, a, f))
-    for m in range(1, max_degree + 1):
+    if 0 in wanted:
+        anm[min_degree:, 0] = lsq(synthesis_matrix_per_order(0, min_degree, max_degree, meridians, parallels, kernel, GM, R, a, f))
+    for m in sorted(wanted - {0}):
         Ac, As = synthesis_matrix_per_order(m, min_degree, max_degree, meridians, parallels, kernel, GM, R, a, f)
         start = max(m, min_degree)
         anm[start:, m] = lsq(Ac)

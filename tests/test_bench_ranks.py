@@ -55,8 +55,9 @@ class StubWorkload:
     def release_synthesis(self):
         del self.x
 
-    def cpu_baseline(self, sample):
-        return {'value': 1.0, 'unit': 'solutions/s', 'cores': 1, 'kind': 'port', 'sample': 'stub'}
+    def synthesis_check(self, sample, timed):
+        check = {'max_rel_err_vs_oracle': 0.0, 'epochs_checked': sample, 'ok': True}
+        return check, ({'value': 1.0, 'unit': 'solutions/s', 'cores': 1, 'kind': 'port', 'sample': 'stub'} if timed else None)
 
     def setup_covariance(self):
         self.cov_nlat, self.cov_nlon, self.P = 7, 5, 9
@@ -75,6 +76,29 @@ class StubWorkload:
         self.cov_mark = self.cov_calls
         return {'covprop': (2.0 * n, n)} if n else {}
 
+    def leg_smoother(self, ctx):
+        """stand-in for the epoch-sharded smoother leg: every rank 'solves' x_t = t for its epochs; exercises the rank context
+        (shard sizes, agreement, gathers of boundary rows, sums and maxima over ranks)"""
+        from grates_amd import distributed as gd
+        T = self.args.smoother_epochs
+        t0, t1 = gd.shard_range(T, ctx.rank, ctx.world)
+        assert ctx.all_counts[ctx.rank] == t1 - t0 and sum(ctx.all_counts) == T
+        assert ctx.all_ranks_agree(True) and not ctx.all_ranks_agree(ctx.rank == 0 and ctx.world > 1)
+        x = torch.arange(t0, t1, dtype=torch.float64)
+        edges = ctx.gather_rows([x[:1].clone(), x[-1:].clone()])
+        if ctx.rank > 0:
+            assert float(edges[ctx.rank - 1][1]) == t0 - 1                     # last epoch of the rank before
+        if ctx.rank + 1 < ctx.world:
+            assert float(edges[ctx.rank + 1][0]) == t1                         # first epoch of the rank behind
+        elapsed, _, step_ms = ctx.timed(lambda: None, 1, 2)
+        assert step_ms is None
+        total = ctx.sum_over_ranks([float(x.sum())])[0]
+        longest = ctx.max_over_ranks(float(t1 - t0))
+        if ctx.rank != 0:
+            return None
+        return {'value': T / max(elapsed, 1e-9), 'unit': 'epochs/s', 'n_gpus': ctx.world, 'scaling': 'strong', 'epochs_per_rank': ctx.all_counts,
+                'check': {'solution_checksum': total, 'longest_shard': longest, 'ok': total == T * (T - 1) / 2}}
+
 
 def _free_port():
     with socket.socket() as s:
@@ -85,7 +109,7 @@ def _free_port():
 def _rank(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     args = bench.parse_args(['--gpus', str(world), '--steps', '4', '--warmup', '2', '--ramp', '3', '--epochs', '6', '--backend', 'gloo',
-                             '--cov-repeats', '2'])
+                             '--cov-repeats', '2', '--smoother-epochs', '11'])
     lines = []
     result = bench.run_rank(args, workload_factory=StubWorkload, emit=lines.append)
     assert (result is not None) == (rank == 0) and len(lines) == (1 if rank == 0 else 0)
@@ -105,8 +129,14 @@ def test_rank_function_gloo(world, tmp_path):
     assert line['metric'] == bench.METRIC and line['unit'] == 'solutions/s' and line['n_gpus'] == world
     assert line['steps'] == 4 and line['warmup'] == 2 and line['scaling'] == 'weak' and line['dtype'] == 'f64'
     assert line['value'] == pytest.approx(world * 6 * 4 / (line['ms_per_step'] * 4e-3))        # whole-job aggregate over all ranks
-    assert line['value_without_ramp'] > 0 and line['cpu_baseline'] is None                    # the CPU baseline runs at N = 1 only
+    assert line['value_after_ramp'] > 0 and line['cpu_baseline'] is None                      # the CPU baseline runs at N = 1 only
+    assert line['check']['epochs_checked'] == 1                                               # ... the oracle check of the output does not
     assert line['roofline']['bound'] == 'hbm' and line['roofline']['avg_launch_ms'] == pytest.approx(0.5)
+    assert line['roofline']['after_ramp']['avg_launch_ms'] == pytest.approx(0.5)
+    sm = line['smoother']
+    assert sm['n_gpus'] == world and sum(sm['epochs_per_rank']) == 11 and sm['check']['ok'] and line['all_checks_ok']
+    assert sm['check']['longest_shard'] == max(sm['epochs_per_rank'])
+    assert 'analysis' not in line and 'filters' not in line                                    # legs the workload does not offer are left out
     cov = line['covariance']
     assert cov['n_gpus'] == world and cov['config']['repeats'] == 2 and len(cov['seconds_all']) == 2
     # the gathered grid is the full grid whatever the number of bands (7 parallels: unequal bands)
@@ -122,7 +152,8 @@ def test_rank_function_single_process(monkeypatch):
     lines = []
     line = bench.run_rank(args, workload_factory=StubWorkload, emit=lines.append)
     assert json.loads(lines[0]) == json.loads(json.dumps(line))
-    assert line['n_gpus'] == 1 and line['cpu_baseline']['kind'] == 'port'
+    assert line['n_gpus'] == 1 and line['cpu_baseline']['kind'] == 'port' and line['check']['epochs_checked'] == 5
+    assert line['smoother']['epochs_per_rank'] == [bench.SMOOTHER_EPOCHS] and line['all_checks_ok']
     assert line['covariance']['sigma_checksum'] == pytest.approx(_expected_sigma().sum(), rel=0, abs=1e-12)
     assert line['covariance']['seconds_min'] <= line['covariance']['seconds_median']
 
@@ -140,6 +171,13 @@ def test_bare_multi_gpu_invocation_launches_ranks(monkeypatch):
     assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '2'
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and os.path.basename(cmd[cmd.index('--master-port') + 2]) == 'bench.py'
     assert cmd[-6:] == ['--gpus', '2', '--steps', '5', '--warmup', '1'] and env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # experiment switches / library overrides in the environment: refused before anything runs
+    for name in bench.FORBIDDEN_ENVIRONMENT:
+        monkeypatch.setenv(name, '1')
+        with pytest.raises(SystemExit) as e:
+            bench.main(['--gpus', '1'])
+        assert name in str(e.value.code) and len(calls) == 1
+        monkeypatch.delenv(name)
     # under a launcher (RANK set) the same command line is a rank, not a launcher
     monkeypatch.setenv('RANK', '0')
     monkeypatch.setenv('WORLD_SIZE', '1')

@@ -50,6 +50,13 @@ def _worker(rank, world, port, nlat, nlon, result_dir):
     counts = torch.zeros(17, dtype=torch.int64)
     counts[start:stop] = 1
     dist.all_reduce(counts)
+    # the epoch shard the sharded synthesis / analysis / filter entry points take from a full batch
+    whole = np.arange(17 * 3, dtype=float).reshape(17, 3)
+    s0, s1, mine_np = gd._epoch_shard(whole, None)
+    t0, t1, mine_t = gd._epoch_shard(torch.from_numpy(whole), None)
+    assert (s0, s1) == (t0, t1) == (start, stop) and mine_np.flags['C_CONTIGUOUS']
+    np.testing.assert_array_equal(mine_np, whole[start:stop])
+    np.testing.assert_array_equal(mine_t.numpy(), whole[start:stop])
     # block gather of the partitioned smoother: every rank contributes a list of blocks, everybody receives all lists
     mine = [torch.full((2, 3), float(rank), dtype=torch.float64), torch.arange(4, dtype=torch.float64).reshape(4, 1) + 10 * rank]
     everyone = gd._gather_blocks(mine)

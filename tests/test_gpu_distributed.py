@@ -252,6 +252,15 @@ def _shard_worker(rank, world, port, result_dir):
     batch = np.stack([inputs.coefficients(300 + e, 20) for e in range(7)])
     e0, e1, grids = gd.synthesize_sharded(batch, grid, kernel='ewh')
     np.save(os.path.join(result_dir, 'grids_{0}.npy'.format(rank)), np.concatenate(([e0, e1], grids.cpu().numpy().ravel())))
+    # epoch-sharded analysis of those grids and epoch-sharded filters (block form and dense form), SURVEY 8(e) row 1
+    whole = ga.engine.to_host(ga.gravityfield.synthesize(batch, grid, kernel='ewh'))
+    a0, a1, anm = gd.analysis_sharded(whole, grid, 0, 20, kernel='ewh')
+    flt = ga.filter.OrderWiseFilter(inputs.orderwise_random_blocks(42, 20))
+    f0, f1, filtered = gd.filter_sharded(flt, batch)
+    g0, g1, dense = gd.filter_sharded(ga.filter.GeneralMatrix(flt.matrix(2, 20), 2, 20), torch.from_numpy(batch).cuda())
+    assert (a0, a1) == (e0, e1) == (f0, f1) == (g0, g1)
+    np.savez(os.path.join(result_dir, 'epochs_{0}.npz'.format(rank)), span=[e0, e1], anm=anm.cpu().numpy(), filtered=filtered.cpu().numpy(),
+             dense=dense.cpu().numpy())
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -278,3 +287,70 @@ def test_sharded_covariance_and_synthesis(tmp_path):
         seen.append((e0, e1))
         np.testing.assert_array_equal(d[2:].reshape(e1 - e0, *whole.shape[1:]), whole[e0:e1])
     assert seen[0][0] == 0 and seen[-1][1] == 7 and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    # sharded analysis / filters: every rank's slice equals the slice of the single-process result, bit for bit
+    plan_anm = ga.engine.to_host(grid._plan('ewh', 20, 3.9860044150e+14, 6.3781363000e+06).analysis(whole, grid.area.reshape(whole.shape[1:]), 0))
+    flt = ga.filter.OrderWiseFilter(inputs.orderwise_random_blocks(42, 20))
+    all_filtered = ga.engine.to_host(flt.filter_batch(batch))
+    all_dense = ga.engine.to_host(ga.filter.GeneralMatrix(flt.matrix(2, 20), 2, 20).filter_batch(batch))
+    assert relerr(plan_anm, batch) < 1e-11                                     # band-limited fields come back
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), 'epochs_{0}.npz'.format(r)))
+        e0, e1 = z['span']
+        np.testing.assert_array_equal(z['anm'], plan_anm[e0:e1])
+        np.testing.assert_array_equal(z['filtered'], all_filtered[e0:e1])
+        np.testing.assert_array_equal(z['dense'], all_dense[e0:e1])
+
+
+def test_bench_rehearsal_world4_real_shard_sizes():
+    """The 4-way shardings of BASELINE configs 4 and 5 at their real per-rank sizes, rehearsed on ONE card (four rank processes
+    under gloo, all mapped to cuda:0; with RCCL each rank has its own GPU) through bench.py itself:
+      * covariance: the whole 360 x 720 grid at d/o 180 in four latitude bands of 90 parallels, Sigma (8.6 GB) replicated per rank
+        -- the gathered sigma must be bit-identical to the single-process result (checksum and CRC);
+      * smoother: d = 1681 with 128 epochs per rank (512 epochs), nested dissection with all_gathers of the separator blocks
+        -- solution and covariance blocks are checked inside bench.py (residual over the whole chain across the rank boundaries,
+        (N N^-1)_tt = I), the solution checksum must agree with the single-chain run to rounding.
+    The record (per-rank shard sizes, gathered payload, times) goes to gpurun_out/r3_rehearsal_world4.json."""
+    import json
+    import subprocess
+    import sys
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip('four replicas of the d/o-180 covariance matrix and a 512-epoch chain need ~150 GB of free device memory')
+    torch.cuda.empty_cache()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, os.path.join(root, 'bench.py'), '--legs', 'covariance,smoother', '--smoother-epochs', '512', '--smoother-repeats', '1',
+              '--cpu-sample', '0', '--cov-repeats', '1', '--cov-extensions', '0', '--steps', '2', '--warmup', '1', '--ramp', '0', '--epochs', '8']
+    lines = {}
+    for world in (1, 4):
+        extra = [] if world == 1 else ['--backend', 'gloo', '--same-device']
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+        run = subprocess.run(common + ['--gpus', str(world)] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert run.returncode == 0, run.stderr[-2000:]
+        lines[world] = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith('{')][-1])
+    one, four = lines[1], lines[4]
+    assert four['n_gpus'] == 4 and four['all_checks_ok'] and one['all_checks_ok']
+    assert four['covariance']['sigma_crc32'] == one['covariance']['sigma_crc32']
+    assert four['covariance']['sigma_checksum'] == one['covariance']['sigma_checksum']
+    assert four['smoother']['config']['epochs_per_rank'] == [128] * 4
+    assert four['smoother']['check']['residual'] < 1e-13 and four['smoother']['check']['identity_defect_max'] < 1e-12
+    a, b = one['smoother']['check']['solution_checksum'], four['smoother']['check']['solution_checksum']
+    assert abs(a - b) < 1e-9 * max(abs(a), 1.0)
+    d = 1681
+    record = {'what': 'bench.py --gpus 4 --backend gloo --same-device: four rank processes on one card, real per-rank shard sizes',
+              'covariance': {'bands': four['covariance']['config']['workload'], 'seconds_world4_one_card': four['covariance']['seconds_median'],
+                             'seconds_world1': one['covariance']['seconds_median'], 'sigma_crc32': four['covariance']['sigma_crc32'],
+                             'gathered_bytes_per_rank': 90 * 720 * 8},
+              'smoother': {'epochs_per_rank': four['smoother']['config']['epochs_per_rank'], 'dim': d,
+                           'gathered_bytes_per_rank': (5 * d * d + 3 * d + d * d) * 8,
+                           'seconds_world4_one_card': four['smoother']['seconds'], 'phases_world4': four['smoother']['phases_s'],
+                           'seconds_world1': one['smoother']['seconds'], 'phases_world1': one['smoother']['phases_s'],
+                           'residual_world4': four['smoother']['check']['residual'], 'identity_defect_world4': four['smoother']['check']['identity_defect_max'],
+                           'solution_checksum_world1': a, 'solution_checksum_world4': b}}
+    print(json.dumps(record))
+    out_dir = os.path.join(root, 'gpurun_out')
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'r3_rehearsal_world4.json'), 'w') as f:
+            f.write(json.dumps(record) + '\n')
+    except OSError:
+        pass
