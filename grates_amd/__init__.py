@@ -14,6 +14,7 @@ from . import grid
 from . import filter
 from . import lstsq
 from . import io
+from . import extras
 
-__all__ = ['data', 'engine', 'filter', 'gravityfield', 'grid', 'io', 'kernel', 'lstsq', 'utilities']
+__all__ = ['data', 'engine', 'extras', 'filter', 'gravityfield', 'grid', 'io', 'kernel', 'lstsq', 'utilities']
 __version__ = '0.1.0'

@@ -36,6 +36,8 @@ PROTOTYPES = {
     'shg_legendre': [ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_legendre_order': [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_trigonometric': [ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_synthesis_matrix_order': [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int,
+                                   c_double_p, c_double_p, ctypes.c_void_p],
     'shg_ravel': [c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_unravel': [c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_covprop_diag': [c_plan_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],

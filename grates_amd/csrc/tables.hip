@@ -191,6 +191,52 @@ extern "C" int shg_legendre_order(int N, int m, const double* colat, int k, doub
     return SHG_OK;
 }
 
+namespace shg {
+// rows of the per-order operator block: thread <-> (row, column); pm [nlat][N + 1 - m] from legendre_order_kernel
+__global__ void order_block_kernel(int N, int m, int c0, int cnt, int nlat, int nlon, int pointwise, const double* __restrict__ pm,
+                                   const double* __restrict__ kn, const double* __restrict__ lon, double* __restrict__ out_cos,
+                                   double* __restrict__ out_sin) {
+    const long long rows = pointwise ? nlat : (long long)nlat * nlon;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * cnt) return;
+    const long long row = e / cnt;
+    const int c = (int)(e - row * cnt);
+    const int i = pointwise ? (int)row : (int)(row / nlon);
+    const int j = pointwise ? (int)row : (int)(row - (long long)i * nlon);
+    const int n = m + c0 + c;
+    const double p = pm[(size_t)i * (N + 1 - m) + c0 + c] * kn[(size_t)i * (N + 1) + n];
+    if (m == 0) {
+        out_cos[e] = p;
+        return;
+    }
+    const double arg = (double)m * lon[j];
+    out_cos[e] = p * cos(arg);
+    out_sin[e] = p * sin(arg);
+}
+}  // namespace shg
+
+extern "C" int shg_synthesis_matrix_order(int N, int m, int nmin, const double* colat, int nlat, const double* lon, int nlon, const double* kn,
+                                          int pointwise, double* out_cos, double* out_sin, void* stream_) {
+    SHG_REQUIRE(N >= 0 && m >= 0 && nmin >= 0 && nlat >= 0 && (pointwise || nlon >= 0), "shg_synthesis_matrix_order: bad size");
+    SHG_REQUIRE(m <= N, "order exceeds maximum degree (%d vs. %d)", m, N);
+    const int c0 = nmin > m ? nmin - m : 0, cnt = N + 1 - m - c0;
+    const long long rows = pointwise ? nlat : (long long)nlat * nlon;
+    if (rows == 0 || cnt <= 0) return SHG_OK;
+    SHG_REQUIRE(colat && kn && out_cos && (m == 0 || (lon && out_sin)), "shg_synthesis_matrix_order: NULL pointer");
+    SHG_REQUIRE(rows * cnt < (1LL << 31) * 256, "shg_synthesis_matrix_order: problem too large");
+    hipStream_t stream = (hipStream_t)stream_;
+    double* pm = nullptr;
+    if (workspace_alloc((void**)&pm, (size_t)nlat * (N + 1 - m) * sizeof(double), stream) != hipSuccess)
+        return fail(SHG_ERR_NOMEM, "shg_synthesis_matrix_order: workspace allocation failed");
+    hipLaunchKernelGGL(legendre_order_kernel, dim3(ceil_div(nlat, 64)), dim3(64), 0, stream, N, m, nlat, colat, pm);
+    hipLaunchKernelGGL(order_block_kernel, dim3((unsigned)ceil_div64(rows * cnt, 256)), dim3(256), 0, stream, N, m, c0, cnt, nlat, nlon, pointwise,
+                       pm, kn, lon, out_cos, out_sin);
+    const hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(pm, stream);
+    if (e != hipSuccess) return fail(SHG_ERR_HIP, "shg_synthesis_matrix_order: launch failed: %s", hipGetErrorString(e));
+    return SHG_OK;
+}
+
 extern "C" int shg_trigonometric(int N, const double* lon, int k, double* cs, void* stream_) {
     SHG_REQUIRE(N >= 0 && k >= 0, "shg_trigonometric: bad size");
     if (k == 0) return SHG_OK;

@@ -272,6 +272,23 @@ def trigonometric_functions(max_degree, lon):
     return out
 
 
+def synthesis_matrix_order(max_degree, order, min_degree, colat, lon, kn, pointwise):
+    """Operator block of one order (device tensors): (cosine block, sine block or None for order 0), rows parallel-major for a
+    regular grid (pointwise=False: colat / kn per parallel, lon = meridians) or one row per point (pointwise=True)."""
+    torch = require_gpu()
+    th, lam, k = to_device(np.atleast_1d(colat)), to_device(np.atleast_1d(lon)), to_device(kn)
+    nlat, nlon = th.numel(), lam.numel()
+    if k.shape != (nlat, max_degree + 1) or (pointwise and nlon != nlat):
+        raise ValueError('synthesis_matrix_order: colat [k], kn [k, max_degree + 1] and, for point lists, lon [k] expected')
+    count = max_degree + 1 - max(order, min_degree)
+    rows = nlat if pointwise else nlat * nlon
+    out_c = torch.empty((rows, max(count, 0)), dtype=torch.float64, device=th.device)
+    out_s = torch.empty_like(out_c) if order > 0 else None
+    _lib.call('shg_synthesis_matrix_order', int(max_degree), int(order), int(min_degree), _ptr(th), nlat, _ptr(lam), nlon, _ptr(k),
+              1 if pointwise else 0, _ptr(out_c), _ptr(out_s) if out_s is not None else None, _stream())
+    return out_c, out_s
+
+
 def synthesis_matrix(max_degree, min_degree, colat, lon, kn):
     """Dense synthesis operator A [npts, P] (device tensor) of the points (colat, lon) with degree factors kn [npts, N+1]."""
     torch = require_gpu()

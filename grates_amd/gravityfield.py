@@ -477,48 +477,6 @@ class TimeSeries:
         self.sort()
 
 
-class TimeVariableGravityField:
-    """Sum of constituents (trend, oscillations, time series ...) that implement `evaluate_at`
-    (grates/gravityfield.py:788-812)."""
-
-    def __init__(self, constituents):
-        self.constituents = constituents
-
-    def evaluate_at(self, epoch):
-        return np.sum([c.evaluate_at(epoch) for c in self.constituents])
-
-
-class Trend:
-    """Linear trend V (t - t0); `time_scale` is the time unit of the coefficients in days (grates/gravityfield.py:1054-1094)."""
-
-    def __init__(self, gravity_field, reference_epoch, time_scale=365.25):
-        self.__data = gravity_field.copy()
-        self.__reference_epoch = reference_epoch
-        self.__time_scale = time_scale
-
-    def evaluate_at(self, epoch):
-        dt = (epoch - self.__reference_epoch).total_seconds() / (86400 * self.__time_scale)
-        output = self.__data * dt
-        output.epoch = epoch
-        return output
-
-
-class Oscillation:
-    """V_c cos 2 pi (t - t0) / T + V_s sin 2 pi (t - t0) / T with the period T in days (grates/gravityfield.py:1097-1140)."""
-
-    def __init__(self, gravity_field_cosine, gravity_field_sine, period, reference_epoch):
-        self.__data_cosine = gravity_field_cosine.copy()
-        self.__data_sine = gravity_field_sine.copy()
-        self.__reference_epoch = reference_epoch
-        self.__period = period
-
-    def evaluate_at(self, epoch):
-        dt = (epoch - self.__reference_epoch).total_seconds() / (86400 * self.__period)
-        output = self.__data_cosine * np.cos(2 * np.pi * dt) + self.__data_sine * np.sin(2 * np.pi * dt)
-        output.epoch = epoch
-        return output
-
-
 def gridded_rms(temporal_gravityfield, epochs, kernel='ewh', base_grid=None, batch=240):
     """
     RMS over `epochs` of a time variable gravity field in the space domain (grates/gravityfield.py:1143-1172).  The fields of up
@@ -713,68 +671,6 @@ def _point_harmonics_adjoint(points, max_degree, values, upward=None):
     return out.reshape(max_degree + 1, max_degree + 1)
 
 
-class SurfaceMasCons:
-    """
-    Point masses / surface elements on a grid whose values are a gravity field functional `kernel`
-    (grates/gravityfield.py:484-570).  Arithmetic is point-wise on the values.
-    """
-
-    def __init__(self, point_distribution, kernel):
-        self.point_distribution = point_distribution
-        if self.point_distribution.values is None:
-            self.point_distribution.values = np.zeros(self.point_distribution.point_count)
-        self.kernel = kernel
-        self.epoch = None
-
-    def copy(self):
-        other = SurfaceMasCons(self.point_distribution.copy(), self.kernel)
-        other.epoch = self.epoch
-        return other
-
-    def is_compatible(self, other):
-        return self.point_distribution.is_compatible(other.point_distribution)
-
-    @property
-    def values(self):
-        return self.point_distribution.values
-
-    @values.setter
-    def values(self, val):
-        self.point_distribution.values = val
-
-    def __combine(self, other, symbol, sign):
-        _check_operand(self, other, SurfaceMasCons, symbol)
-        if not self.is_compatible(other):
-            raise ValueError("point distributions of '" + str(type(self)) + "' instances are not compatible")
-        result = self.copy()
-        result.values = result.values + sign * other.values
-        return result
-
-    def __add__(self, other):
-        return self.__combine(other, '+', 1.0)
-
-    def __sub__(self, other):
-        return self.__combine(other, '-', -1.0)
-
-    def __mul__(self, other):
-        _check_operand(self, other, (int, float), '*')
-        result = self.copy()
-        result.values = result.values * other
-        return result
-
-    def __truediv__(self, other):
-        _check_operand(self, other, (int, float), '/')
-        return self * (1.0 / other)
-
-    def to_potential_coefficients(self, min_degree, max_degree, GM=3.9860044150e+14, R=6.3781363000e+06):
-        """
-        Spherical harmonic analysis of the mascon values through the analysis operator of the point distribution.
-        (Upstream hands the builtin ``round`` to the grid in place of R, grates/gravityfield.py:570, and cannot run; R is
-        passed here.)
-        """
-        return self.point_distribution.to_potential_coefficients(min_degree, max_degree, self.kernel, GM, R)
-
-
 class RadialBasisFunctions:
     """
     Gravity field as radial basis functions at the nodal points of `point_distribution`: shape factors `K` in the
@@ -835,54 +731,6 @@ class RadialBasisFunctions:
 
     def to_grid(self, grid=None, kernel='ewh'):
         """gridded values through the spherical harmonic representation (grates/gravityfield.py:766-785)"""
-        from .grid import GeographicGrid
-        return self.to_potential_coefficients().to_grid(GeographicGrid() if grid is None else grid, kernel)
-
-
-class AnisotropicBasisFunctions:
-    """
-    Gravity field as anisotropic kernel functions at the nodal points: `K` [P, P] acts on the degree-wise vector of the
-    point harmonics, band min_degree .. max_degree (grates/gravityfield.py:573-649).
-    """
-
-    def __init__(self, point_distribution, K, min_degree, max_degree, GM=3.9860044150e+14, R=6.3781363000e+06):
-        self.__K = K.copy()
-        self.point_distribution = point_distribution
-        self.__min_degree = min_degree
-        self.__max_degree = max_degree
-        self.GM = GM
-        self.R = R
-        self.epoch = None
-        self.values = np.zeros((self.point_distribution.size))
-
-    @property
-    def values(self):
-        return self.point_distribution.values
-
-    @values.setter
-    def values(self, val):
-        self.point_distribution.values = val
-
-    def is_compatible(self, other):
-        return self.point_distribution.is_compatible(other.point_distribution)
-
-    def to_potential_coefficients(self):
-        """x = K (Y^T values) as potential coefficients (degrees below min_degree zero): the coefficient vector the
-        reference forms per block of nodal points inside to_grid (grates/gravityfield.py:637-639)."""
-        total = _point_harmonics_adjoint(self.point_distribution, self.__max_degree, self.values)
-        y = engine.ravel(total.unsqueeze(0), self.__min_degree, self.__max_degree)
-        x = engine.gemm(engine.to_device(self.__K), y.reshape(-1, 1))
-        coefficients = PotentialCoefficients(self.GM, self.R)
-        coefficients.anm = utilities.unravel_coefficients(engine.to_host(x).ravel(), self.__min_degree, self.__max_degree)
-        coefficients.epoch = self.epoch
-        return coefficients
-
-    def to_grid(self, grid=None, kernel='ewh'):
-        """
-        Gridded values: the kernel coefficient vector K Y^T values is synthesised on the parallels of `grid` with the
-        kernel factors, the upward continuation (R / r)^(n+1) and GM / R (grates/gravityfield.py:604-649) -- the regular
-        grid synthesis of the hot path.
-        """
         from .grid import GeographicGrid
         return self.to_potential_coefficients().to_grid(GeographicGrid() if grid is None else grid, kernel)
 

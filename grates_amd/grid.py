@@ -222,17 +222,9 @@ class RegularGrid(Grid):
     def synthesis_matrix_per_order(self, m, min_degree, max_degree, kernel, GM, R):
         """Operator block of order m (rows parallel-major): one matrix for m = 0, a (cosine, sine) tuple
         otherwise; columns are degrees max(m, min_degree)..max_degree (grates/grid.py:653-663)."""
-        torch = engine.require_gpu()
         colat, _, kn = self._parallel_tables(kernel, max_degree, GM, R)
-        Pm = engine.legendre_functions_per_order(max_degree, m, colat) * engine.to_device(kn[:, m:])
-        Pm = Pm[:, max(min_degree - m, 0):]
-        nlon = self.meridians.size
-        if m == 0:
-            return engine.to_host(Pm.repeat_interleave(nlon, dim=0))
-        lam = engine.to_device(m * self.meridians)
-        Ac = (Pm[:, None, :] * torch.cos(lam)[None, :, None]).reshape(-1, Pm.shape[1])
-        As = (Pm[:, None, :] * torch.sin(lam)[None, :, None]).reshape(-1, Pm.shape[1])
-        return engine.to_host(Ac), engine.to_host(As)
+        Ac, As = engine.synthesis_matrix_order(max_degree, m, min_degree, colat, self.meridians, kn, pointwise=False)
+        return engine.to_host(Ac) if m == 0 else (engine.to_host(Ac), engine.to_host(As))
 
     def analysis_matrix_device(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
         """The dense analysis operator as a device tensor [coefficients, points]: the cached per-order least-squares operator
@@ -364,14 +356,9 @@ class IrregularGrid(Grid):
 
     def synthesis_matrix_per_order(self, m, min_degree, max_degree, kernel, GM, R):
         """Operator block of order m for a point list (grates/grid.py:981-991)."""
-        torch = engine.require_gpu()
         colat, lon, kn = self._point_tables(kernel, max_degree, GM, R)
-        Pm = engine.legendre_functions_per_order(max_degree, m, colat) * engine.to_device(kn[:, m:])
-        Pm = Pm[:, max(min_degree - m, 0):]
-        if m == 0:
-            return engine.to_host(Pm)
-        lam = engine.to_device(m * lon)
-        return engine.to_host(Pm * torch.cos(lam)[:, None]), engine.to_host(Pm * torch.sin(lam)[:, None])
+        Ac, As = engine.synthesis_matrix_order(max_degree, m, min_degree, colat, lon, kn, pointwise=True)
+        return engine.to_host(Ac) if m == 0 else (engine.to_host(Ac), engine.to_host(As))
 
     def analysis_matrix(self, min_degree, max_degree, kernel='potential', GM=_GM, R=_R):
         """(A^T W A)^-1 A^T W with W = diag(area) (grates/grid.py:1015-1017); the normal matrix and the
@@ -439,44 +426,6 @@ class GaussGrid(RegularGrid):
             grid.values = self.values.copy()
         grid.epoch = self.epoch
         return grid
-
-
-class ReuterGrid(IrregularGrid):
-    """
-    Reuter grid of a given level: level + 1 parallels at equal spacing on the unit sphere, on each of them as many points as
-    keep the spherical distance to the neighbours near pi / level; poles are single points.  The sphere is mapped onto the
-    ellipsoid by `latitude_mapping` ('geocentric', 'authalic' or 'conformal') (grates/grid.py:1207-1278).  The usual nodal
-    point distribution of `RadialBasisFunctions` / `SurfaceMasCons`; area elements are those of the unit sphere.
-    """
-
-    def __init__(self, level, a=6378137.0, f=298.2572221010**-1, latitude_mapping='geocentric'):
-        mappings = {'authalic': authalic2geodetic, 'geocentric': geocentric2geodetic, 'conformal': conformal2geodetic}
-        if latitude_mapping.lower() not in mappings:
-            raise ValueError('Unknown latitude mapping "{0}".'.format(latitude_mapping))
-        dlat = np.pi / level
-        polar_cap = 2 * np.pi * (1 - np.cos(dlat * 0.5))
-        latitude, counts, areas = [0.5 * np.pi], [1], [polar_cap]
-        for k in range(1, level):
-            theta = k * dlat
-            count = int(2 * np.pi / np.arccos((np.cos(dlat) - np.cos(theta) ** 2) / (np.sin(theta) ** 2)))
-            latitude.append(np.pi * 0.5 - theta)
-            counts.append(count)
-            areas.append(4 * np.pi / count * np.sin(0.5 * dlat) * np.cos(latitude[-1]))
-        latitude.append(-0.5 * np.pi)
-        counts.append(1)
-        areas.append(polar_cap)
-        latitude = mappings[latitude_mapping.lower()](np.array(latitude), f)
-        lon = [np.zeros(1) if k in (0, level) else np.mod((np.arange(n) + 1.5) * 2 * np.pi / n + np.pi, 2 * np.pi) - np.pi
-               for k, n in enumerate(counts)]
-        super().__init__(np.concatenate(lon), np.repeat(latitude, counts), np.repeat(np.array(areas), counts), a, f)
-        self.__level, self.__mapping = level, latitude_mapping
-
-    def copy(self):
-        # (upstream's copy falls back to the geocentric mapping; the mapping is kept here)
-        other = ReuterGrid(self.__level, self.semimajor_axis, self.flattening, self.__mapping)
-        other.values = None if self.values is None else self.values.copy()
-        other.epoch = self.epoch
-        return other
 
 
 # -------------------------------------------------------------------------------------------------------

@@ -109,6 +109,16 @@ int shg_legendre(int N, const double* colat, int k, double* pnm, void* stream);
 int shg_legendre_order(int N, int m, const double* colat, int k, double* pm, void* stream);
 int shg_trigonometric(int N, const double* lon, int k, double* cs, void* stream);
 
+/* Operator block of one order m (RegularGrid.synthesis_matrix_per_order, grates/grid.py:627-663, and
+ * IrregularGrid.synthesis_matrix_per_order, grates/grid.py:957-991): columns = degrees max(m, nmin) .. N,
+ *   out_cos[row][c] = kn[i][n] P_nm(colat_i) cos(m lon_j),   out_sin likewise with sin   (n = max(m, nmin) + c),
+ * with P_nm from the per-order recursion (s = sqrt(1 - t^2), like shg_legendre_order).
+ *   pointwise = 0: regular grid, colat / kn rows of the nlat parallels, lon of the nlon meridians, row = i * nlon + j;
+ *   pointwise = 1: point list, colat / lon / kn rows of the nlat points (nlon is ignored), row = i.
+ * m = 0: only out_cos is written (cos 0 = 1); out_sin may be NULL. */
+int shg_synthesis_matrix_order(int N, int m, int nmin, const double* colat, int nlat, const double* lon, int nlon, const double* kn,
+                               int pointwise, double* out_cos, double* out_sin, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Degree-wise ravel / unravel of batches (integer index maps applied on the device)
  *   replaces utilities.ravel_coefficients / unravel_coefficients   (grates/utilities.py:310-411)

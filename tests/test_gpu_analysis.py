@@ -52,6 +52,21 @@ def test_golden_random_values_and_matrices(golden):
     Ac, As = grid.synthesis_matrix_per_order(3, 1, 8, 'ewh', 3.9860044150e+14, 6.3781363000e+06)
     ref_c, ref_s = orc.synthesis_matrix_per_order(3, 1, 8, grid.meridians, grid.parallels, orc.KernelTable('ewh', love()))
     assert relerr(Ac, ref_c) < 1e-12 and relerr(As, ref_s) < 1e-12
+    # order 0 (one block, no longitude dependence), an order below min_degree (columns start at min_degree) and the last order
+    ker = orc.KernelTable('ewh', love())
+    A0 = grid.synthesis_matrix_per_order(0, 1, 8, 'ewh', 3.9860044150e+14, 6.3781363000e+06)
+    assert A0.shape == (grid.point_count, 8) and relerr(A0, orc.synthesis_matrix_per_order(0, 1, 8, grid.meridians, grid.parallels, ker)) < 1e-12
+    for m, nmin in ((2, 5), (8, 0)):
+        Ac, As = grid.synthesis_matrix_per_order(m, nmin, 8, 'ewh', 3.9860044150e+14, 6.3781363000e+06)
+        ref_c, ref_s = orc.synthesis_matrix_per_order(m, nmin, 8, grid.meridians, grid.parallels, ker)
+        assert Ac.shape == ref_c.shape == (grid.point_count, 9 - max(m, nmin)) and relerr(Ac, ref_c) < 1e-12 and relerr(As, ref_s) < 1e-12
+    # point list (IrregularGrid.synthesis_matrix_per_order, grates/grid.py:957-991): the rows of the regular block, point by point
+    pts = ga.grid.IrregularGrid(grid.longitude, grid.latitude)
+    Pc, Ps = pts.synthesis_matrix_per_order(3, 1, 8, 'ewh', 3.9860044150e+14, 6.3781363000e+06)
+    Rc, Rs = orc.synthesis_matrix_per_order(3, 1, 8, grid.meridians, grid.parallels, ker)
+    assert relerr(Pc, Rc) < 1e-12 and relerr(Ps, Rs) < 1e-12
+    assert relerr(pts.synthesis_matrix_per_order(0, 0, 8, 'potential', 3.9860044150e+14, 6.3781363000e+06),
+                  orc.synthesis_matrix_per_order(0, 0, 8, grid.meridians, grid.parallels, orc.KernelTable('potential', love()))) < 1e-12
 
 
 def test_round_trip_d60_one_degree(golden):

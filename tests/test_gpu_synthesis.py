@@ -374,12 +374,12 @@ def test_basis_function_representations_golden(golden):
     finally:
         ga.gravityfield._POINT_CHUNK_BYTES = saved
 
-    aniso = ga.gravityfield.AnisotropicBasisFunctions(ga.grid.IrregularGrid(lon, lat), k_aniso, 2, 12)
+    aniso = ga.extras.AnisotropicBasisFunctions(ga.grid.IrregularGrid(lon, lat), k_aniso, 2, 12)
     aniso.values = values
     assert relerr(aniso.to_grid(ga.grid.GeographicGrid(10.0, 10.0), 'ewh').value_array, g['aniso_grid_ewh']) < 1e-12
     assert relerr(aniso.to_grid(ga.grid.GeographicGrid(10.0, 10.0), 'potential').value_array, g['aniso_grid_potential']) < 1e-12
 
-    a = ga.gravityfield.SurfaceMasCons(ga.grid.IrregularGrid(lon, lat), 'ewh')
+    a = ga.extras.SurfaceMasCons(ga.grid.IrregularGrid(lon, lat), 'ewh')
     b = a.copy()
     a.values = values
     b.values = values[::-1].copy()
@@ -389,13 +389,13 @@ def test_basis_function_representations_golden(golden):
     with pytest.raises(TypeError):
         a * b
     with pytest.raises(ValueError):
-        a + ga.gravityfield.SurfaceMasCons(ga.grid.IrregularGrid(lon[:10], lat[:10]), 'ewh')
+        a + ga.extras.SurfaceMasCons(ga.grid.IrregularGrid(lon[:10], lat[:10]), 'ewh')
     # analysis of mascon values = analysis of the same values on the grid itself
     lon2, lat2 = inputs.scattered_points(5, 400)
     pts = ga.grid.IrregularGrid(lon2, lat2)
     pts.values = np.random.default_rng(3).standard_normal(400)
     expected = pts.to_potential_coefficients(0, 8, 'ewh').anm
-    assert relerr(ga.gravityfield.SurfaceMasCons(pts, 'ewh').to_potential_coefficients(0, 8).anm, expected) < 1e-13
+    assert relerr(ga.extras.SurfaceMasCons(pts, 'ewh').to_potential_coefficients(0, 8).anm, expected) < 1e-13
 
 
 def test_time_variable_field_and_gridded_rms_golden(golden):
@@ -414,7 +414,19 @@ def test_time_variable_field_and_gridded_rms_golden(golden):
         gf.epoch = t0 + datetime.timedelta(days=61 * k)
         series.append(gf)
     gfm = ga.gravityfield
-    model = gfm.TimeVariableGravityField([gfm.Trend(field(110), t0), gfm.Oscillation(field(111), field(112), 365.25, t0), gfm.TimeSeries(series)])
+
+    class Model:
+        """a time-variable field for gridded_rms (anything with evaluate_at): linear trend per year + annual oscillation + the
+        interpolated series -- the constituents the fixture was generated with (grates/gravityfield.py:788-812, 1054-1140)"""
+        trend, cosine, sine, interpolated = field(110), field(111), field(112), gfm.TimeSeries(series)
+
+        def evaluate_at(self, epoch):
+            days = (epoch - t0).total_seconds() / 86400
+            phase = 2 * np.pi * days / 365.25
+            out = np.sum([self.trend * (days / 365.25), self.cosine * np.cos(phase) + self.sine * np.sin(phase), self.interpolated.evaluate_at(epoch)])
+            out.epoch = epoch
+            return out
+    model = Model()
     epochs = [t0 + datetime.timedelta(days=9.5 * k) for k in range(30)]
     at7 = model.evaluate_at(epochs[7])
     assert at7.epoch == epochs[7]
@@ -487,7 +499,7 @@ def test_synthesis_on_reuter_grid_golden(golden):
     g = golden('g17_reuter')
     gf = ga.gravityfield.PotentialCoefficients()
     gf.anm = inputs.coefficients(150, 40)
-    grid = ga.grid.ReuterGrid(30)
+    grid = ga.extras.ReuterGrid(30)
     out = gf.to_grid(grid, kernel='ewh')
-    assert type(out) is ga.grid.ReuterGrid and out.values.shape == g['reuter30_ewh'].shape
+    assert type(out) is ga.extras.ReuterGrid and out.values.shape == g['reuter30_ewh'].shape
     assert relerr(out.values, g['reuter30_ewh']) < 1e-12

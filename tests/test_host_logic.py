@@ -403,21 +403,21 @@ def test_reuter_grid_and_latitude_mappings(golden):
     latitude mappings themselves (:2047-2110) against the reference (tests/golden/g17_reuter.npz)."""
     g = golden('g17_reuter')
     for mapping in ('geocentric', 'authalic', 'conformal'):
-        grid = ga.grid.ReuterGrid(18, latitude_mapping=mapping)
+        grid = ga.extras.ReuterGrid(18, latitude_mapping=mapping)
         expected = g['reuter18_' + mapping]
         assert grid.point_count == expected.shape[1] == 403
         np.testing.assert_array_equal(grid.longitude, expected[0])
         np.testing.assert_allclose(grid.latitude, expected[1], rtol=0, atol=2e-16)
         np.testing.assert_array_equal(grid.area, expected[2])
         assert abs(grid.area.sum() - 4 * np.pi) < 0.02 * 4 * np.pi                   # Reuter areas tile the sphere approximately
-    clone = ga.grid.ReuterGrid(18, latitude_mapping='authalic')
+    clone = ga.extras.ReuterGrid(18, latitude_mapping='authalic')
     clone.values = np.arange(403.0)
     twin = clone.copy()
-    assert type(twin) is ga.grid.ReuterGrid and twin.is_compatible(clone)
+    assert type(twin) is ga.extras.ReuterGrid and twin.is_compatible(clone)
     np.testing.assert_array_equal(twin.latitude, clone.latitude)
     np.testing.assert_array_equal(twin.values, clone.values)
     with pytest.raises(ValueError, match='Unknown latitude mapping'):
-        ga.grid.ReuterGrid(5, latitude_mapping='mercator')
+        ga.extras.ReuterGrid(5, latitude_mapping='mercator')
     beta = np.linspace(-0.5 * np.pi, 0.5 * np.pi, 37)
     G = ga.grid
     with np.errstate(invalid='ignore'):                                              # q / q0 exceeds 1 by an ulp at the poles, as upstream
