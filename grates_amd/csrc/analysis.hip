@@ -716,17 +716,22 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     SHG_REQUIRE(p != nullptr, "shg_analysis: NULL plan");
     SHG_REQUIRE(B >= 0 && nmin >= 0, "shg_analysis: negative size");
     if (B == 0) return SHG_OK;
-    SHG_REQUIRE(grid && area && anm, "shg_analysis: NULL pointer");
+    SHG_REQUIRE(grid && anm, "shg_analysis: NULL pointer");
     SHG_REQUIRE(nmin <= p->N, "shg_analysis: min_degree %d out of range", nmin);
     hipStream_t stream = (hipStream_t)stream_;
     PlanGuard guard(p, stream);
+    const bool trusted = area == nullptr;               // the weights of the previous call: the plan's own copy, nothing to compare
+    if (trusted) {
+        SHG_REQUIRE(analysis_operator_cached(p, nmin), "shg_analysis: area == NULL, but the plan holds no operators for min_degree %d", nmin);
+        area = p->ana_area;
+    }
     const int N = p->N, S = 2 * N + 1, nlat = p->nlat, nlon = p->nlon;
     int rc = analysis_tables(p, stream);
     if (rc) return rc;
     // With a cached operator the pass is queued at once and the comparison of the weights with the ones the operator was
     // built for rides along on the stream: its verdict is read after the pass (the host never waits in the middle of the
     // call), and only weights that did change cost a rebuild and a second pass.
-    const bool optimistic = analysis_operator_cached(p, nmin);
+    const bool optimistic = !trusted && analysis_operator_cached(p, nmin);
     if (!optimistic && (rc = rebuild_analysis_operator(p, area, nmin, stream)) != SHG_OK) return rc;
 
     const int chunk = std::min(B, kAnaEpochChunk);

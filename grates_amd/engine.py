@@ -166,23 +166,40 @@ class Plan:
         return out
 
     def analysis(self, grid, area, min_degree):
-        """grid [B, nlat, nlon], area [nlat, nlon] -> anm [B, N+1, N+1]."""
+        """grid [B, nlat, nlon], area [nlat, nlon] -> anm [B, N+1, N+1].
+
+        The library validates `area` against the weights its cached operators were built for on every call (a device compare and
+        one host synchronisation).  A device tensor that is the very tensor of the previous call (same storage, same torch
+        version counter: not written to since) need not be compared again -- the call then passes area = NULL ("the weights of
+        the previous call", include/shg.h) and nothing waits for the device."""
         torch = _torch()
         g = to_device(grid, self.device)
         single = g.dim() == 2
         if single:
             g = g.unsqueeze(0)
-        a = to_device(area, self.device).reshape(self.nlat, self.nlon)
         n1 = self.max_degree + 1
         out = torch.empty((g.shape[0], n1, n1), dtype=torch.float64, device=self.device)    # zeroed by the library
+        token = None
+        if torch.is_tensor(area) and area.is_cuda and area.dtype == torch.float64 and area.is_contiguous():
+            token = (area.data_ptr(), area._version, tuple(area.shape), int(min_degree))
         with torch.cuda.device(self.device):
-            _lib.call('shg_analysis', self._handle, _ptr(g), _ptr(a), int(min_degree), g.shape[0], _ptr(out), _stream())
+            if g.shape[0] > 0 and token is not None and token == self._analysis_token:
+                _lib.call('shg_analysis', self._handle, _ptr(g), None, int(min_degree), g.shape[0], _ptr(out), _stream())
+            else:
+                a = to_device(area, self.device).reshape(self.nlat, self.nlon)
+                self._analysis_token = None
+                _lib.call('shg_analysis', self._handle, _ptr(g), _ptr(a), int(min_degree), g.shape[0], _ptr(out), _stream())
+                if g.shape[0] > 0:       # (the tensor is kept alive: its address cannot be handed to another one meanwhile)
+                    self._analysis_token, self._analysis_weights = token, (area if token is not None else None)
         return out[0] if single else out
 
+    _analysis_token = None
+    _analysis_weights = None
 
     def analysis_matrix(self, area, min_degree):
         """Dense analysis operator F [P, nlat * nlon] (device tensor) for the area weights `area`: F @ values = analysis(values)."""
         torch = _torch()
+        self._analysis_token = None                    # the call may rebuild the cached operators for other weights
         a = to_device(area, self.device).reshape(self.nlat, self.nlon)
         P = (self.max_degree + 1) ** 2 - min_degree ** 2
         out = torch.empty((P, self.nlat * self.nlon), dtype=torch.float64, device=self.device)

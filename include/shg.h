@@ -238,6 +238,10 @@ int shg_block_multiply(int nb, const int* bounds, const int* rowptr, const int* 
  * Analysis (area-weighted least squares per order)
  *   replaces RegularGrid.to_potential_coefficients                    (grates/grid.py:665-696, 752-790)
  *   grid [B][nlat][nlon]; area [nlat][nlon]; anm [B][N+1][N+1] (degrees < nmin left zero)
+ * The per-order operators depend on the plan, the weights and nmin only; they are cached in the plan and every call compares
+ * `area` with the weights they were built for (on the device; the verdict costs one host synchronisation at the end of the call).
+ * area == NULL: "the weights of the previous call" -- the cached operators are used as they are and nothing is compared or
+ * waited for; an error if the plan holds no operators for this nmin.
  * ------------------------------------------------------------------------------------------------ */
 int shg_analysis(shg_plan* plan, const double* grid, const double* area, int nmin, int B, double* anm, void* stream);
 

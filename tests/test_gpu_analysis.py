@@ -182,3 +182,42 @@ def test_window_matrix_golden(golden):
     Wi = irr.window_matrix(0, 6, 'potential')
     Fi, Ai = irr.analysis_matrix(0, 6, 'potential'), irr.synthesis_matrix(0, 6, 'potential')
     assert relerr(Wi, (Fi * irr.values) @ Ai) < 1e-11
+
+
+def test_same_weight_tensor_skips_the_comparison_and_stays_correct():
+    """engine.Plan.analysis passes area = NULL ("the weights of the previous call", include/shg.h) when it is handed the very
+    device tensor of the previous call, unmodified: no device compare, no host synchronisation.  The results must not depend on
+    that, and a tensor that was written to in place (or another tensor, or an operator rebuilt through analysis_matrix) must
+    be validated again."""
+    import torch
+    N = 24
+    grid = ga.grid.GeographicGrid(5.0, 5.0)
+    colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel('potential'), N, grid.parallels, 3.9860044150e+14, 6.3781363000e+06,
+                                                   grid.semimajor_axis, grid.flattening)
+    plan = ga.engine.Plan(N, colat, kn, grid.meridians)
+    shape = (grid.parallels.size, grid.meridians.size)
+    vals = torch.from_numpy(np.random.default_rng(77).standard_normal((5,) + shape)).cuda()
+    area = ga.engine.to_device(grid.area.reshape(shape))
+    first = plan.analysis(vals, area, 0)
+    assert plan._analysis_token is not None
+    again = plan.analysis(vals, area, 0)                      # fast path
+    assert torch.equal(first, again)
+    ker = orc.KernelTable('potential', love())
+    assert relerr(ga.engine.to_host(again[3]), orc.analysis_regular(ga.engine.to_host(vals[3]).ravel(), grid.area, 0, N, grid.meridians, grid.parallels, ker)) < TOL
+    # in-place change of the weights: the version counter moves, the operators are rebuilt
+    area[0:6] *= 3.0
+    changed = plan.analysis(vals, area, 0)
+    fresh = ga.engine.Plan(N, colat, kn, grid.meridians).analysis(vals, area.clone(), 0)
+    assert torch.equal(changed, fresh) and not torch.equal(changed, first)
+    assert torch.equal(plan.analysis(vals, area, 0), changed)                     # fast path on the new weights
+    # operators rebuilt for other weights through analysis_matrix: the next analysis call validates again
+    plan.analysis_matrix(grid.area.reshape(shape), 0)
+    assert plan._analysis_token is None
+    assert torch.equal(plan.analysis(vals, area, 0), changed)
+    # another minimum degree is another set of operators
+    assert not torch.equal(plan.analysis(vals, area, 2), changed)
+    assert torch.equal(plan.analysis(vals, area, 0), changed)
+    # a NULL weight pointer on a plan without cached operators is an error, not a fault
+    empty = ga.engine.Plan(N, colat, kn, grid.meridians)
+    with pytest.raises(Exception):
+        ga.engine._lib.call('shg_analysis', empty._handle, ga.engine._ptr(vals), None, 0, 5, ga.engine._ptr(first), ga.engine._stream())
