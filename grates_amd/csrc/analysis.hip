@@ -451,6 +451,10 @@ __global__ __launch_bounds__(256) void analysis_operator_kernel(int N, int nmin,
     }
 }
 
+__global__ __launch_bounds__(256) void analysis_zero_kernel(long long n, double* __restrict__ x) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) x[e] = 0.0;
+}
+
 // *varies becomes non-zero when the weights are not constant along every parallel
 __global__ __launch_bounds__(256) void analysis_rowconst_kernel(int nlat, int nlon, const double* __restrict__ area, int* __restrict__ varies) {
     int d = 0;
@@ -663,7 +667,8 @@ static int folded_transform(shg_plan* p, const double* grid, const double* area,
 static int analysis_pass(shg_plan* p, const double* grid, const double* area, int nmin, int B, int chunk, bool folded, double* wvt, double* gt,
                          double* X, double* anm, hipStream_t stream) {
     const int N = p->N, S = 2 * N + 1, nlat = p->nlat, nlon = p->nlon, R = N + 1;
-    SHG_HIP(hipMemsetAsync(anm, 0, (size_t)B * R * R * sizeof(double), stream));
+    hipLaunchKernelGGL(analysis_zero_kernel, dim3((unsigned)std::min<long long>(ceil_div64((long long)B * R * R, 2 * 256), 4096)), dim3(256), 0, stream,
+                       (long long)B * R * R, anm);
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);
         const long long rows = (long long)nb * nlat;
@@ -732,7 +737,7 @@ extern "C" int shg_analysis(shg_plan* p, const double* grid, const double* area,
     // built for rides along on the stream: its verdict is read after the pass (the host never waits in the middle of the
     // call), and only weights that did change cost a rebuild and a second pass.
     const bool optimistic = !trusted && analysis_operator_cached(p, nmin);
-    if (!optimistic && (rc = rebuild_analysis_operator(p, area, nmin, stream)) != SHG_OK) return rc;
+    if (!optimistic && !trusted && (rc = rebuild_analysis_operator(p, area, nmin, stream)) != SHG_OK) return rc;
 
     const int chunk = std::min(B, kAnaEpochChunk);
     const int R = N + 1;
