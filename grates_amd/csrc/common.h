@@ -183,7 +183,7 @@ struct shg_plan {
     bool ana_rowconst = false;  // the weights of the cached operator are constant along every parallel (geographic and Gauss grids)
     double* ana_trig = nullptr; // trig table of the fused transform kernel in chunk order [chunk][8 columns][4 groups x MT x 16 orders], zero padded
     int ana_trig_mt = 0;
-    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 4 the same without the north-south symmetry, 5 fused kernel with 32-row panels (two workgroups per CU), 6 rotation-folded fused kernel, 7 the same without the north-south symmetry
+    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 5 fused kernel with 32-row panels (two workgroups per CU), 6 rotation-folded fused kernel
 
     // users of the plan are serialised (PlanGuard): its tables are built lazily and its workspaces are per plan, not per stream
     std::mutex mtx;

@@ -762,7 +762,7 @@ int pack_coefficients_fused(shg_plan* p, bool ns, int rotR, const double* anm, i
 
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
     if (fused_chunk_for(p) == 0) return fail(SHG_ERR_UNSUPPORTED, "fused synthesis not applicable to this plan");
-    const bool ns = p->sym_ns && p->path != 4;      // north-south symmetric variant (path 4 forces the plain one)
+    const bool ns = p->sym_ns;                      // north-south symmetric variant where the parallels allow it
     int rc = build_pkf_table(p, ns, 0, stream);
     if (rc) return rc;
     const int nbt = ceil_div(B, 4);

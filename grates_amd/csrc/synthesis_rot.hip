@@ -705,7 +705,7 @@ static int launch_rot(shg_plan* p, bool ns, const RotParams& P, size_t lds, dim3
 int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
     if (!rot_applicable(p)) return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel not applicable to this plan");
     const int R = p->rotR;
-    const bool ns = p->sym_ns && p->path != 7;
+    const bool ns = p->sym_ns;
     int rc = build_pkf_table(p, ns, R, stream);
     if (rc) return rc;
     const int nbt = ceil_div(B, 4);

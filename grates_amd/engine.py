@@ -93,11 +93,10 @@ class Plan:
                 'rotation_symmetry': bool(arr[3] & 4), 'epochs_per_pass': arr[4], 'k_slots': arr[5], 'fused': bool(arr[6]), 'path': int(arr[7])}
 
     def set_path(self, path):
-        """'auto', 'staged' (three kernels, any grid), 'fused' (single kernel on 4-fold symmetric meridians; uses the
-        north-south symmetry of the parallels when present), 'fused_plain' (the same without the north-south symmetry),
-        'fused32' (32-row panels), 'rot' (rotation-folded kernel on equi-angular meridians with nlon % 96 == 0 or
-        nlon % 48 == 0) or 'rot_plain' (without the north-south symmetry)."""
-        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'fused_plain': 4, 'fused32': 5, 'rot': 6, 'rot_plain': 7}[path])
+        """'auto', 'staged' (three kernels, any grid), 'fused' (single kernel on 4-fold symmetric meridians), 'fused32' (32-row
+        panels) or 'rot' (rotation-folded kernel on equi-angular meridians with nlon % 96 == 0 or nlon % 48 == 0).  The fused
+        kernels use the north-south symmetry of the parallels when the grid has it (their plain variants otherwise)."""
+        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'fused32': 5, 'rot': 6}[path])
 
     def set_chunk(self, epochs_per_pass):
         _lib.call('shg_plan_set_chunk', self._handle, int(epochs_per_pass))

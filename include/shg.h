@@ -57,16 +57,15 @@ int shg_plan_destroy(shg_plan* plan);
 int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
 
 /* Synthesis path: 0 = automatic, 1 = three-kernel path (pack, Legendre stage, longitude stage; any grid, any degree),
- * 2 = single fused kernel (uses the north-south symmetry of the parallels when present), 4 = the same without the
- * north-south symmetry (2 and 4: 4-fold symmetric meridians, degree <= 126), 5 = fused kernel with 32-row panels (both
- * symmetries, degree <= ~210; chosen automatically above degree 126), 6 = single fused kernel for equi-angular cell-centred
- * meridians that folds the longitude stage over 6 (nlon a multiple of 96) or 3 (nlon a multiple of 48) rotations and the
- * reflection of the meridian set (degree <= ~110; the automatic choice where it applies), 7 = the same without the
- * north-south symmetry. */
+ * 2 = single fused kernel (4-fold symmetric meridians, degree <= 126), 5 = fused kernel with 32-row panels (both symmetries,
+ * degree <= ~210; chosen automatically above degree 126), 6 = single fused kernel for equi-angular cell-centred meridians that
+ * folds the longitude stage over 6 (nlon a multiple of 96) or 3 (nlon a multiple of 48) rotations and the reflection of the
+ * meridian set (degree <= ~110; the automatic choice where it applies).  Kernels 2 and 6 use the north-south symmetry of the
+ * parallels when the grid has it and their plain variant otherwise; the variant is not a choice of the caller. */
 int shg_plan_set_path(shg_plan* plan, int path);
 
 /* Introspection: which[0]=N, [1]=nlat, [2]=nlon, [3]=bit 0: 4-fold longitude symmetry, bit 1: parallels symmetric about the
- * equator, bit 2: the rotation-folded kernel (paths 6 and 7) applies, [4]=epochs per pass, [5]=K slots of the longitude stage, [6]=1 if synthesis uses the fused kernel, [7]=path. */
+ * equator, bit 2: the rotation-folded kernel (path 6) applies, [4]=epochs per pass, [5]=K slots of the longitude stage, [6]=1 if synthesis uses the fused kernel, [7]=path. */
 int shg_plan_info(const shg_plan* plan, int64_t which[8]);
 
 /* Per-kernel timing with HIP events recorded on the caller's stream around every kernel a plan launches.

@@ -204,8 +204,8 @@ def test_fused_and_staged_paths(N, dlon, dlat):
     assert plan.info()['fourfold_symmetry'] and plan.info()['fused']
     assert plan.info()['north_south_symmetry'] == (grid.parallels.size % 2 == 0)
     fused32_ok = plan.info()['north_south_symmetry'] and plan.info()['k_slots'] * 48 * 8 <= 160 * 1024
-    for path in ('fused', 'fused_plain', 'fused32', 'staged', 'rot', 'rot_plain', 'auto'):
-        if (path == 'fused32' and not fused32_ok) or (path in ('rot', 'rot_plain') and not plan.info()['rotation_symmetry']):
+    for path in ('fused', 'fused32', 'staged', 'rot', 'auto'):
+        if (path == 'fused32' and not fused32_ok) or (path == 'rot' and not plan.info()['rotation_symmetry']):
             with pytest.raises(ga._lib.ShgError):
                 plan.set_path(path)
             continue
@@ -230,7 +230,7 @@ def test_rotation_folded_kernel(N, nlon, nlat, B):
     info = plan.info()
     assert info['rotation_symmetry'] and info['fused'] and info['north_south_symmetry']
     outs = {}
-    for path in ('auto', 'rot', 'rot_plain', 'fused'):
+    for path in ('auto', 'rot', 'fused'):
         plan.set_path(path)
         outs[path] = ga.engine.to_host(plan.synthesis(batch))
         assert relerr(outs[path][0:nref], ref) < TOL, path

@@ -67,7 +67,7 @@ def main():
     batch = torch.from_numpy(rng.standard_normal((240, 97, 97)) * 1e-10).cuda()
     plan = plan_for(g025, 96, 'ewh')
     out = torch.empty((240, 720, 1440), dtype=torch.float64, device='cuda')
-    for path in ('fused', 'panel', 'staged'):
+    for path in ('rot', 'fused', 'staged'):
         plan.set_path(path)
         ms = device_ms(lambda: plan.synthesis(batch, out=out), reps=40, warmup=10)
         emit('synthesis d/o 96 -> 0.25 deg, 240 epochs, path=' + path, ms, solutions_per_s=round(240 / ms * 1e3), GBs_algorithmic=round(240 * 8369672 / ms / 1e6, 1))
