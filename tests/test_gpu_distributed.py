@@ -301,15 +301,16 @@ def test_sharded_covariance_and_synthesis(tmp_path):
         np.testing.assert_array_equal(z['dense'], all_dense[e0:e1])
 
 
-def test_bench_rehearsal_world4_real_shard_sizes():
-    """The 4-way shardings of BASELINE configs 4 and 5 at their real per-rank sizes, rehearsed on ONE card (four rank processes
-    under gloo, all mapped to cuda:0; with RCCL each rank has its own GPU) through bench.py itself:
+def test_bench_rehearsal_world2_and_world4_real_shard_sizes():
+    """The 2- and 4-way shardings of BASELINE configs 4 and 5 at their real per-rank sizes, rehearsed on ONE card (two / four rank
+    processes under gloo, all mapped to cuda:0; with RCCL each rank has its own GPU) through bench.py itself:
       * covariance: the whole 360 x 720 grid at d/o 180 in four latitude bands of 90 parallels, Sigma (8.6 GB) replicated per rank
         -- the gathered sigma must be bit-identical to the single-process result (checksum and CRC);
       * smoother: d = 1681 with 128 epochs per rank (512 epochs), nested dissection with all_gathers of the separator blocks
         -- solution and covariance blocks are checked inside bench.py (residual over the whole chain across the rank boundaries,
         (N N^-1)_tt = I), the solution checksum must agree with the single-chain run to rounding.
-    The record (per-rank shard sizes, gathered payload, times) goes to gpurun_out/r3_rehearsal_world4.json."""
+    World size 2 runs the smoother only (256 epochs per rank).  The record (per-rank shard sizes, gathered payload, times) goes to
+    gpurun_out/r3_rehearsal_world4.json."""
     import json
     import subprocess
     import sys
@@ -321,14 +322,18 @@ def test_bench_rehearsal_world4_real_shard_sizes():
     common = [sys.executable, os.path.join(root, 'bench.py'), '--legs', 'covariance,smoother', '--smoother-epochs', '512', '--smoother-repeats', '1',
               '--cpu-sample', '0', '--cov-repeats', '1', '--cov-extensions', '0', '--steps', '2', '--warmup', '1', '--ramp', '0', '--epochs', '8']
     lines = {}
-    for world in (1, 4):
+    for world in (1, 2, 4):
         extra = [] if world == 1 else ['--backend', 'gloo', '--same-device']
+        if world == 2:
+            extra += ['--legs', 'smoother']                   # (argparse: the last --legs wins)
         env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
         run = subprocess.run(common + ['--gpus', str(world)] + extra, env=env, capture_output=True, text=True, timeout=900)
         assert run.returncode == 0, run.stderr[-2000:]
         lines[world] = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith('{')][-1])
-    one, four = lines[1], lines[4]
-    assert four['n_gpus'] == 4 and four['all_checks_ok'] and one['all_checks_ok']
+    one, two, four = lines[1], lines[2], lines[4]
+    assert four['n_gpus'] == 4 and four['all_checks_ok'] and one['all_checks_ok'] and two['n_gpus'] == 2 and two['all_checks_ok']
+    assert two['smoother']['config']['epochs_per_rank'] == [256] * 2 and two['smoother']['check']['residual'] < 1e-13
+    assert abs(two['smoother']['check']['solution_checksum'] - one['smoother']['check']['solution_checksum']) < 1e-9 * max(abs(one['smoother']['check']['solution_checksum']), 1.0)
     assert four['covariance']['sigma_crc32'] == one['covariance']['sigma_crc32']
     assert four['covariance']['sigma_checksum'] == one['covariance']['sigma_checksum']
     assert four['smoother']['config']['epochs_per_rank'] == [128] * 4
@@ -344,6 +349,8 @@ def test_bench_rehearsal_world4_real_shard_sizes():
                            'gathered_bytes_per_rank': (5 * d * d + 3 * d + d * d) * 8,
                            'seconds_world4_one_card': four['smoother']['seconds'], 'phases_world4': four['smoother']['phases_s'],
                            'seconds_world1': one['smoother']['seconds'], 'phases_world1': one['smoother']['phases_s'],
+                           'seconds_world2_one_card': two['smoother']['seconds'], 'phases_world2': two['smoother']['phases_s'],
+                           'residual_world2': two['smoother']['check']['residual'],
                            'residual_world4': four['smoother']['check']['residual'], 'identity_defect_world4': four['smoother']['check']['identity_defect_max'],
                            'solution_checksum_world1': a, 'solution_checksum_world4': b}}
     print(json.dumps(record))
