@@ -90,7 +90,6 @@ int check(const BlockView& V, double* const* inv, const char* who) {
     SHG_REQUIRE(V.nb >= 0 && V.bounds && V.rowptr && (V.nb == 0 || (V.colidx && V.blk)), "%s: NULL block table", who);
     SHG_REQUIRE(V.nb == 0 || V.rowptr[0] == 0, "%s: rowptr must start at 0", who);
     SHG_REQUIRE(V.nb == 0 || inv != nullptr, "%s: NULL table of scratch matrices for the inverses of the diagonal factor blocks", who);
-    SHG_REQUIRE(V.nb == 0 || inv != nullptr, "%s: NULL table of scratch matrices for the inverses of the diagonal factor blocks", who);
     for (int i = 0; i < V.nb; ++i) {
         SHG_REQUIRE(V.size(i) > 0, "%s: empty block row %d", who, i);
         SHG_REQUIRE(V.end(i) > V.begin(i) && V.colidx[V.begin(i)] == i && V.blk[V.begin(i)] != nullptr, "%s: diagonal block %d is missing", who, i);
@@ -106,6 +105,23 @@ int check(const BlockView& V, double* const* inv, const char* who) {
 
 __global__ void merge_info_kernel(int* __restrict__ dst, const int* __restrict__ src, int offset) {
     if (*dst == 0 && *src != 0) *dst = *src + offset;
+}
+
+// strictly lower triangle <- mirror image of the upper one (a symmetric sum that was accumulated on its upper tiles only)
+__global__ __launch_bounds__(256) void mirror_upper_to_lower_kernel(int n, double* __restrict__ C, int ldc) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int q = ty; q < 32; q += 8) {
+        const int r = bi * 32 + q, c = bj * 32 + tx;
+        tile[q][tx] = (r < n && c < n) ? C[(size_t)r * ldc + c] : 0.0;
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {
+        const int r = bj * 32 + q, c = bi * 32 + tx;
+        if (r < n && c < n && r > c) C[(size_t)r * ldc + c] = tile[tx][q];
+    }
 }
 
 }  // namespace shg
@@ -180,11 +196,17 @@ extern "C" int shg_block_potrf(int nb, const int* bounds, const int* rowptr, con
 
 // Solve W x = b (transpose == 0) or W^T x = b (transpose != 0) with the block factor; B [n][k] row-major with leading
 // dimension ldb holds b on entry and x on exit.
-extern "C" int shg_block_solve(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
-                               int transpose, double* B, int k, int ldb, void* stream_) {
+// Only the block rows first <= r < last take part (shg_block_solve: all).  Forward sweep (transpose): the rows before `first` count
+// as done, the rows from `last` on receive the updates b_c -= W_rc^T x_r and are left as the reduced right-hand side of what
+// has been eliminated.  Backward sweep: the rows from `last` on hold the solution already (the caller put it there), the rows
+// last - 1 .. first are substituted.  A chain that was factored up to its last block row (shg_block_potrf_rows) -- a separator
+// shared with its neighbour, whose solution comes from the separator system -- is swept this way.
+extern "C" int shg_block_solve_rows(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
+                                    int transpose, int first, int last, double* B, int k, int ldb, void* stream_) {
     const BlockView V{nb, bounds, rowptr, colidx, blk};
     int rc = check(V, inv, "shg_block_solve");
     if (rc) return rc;
+    SHG_REQUIRE(first >= 0 && first <= last && last <= nb, "shg_block_solve_rows: rows %d .. %d outside 0 .. %d", first, last, nb);
     SHG_REQUIRE(k >= 0, "shg_block_solve: negative number of right-hand sides");
     if (k == 0 || nb == 0) return SHG_OK;
     SHG_REQUIRE(B != nullptr && ldb >= k, "shg_block_solve: bad right-hand side");
@@ -194,7 +216,7 @@ extern "C" int shg_block_solve(int nb, const int* bounds, const int* rowptr, con
     SHG_REQUIRE(tmp != nullptr, "shg_block_solve: workspace allocation failed");
     auto rows = [&](int i) { return B + (size_t)(bounds[i] - bounds[0]) * ldb; };
     if (transpose) {
-        for (int r = 0; r < nb; ++r) {
+        for (int r = first; r < last; ++r) {
             const int dr = V.size(r);
             rc = gemm_tri(true, false, dr, k, dr, 1.0, inv[r], dr, rows(r), ldb, 0.0, tmp, k, 2, stream);             // x_r = U_rr^-T b_r
             if (rc) return rc;
@@ -208,7 +230,7 @@ extern "C" int shg_block_solve(int nb, const int* bounds, const int* rowptr, con
             }
         }
     } else {
-        for (int r = nb - 1; r >= 0; --r) {
+        for (int r = last - 1; r >= first; --r) {
             const int dr = V.size(r);
             for (int e = V.begin(r) + 1; e < V.end(r); ++e) {
                 const int c = colidx[e];
@@ -226,12 +248,21 @@ extern "C" int shg_block_solve(int nb, const int* bounds, const int* rowptr, con
     return SHG_OK;
 }
 
+extern "C" int shg_block_solve(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
+                               int transpose, double* B, int k, int ldb, void* stream) {
+    return shg_block_solve_rows(nb, bounds, rowptr, colidx, blk, inv, transpose, 0, nb, B, k, ldb, stream);
+}
+
 // Z = (W^T W)^-1 on the pattern of the factor W held by the blocks, in place (upper blocks); inv[r] = U_rr^-1 on entry.
-extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
-                                        void* stream_) {
+// Only the block rows last - 1 .. first are processed (shg_block_sparse_inverse: all): the stored blocks of the rows from `last` on
+// must hold their entries of the inverse already -- the Takahashi recursion of a row only reads entries of later rows.  For
+// a chain whose last block row is a separator shared with a neighbour (its entry of the inverse comes from the separator system).
+extern "C" int shg_block_sparse_inverse_rows(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk,
+                                             double* const* inv, int first, int last, void* stream_) {
     const BlockView V{nb, bounds, rowptr, colidx, blk};
     int rc = check(V, inv, "shg_block_sparse_inverse");
     if (rc) return rc;
+    SHG_REQUIRE(first >= 0 && first <= last && last <= nb, "shg_block_sparse_inverse_rows: rows %d .. %d outside 0 .. %d", first, last, nb);
     hipStream_t stream = (hipStream_t)stream_;
     Scratch scratch(stream);
     const int dmax = V.max_size();
@@ -242,7 +273,7 @@ extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, const int* ro
     double* tbuf = scratch.get((size_t)(most_slot + 1) * dmax * dmax);
     SHG_REQUIRE(tbuf != nullptr, "shg_block_sparse_inverse: workspace allocation failed");
     auto T = [&](int e, int r) { return tbuf + (size_t)(e - V.begin(r) - 1) * dmax * dmax; };       // scratch of entry e of row r
-    for (int r = nb - 1; r >= 0; --r) {
+    for (int r = last - 1; r >= first; --r) {
         const int dr = V.size(r);
         const int e0 = V.begin(r), e1 = V.end(r);
         for (int e = e0 + 1; e < e1; ++e) {
@@ -277,6 +308,11 @@ extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, const int* ro
     }
     SHG_HIP(hipGetLastError());
     return SHG_OK;
+}
+
+extern "C" int shg_block_sparse_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
+                                        void* stream) {
+    return shg_block_sparse_inverse_rows(nb, bounds, rowptr, colidx, blk, inv, 0, nb, stream);
 }
 
 // Full inverse (W^T W)^-1 from the factor, in place, upper blocks: every block (i, j), j >= i, must be allocated.
@@ -329,6 +365,114 @@ extern "C" int shg_block_inverse(int nb, const int* bounds, const int* rowptr, c
             SHG_HIP(hipMemcpyAsync(V.at(i, j), acc, (size_t)di * dj * sizeof(double), hipMemcpyDeviceToDevice, stream));
         }
     }
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+// Schur complement of a block-tridiagonal chain onto its two neighbours, streamed through the chain without modifying it (nested
+// dissection of a long chain into segments: grates_amd/distributed.py; the chain of grates/lstsq.py:364-392, 698-717 cut at
+// separator epochs).  Chain blocks D[t] = N[t, t] (d_t x d_t, upper triangle significant) and R[t] = N[t, t + 1] (d_t x d_{t+1}),
+// t = 0 .. n - 1 with bounds[0 .. n]; R[n - 1] couples the last chain block to the right neighbour c (d_{n-1} x dc, dc = 0: none);
+// L = N[a, 0-th chain block] (da x d_0, da = 0: none) couples the left neighbour a to the first chain block; b [sum d_t][k] the
+// right-hand side of the chain (k = 0: none).  With E_a, E_c the coupling columns of the chain and A its matrix:
+//     Saa = E_a^T A^-1 E_a [da][da]   Sac = E_a^T A^-1 E_c [da][dc]   Scc = E_c^T A^-1 E_c [dc][dc]
+//     ga  = E_a^T A^-1 b   [da][k]    gc  = E_c^T A^-1 b   [dc][k]
+// One sweep from the top: S_t = D_t - W^T W, U = chol(S_t), W = U^-T R_t, the coupling to a carried along as
+// C_{t+1} = -W^T (U^-T C_t) -- the fill-in column of an elimination that keeps a as its last row -- with the current pivot, the
+// current coupling and two products as the only scratch: the blocks of the chain are read, never written, so the caller can
+// factor them afterwards in the order the whole matrix asks for.  (7/3 + 13/3) d^3 flops per block for equal sizes.
+extern "C" int shg_chain_schur(int n, const int* bounds, int da, int dc, const double* const* D, const double* const* R, const double* L,
+                               const double* b, int k, int ldb, double* Saa, double* Sac, double* Scc, double* ga, double* gc, int* info,
+                               void* stream_) {
+    SHG_REQUIRE(n >= 1 && bounds && D && da >= 0 && dc >= 0 && k >= 0, "shg_chain_schur: bad arguments");
+    SHG_REQUIRE(n == 1 || R != nullptr, "shg_chain_schur: NULL coupling table");
+    SHG_REQUIRE(da == 0 || (L && Saa && (k == 0 || ga)), "shg_chain_schur: NULL left-neighbour argument");
+    SHG_REQUIRE(dc == 0 || (R && R[n - 1] && Scc && (k == 0 || gc)), "shg_chain_schur: NULL right-neighbour argument");
+    SHG_REQUIRE(da == 0 || dc == 0 || Sac, "shg_chain_schur: NULL output");
+    SHG_REQUIRE(k == 0 || (b && ldb >= k), "shg_chain_schur: bad right-hand side");
+    int dmax = 0;
+    for (int t = 0; t < n; ++t) {
+        SHG_REQUIRE(bounds[t + 1] > bounds[t] && D[t] && (t == n - 1 || R[t]), "shg_chain_schur: empty or missing block %d", t);
+        dmax = std::max(dmax, bounds[t + 1] - bounds[t]);
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    Scratch scratch(stream);
+    const int wmax = std::max(dmax, dc);
+    double* S = scratch.get((size_t)dmax * dmax);                   // current pivot block (destroyed by its factorisation)
+    double* X = scratch.get((size_t)dmax * dmax);                   // U^-1
+    double* W1 = scratch.get((size_t)dmax * wmax);                  // U^-T R_t
+    double* C[2] = {scratch.get((size_t)dmax * std::max(da, 1)), scratch.get((size_t)dmax * std::max(da, 1))};     // coupling to a: current, next
+    double* Wa = scratch.get((size_t)dmax * std::max(da, 1));       // U^-T C_t
+    double* bc[2] = {scratch.get((size_t)dmax * std::max(k, 1)), scratch.get((size_t)dmax * std::max(k, 1))};      // current right-hand side, next
+    double* y = scratch.get((size_t)dmax * std::max(k, 1));         // U^-T b_t
+    double* work = scratch.get(potrf_inverse_work(dmax));
+    int* info_blk = (int*)scratch.get(1);
+    SHG_REQUIRE(S && X && W1 && C[0] && C[1] && Wa && bc[0] && bc[1] && y && work && info_blk, "shg_chain_schur: workspace allocation failed");
+    if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
+    if (da) SHG_HIP(hipMemsetAsync(Saa, 0, (size_t)da * da * sizeof(double), stream));
+    if (da && k) SHG_HIP(hipMemsetAsync(ga, 0, (size_t)da * k * sizeof(double), stream));
+    int rc = SHG_OK;
+    const int d0 = bounds[1] - bounds[0];
+    SHG_HIP(hipMemcpyAsync(S, D[0], (size_t)d0 * d0 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    if (k) SHG_HIP(hipMemcpy2DAsync(bc[0], (size_t)k * sizeof(double), b, (size_t)ldb * sizeof(double), (size_t)k * sizeof(double), d0, hipMemcpyDeviceToDevice, stream));
+    for (int t = 0; t < n; ++t) {
+        const int dt = bounds[t + 1] - bounds[t];
+        const int cur = t & 1, nxt = cur ^ 1;
+        SHG_HIP(hipMemsetAsync(info_blk, 0, sizeof(int), stream));
+        rc = potrf_inverse_upper(dt, S, dt, X, dt, work, info_blk, stream);
+        if (rc) return rc;
+        if (info) hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, stream, info, info_blk, bounds[t] - bounds[0]);
+        if (da) {
+            // Wa = U^-T C_t; the first coupling is L^T (L is stored [da][d_0])
+            if (t == 0)
+                rc = gemm_tri(true, true, dt, da, dt, 1.0, X, dt, L, dt, 0.0, Wa, da, 2, stream);
+            else
+                rc = gemm_tri(true, false, dt, da, dt, 1.0, X, dt, C[cur], da, 0.0, Wa, da, 2, stream);
+            if (rc) return rc;
+            rc = gemm(true, false, da, da, dt, 1.0, Wa, da, Wa, da, 1.0, Saa, da, true, stream);                 // Saa += Wa^T Wa (upper tiles)
+            if (rc) return rc;
+        }
+        if (k) {
+            rc = gemm_tri(true, false, dt, k, dt, 1.0, X, dt, bc[cur], k, 0.0, y, k, 2, stream);                 // y = U^-T b_t
+            if (rc) return rc;
+            if (da) {
+                rc = gemm(true, false, da, k, dt, 1.0, Wa, da, y, k, 1.0, ga, k, false, stream);                  // ga += Wa^T y
+                if (rc) return rc;
+            }
+        }
+        if (t + 1 < n) {
+            const int dn = bounds[t + 2] - bounds[t + 1];
+            rc = gemm_tri(true, false, dt, dn, dt, 1.0, X, dt, R[t], dn, 0.0, W1, dn, 2, stream);                // W1 = U^-T R_t
+            if (rc) return rc;
+            SHG_HIP(hipMemcpyAsync(S, D[t + 1], (size_t)dn * dn * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            rc = gemm(true, false, dn, dn, dt, -1.0, W1, dn, W1, dn, 1.0, S, dn, true, stream);                  // S_{t+1} = D_{t+1} - W1^T W1
+            if (rc) return rc;
+            if (da) {
+                rc = gemm(true, false, dn, da, dt, -1.0, W1, dn, Wa, da, 0.0, C[nxt], da, false, stream);        // C_{t+1} = -W1^T Wa
+                if (rc) return rc;
+            }
+            if (k) {
+                SHG_HIP(hipMemcpy2DAsync(bc[nxt], (size_t)k * sizeof(double), b + (size_t)(bounds[t + 1] - bounds[0]) * ldb, (size_t)ldb * sizeof(double),
+                                         (size_t)k * sizeof(double), dn, hipMemcpyDeviceToDevice, stream));
+                rc = gemm(true, false, dn, k, dt, -1.0, W1, dn, y, k, 1.0, bc[nxt], k, false, stream);           // b_{t+1} -= W1^T y
+                if (rc) return rc;
+            }
+        } else if (dc) {
+            rc = gemm_tri(true, false, dt, dc, dt, 1.0, X, dt, R[t], dc, 0.0, W1, dc, 2, stream);                // coupling of the last block to c
+            if (rc) return rc;
+            rc = gemm(true, false, dc, dc, dt, 1.0, W1, dc, W1, dc, 0.0, Scc, dc, false, stream);
+            if (rc) return rc;
+            if (da) {
+                rc = gemm(true, false, da, dc, dt, 1.0, Wa, da, W1, dc, 0.0, Sac, dc, false, stream);
+                if (rc) return rc;
+            }
+            if (k) {
+                rc = gemm(true, false, dc, k, dt, 1.0, W1, dc, y, k, 0.0, gc, k, false, stream);
+                if (rc) return rc;
+            }
+        }
+    }
+    if (da > 1) hipLaunchKernelGGL(mirror_upper_to_lower_kernel, dim3(ceil_div(da, 32), ceil_div(da, 32)), dim3(256), 0, stream, da, Saa, da);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }

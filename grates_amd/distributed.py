@@ -320,113 +320,320 @@ def _make_chain(diag, upper, consume=False):
     return _Chain(diag, upper, consume)
 
 
-class _PartitionedChain:
+_stream_pool = {}
+
+
+def _streams(device, count):
+    """`count` side streams of the device (kept between calls)"""
+    import torch
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    pool = _stream_pool.setdefault(key, [])
+    while len(pool) < count:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:count]
+
+
+def _segment_bounds(n_loc, count, first_is_end, last_is_end):
+    """Local epoch ranges [lo, hi) of `count` segments of a rank with n_loc epochs.  The two end segments of the whole chain cost
+    about half as much per epoch as the segments between separators (they are factored once, the others twice), so they get
+    twice the epochs; every segment keeps at least two epochs (interior + separator; the very last one needs only one)."""
+    weights = [2.0 if (i == 0 and first_is_end) or (i == count - 1 and last_is_end) else 1.0 for i in range(count)]
+    total = sum(weights)
+    sizes = [max(2, int(round(n_loc * w / total))) for w in weights]
+    # the rounding error goes to the largest segment
+    sizes[int(np.argmax(sizes))] += n_loc - sum(sizes)
+    if min(sizes) < (1 if last_is_end else 2) or min(sizes[:-1] + [2]) < 2:
+        raise ValueError('{0} epochs are too few for {1} segments'.format(n_loc, count))
+    bounds = np.concatenate(([0], np.cumsum(sizes)))
+    return [(int(bounds[i]), int(bounds[i + 1])) for i in range(count)]
+
+
+def default_segments(n_loc_min, world):
+    """Segments per rank: a chain is latency bound (a block Cholesky factorisation of one epoch is a chain of small kernels), so a
+    rank works on several segments at once, each on its own stream; segments between separators are factored twice, so more
+    than a handful per GPU does not pay."""
+    want = int(os.environ.get('GRATES_AMD_SEGMENTS', '0'))
+    if want <= 0:
+        want = 6 if world == 1 else 3
+    return max(1, min(want, n_loc_min // 16))
+
+
+class _SegmentedChain:
     """
-    Nested dissection of a symmetric positive definite block-tridiagonal matrix whose block rows (epochs) are distributed over
-    the ranks in contiguous ranges, with the last epoch of every rank but the last as separator: the factored interior chain of
-    this rank, Y = A_II^-1 [C_left, C_right, b] for its two coupling blocks and the right-hand side, and the factored
-    separator (Schur complement) system, which every rank holds redundantly after ONE all_gather of 5 d x d blocks (and a few
-    vectors) per rank.  A second, small all_gather beforehand hands every rank the coupling block to its left separator.
+    Nested dissection of a symmetric positive definite block-tridiagonal matrix (the normal equations of a fixed-interval smoother,
+    grates/lstsq.py:364-392) whose block rows (epochs) are distributed over the ranks in contiguous ranges and, inside a rank,
+    cut into `segments` pieces that are worked on at the same time (one host thread and one HIP stream each).  The last epoch
+    of every segment but the very last one is a separator.
+
+      1. Every segment reduces its interior onto its separators, all at once:
+         * the first segment of the chain eliminates its interior from the top (shg_block_potrf_rows up to the separator row) and the
+           last one from the bottom: for them that factor is final;
+         * a segment between two separators computes the Schur complement of its interior onto both in one streaming sweep that
+           leaves its blocks untouched (shg_chain_schur).
+      2. ONE all_gather (RCCL) of five d x d / d x k pieces per segment; every rank factors the separator system (block tridiagonal,
+         segments - 1 rows) redundantly: solution and entries of the inverse at the separators, and -- from its Cholesky factor --
+         the state of the NATURAL-ORDER elimination of the whole chain in front of every segment: pivot F and right-hand side y of
+         the separator on its left.
+      3. A segment between separators now continues that natural-order elimination through its own epochs (its first block and
+         right-hand side corrected by the separator on its left): what it computes is, block for block, the factorisation of
+         the single chain, and the back substitution and the Takahashi recursion start from its right separator, whose solution and
+         covariance block are known from 2.  Segments cost 20/3 d^3 per epoch at the ends of the chain and twice that in between
+         (`_segment_bounds` gives the end segments twice the epochs), no matter how many there are.
+    One more all_gather of a single d x d block per rank hands the covariance block that couples a rank's last epoch to the next
+    rank's first epoch to its owner.  Separator blocks must all have the same size.
     """
 
-    def __init__(self, diag, upper, rhs, group, consume=False):
+    def __init__(self, diag, upper, rhs, group, consume=False, segments=None):
         import torch
         import torch.distributed as dist
         from . import engine
         from .lstsq import BlockMatrix
-        self.torch, self.engine, self.group = torch, engine, group
+        self.torch, self.engine, self.group, self.BlockMatrix = torch, engine, group, BlockMatrix
         self.rank = rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n_loc = n_loc = len(diag)
-        self.last = last = rank == world - 1
-        if n_loc < (1 if last else 2):
-            raise ValueError('every rank but the last needs at least two epochs (got {0})'.format(n_loc))
+        self.device = diag[0].device
         self.sizes = sizes = [int(b.shape[0]) for b in diag]
-        self.bounds = bounds = np.concatenate(([0], np.cumsum(sizes)))
-        device = diag[0].device
-        self.k = k = 0 if rhs is None else rhs.shape[1]
+        self.bounds = np.concatenate(([0], np.cumsum(sizes)))
+        self.k = k = 0 if rhs is None else int(rhs.shape[1])
+        self.kk = max(k, 1)
+        if not consume:
+            diag, upper = [b.clone() for b in diag], [b.clone() if b is not None else None for b in upper]
+        self.diag, self.upper = list(diag), list(upper)
+        self.rhs = None if rhs is None else rhs.clone()
+        # the same number of segments on every rank (the gathered lists must have the same length)
+        n_min = n_loc
+        if world > 1:
+            t = torch.tensor([n_loc], dtype=torch.int64, device=self.device if dist.get_backend(group) != 'gloo' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            n_min = int(t.item())
+        self.count = count = default_segments(n_min, world) if segments is None else int(segments)
+        if len(set(sizes)) > 1 and count > 1:
+            self.count = count = 1                                   # ragged blocks: separators only at the rank boundaries
+        self.K = world * count
+        if self.K < 2:
+            raise ValueError('a single segment is a plain chain')
+        last_rank = rank == world - 1
+        self.segs = [dict(lo=lo, hi=hi, g=rank * count + i) for i, (lo, hi) in enumerate(_segment_bounds(n_loc, count, rank == 0, last_rank))]
+        for sg in self.segs:
+            sg['kind'] = 'first' if sg['g'] == 0 else ('last' if sg['g'] == self.K - 1 else 'middle')
+            sg['ni'] = sg['hi'] - sg['lo'] - (0 if sg['kind'] == 'last' else 1)             # interior epochs
+            if sg['ni'] < 1:
+                raise ValueError('every segment needs an interior epoch')
+        # separator size (equal everywhere) and the coupling of the previous rank's last epoch to this rank's first one
+        self.d = d = sizes[self.segs[0]['hi'] - 1] if not (last_rank and count == 1) else None
+        boundary = upper[n_loc - 1] if not last_rank else None
+        if world > 1:
+            shape = (sizes[-1], sizes[-1])
+            gathered = _gather_blocks([boundary.contiguous() if boundary is not None else torch.zeros(shape, dtype=torch.float64, device=self.device)], group)
+            self.left_of_rank = gathered[rank - 1][0] if rank > 0 else None
+            if self.d is None:
+                self.d = d = int(self.left_of_rank.shape[0])
+        else:
+            self.left_of_rank = None
+        for sg in self.segs:
+            if sg['kind'] != 'last' and sizes[sg['hi'] - 1] != d:
+                raise ValueError('all separator blocks must have the same size')
+        self.streams = _streams(self.device, len(self.segs))
+        self._factor()
 
-        def zeros(r, c):
-            return torch.zeros((r, c), dtype=torch.float64, device=device)
-        self.zeros = zeros
+    # ---- helpers
+    def zeros(self, r, c):
+        return self.torch.zeros((r, c), dtype=self.torch.float64, device=self.device)
 
-        self.ni = ni = n_loc if (last or world == 1) else n_loc - 1         # interior epochs
-        self.n_int = n_int = int(bounds[ni])
-        if world == 1:
-            self.interior = _make_chain(diag, upper[:n_loc - 1], consume)
-            self.interior.factor()
-            return
+    def _rows(self, lo, hi):
+        return slice(int(self.bounds[lo]), int(self.bounds[hi]))
 
-        # coupling to the left separator: N[s_(g-1), t0] lives on the previous rank
-        d_sep = sizes[-1]
-        boundary = upper[n_loc - 1] if not last else zeros(d_sep, d_sep)
-        if not last and boundary.shape[1] != boundary.shape[0]:
-            raise ValueError('partitioned solve expects equal block sizes at the rank boundaries')
-        boundaries = _gather_blocks([boundary.contiguous()], group)           # collective: every rank takes part
-        self.left = left = boundaries[rank - 1][0] if rank > 0 else None      # [d_sep_left, d_first]
-        self.right = upper[ni - 1] if not last else None                      # N[t1-2, t1-1]
+    def _left(self, sg):
+        """N[a, lo]: coupling of the separator on the left of the segment to its first epoch"""
+        return self.upper[sg['lo'] - 1] if sg['lo'] > 0 else self.left_of_rank
 
-        self.interior = interior = _make_chain(diag[:ni], upper[:ni - 1], consume)
-        interior.factor()
-        columns = [rhs[:n_int]] if k else []
-        if left is not None:                                                # C_left = left^T in the first interior block rows
-            cl = zeros(n_int, left.shape[0])
-            cl[:sizes[0]] = left.t()
-            columns.append(cl)
-        if not last:                                                        # C_right = N[t1-2, t1-1] in the last interior block rows
-            cr = zeros(n_int, d_sep)
-            cr[int(bounds[ni - 1]):n_int] = upper[ni - 1]
-            columns.append(cr)
-        W = torch.cat(columns, dim=1).contiguous()
-        del columns
-        Z = interior.solve(W)
-        del W
-        self.zb = Z[:, :k]
-        pos = k
-        self.ZL = self.ZR = None
-        if left is not None:
-            self.ZL = Z[:, pos:pos + left.shape[0]]
-            pos += left.shape[0]
-        if not last:
-            self.ZR = Z[:, pos:pos + d_sep]
-        self.Y = Z[:, k:]                                                   # [Y_left, Y_right]
-        zb, ZL, ZR = self.zb, self.ZL, self.ZR
+    def _each(self, job):
+        """job(segment) for all local segments at once, one thread and one stream each; the streams are drained on return"""
+        from concurrent.futures import ThreadPoolExecutor
+        torch = self.torch
+        main = torch.cuda.current_stream(self.device)
 
-        first = slice(0, sizes[0])
-        tail = slice(int(bounds[ni - 1]), n_int)
-        # Schur complement pieces of this rank's interior chain (d = separator block size; equal sizes at the boundaries)
-        self.d = d = d_sep if not last else left.shape[0]
-        kk = max(k, 1)
-        has_b = k > 0
-        S_ll = engine.gemm(left, ZL[first].contiguous()) if left is not None else zeros(d, d)
-        b_l = engine.gemm(left, zb[first].contiguous()) if (left is not None and has_b) else zeros(d, kk)
-        S_lr = engine.gemm(left, ZR[first].contiguous()) if (left is not None and not last) else zeros(d, d)
-        S_rr = engine.gemm(upper[ni - 1], ZR[tail].contiguous(), transa=True) if not last else zeros(d, d)
-        b_r = engine.gemm(upper[ni - 1], zb[tail].contiguous(), transa=True) if (not last and has_b) else zeros(d, kk)
-        sep_d = diag[n_loc - 1] if not last else zeros(d, d)
-        sep_b = rhs[n_int:] if (not last and has_b) else zeros(d, kk)
-        gathered = _gather_blocks([sep_d.contiguous(), S_ll, S_lr, S_rr, sep_b.contiguous(), b_l, b_r], group)
+        def run(sg, stream):
+            torch.cuda.set_device(self.device)
+            stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                out = job(sg)
+            stream.synchronize()
+            return out
+        if len(self.segs) == 1:
+            return [job(self.segs[0])]
+        with ThreadPoolExecutor(max_workers=len(self.segs)) as pool:
+            futures = [pool.submit(run, sg, st) for sg, st in zip(self.segs, self.streams)]
+            return [f.result() for f in futures]
 
-        # separator system (world - 1 block rows), held redundantly on every rank
-        self.nsep = nsep = world - 1
+    def _chain(self, blocks_d, blocks_u):
+        return _chain_matrix(self.BlockMatrix, blocks_d, blocks_u, False)
+
+    # ---- step 1: every segment onto its separators
+    def _reduce(self, sg):
+        torch, engine = self.torch, self.engine
+        lo, hi, ni, d, kk = sg['lo'], sg['hi'], sg['ni'], self.d, self.kk
+        Z = self.zeros
+        if sg['kind'] == 'first':
+            M = sg['M'] = self._chain(self.diag[lo:hi], self.upper[lo:hi - 1])
+            M._cholesky_rows(0, ni)
+            y = sg['y'] = self.rhs[self._rows(lo, hi)].clone() if self.k else Z(int(self.bounds[hi] - self.bounds[lo]), 1)
+            M._solve_rows(y, True, 0, ni)
+            return [M.device_block(ni, ni).clone(), Z(d, d), Z(d, d), y[-d:].clone(), Z(d, kk)]
+        if sg['kind'] == 'last':
+            # reversed order: position p = epoch hi - 1 - p, then the separator a on the left (zero block: it collects -S_aa)
+            left = self._left(sg)
+            dd = [self.diag[t] for t in range(hi - 1, lo - 1, -1)] + [Z(d, d)]
+            uu = [_transposed(self.upper[t - 1], True) for t in range(hi - 1, lo, -1)] + [left.t().contiguous()]
+            M = sg['M'] = self._chain(dd, uu)
+            M._cholesky_rows(0, ni)
+            parts = [self.rhs[self._rows(t, t + 1)] for t in range(hi - 1, lo - 1, -1)] if self.k else [Z(self.sizes[t], 1) for t in range(hi - 1, lo - 1, -1)]
+            y = sg['y'] = torch.cat(parts + [Z(d, kk)], dim=0)
+            M._solve_rows(y, True, 0, ni)
+            return [Z(d, d), M.device_block(ni, ni).clone(), Z(d, d), Z(d, kk), y[-d:].clone()]
+        # between two separators: streaming Schur complement, blocks untouched
+        rhs_int = self.rhs[self._rows(lo, hi - 1)].contiguous() if self.k else None
+        (Saa, Sac, Scc, ga, gc), info = engine.chain_schur(self.diag[lo:hi - 1], self.upper[lo:hi - 1], self._left(sg), d, rhs_int)
+        sg['info'] = info
+        Acc = self.diag[hi - 1].clone()
+        engine.axpby(-1.0, Scc, 1.0, Acc)
+        rc = self.rhs[self._rows(hi - 1, hi)].clone() if self.k else Z(d, 1)
+        if self.k:
+            engine.axpby(-1.0, gc, 1.0, rc)
+        return [Acc, -Saa, -Sac, rc, (-ga if self.k else Z(d, 1))]
+
+    # ---- steps 2 and 3 up to the factorisation of the segments between separators
+    def _factor(self):
+        torch, engine, d, kk, K = self.torch, self.engine, self.d, self.kk, self.K
+        pieces = self._each(self._reduce)
+        for sg in self.segs:
+            if 'info' in sg and int(sg['info'].item()):
+                raise np.linalg.LinAlgError('{0}-th leading minor of a segment is not positive definite'.format(int(sg['info'].item())))
+        flat = [t.contiguous() for p in pieces for t in p]
+        if self.world > 1:
+            everyone = _gather_blocks(flat, self.group)
+            flat_all = [t for part in everyone for t in part]
+        else:
+            flat_all = flat
+        P = [flat_all[5 * g:5 * g + 5] for g in range(K)]                  # per segment: Acc, Aaa, Aac, rc, ra
+        # separator system: diag_j = Acc(j) + Aaa(j + 1), coupling (j, j + 1) = Aac(j + 1), right-hand side rc(j) + ra(j + 1)
+        nsep = K - 1
         index = np.arange(0, (nsep + 1) * d, d)
-        self.reduced = reduced = BlockMatrix(index, index)
-        self.red_rhs = red_rhs = zeros(nsep * d, kk)
-        for i in range(nsep):
-            own, nxt = gathered[i], gathered[i + 1]
-            block = own[0].clone()
-            engine.axpby(-1.0, own[3], 1.0, block)                           # - S_rr of the chain on its left
-            engine.axpby(-1.0, nxt[1], 1.0, block)                           # - S_ll of the chain on its right
-            reduced._set_device(i, i, block)
-            if i + 1 < nsep:
-                coupling = zeros(d, d)
-                engine.axpby(-1.0, nxt[2], 0.0, coupling)                    # - S_lr of the chain between separators i and i + 1
-                reduced._set_device(i, i + 1, coupling)
-            r = red_rhs[i * d:(i + 1) * d]
-            engine.axpby(1.0, own[4], 0.0, r)
-            engine.axpby(-1.0, own[6], 1.0, r)
-            engine.axpby(-1.0, nxt[5], 1.0, r)
+        self.reduced = reduced = self.BlockMatrix(index, index)
+        red_rhs = self.zeros(nsep * d, kk)
+        for j in range(nsep):
+            block = P[j][0].clone()
+            engine.axpby(1.0, P[j + 1][1], 1.0, block)
+            reduced._set_device(j, j, block)
+            if j + 1 < nsep:
+                reduced._set_device(j, j + 1, P[j + 1][2].clone())
+            r = red_rhs[j * d:(j + 1) * d]
+            engine.axpby(1.0, P[j][3], 0.0, r)
+            engine.axpby(1.0, P[j + 1][4], 1.0, r)
         reduced.cholesky()
+        y_red = reduced.solve_triangular(red_rhs, transpose=True)
+        self.x_sep = reduced.solve_triangular(y_red)
+        # natural-order state in front of a segment between separators (left separator j = g - 1): the pivot of the separator system
+        # there is F_j + Aaa(g), its swept right-hand side U_jj^T y_j = y~_j + ra(g)
+        for sg in self.segs:
+            if sg['kind'] == 'middle':
+                j = sg['g'] - 1
+                U = reduced.device_block(j, j)
+                F = engine.gemm(U, U, transa=True)
+                engine.axpby(-1.0, P[sg['g']][1], 1.0, F)
+                yt = engine.gemm(U, y_red[j * d:(j + 1) * d].contiguous(), transa=True)
+                engine.axpby(-1.0, P[sg['g']][4], 1.0, yt)
+                sg['F'], sg['yt'] = F, yt
+        reduced.sparse_inverse()                                             # Z_SS: blocks (j, j) and (j, j + 1)
+        self._each(self._continue)
+
+    def _continue(self, sg):
+        """a segment between separators: the natural-order elimination of the whole chain, continued through its epochs"""
+        if sg['kind'] != 'middle':
+            return
+        engine = self.engine
+        lo, hi, ni = sg['lo'], sg['hi'], sg['ni']
+        left = self._left(sg)
+        U = engine.potrf(sg['F'])
+        X = engine.trtri(U)                                                  # F^-1 = X X^T
+        Wl = engine.gemm(X, left, transa=True)                               # U^-T N[a, lo]
+        engine.gemm(Wl, Wl, transa=True, alpha=-1.0, beta=1.0, out=self.diag[lo])
+        sg['T'] = engine.gemm(X, Wl)                                         # F^-1 N[a, lo]: Z[a, lo] = -T Z[lo, lo]
+        y = sg['y'] = self.rhs[self._rows(lo, hi)].clone() if self.k else self.zeros(int(self.bounds[hi] - self.bounds[lo]), 1)
+        if self.k:
+            first = y[:self.sizes[lo]]
+            engine.gemm(Wl, engine.gemm(X, sg['yt'], transa=True), transa=True, alpha=-1.0, beta=1.0, out=first)
+        M = sg['M'] = self._chain(self.diag[lo:hi], self.upper[lo:hi - 1])
+        M._cholesky_rows(0, ni)
+        M._solve_rows(y, True, 0, ni)
+        del sg['F']
+
+    # ---- solution
+    def solve(self):
+        d = self.d
+
+        def job(sg):
+            M, y, ni = sg['M'], sg['y'], sg['ni']
+            j = sg['g'] - 1 if sg['kind'] == 'last' else sg['g']            # the separator in the segment's last row
+            y[-d:] = self.x_sep[j * d:(j + 1) * d]
+            M._solve_rows(y, False, 0, ni)
+            if sg['kind'] != 'last':
+                return y
+            # reversed segment: back into epoch order, without the separator row
+            parts, pos = [], 0
+            for t in range(sg['hi'] - 1, sg['lo'] - 1, -1):
+                parts.append(y[pos:pos + self.sizes[t]])
+                pos += self.sizes[t]
+            return self.torch.cat(parts[::-1], dim=0)
+        return self.torch.cat(self._each(job), dim=0)
+
+    # ---- covariance blocks
+    def covariance(self):
+        torch, engine, d = self.torch, self.engine, self.d
+        sep = self.reduced.device_block
+
+        def job(sg):
+            M, ni, lo, hi = sg['M'], sg['ni'], sg['lo'], sg['hi']
+            block = M.device_block
+            j = sg['g'] - 1 if sg['kind'] == 'last' else sg['g']
+            block(ni, ni).copy_(sep(j, j))
+            M._sparse_inverse_rows(0, ni)
+            if sg['kind'] == 'last':
+                n = hi - lo
+                zd = [block(n - 1 - q, n - 1 - q) for q in range(n)]
+                zu = [_transposed(block(n - 2 - q, n - 1 - q), True) for q in range(n - 1)]
+                to_left = block(ni - 1, ni).t().contiguous()               # Z[a, lo]
+                return zd, zu, to_left
+            zd = [block(q, q) for q in range(hi - lo)]
+            zu = [block(q, q + 1) for q in range(hi - lo - 1)]
+            to_left = None
+            if sg['kind'] == 'middle':
+                to_left = engine.gemm(sg['T'], zd[0], alpha=-1.0)           # Z[a, lo] = -F^-1 N[a, lo] Z[lo, lo]
+            return zd, zu, to_left
+        results = self._each(job)
+        zdiag, zupper = [], []
+        for i, (zd, zu, to_left) in enumerate(results):
+            if i > 0:
+                zupper.append(to_left)                                       # coupling of the previous segment's separator to this segment
+            zdiag += zd
+            zupper += zu
+        first_left = results[0][2]
+        if self.world > 1:
+            send = first_left if first_left is not None else self.zeros(d, self.sizes[0])
+            from_right = _gather_blocks([send.contiguous()], self.group)
+            if self.rank < self.world - 1:
+                zupper.append(from_right[self.rank + 1][0])
+        return zdiag, zupper
+
+
+def _segmented(diag, upper, rhs, group, consume, segments=None):
+    """the segmented chain for this call, or None when the whole chain is one rank's and too short to cut"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and (default_segments(len(diag), 1) if segments is None else segments) < 2:
+        return None
+    return _SegmentedChain(diag, upper, rhs, group, consume, segments)
 
 
 def solve_block_tridiagonal_partitioned(diag, upper, rhs, group=None, consume=False):
@@ -450,22 +657,12 @@ def solve_block_tridiagonal_partitioned(diag, upper, rhs, group=None, consume=Fa
     consume=True lets the factorisation work in the caller's blocks instead of copies of them (they are overwritten): a chain
     of BASELINE config 5's size (3650 epochs x 2 x 22.6 MB plus the inverses of the diagonal factor blocks) fits the card only once.
     """
-    return _partitioned_solution(_PartitionedChain(diag, upper, rhs, group, consume), rhs)
-
-
-def _partitioned_solution(pc, rhs):
-    if pc.world == 1:
-        return pc.interior.solve(rhs)
-    engine, d, rank = pc.engine, pc.d, pc.rank
-    x_sep = pc.reduced.solve_triangular(pc.reduced.solve_triangular(pc.red_rhs, transpose=True))
-    # back substitution of the interior chain
-    x_int = pc.zb.clone()
-    if pc.left is not None:
-        engine.gemm(pc.ZL.contiguous(), x_sep[(rank - 1) * d:rank * d], alpha=-1.0, beta=1.0, out=x_int)
-    if not pc.last:
-        engine.gemm(pc.ZR.contiguous(), x_sep[rank * d:(rank + 1) * d], alpha=-1.0, beta=1.0, out=x_int)
-        return pc.torch.cat((x_int, x_sep[rank * d:(rank + 1) * d]), dim=0)
-    return x_int
+    sc = _segmented(diag, upper, rhs, group, consume)
+    if sc is None:
+        chain = _make_chain(diag, upper[:len(diag) - 1], consume)
+        chain.factor()
+        return chain.solve(rhs)
+    return sc.solve()
 
 
 def sparse_inverse_block_tridiagonal_partitioned(diag, upper, group=None, consume=False):
@@ -485,7 +682,12 @@ def sparse_inverse_block_tridiagonal_partitioned(diag, upper, group=None, consum
     The only collectives are the two all_gathers of the factorisation and one more of a single d x d block per rank (the
     covariance block that couples a separator to the first epoch of the next rank is computed by that next rank).
     """
-    return _partitioned_covariance(_PartitionedChain(diag, upper, None, group, consume))
+    sc = _segmented(diag, upper, None, group, consume)
+    if sc is None:
+        chain = _make_chain(diag, upper[:len(diag) - 1], consume)
+        chain.factor()
+        return chain.sparse_inverse()
+    return sc.covariance()
 
 
 def smooth_block_tridiagonal_partitioned(diag, upper, rhs, group=None, consume=False, timings=None):
@@ -511,46 +713,19 @@ def smooth_block_tridiagonal_partitioned(diag, upper, rhs, group=None, consume=F
     if timings is not None:
         pc_torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pc = _PartitionedChain(diag, upper, rhs, group, consume)
+    sc = _segmented(diag, upper, rhs, group, consume)
+    if sc is None:
+        chain = _make_chain(diag, upper[:len(diag) - 1], consume)
+        chain.factor()
+        t0 = lap('factor_s', t0)
+        x = chain.solve(rhs)
+        t0 = lap('solve_s', t0)
+        zdiag, zupper = chain.sparse_inverse()
+        lap('covariance_s', t0)
+        return x, zdiag, zupper
     t0 = lap('factor_s', t0)
-    x = _partitioned_solution(pc, rhs)
+    x = sc.solve()
     t0 = lap('solve_s', t0)
-    zdiag, zupper = _partitioned_covariance(pc)
+    zdiag, zupper = sc.covariance()
     lap('covariance_s', t0)
     return x, zdiag, zupper
-
-
-def _partitioned_covariance(pc):
-    torch, engine = pc.torch, pc.engine
-    ni, bounds = pc.ni, pc.bounds
-    if pc.world == 1:
-        return pc.interior.sparse_inverse()
-    d, rank, last = pc.d, pc.rank, pc.last
-    pc.reduced.sparse_inverse()
-    sep = pc.reduced.device_block
-    # Z_SS restricted to the (at most two) separators next to this rank's chain
-    parts = []
-    if pc.left is not None:
-        row = [sep(rank - 1, rank - 1)] + ([sep(rank - 1, rank)] if not last else [])
-        parts.append(torch.cat(row, dim=1))
-    if not last:
-        row = ([sep(rank - 1, rank).t()] if pc.left is not None else []) + [sep(rank, rank)]
-        parts.append(torch.cat(row, dim=1))
-    M = torch.cat(parts, dim=0).contiguous()
-    dl = d if pc.left is not None else 0
-    Y = pc.Y.contiguous()
-    P = engine.gemm(Y, M)                                                   # [n_int, dl + dr] = Y Z_SS
-    Zdiag, Zupper = pc.interior.sparse_inverse()
-    rows = lambda t: slice(int(bounds[t]), int(bounds[t + 1]))          # noqa: E731
-    for t in range(ni):
-        engine.gemm(P[rows(t)], Y[rows(t)], transb=True, beta=1.0, out=Zdiag[t])
-        if t + 1 < ni:
-            engine.gemm(P[rows(t)], Y[rows(t + 1)], transb=True, beta=1.0, out=Zupper[t])
-    # blocks next to the separators: Z[t, r] = -(Y Z_SS)[t, r],  Z[l, t] = -(Y Z_SS)[t, l]^T
-    to_left = (-P[rows(0), :dl]).t().contiguous() if pc.left is not None else pc.zeros(d, pc.sizes[0])
-    from_right = _gather_blocks([to_left], pc.group)
-    if not last:
-        Zupper.append((-P[rows(ni - 1), dl:]).contiguous())
-        Zdiag.append(sep(rank, rank))
-        Zupper.append(from_right[rank + 1][0])
-    return Zdiag, Zupper

@@ -419,6 +419,20 @@ class BlockMatrix:
         if pivot:
             raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(pivot))
 
+    def _solve_rows(self, x, transpose, first, last):
+        """in place on the device tensor x [n, k]: the sweep of solve_triangular over the block rows first <= r < last only
+        (shg_block_solve_rows)"""
+        engine.block_solve_rows(self.__block_table(), self.__inverse_table(), bool(transpose), first, last, x)
+        return x
+
+    def _sparse_inverse_rows(self, first, last):
+        """sparse_inverse() for the block rows last - 1 .. first; the blocks of the later rows hold their entries of the inverse
+        already (shg_block_sparse_inverse_rows).  The matrix is an ordinary (covariance) matrix afterwards."""
+        engine.block_sparse_inverse_rows(self.__block_table(), self.__inverse_table(), first, last)
+        self.__inverse_factor.clear()
+        self._inverse_in_place = False
+        self._holds_factor_inverses = False
+
     def __vector(self, b):
         v = _dev(b)
         return v.reshape(1, -1) if v.dim() == 1 else v

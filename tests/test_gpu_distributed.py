@@ -129,6 +129,88 @@ def test_two_ended_chain_matches_natural_order(sizes):
     assert relerr(results[0][0], results[1][0]) < 1e-12
 
 
+def _dense_chain(diag, upper):
+    bounds = np.concatenate(([0], np.cumsum([b.shape[0] for b in diag])))
+    N = np.zeros((bounds[-1], bounds[-1]))
+    for t, D in enumerate(diag):
+        N[bounds[t]:bounds[t + 1], bounds[t]:bounds[t + 1]] = D
+        if t + 1 < len(diag):
+            N[bounds[t]:bounds[t + 1], bounds[t + 1]:bounds[t + 2]] = upper[t]
+            N[bounds[t + 1]:bounds[t + 2], bounds[t]:bounds[t + 1]] = upper[t].T
+    return N, bounds
+
+
+def test_chain_schur_against_dense():
+    """shg_chain_schur: Schur complement of a chain onto its neighbours in one streaming sweep, chain blocks untouched; ragged
+    block sizes, with and without either neighbour, against numpy on the dense matrices."""
+    from grates_amd import engine
+    rng = np.random.default_rng(21)
+    sizes, da, dc, k = [33, 7, 130, 64, 5], 19, 41, 3
+    diag = [rng.standard_normal((d, d + 4)) for d in sizes]
+    diag = [G @ G.T / G.shape[0] + 3.0 * np.eye(G.shape[0]) for G in diag]
+    upper = [rng.standard_normal((sizes[t], sizes[t + 1])) * 0.3 / np.sqrt(sizes[t]) for t in range(len(sizes) - 1)]
+    right = rng.standard_normal((sizes[-1], dc)) * 0.3
+    left = rng.standard_normal((da, sizes[0])) * 0.3
+    rhs = rng.standard_normal((sum(sizes), k))
+    A, bounds = _dense_chain(diag, upper)
+    Ea = np.zeros((A.shape[0], da))
+    Ea[:sizes[0]] = left.T
+    Ec = np.zeros((A.shape[0], dc))
+    Ec[-sizes[-1]:] = right
+    Ai = np.linalg.inv(A)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dd, du = [dev(b) for b in diag], [dev(b) for b in upper]
+    keep = [b.clone() for b in dd + du]
+    (Saa, Sac, Scc, ga, gc), info = engine.chain_schur(dd, du + [dev(right)], dev(left), dc, dev(rhs))
+    assert int(info.item()) == 0 and all(torch.equal(a, b) for a, b in zip(keep, dd + du))
+    for got, ref in ((Saa, Ea.T @ Ai @ Ea), (Sac, Ea.T @ Ai @ Ec), (Scc, Ec.T @ Ai @ Ec), (ga, Ea.T @ Ai @ rhs), (gc, Ec.T @ Ai @ rhs)):
+        assert relerr(got.cpu().numpy(), ref) < 1e-12
+    (Saa, Sac, Scc, ga, gc), _ = engine.chain_schur(dd, du, dev(left), 0, None)                 # left neighbour only, no right-hand side
+    assert Sac is None and Scc is None and ga is None and relerr(Saa.cpu().numpy(), Ea.T @ Ai @ Ea) < 1e-12
+    (Saa, Sac, Scc, ga, gc), _ = engine.chain_schur(dd[:1], [dev(upper[0])], None, sizes[1], dev(rhs[:sizes[0]]))     # one block, right neighbour
+    one = np.linalg.inv(diag[0])
+    assert Saa is None and relerr(Scc.cpu().numpy(), upper[0].T @ one @ upper[0]) < 1e-12 and relerr(gc.cpu().numpy(), upper[0].T @ one @ rhs[:sizes[0]]) < 1e-12
+    bad = [b.clone() for b in dd]
+    bad[2] -= 10.0 * torch.eye(sizes[2], dtype=torch.float64, device='cuda')
+    _, info = engine.chain_schur(bad, du, dev(left), 0, None)
+    assert int(info.item()) > sizes[0] + sizes[1]                                           # first non-positive pivot inside the third block
+
+
+@pytest.mark.parametrize('segments,epochs,dim', [(2, 9, 48), (3, 11, 40), (4, 17, 130), (6, 40, 33)])
+def test_segmented_chain_single_rank(segments, epochs, dim):
+    """The segmented elimination on one rank (first / last segments factored once from their free ends, segments between separators
+    reduced by shg_chain_schur and then continued in natural order), every segment on its own stream: solution and covariance
+    blocks against the dense solve / inverse, and against the plain chain."""
+    from grates_amd import distributed as gd
+    diag, upper, rhs = _system(epochs, dim, 3, seed=epochs)
+    upper = upper[:epochs - 1]
+    N, bounds = _dense_chain(diag, upper)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dd, du, db = [dev(b) for b in diag], [dev(b) for b in upper], dev(rhs)
+    keep = [b.clone() for b in dd + du]
+    sc = gd._SegmentedChain(dd, du, db, None, consume=False, segments=segments)
+    assert len(sc.segs) == segments and [s['kind'] for s in sc.segs] == ['first'] + ['middle'] * (segments - 2) + ['last']
+    assert sc.segs[0]['hi'] - sc.segs[0]['lo'] >= sc.segs[1]['hi'] - sc.segs[1]['lo'] or segments == 2
+    x = sc.solve().cpu().numpy()
+    zd, zu = sc.covariance()
+    assert all(torch.equal(a, b) for a, b in zip(keep, dd + du))                                  # consume=False: the caller's blocks stay
+    assert relerr(x, np.linalg.solve(N, rhs)) < 1e-11
+    Z = np.linalg.inv(N)
+    scale = np.abs(Z).max()
+    assert len(zd) == epochs and len(zu) == epochs - 1
+    for t in range(epochs):
+        assert np.abs(zd[t].cpu().numpy() - Z[bounds[t]:bounds[t + 1], bounds[t]:bounds[t + 1]]).max() < 1e-11 * scale, t
+        if t + 1 < epochs:
+            assert np.abs(zu[t].cpu().numpy() - Z[bounds[t]:bounds[t + 1], bounds[t + 1]:bounds[t + 2]]).max() < 1e-11 * scale, t
+    # covariance only (no right-hand side), through the entry point, blocks consumed
+    zd2, zu2 = gd._SegmentedChain([b.clone() for b in dd], [b.clone() for b in du], None, None, consume=True, segments=segments).covariance()
+    assert all(torch.equal(a, b) for a, b in zip(zd, zd2)) and all(torch.equal(a, b) for a, b in zip(zu, zu2))
+    with pytest.raises(np.linalg.LinAlgError):
+        broken = [b.clone() for b in dd]
+        broken[epochs // 2] -= 10.0 * torch.eye(dim, dtype=torch.float64, device='cuda')
+        gd._SegmentedChain(broken, du, db, None, segments=segments)
+
+
 def test_two_ended_chain_reports_indefinite_blocks():
     from grates_amd import distributed as gd
     d = [torch.eye(4, dtype=torch.float64, device='cuda') * (1.0 if t != 6 else -1.0) for t in range(9)]
