@@ -68,8 +68,6 @@ PROTOTYPES = {
     'shg_block_sparse_inverse': [ctypes.c_int] + [ctypes.c_void_p] * 6,
     'shg_block_solve_rows': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     'shg_block_sparse_inverse_rows': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
-    'shg_chain_schur': [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int,
-                        ctypes.c_int] + [c_double_p] * 5 + [ctypes.c_void_p, ctypes.c_void_p],
     'shg_block_inverse': [ctypes.c_int] + [ctypes.c_void_p] * 6,
     'shg_block_multiply': [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
     'shg_congruence': [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],

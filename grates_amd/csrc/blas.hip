@@ -443,10 +443,10 @@ int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const doubl
 #define SHG_GEMM_EX(TA_, TB_)                                                                                                          \
     do {                                                                                                                                \
         if (small_tiles) {                                                                                                              \
-            SHG_HIP(hipFuncSetAttribute((const void*)gemm_ex_kernel<TA_, TB_, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+            SHG_SET_LDS_ONCE((gemm_ex_kernel<TA_, TB_, 64>), lds);                                                                      \
             hipLaunchKernelGGL((gemm_ex_kernel<TA_, TB_, 64>), grid, dim3(256), lds, stream, P);                                        \
         } else {                                                                                                                        \
-            SHG_HIP(hipFuncSetAttribute((const void*)gemm_ex_kernel<TA_, TB_, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            SHG_SET_LDS_ONCE((gemm_ex_kernel<TA_, TB_, 128>), lds);                                                                     \
             hipLaunchKernelGGL((gemm_ex_kernel<TA_, TB_, 128>), grid, dim3(256), lds, stream, P);                                       \
         }                                                                                                                               \
     } while (0)
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(512) void leaf_kernel(int n, double* __restrict__ A
 static int launch_leaf(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, int batch, int mode, int* info,
                        int info_base, hipStream_t stream) {
     const size_t lds = (mode & 2) ? (size_t)LEAF * LLD * sizeof(double) : 0;
-    SHG_HIP(hipFuncSetAttribute((const void*)leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LEAF * LLD * sizeof(double))));
+    SHG_SET_LDS_ONCE(leaf_kernel, LEAF * LLD * sizeof(double));
     hipLaunchKernelGGL(leaf_kernel, dim3(batch), dim3(512), lds, stream, n, A, lda, strideA, X, ldx, strideX, mode, info, info_base);
     SHG_HIP(hipGetLastError());
     return SHG_OK;

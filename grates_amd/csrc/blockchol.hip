@@ -107,23 +107,6 @@ __global__ void merge_info_kernel(int* __restrict__ dst, const int* __restrict__
     if (*dst == 0 && *src != 0) *dst = *src + offset;
 }
 
-// strictly lower triangle <- mirror image of the upper one (a symmetric sum that was accumulated on its upper tiles only)
-__global__ __launch_bounds__(256) void mirror_upper_to_lower_kernel(int n, double* __restrict__ C, int ldc) {
-    __shared__ double tile[32][33];
-    const int bi = blockIdx.y, bj = blockIdx.x;
-    if (bj < bi) return;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int q = ty; q < 32; q += 8) {
-        const int r = bi * 32 + q, c = bj * 32 + tx;
-        tile[q][tx] = (r < n && c < n) ? C[(size_t)r * ldc + c] : 0.0;
-    }
-    __syncthreads();
-    for (int q = ty; q < 32; q += 8) {
-        const int r = bj * 32 + q, c = bi * 32 + tx;
-        if (r < n && c < n && r > c) C[(size_t)r * ldc + c] = tile[tx][q];
-    }
-}
-
 }  // namespace shg
 
 using namespace shg;
@@ -365,114 +348,6 @@ extern "C" int shg_block_inverse(int nb, const int* bounds, const int* rowptr, c
             SHG_HIP(hipMemcpyAsync(V.at(i, j), acc, (size_t)di * dj * sizeof(double), hipMemcpyDeviceToDevice, stream));
         }
     }
-    SHG_HIP(hipGetLastError());
-    return SHG_OK;
-}
-
-// Schur complement of a block-tridiagonal chain onto its two neighbours, streamed through the chain without modifying it (nested
-// dissection of a long chain into segments: grates_amd/distributed.py; the chain of grates/lstsq.py:364-392, 698-717 cut at
-// separator epochs).  Chain blocks D[t] = N[t, t] (d_t x d_t, upper triangle significant) and R[t] = N[t, t + 1] (d_t x d_{t+1}),
-// t = 0 .. n - 1 with bounds[0 .. n]; R[n - 1] couples the last chain block to the right neighbour c (d_{n-1} x dc, dc = 0: none);
-// L = N[a, 0-th chain block] (da x d_0, da = 0: none) couples the left neighbour a to the first chain block; b [sum d_t][k] the
-// right-hand side of the chain (k = 0: none).  With E_a, E_c the coupling columns of the chain and A its matrix:
-//     Saa = E_a^T A^-1 E_a [da][da]   Sac = E_a^T A^-1 E_c [da][dc]   Scc = E_c^T A^-1 E_c [dc][dc]
-//     ga  = E_a^T A^-1 b   [da][k]    gc  = E_c^T A^-1 b   [dc][k]
-// One sweep from the top: S_t = D_t - W^T W, U = chol(S_t), W = U^-T R_t, the coupling to a carried along as
-// C_{t+1} = -W^T (U^-T C_t) -- the fill-in column of an elimination that keeps a as its last row -- with the current pivot, the
-// current coupling and two products as the only scratch: the blocks of the chain are read, never written, so the caller can
-// factor them afterwards in the order the whole matrix asks for.  (7/3 + 13/3) d^3 flops per block for equal sizes.
-extern "C" int shg_chain_schur(int n, const int* bounds, int da, int dc, const double* const* D, const double* const* R, const double* L,
-                               const double* b, int k, int ldb, double* Saa, double* Sac, double* Scc, double* ga, double* gc, int* info,
-                               void* stream_) {
-    SHG_REQUIRE(n >= 1 && bounds && D && da >= 0 && dc >= 0 && k >= 0, "shg_chain_schur: bad arguments");
-    SHG_REQUIRE(n == 1 || R != nullptr, "shg_chain_schur: NULL coupling table");
-    SHG_REQUIRE(da == 0 || (L && Saa && (k == 0 || ga)), "shg_chain_schur: NULL left-neighbour argument");
-    SHG_REQUIRE(dc == 0 || (R && R[n - 1] && Scc && (k == 0 || gc)), "shg_chain_schur: NULL right-neighbour argument");
-    SHG_REQUIRE(da == 0 || dc == 0 || Sac, "shg_chain_schur: NULL output");
-    SHG_REQUIRE(k == 0 || (b && ldb >= k), "shg_chain_schur: bad right-hand side");
-    int dmax = 0;
-    for (int t = 0; t < n; ++t) {
-        SHG_REQUIRE(bounds[t + 1] > bounds[t] && D[t] && (t == n - 1 || R[t]), "shg_chain_schur: empty or missing block %d", t);
-        dmax = std::max(dmax, bounds[t + 1] - bounds[t]);
-    }
-    hipStream_t stream = (hipStream_t)stream_;
-    Scratch scratch(stream);
-    const int wmax = std::max(dmax, dc);
-    double* S = scratch.get((size_t)dmax * dmax);                   // current pivot block (destroyed by its factorisation)
-    double* X = scratch.get((size_t)dmax * dmax);                   // U^-1
-    double* W1 = scratch.get((size_t)dmax * wmax);                  // U^-T R_t
-    double* C[2] = {scratch.get((size_t)dmax * std::max(da, 1)), scratch.get((size_t)dmax * std::max(da, 1))};     // coupling to a: current, next
-    double* Wa = scratch.get((size_t)dmax * std::max(da, 1));       // U^-T C_t
-    double* bc[2] = {scratch.get((size_t)dmax * std::max(k, 1)), scratch.get((size_t)dmax * std::max(k, 1))};      // current right-hand side, next
-    double* y = scratch.get((size_t)dmax * std::max(k, 1));         // U^-T b_t
-    double* work = scratch.get(potrf_inverse_work(dmax));
-    int* info_blk = (int*)scratch.get(1);
-    SHG_REQUIRE(S && X && W1 && C[0] && C[1] && Wa && bc[0] && bc[1] && y && work && info_blk, "shg_chain_schur: workspace allocation failed");
-    if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
-    if (da) SHG_HIP(hipMemsetAsync(Saa, 0, (size_t)da * da * sizeof(double), stream));
-    if (da && k) SHG_HIP(hipMemsetAsync(ga, 0, (size_t)da * k * sizeof(double), stream));
-    int rc = SHG_OK;
-    const int d0 = bounds[1] - bounds[0];
-    SHG_HIP(hipMemcpyAsync(S, D[0], (size_t)d0 * d0 * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    if (k) SHG_HIP(hipMemcpy2DAsync(bc[0], (size_t)k * sizeof(double), b, (size_t)ldb * sizeof(double), (size_t)k * sizeof(double), d0, hipMemcpyDeviceToDevice, stream));
-    for (int t = 0; t < n; ++t) {
-        const int dt = bounds[t + 1] - bounds[t];
-        const int cur = t & 1, nxt = cur ^ 1;
-        SHG_HIP(hipMemsetAsync(info_blk, 0, sizeof(int), stream));
-        rc = potrf_inverse_upper(dt, S, dt, X, dt, work, info_blk, stream);
-        if (rc) return rc;
-        if (info) hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, stream, info, info_blk, bounds[t] - bounds[0]);
-        if (da) {
-            // Wa = U^-T C_t; the first coupling is L^T (L is stored [da][d_0])
-            if (t == 0)
-                rc = gemm_tri(true, true, dt, da, dt, 1.0, X, dt, L, dt, 0.0, Wa, da, 2, stream);
-            else
-                rc = gemm_tri(true, false, dt, da, dt, 1.0, X, dt, C[cur], da, 0.0, Wa, da, 2, stream);
-            if (rc) return rc;
-            rc = gemm(true, false, da, da, dt, 1.0, Wa, da, Wa, da, 1.0, Saa, da, true, stream);                 // Saa += Wa^T Wa (upper tiles)
-            if (rc) return rc;
-        }
-        if (k) {
-            rc = gemm_tri(true, false, dt, k, dt, 1.0, X, dt, bc[cur], k, 0.0, y, k, 2, stream);                 // y = U^-T b_t
-            if (rc) return rc;
-            if (da) {
-                rc = gemm(true, false, da, k, dt, 1.0, Wa, da, y, k, 1.0, ga, k, false, stream);                  // ga += Wa^T y
-                if (rc) return rc;
-            }
-        }
-        if (t + 1 < n) {
-            const int dn = bounds[t + 2] - bounds[t + 1];
-            rc = gemm_tri(true, false, dt, dn, dt, 1.0, X, dt, R[t], dn, 0.0, W1, dn, 2, stream);                // W1 = U^-T R_t
-            if (rc) return rc;
-            SHG_HIP(hipMemcpyAsync(S, D[t + 1], (size_t)dn * dn * sizeof(double), hipMemcpyDeviceToDevice, stream));
-            rc = gemm(true, false, dn, dn, dt, -1.0, W1, dn, W1, dn, 1.0, S, dn, true, stream);                  // S_{t+1} = D_{t+1} - W1^T W1
-            if (rc) return rc;
-            if (da) {
-                rc = gemm(true, false, dn, da, dt, -1.0, W1, dn, Wa, da, 0.0, C[nxt], da, false, stream);        // C_{t+1} = -W1^T Wa
-                if (rc) return rc;
-            }
-            if (k) {
-                SHG_HIP(hipMemcpy2DAsync(bc[nxt], (size_t)k * sizeof(double), b + (size_t)(bounds[t + 1] - bounds[0]) * ldb, (size_t)ldb * sizeof(double),
-                                         (size_t)k * sizeof(double), dn, hipMemcpyDeviceToDevice, stream));
-                rc = gemm(true, false, dn, k, dt, -1.0, W1, dn, y, k, 1.0, bc[nxt], k, false, stream);           // b_{t+1} -= W1^T y
-                if (rc) return rc;
-            }
-        } else if (dc) {
-            rc = gemm_tri(true, false, dt, dc, dt, 1.0, X, dt, R[t], dc, 0.0, W1, dc, 2, stream);                // coupling of the last block to c
-            if (rc) return rc;
-            rc = gemm(true, false, dc, dc, dt, 1.0, W1, dc, W1, dc, 0.0, Scc, dc, false, stream);
-            if (rc) return rc;
-            if (da) {
-                rc = gemm(true, false, da, dc, dt, 1.0, Wa, da, W1, dc, 0.0, Sac, dc, false, stream);
-                if (rc) return rc;
-            }
-            if (k) {
-                rc = gemm(true, false, dc, k, dt, 1.0, W1, dc, y, k, 0.0, gc, k, false, stream);
-                if (rc) return rc;
-            }
-        }
-    }
-    if (da > 1) hipLaunchKernelGGL(mirror_upper_to_lower_kernel, dim3(ceil_div(da, 32), ceil_div(da, 32)), dim3(256), 0, stream, da, Saa, da);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }

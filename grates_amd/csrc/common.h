@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -57,6 +58,20 @@ inline int experiment_switches() {
 #error "SHG_ROT_X / SHG_GEMM_X / SHG_ANA_X are timing experiments: build with -DSHG_EXPERIMENT (make timeline)"
 #endif
 #endif
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device instead of in front of every launch: the call goes
+// through the runtime's process-wide lock, and a smoother chain issues ~100 launches per epoch from several host threads.
+#define SHG_SET_LDS_ONCE(fn, bytes)                                                                                        \
+    do {                                                                                                                   \
+        static std::atomic<unsigned long long> done_{0};                                                                   \
+        int dev_ = 0;                                                                                                      \
+        (void)hipGetDevice(&dev_);                                                                                         \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                               \
+        if (!(done_.load(std::memory_order_acquire) & bit_)) {                                                             \
+            SHG_HIP(hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));     \
+            done_.fetch_or(bit_, std::memory_order_release);                                                               \
+        }                                                                                                                  \
+    } while (0)
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

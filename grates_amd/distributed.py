@@ -334,10 +334,12 @@ def _streams(device, count):
 
 
 def _segment_bounds(n_loc, count, first_is_end, last_is_end):
-    """Local epoch ranges [lo, hi) of `count` segments of a rank with n_loc epochs.  The two end segments of the whole chain cost
-    about half as much per epoch as the segments between separators (they are factored once, the others twice), so they get
-    twice the epochs; every segment keeps at least two epochs (interior + separator; the very last one needs only one)."""
-    weights = [2.0 if (i == 0 and first_is_end) or (i == count - 1 and last_is_end) else 1.0 for i in range(count)]
+    """Local epoch ranges [lo, hi) of `count` segments of a rank with n_loc epochs.  An epoch of a segment between two separators
+    takes about 1.4 times as long as one of the two end segments of the chain (measured at d = 1681: 6.9 against 4.8 ms per
+    epoch and stream -- three blocks per row in the sweeps and the Takahashi recursion, but the same latency-bound
+    factorisation of the diagonal block), so the end segments get 1.5 times the epochs; every segment keeps at least two
+    epochs (interior + separator; the very last one needs only one)."""
+    weights = [1.5 if (i == 0 and first_is_end) or (i == count - 1 and last_is_end) else 1.0 for i in range(count)]
     total = sum(weights)
     sizes = [max(2, int(round(n_loc * w / total))) for w in weights]
     # the rounding error goes to the largest segment
@@ -349,13 +351,15 @@ def _segment_bounds(n_loc, count, first_is_end, last_is_end):
 
 
 def default_segments(n_loc_min, world):
-    """Segments per rank: a chain is latency bound (a block Cholesky factorisation of one epoch is a chain of small kernels), so a
-    rank works on several segments at once, each on its own stream; segments between separators are factored twice, so more
-    than a handful per GPU does not pay."""
+    """Segments per rank.  A chain is latency bound (the block Cholesky factorisation of one epoch is a chain of ~100 small
+    kernels), so a rank works on two segments at once, each on its own stream.  More than two per process did not pay on one
+    MI355X (config 5, 3650 x 1681: 7.3 s with 2 segments, 9.3 / 10.1 / 9.3 s with 4 / 6 / 8): the segments between separators
+    are factored twice, and the HIP runtime serialises the kernel launches of the threads of one process, so the host becomes
+    the pace-maker (~650 000 launches per call)."""
     want = int(os.environ.get('GRATES_AMD_SEGMENTS', '0'))
     if want <= 0:
-        want = 6 if world == 1 else 3
-    return max(1, min(want, n_loc_min // 16))
+        want = 2
+    return max(1, min(want, n_loc_min // 4))
 
 
 class _SegmentedChain:
@@ -365,20 +369,18 @@ class _SegmentedChain:
     cut into `segments` pieces that are worked on at the same time (one host thread and one HIP stream each).  The last epoch
     of every segment but the very last one is a separator.
 
-      1. Every segment reduces its interior onto its separators, all at once:
-         * the first segment of the chain eliminates its interior from the top (shg_block_potrf_rows up to the separator row) and the
-           last one from the bottom: for them that factor is final;
-         * a segment between two separators computes the Schur complement of its interior onto both in one streaming sweep that
-           leaves its blocks untouched (shg_chain_schur).
+      1. Every segment eliminates its interior, all at once (shg_block_potrf_rows up to the separator rows, which collect the Schur
+         complement): the first segment of the chain from the top, the last one from the bottom, a segment between two separators
+         a and c from the top with a and c as its last two block rows -- the coupling to a is carried along as one fill-in block per
+         epoch (W[t, a]), the only extra memory of the scheme.  The forward sweep of the right-hand side goes the same way.
       2. ONE all_gather (RCCL) of five d x d / d x k pieces per segment; every rank factors the separator system (block tridiagonal,
-         segments - 1 rows) redundantly: solution and entries of the inverse at the separators, and -- from its Cholesky factor --
-         the state of the NATURAL-ORDER elimination of the whole chain in front of every segment: pivot F and right-hand side y of
-         the separator on its left.
-      3. A segment between separators now continues that natural-order elimination through its own epochs (its first block and
-         right-hand side corrected by the separator on its left): what it computes is, block for block, the factorisation of
-         the single chain, and the back substitution and the Takahashi recursion start from its right separator, whose solution and
-         covariance block are known from 2.  Segments cost 20/3 d^3 per epoch at the ends of the chain and twice that in between
-         (`_segment_bounds` gives the end segments twice the epochs), no matter how many there are.
+         segments - 1 rows) redundantly: solution and entries of the inverse at the separators.
+      3. Back substitution and Takahashi recursion of every segment run over its interior rows only, starting from the values of
+         its separator rows (shg_block_solve_rows, shg_block_sparse_inverse_rows).
+    Per epoch an end segment costs what the single chain costs (20/3 d^3 for equal block sizes), a segment between separators
+    about three times as many flops, most of them in the Takahashi recursion over three blocks per row -- fat products; the
+    latency-bound factorisation of the diagonal block happens once per epoch everywhere, so the time per epoch differs by 1.4
+    only (`_segment_bounds`).
     One more all_gather of a single d x d block per rank hands the covariance block that couples a rank's last epoch to the next
     rank's first epoch to its owner.  Separator blocks must all have the same size.
     """
@@ -435,6 +437,11 @@ class _SegmentedChain:
             if sg['kind'] != 'last' and sizes[sg['hi'] - 1] != d:
                 raise ValueError('all separator blocks must have the same size')
         self.streams = _streams(self.device, len(self.segs))
+        # Rehearsals of several ranks on ONE card (tests, bench.py --same-device): with GRATES_AMD_REHEARSAL_TURNS=1 the ranks take
+        # turns with their segment work instead of sharing the card, and `busy_s` adds up what a rank spends in its own turns --
+        # the time the rank would need on a GPU of its own (the elapsed time of such a run is the sum over the ranks).
+        self.turns = world > 1 and os.environ.get('GRATES_AMD_REHEARSAL_TURNS', '0') == '1'
+        self.busy_s = 0.0
         self._factor()
 
     # ---- helpers
@@ -461,16 +468,32 @@ class _SegmentedChain:
                 out = job(sg)
             stream.synchronize()
             return out
-        if len(self.segs) == 1:
-            return [job(self.segs[0])]
-        with ThreadPoolExecutor(max_workers=len(self.segs)) as pool:
-            futures = [pool.submit(run, sg, st) for sg, st in zip(self.segs, self.streams)]
-            return [f.result() for f in futures]
+        def all_segments():
+            if len(self.segs) == 1:
+                return [job(self.segs[0])]
+            with ThreadPoolExecutor(max_workers=len(self.segs)) as pool:
+                futures = [pool.submit(run, sg, st) for sg, st in zip(self.segs, self.streams)]
+                return [f.result() for f in futures]
+        import time
+        import torch.distributed as dist
+        out = None
+        for turn in range(self.world if self.turns else 1):
+            if self.turns:
+                torch.cuda.synchronize(self.device)
+                dist.barrier(self.group)
+            if not self.turns or turn == self.rank:
+                t0 = time.perf_counter()
+                out = all_segments()
+                torch.cuda.synchronize(self.device)
+                self.busy_s += time.perf_counter() - t0
+        if self.turns:
+            dist.barrier(self.group)
+        return out
 
     def _chain(self, blocks_d, blocks_u):
         return _chain_matrix(self.BlockMatrix, blocks_d, blocks_u, False)
 
-    # ---- step 1: every segment onto its separators
+    # ---- step 1: every segment eliminates its interior; its separator rows collect the Schur complement
     def _reduce(self, sg):
         torch, engine = self.torch, self.engine
         lo, hi, ni, d, kk = sg['lo'], sg['hi'], sg['ni'], self.d, self.kk
@@ -481,9 +504,9 @@ class _SegmentedChain:
             y = sg['y'] = self.rhs[self._rows(lo, hi)].clone() if self.k else Z(int(self.bounds[hi] - self.bounds[lo]), 1)
             M._solve_rows(y, True, 0, ni)
             return [M.device_block(ni, ni).clone(), Z(d, d), Z(d, d), y[-d:].clone(), Z(d, kk)]
+        left = self._left(sg)
         if sg['kind'] == 'last':
             # reversed order: position p = epoch hi - 1 - p, then the separator a on the left (zero block: it collects -S_aa)
-            left = self._left(sg)
             dd = [self.diag[t] for t in range(hi - 1, lo - 1, -1)] + [Z(d, d)]
             uu = [_transposed(self.upper[t - 1], True) for t in range(hi - 1, lo, -1)] + [left.t().contiguous()]
             M = sg['M'] = self._chain(dd, uu)
@@ -492,24 +515,33 @@ class _SegmentedChain:
             y = sg['y'] = torch.cat(parts + [Z(d, kk)], dim=0)
             M._solve_rows(y, True, 0, ni)
             return [Z(d, d), M.device_block(ni, ni).clone(), Z(d, d), Z(d, kk), y[-d:].clone()]
-        # between two separators: streaming Schur complement, blocks untouched
-        rhs_int = self.rhs[self._rows(lo, hi - 1)].contiguous() if self.k else None
-        (Saa, Sac, Scc, ga, gc), info = engine.chain_schur(self.diag[lo:hi - 1], self.upper[lo:hi - 1], self._left(sg), d, rhs_int)
-        sg['info'] = info
+        # between two separators a and c: block rows [interior ..., a, c]; a and c start from zero and collect -S_aa, -S_ac, -S_cc,
+        # the coupling to a is carried from row to row as fill-in (allocated by the symbolic step of the block Cholesky)
+        offset = self.bounds[lo:hi] - self.bounds[lo]
+        index = np.concatenate((offset, [offset[-1] + d, offset[-1] + 2 * d]))
+        M = sg['M'] = self.BlockMatrix(index, index)
+        M._inverse_in_place = True
+        for q in range(ni):
+            M._set_device(q, q, self.diag[lo + q])
+            if q + 1 < ni:
+                M._set_device(q, q + 1, self.upper[lo + q])
+        M._set_device(0, ni, left.t().contiguous())                       # N[lo, a]
+        M._set_device(ni - 1, ni + 1, self.upper[hi - 2])                  # N[last interior epoch, c]
+        for i, j in ((ni, ni), (ni, ni + 1), (ni + 1, ni + 1)):
+            M._set_device(i, j, Z(d, d))
+        M._cholesky_rows(0, ni)
+        y = sg['y'] = torch.cat(((self.rhs[self._rows(lo, hi - 1)] if self.k else Z(int(offset[-1]), 1)), Z(2 * d, kk)), dim=0)
+        M._solve_rows(y, True, 0, ni)
         Acc = self.diag[hi - 1].clone()
-        engine.axpby(-1.0, Scc, 1.0, Acc)
+        engine.axpby(1.0, M.device_block(ni + 1, ni + 1), 1.0, Acc)
         rc = self.rhs[self._rows(hi - 1, hi)].clone() if self.k else Z(d, 1)
-        if self.k:
-            engine.axpby(-1.0, gc, 1.0, rc)
-        return [Acc, -Saa, -Sac, rc, (-ga if self.k else Z(d, 1))]
+        engine.axpby(1.0, y[-d:], 1.0, rc)
+        return [Acc, M.device_block(ni, ni).clone(), M.device_block(ni, ni + 1).clone(), rc, y[-2 * d:-d].clone()]
 
-    # ---- steps 2 and 3 up to the factorisation of the segments between separators
+    # ---- step 2: the separator system, redundantly on every rank
     def _factor(self):
-        torch, engine, d, kk, K = self.torch, self.engine, self.d, self.kk, self.K
+        engine, d, kk, K = self.engine, self.d, self.kk, self.K
         pieces = self._each(self._reduce)
-        for sg in self.segs:
-            if 'info' in sg and int(sg['info'].item()):
-                raise np.linalg.LinAlgError('{0}-th leading minor of a segment is not positive definite'.format(int(sg['info'].item())))
         flat = [t.contiguous() for p in pieces for t in p]
         if self.world > 1:
             everyone = _gather_blocks(flat, self.group)
@@ -517,7 +549,7 @@ class _SegmentedChain:
         else:
             flat_all = flat
         P = [flat_all[5 * g:5 * g + 5] for g in range(K)]                  # per segment: Acc, Aaa, Aac, rc, ra
-        # separator system: diag_j = Acc(j) + Aaa(j + 1), coupling (j, j + 1) = Aac(j + 1), right-hand side rc(j) + ra(j + 1)
+        # diag_j = Acc(j) + Aaa(j + 1), coupling (j, j + 1) = Aac(j + 1), right-hand side rc(j) + ra(j + 1)
         nsep = K - 1
         index = np.arange(0, (nsep + 1) * d, d)
         self.reduced = reduced = self.BlockMatrix(index, index)
@@ -532,44 +564,10 @@ class _SegmentedChain:
             engine.axpby(1.0, P[j][3], 0.0, r)
             engine.axpby(1.0, P[j + 1][4], 1.0, r)
         reduced.cholesky()
-        y_red = reduced.solve_triangular(red_rhs, transpose=True)
-        self.x_sep = reduced.solve_triangular(y_red)
-        # natural-order state in front of a segment between separators (left separator j = g - 1): the pivot of the separator system
-        # there is F_j + Aaa(g), its swept right-hand side U_jj^T y_j = y~_j + ra(g)
-        for sg in self.segs:
-            if sg['kind'] == 'middle':
-                j = sg['g'] - 1
-                U = reduced.device_block(j, j)
-                F = engine.gemm(U, U, transa=True)
-                engine.axpby(-1.0, P[sg['g']][1], 1.0, F)
-                yt = engine.gemm(U, y_red[j * d:(j + 1) * d].contiguous(), transa=True)
-                engine.axpby(-1.0, P[sg['g']][4], 1.0, yt)
-                sg['F'], sg['yt'] = F, yt
+        self.x_sep = reduced.solve_triangular(reduced.solve_triangular(red_rhs, transpose=True))
         reduced.sparse_inverse()                                             # Z_SS: blocks (j, j) and (j, j + 1)
-        self._each(self._continue)
 
-    def _continue(self, sg):
-        """a segment between separators: the natural-order elimination of the whole chain, continued through its epochs"""
-        if sg['kind'] != 'middle':
-            return
-        engine = self.engine
-        lo, hi, ni = sg['lo'], sg['hi'], sg['ni']
-        left = self._left(sg)
-        U = engine.potrf(sg['F'])
-        X = engine.trtri(U)                                                  # F^-1 = X X^T
-        Wl = engine.gemm(X, left, transa=True)                               # U^-T N[a, lo]
-        engine.gemm(Wl, Wl, transa=True, alpha=-1.0, beta=1.0, out=self.diag[lo])
-        sg['T'] = engine.gemm(X, Wl)                                         # F^-1 N[a, lo]: Z[a, lo] = -T Z[lo, lo]
-        y = sg['y'] = self.rhs[self._rows(lo, hi)].clone() if self.k else self.zeros(int(self.bounds[hi] - self.bounds[lo]), 1)
-        if self.k:
-            first = y[:self.sizes[lo]]
-            engine.gemm(Wl, engine.gemm(X, sg['yt'], transa=True), transa=True, alpha=-1.0, beta=1.0, out=first)
-        M = sg['M'] = self._chain(self.diag[lo:hi], self.upper[lo:hi - 1])
-        M._cholesky_rows(0, ni)
-        M._solve_rows(y, True, 0, ni)
-        del sg['F']
-
-    # ---- solution
+    # ---- step 3: solution
     def solve(self):
         d = self.d
 
@@ -577,8 +575,12 @@ class _SegmentedChain:
             M, y, ni = sg['M'], sg['y'], sg['ni']
             j = sg['g'] - 1 if sg['kind'] == 'last' else sg['g']            # the separator in the segment's last row
             y[-d:] = self.x_sep[j * d:(j + 1) * d]
+            if sg['kind'] == 'middle':
+                y[-2 * d:-d] = self.x_sep[(j - 1) * d:j * d]               # ... and the one on its left in the row before
             M._solve_rows(y, False, 0, ni)
-            if sg['kind'] != 'last':
+            if sg['kind'] == 'middle':
+                return self.torch.cat((y[:-2 * d], y[-d:]), dim=0)          # interior epochs, then the segment's own separator
+            if sg['kind'] == 'first':
                 return y
             # reversed segment: back into epoch order, without the separator row
             parts, pos = [], 0
@@ -588,29 +590,31 @@ class _SegmentedChain:
             return self.torch.cat(parts[::-1], dim=0)
         return self.torch.cat(self._each(job), dim=0)
 
-    # ---- covariance blocks
+    # ---- step 3: covariance blocks
     def covariance(self):
-        torch, engine, d = self.torch, self.engine, self.d
+        d = self.d
         sep = self.reduced.device_block
 
         def job(sg):
             M, ni, lo, hi = sg['M'], sg['ni'], sg['lo'], sg['hi']
             block = M.device_block
             j = sg['g'] - 1 if sg['kind'] == 'last' else sg['g']
+            if sg['kind'] == 'middle':                                      # rows [interior ..., a, c]
+                block(ni, ni).copy_(sep(j - 1, j - 1))
+                block(ni, ni + 1).copy_(sep(j - 1, j))
+                block(ni + 1, ni + 1).copy_(sep(j, j))
+                M._sparse_inverse_rows(0, ni)
+                zd = [block(q, q) for q in range(ni)] + [block(ni + 1, ni + 1)]
+                zu = [block(q, q + 1) for q in range(ni - 1)] + [block(ni - 1, ni + 1)]
+                return zd, zu, block(0, ni).t().contiguous()                # Z[a, lo]
             block(ni, ni).copy_(sep(j, j))
             M._sparse_inverse_rows(0, ni)
             if sg['kind'] == 'last':
                 n = hi - lo
                 zd = [block(n - 1 - q, n - 1 - q) for q in range(n)]
                 zu = [_transposed(block(n - 2 - q, n - 1 - q), True) for q in range(n - 1)]
-                to_left = block(ni - 1, ni).t().contiguous()               # Z[a, lo]
-                return zd, zu, to_left
-            zd = [block(q, q) for q in range(hi - lo)]
-            zu = [block(q, q + 1) for q in range(hi - lo - 1)]
-            to_left = None
-            if sg['kind'] == 'middle':
-                to_left = engine.gemm(sg['T'], zd[0], alpha=-1.0)           # Z[a, lo] = -F^-1 N[a, lo] Z[lo, lo]
-            return zd, zu, to_left
+                return zd, zu, block(ni - 1, ni).t().contiguous()           # Z[a, lo]
+            return [block(q, q) for q in range(hi - lo)], [block(q, q + 1) for q in range(hi - lo - 1)], None
         results = self._each(job)
         zdiag, zupper = [], []
         for i, (zd, zu, to_left) in enumerate(results):
@@ -728,4 +732,6 @@ def smooth_block_tridiagonal_partitioned(diag, upper, rhs, group=None, consume=F
     t0 = lap('solve_s', t0)
     zdiag, zupper = sc.covariance()
     lap('covariance_s', t0)
+    if timings is not None:
+        timings['segment_work_s'] = sc.busy_s
     return x, zdiag, zupper

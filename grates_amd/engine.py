@@ -395,37 +395,6 @@ def block_sparse_inverse_rows(table, inverses, first, last):
     _lib.call('shg_block_sparse_inverse_rows', *table.args(), pi, int(first), int(last), _stream())
 
 
-def chain_schur(diag, upper, left, right_size, rhs):
-    """Schur complement of the block-tridiagonal chain (diag[t], upper[t] = N[t, t+1], device tensors; upper[-1] couples the last block
-    to the right neighbour when right_size > 0, else upper has one entry less) onto its neighbours, chain untouched (shg_chain_schur).
-    left = N[a, first block] or None; rhs [n, k] or None.  Returns (Saa, Sac, Scc, ga, gc), None where a neighbour is absent."""
-    torch = require_gpu()
-    n = len(diag)
-    for t in list(diag) + list(upper) + ([left] if left is not None else []) + ([rhs] if rhs is not None else []):
-        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
-            raise ValueError('chain_schur: contiguous fp64 device tensors expected')
-    sizes = [int(b.shape[0]) for b in diag]
-    bounds = np.concatenate(([0], np.cumsum(sizes))).astype(np.int32)
-    da = 0 if left is None else int(left.shape[0])
-    dc = int(right_size)
-    if len(upper) != (n if dc else n - 1) or (left is not None and left.shape[1] != sizes[0]) or (dc and tuple(upper[-1].shape) != (sizes[-1], dc)):
-        raise ValueError('chain_schur: block shapes do not form a chain')
-    k = 0 if rhs is None else int(rhs.shape[1])
-    dev = diag[0].device
-
-    def out(r, c):
-        return torch.empty((r, c), dtype=torch.float64, device=dev) if r and c else None
-    Saa, Sac, Scc, ga, gc = out(da, da), out(da, dc), out(dc, dc), out(da, k), out(dc, k)
-    dptr = np.array([b.data_ptr() for b in diag], dtype=np.uint64)
-    rptr = np.array([b.data_ptr() for b in upper] + [0] * (n - len(upper)), dtype=np.uint64)
-    info = torch.zeros(1, dtype=torch.int32, device=dev)
-    as_ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)       # noqa: E731
-    opt = lambda t: _ptr(t) if t is not None else None          # noqa: E731
-    _lib.call('shg_chain_schur', n, as_ptr(bounds), da, dc, as_ptr(dptr), as_ptr(rptr), opt(left), opt(rhs), k, max(k, 1) if rhs is None else max(rhs.stride(0), 1),
-              opt(Saa), opt(Sac), opt(Scc), opt(ga), opt(gc), _ptr(info), _stream())
-    return (Saa, Sac, Scc, ga, gc), info
-
-
 def block_inverse(table, inverses):
     inverses, pi = _table(inverses)
     _lib.call('shg_block_inverse', *table.args(), pi, _stream())

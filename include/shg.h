@@ -236,13 +236,6 @@ int shg_block_solve_rows(int nb, const int* bounds, const int* rowptr, const int
                          int first, int last, double* B, int k, int ldb, void* stream);
 int shg_block_sparse_inverse_rows(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
                                   int first, int last, void* stream);
-/* Schur complement of a block-tridiagonal chain onto its two neighbours without modifying the chain (one streaming sweep):
- * D[t] = N[t, t], R[t] = N[t, t + 1] for the n chain blocks with bounds[0 .. n]; R[n - 1] [d_{n-1}][dc] couples the last block to
- * the right neighbour c (dc = 0: none), L = N[a, first chain block] [da][d_0] the left neighbour a to the first block (da = 0:
- * none); b [sum d_t][k] with leading dimension ldb (k = 0: none).  Out, with E_a / E_c the coupling columns and A the chain matrix:
- * Saa = E_a^T A^-1 E_a, Sac = E_a^T A^-1 E_c, Scc = E_c^T A^-1 E_c, ga = E_a^T A^-1 b, gc = E_c^T A^-1 b.  *info as in shg_block_potrf. */
-int shg_chain_schur(int n, const int* bounds, int da, int dc, const double* const* D, const double* const* R, const double* L, const double* b,
-                    int k, int ldb, double* Saa, double* Sac, double* Scc, double* ga, double* gc, int* info, void* stream);
 int shg_block_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, void* stream);
 int shg_block_multiply(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, int mode, const double* B, int k, int ldb,
                        double* V, int ldv, void* stream);

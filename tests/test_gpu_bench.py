@@ -37,5 +37,5 @@ def test_bench_line_small_sizes():
     assert flt['block']['roofline']['bound'] == 'hbm' and flt['dense']['roofline']['bound'] == 'mfma'
     sm = line['smoother']
     assert sm['config']['epochs'] == 24 and sm['check']['ok'] and sm['check']['residual'] < 1e-13 and sm['check']['short_chain_max_rel_err_vs_oracle'] < 1e-9
-    assert set(sm['phases_s']) == {'factor_s', 'solve_s', 'covariance_s'}
+    assert {'factor_s', 'solve_s', 'covariance_s'} <= set(sm['phases_s'])
     assert line['all_checks_ok']

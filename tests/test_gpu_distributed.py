@@ -140,47 +140,11 @@ def _dense_chain(diag, upper):
     return N, bounds
 
 
-def test_chain_schur_against_dense():
-    """shg_chain_schur: Schur complement of a chain onto its neighbours in one streaming sweep, chain blocks untouched; ragged
-    block sizes, with and without either neighbour, against numpy on the dense matrices."""
-    from grates_amd import engine
-    rng = np.random.default_rng(21)
-    sizes, da, dc, k = [33, 7, 130, 64, 5], 19, 41, 3
-    diag = [rng.standard_normal((d, d + 4)) for d in sizes]
-    diag = [G @ G.T / G.shape[0] + 3.0 * np.eye(G.shape[0]) for G in diag]
-    upper = [rng.standard_normal((sizes[t], sizes[t + 1])) * 0.3 / np.sqrt(sizes[t]) for t in range(len(sizes) - 1)]
-    right = rng.standard_normal((sizes[-1], dc)) * 0.3
-    left = rng.standard_normal((da, sizes[0])) * 0.3
-    rhs = rng.standard_normal((sum(sizes), k))
-    A, bounds = _dense_chain(diag, upper)
-    Ea = np.zeros((A.shape[0], da))
-    Ea[:sizes[0]] = left.T
-    Ec = np.zeros((A.shape[0], dc))
-    Ec[-sizes[-1]:] = right
-    Ai = np.linalg.inv(A)
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    dd, du = [dev(b) for b in diag], [dev(b) for b in upper]
-    keep = [b.clone() for b in dd + du]
-    (Saa, Sac, Scc, ga, gc), info = engine.chain_schur(dd, du + [dev(right)], dev(left), dc, dev(rhs))
-    assert int(info.item()) == 0 and all(torch.equal(a, b) for a, b in zip(keep, dd + du))
-    for got, ref in ((Saa, Ea.T @ Ai @ Ea), (Sac, Ea.T @ Ai @ Ec), (Scc, Ec.T @ Ai @ Ec), (ga, Ea.T @ Ai @ rhs), (gc, Ec.T @ Ai @ rhs)):
-        assert relerr(got.cpu().numpy(), ref) < 1e-12
-    (Saa, Sac, Scc, ga, gc), _ = engine.chain_schur(dd, du, dev(left), 0, None)                 # left neighbour only, no right-hand side
-    assert Sac is None and Scc is None and ga is None and relerr(Saa.cpu().numpy(), Ea.T @ Ai @ Ea) < 1e-12
-    (Saa, Sac, Scc, ga, gc), _ = engine.chain_schur(dd[:1], [dev(upper[0])], None, sizes[1], dev(rhs[:sizes[0]]))     # one block, right neighbour
-    one = np.linalg.inv(diag[0])
-    assert Saa is None and relerr(Scc.cpu().numpy(), upper[0].T @ one @ upper[0]) < 1e-12 and relerr(gc.cpu().numpy(), upper[0].T @ one @ rhs[:sizes[0]]) < 1e-12
-    bad = [b.clone() for b in dd]
-    bad[2] -= 10.0 * torch.eye(sizes[2], dtype=torch.float64, device='cuda')
-    _, info = engine.chain_schur(bad, du, dev(left), 0, None)
-    assert int(info.item()) > sizes[0] + sizes[1]                                           # first non-positive pivot inside the third block
-
-
 @pytest.mark.parametrize('segments,epochs,dim', [(2, 9, 48), (3, 11, 40), (4, 17, 130), (6, 40, 33)])
 def test_segmented_chain_single_rank(segments, epochs, dim):
-    """The segmented elimination on one rank (first / last segments factored once from their free ends, segments between separators
-    reduced by shg_chain_schur and then continued in natural order), every segment on its own stream: solution and covariance
-    blocks against the dense solve / inverse, and against the plain chain."""
+    """The segmented elimination on one rank (first / last segments eliminated from their free ends, segments between separators with
+    both separators as their last block rows and the coupling to the left one carried along as fill-in), every segment on its
+    own stream: solution and covariance blocks against the dense solve / inverse."""
     from grates_amd import distributed as gd
     diag, upper, rhs = _system(epochs, dim, 3, seed=epochs)
     upper = upper[:epochs - 1]
@@ -412,6 +376,18 @@ def test_bench_rehearsal_world2_and_world4_real_shard_sizes():
         run = subprocess.run(common + ['--gpus', str(world)] + extra, env=env, capture_output=True, text=True, timeout=900)
         assert run.returncode == 0, run.stderr[-2000:]
         lines[world] = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith('{')][-1])
+    # once more with the ranks taking turns on the card (smoother only): what every rank spends on its own segments, i.e. the time a
+    # rank with a GPU of its own would need
+    turns = {}
+    for world in (2, 4):
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+        env['GRATES_AMD_REHEARSAL_TURNS'] = '1'
+        run = subprocess.run(common + ['--gpus', str(world), '--backend', 'gloo', '--same-device', '--legs', 'smoother'], env=env, capture_output=True,
+                             text=True, timeout=900)
+        assert run.returncode == 0, run.stderr[-2000:]
+        line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith('{')][-1])
+        assert line['all_checks_ok']
+        turns[world] = line['smoother']['phases_s']['segment_work_s']
     one, two, four = lines[1], lines[2], lines[4]
     assert four['n_gpus'] == 4 and four['all_checks_ok'] and one['all_checks_ok'] and two['n_gpus'] == 2 and two['all_checks_ok']
     assert two['smoother']['config']['epochs_per_rank'] == [256] * 2 and two['smoother']['check']['residual'] < 1e-13
@@ -433,6 +409,8 @@ def test_bench_rehearsal_world2_and_world4_real_shard_sizes():
                            'seconds_world1': one['smoother']['seconds'], 'phases_world1': one['smoother']['phases_s'],
                            'seconds_world2_one_card': two['smoother']['seconds'], 'phases_world2': two['smoother']['phases_s'],
                            'residual_world2': two['smoother']['check']['residual'],
+                           'per_rank_segment_work_s_when_ranks_take_turns': {'world2': turns[2], 'world4': turns[4],
+                                                                            'note': 'max over ranks; single chain (world 1, two segments on two streams): seconds_world1'},
                            'residual_world4': four['smoother']['check']['residual'], 'identity_defect_world4': four['smoother']['check']['identity_defect_max'],
                            'solution_checksum_world1': a, 'solution_checksum_world4': b}}
     print(json.dumps(record))
