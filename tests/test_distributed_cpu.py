@@ -86,3 +86,22 @@ def test_single_process_paths_need_no_process_group():
     os.environ.pop('WORLD_SIZE', None)
     os.environ.pop('RANK', None)
     assert gd.init() == (0, 1)
+
+
+def test_segment_bounds_and_defaults(monkeypatch):
+    """Segments of a rank: contiguous, complete, at least two epochs each (one for the very last segment of the chain), the end
+    segments of the chain about 1.5 times as long as the ones between separators."""
+    for n_loc, count, first, last in ((456, 2, False, False), (456, 2, True, False), (3650, 2, True, True), (3650, 6, True, True), (9, 4, True, True),
+                                      (5, 2, False, True), (3, 1, False, True), (1, 1, False, True)):
+        segs = gd._segment_bounds(n_loc, count, first, last)
+        assert segs[0][0] == 0 and segs[-1][1] == n_loc and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+        sizes = [hi - lo for lo, hi in segs]
+        assert min(sizes[:-1] + [2]) >= 2 and sizes[-1] >= (1 if last else 2)
+    sizes = [hi - lo for lo, hi in gd._segment_bounds(3650, 6, True, True)]
+    assert abs(sizes[0] - sizes[-1]) <= 2 and abs(sizes[0] - 1.5 * sizes[2]) <= 3 and len(set(sizes[1:-1])) <= 2
+    with pytest.raises(ValueError):
+        gd._segment_bounds(3, 2, False, False)
+    monkeypatch.delenv('GRATES_AMD_SEGMENTS', raising=False)
+    assert gd.default_segments(3650, 1) == 2 and gd.default_segments(456, 8) == 2 and gd.default_segments(7, 1) == 1 and gd.default_segments(3, 2) == 1
+    monkeypatch.setenv('GRATES_AMD_SEGMENTS', '6')
+    assert gd.default_segments(3650, 1) == 6 and gd.default_segments(20, 1) == 5
