@@ -505,7 +505,7 @@ static int build_analysis_operator(shg_plan* p, const double* w2, int nmin, hipS
             if (q) (void)hipFreeAsync(q, stream);
         return fail(SHG_ERR_NOMEM, "analysis operator workspace allocation failed");
     }
-    SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
+    if (zero_fill(info, stream) != SHG_OK) return SHG_ERR_HIP;
     hipLaunchKernelGGL(analysis_gather_kernel, dim3(ceil_div(nlat, 128), R, S), dim3(128), 0, stream, N, nmin, nlat, p->ldlat, p->pk, w2, pks, pkw);
     // normal matrices N_s = PKw_s PKs_s^T
     int rc = gemm_ex(false, true, R, R, nlat, 1.0, pkw, nlat, (long long)R * nlat, pks, nlat, (long long)R * nlat, 0.0, nmat, R, (long long)R * R, S,
@@ -570,7 +570,7 @@ static int rebuild_analysis_operator(shg_plan* p, const double* area, int nmin, 
         int* varies = (int*)lease.get(kScratchAnaFlag, sizeof(int));
         if (!varies) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
         int host = 1;
-        SHG_HIP(hipMemsetAsync(varies, 0, sizeof(int), stream));
+        if (zero_fill(varies, stream) != SHG_OK) return SHG_ERR_HIP;
         hipLaunchKernelGGL(analysis_rowconst_kernel, dim3(256), dim3(256), 0, stream, nlat, nlon, area, varies);
         SHG_HIP(hipMemcpyAsync(&host, varies, sizeof(int), hipMemcpyDeviceToHost, stream));
         SHG_HIP(hipStreamSynchronize(stream));
@@ -582,7 +582,7 @@ static int rebuild_analysis_operator(shg_plan* p, const double* area, int nmin, 
 
 // *diff (device, zeroed here) becomes non-zero when `area` is not the set of weights the cached operator was built for
 static int launch_weight_compare(shg_plan* p, const double* area, int* diff, hipStream_t stream) {
-    SHG_HIP(hipMemsetAsync(diff, 0, sizeof(int), stream));
+    if (zero_fill(diff, stream) != SHG_OK) return SHG_ERR_HIP;
     hipLaunchKernelGGL(analysis_compare_kernel, dim3(256), dim3(256), 0, stream, (long long)p->nlat * p->nlon, area, p->ana_area, diff);
     SHG_HIP(hipGetLastError());
     return SHG_OK;

@@ -735,7 +735,7 @@ __global__ void zero_lower_kernel(int n, double* __restrict__ A, int lda) {
 // X = U^-1 for an upper triangular U [n][ldu]; X [n][ldx] (the strictly lower part of X is set to zero); work: n * 128 doubles
 int trtri_upper(int n, const double* U, int ldu, double* X, int ldx, double* work, hipStream_t stream) {
     if (n <= 0) return SHG_OK;
-    SHG_HIP(hipMemset2DAsync(X, (size_t)ldx * sizeof(double), 0, (size_t)n * sizeof(double), n, stream));
+    if (int zrc = zero_fill(X, ldx, n, n, stream)) return zrc;
     // leaves: X_kk = U_kk^-1 for all diagonal blocks at once (the ragged last one separately)
     const int nfullb = n / LEAF, rest = n % LEAF;
     int rc;
@@ -841,7 +841,7 @@ size_t potrf_inverse_work(int n) { return (size_t)(n / 2 + LEAF) * (n / 2 + LEAF
 
 int potrf_inverse_upper(int n, double* A, int lda, double* X, int ldx, double* work, int* info, hipStream_t stream) {
     if (n <= 0) return SHG_OK;
-    SHG_HIP(hipMemset2DAsync(X, (size_t)ldx * sizeof(double), 0, (size_t)n * sizeof(double), n, stream));
+    if (int zrc = zero_fill(X, ldx, n, n, stream)) return zrc;
     const int rc = potrf_inverse_rec(n, A, lda, X, ldx, work, info, 0, stream);
     if (rc) return rc;
     if (n > 1) {
@@ -901,7 +901,7 @@ extern "C" int shg_potrf(int n, double* A, int lda, int* info, void* stream_) {
     double* work = nullptr;
     if (workspace_alloc((void**)&work, (size_t)LEAF * LEAF * sizeof(double), stream) != hipSuccess)
         return fail(SHG_ERR_NOMEM, "shg_potrf: workspace allocation failed");
-    if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
+    if (info && (zero_fill(info, stream) != SHG_OK)) return SHG_ERR_HIP;
     const int rc = potrf_upper(n, A, lda, work, info, stream);
     (void)hipFreeAsync(work, stream);
     return rc;

@@ -71,19 +71,15 @@ inline int gemm_tri(bool ta, bool tb, int M, int N, int K, double alpha, const d
     return gemm_ex_tri(ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, false, tri, s);
 }
 
-struct Scratch {                       // stream-ordered scratch, released when the call returns
-    hipStream_t stream;
-    std::vector<void*> held;
-    explicit Scratch(hipStream_t s) : stream(s) {}
-    ~Scratch() {
-        for (void* p : held) (void)hipFreeAsync(p, stream);
-    }
-    double* get(size_t doubles) {
-        void* p = nullptr;
-        if (workspace_alloc(&p, std::max<size_t>(doubles, 1) * sizeof(double), stream) != hipSuccess) return nullptr;
-        held.push_back(p);
-        return (double*)p;
-    }
+// Workspaces of one call: the stream's own grow-only scratch buffers (ScratchLease, plan.hip), one slot per request in the
+// order of the requests; the stream orders the calls that share them.  (Not hipMallocAsync / hipFreeAsync per call: the free
+// keeps the calling thread until the stream has caught up, see plan.hip, and a chain of per-row calls -- the segmented
+// smoother -- then runs at the pace of the host.)
+struct Scratch {
+    ScratchLease lease;
+    int next = kScratchBlocks;
+    explicit Scratch(hipStream_t s) : lease(s) {}
+    double* get(size_t doubles) { return (double*)lease.get(next++, std::max<size_t>(doubles, 1) * sizeof(double)); }
 };
 
 int check(const BlockView& V, double* const* inv, const char* who) {
@@ -134,7 +130,7 @@ extern "C" int shg_block_potrf_rows(int nb, const int* bounds, const int* rowptr
     // inv[r] == blk[diagonal r]: the caller keeps U_rr^-1 INSTEAD of U_rr (nothing but shg_block_multiply needs the diagonal
     // factor blocks once their inverses exist): the block is factored in a scratch copy and its inverse goes where it was
     double* diag_copy = nullptr;
-    if (info) SHG_HIP(hipMemsetAsync(info, 0, sizeof(int), stream));
+    if (info && (rc = zero_fill(info, stream)) != SHG_OK) return rc;
     for (int r = first; r < last; ++r) {
         const int dr = V.size(r);
         const int e0 = V.begin(r), e1 = V.end(r);
@@ -145,7 +141,8 @@ extern "C" int shg_block_potrf_rows(int nb, const int* bounds, const int* rowptr
             SHG_HIP(hipMemcpyAsync(diag_copy, Arr, (size_t)dr * dr * sizeof(double), hipMemcpyDeviceToDevice, stream));
             Arr = diag_copy;
         }
-        SHG_HIP(hipMemsetAsync(info_blk, 0, sizeof(int), stream));
+        rc = zero_fill(info_blk, stream);
+        if (rc) return rc;
         rc = potrf_inverse_upper(dr, Arr, dr, inv[r], dr, work, info_blk, stream);      // factor and inverse in one recursive sweep
         if (rc) return rc;
         if (info) hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, stream, info, info_blk, bounds[r] - bounds[0]);     // first failure wins
@@ -263,7 +260,8 @@ extern "C" int shg_block_sparse_inverse_rows(int nb, const int* bounds, const in
             const int dk = V.size(colidx[e]);
             rc = gemm_tri(false, false, dr, dk, dr, 1.0, inv[r], dr, blk[e], dk, 0.0, T(e, r), dk, 1, stream);
             if (rc) return rc;
-            SHG_HIP(hipMemsetAsync(blk[e], 0, (size_t)dr * dk * sizeof(double), stream));
+            rc = zero_fill(blk[e], dk, dk, dr, stream);
+            if (rc) return rc;
         }
         if (inv[r] == blk[e0]) {                                                                                       // (inverse kept in the diagonal block itself)
             double* zrr = T(e0 + 1 + most_slot, r);
@@ -368,7 +366,7 @@ extern "C" int shg_block_multiply(int nb, const int* bounds, const int* rowptr, 
                         "shg_block_multiply: block row %d: columns must ascend within the upper triangle", i);
     hipStream_t stream = (hipStream_t)stream_;
     const int n = bounds[nb] - bounds[0];
-    SHG_HIP(hipMemset2DAsync(Vout, (size_t)ldv * sizeof(double), 0, (size_t)k * sizeof(double), n, stream));
+    if (int zrc = zero_fill(Vout, ldv, k, n, stream)) return zrc;
     auto rb = [&](int i) { return B + (size_t)(bounds[i] - bounds[0]) * ldb; };
     auto rv = [&](int i) { return Vout + (size_t)(bounds[i] - bounds[0]) * ldv; };
     int rc = SHG_OK;

@@ -16,8 +16,15 @@
 namespace shg {
 
 int fail(int code, const char* fmt, ...);
+// Zero fills as kernels of this library (plan.hip), for the paths that several host threads feed at once (the chains of the
+// block-banded smoother, one thread and one stream each): on ROCm 7.2 a 4-byte hipMemsetAsync issued from four threads on
+// four streams left 0x80808080 in its target about four runs in five (the pivot flag of blockchol.hip's factorisation; with a
+// kernel in its place, never).  rows x cols doubles with leading dimension ld (ld == cols: one contiguous run).
+int zero_fill(double* p, long long ld, long long cols, long long rows, hipStream_t stream);
+int zero_fill(int* p, hipStream_t stream);
 // grow-only scratch of a stream (plan.hip), kept until shg_scratch_release(); one slot per buffer that is live at the same time
-enum ScratchSlot { kScratchSplitK = 0, kScratchAnaFold = 1, kScratchAnaTransform = 2, kScratchAnaSolution = 3, kScratchAnaFlag = 4 };
+enum ScratchSlot { kScratchSplitK = 0, kScratchAnaFold = 1, kScratchAnaTransform = 2, kScratchAnaSolution = 3, kScratchAnaFlag = 4,
+                   kScratchBlocks = 8 /* and up: the workspaces of one block-matrix call (blockchol.hip) */ };
 class ScratchLease {          // the scratch buffers of one stream, held while the operations that use them are enqueued (plan.hip)
 public:
     explicit ScratchLease(hipStream_t stream);

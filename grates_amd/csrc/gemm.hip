@@ -867,7 +867,7 @@ extern "C" int shg_symmetry_defect(const double* S, int n, int ld, double* defec
     SHG_REQUIRE(n >= 0 && ld >= n, "shg_symmetry_defect: bad size");
     SHG_REQUIRE(defect != nullptr, "shg_symmetry_defect: NULL output");
     hipStream_t stream = (hipStream_t)stream_;
-    SHG_HIP(hipMemsetAsync(defect, 0, sizeof(double), stream));
+    if (zero_fill(defect, 1, 1, 1, stream) != SHG_OK) return SHG_ERR_HIP;
     if (n == 0) return SHG_OK;
     SHG_REQUIRE(S != nullptr, "shg_symmetry_defect: NULL matrix");
     const int nt = ceil_div(n, 32);

@@ -43,6 +43,29 @@ hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream) {
     return hipMallocAsync(ptr, bytes, stream);
 }
 
+__global__ void zero_fill_kernel(double* __restrict__ p, long long ld, long long cols, long long count) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long long)gridDim.x * blockDim.x)
+        p[ld == cols ? e : (e / cols) * ld + e % cols] = 0.0;
+}
+
+__global__ void zero_int_kernel(int* __restrict__ p) { *p = 0; }
+
+int zero_fill(double* p, long long ld, long long cols, long long rows, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return SHG_OK;
+    if (rows == 1) ld = cols;
+    const long long count = rows * cols;
+    const unsigned blocks = (unsigned)std::min<long long>(ceil_div64(count, 256), 256 * 16);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, stream, p, ld, cols, count);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+int zero_fill(int* p, hipStream_t stream) {
+    hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, stream, p);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
 // Scratch that lives as long as its stream is in use: grow-only buffers per (stream, slot), handed to successive
 // operations of that stream (which the stream orders, so they may share them).  For workspaces inside chains of thousands of
 // small operations: on ROCm 7.2 hipFreeAsync keeps the calling thread until the stream has caught up (0.2 - 1.4 ms per call

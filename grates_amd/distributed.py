@@ -442,6 +442,23 @@ class _SegmentedChain:
         # the time the rank would need on a GPU of its own (the elapsed time of such a run is the sum over the ranks).
         self.turns = world > 1 and os.environ.get('GRATES_AMD_REHEARSAL_TURNS', '0') == '1'
         self.busy_s = 0.0
+        # The fill-in blocks W[t, a] of the segments between separators, one allocation per segment made HERE, before the segment
+        # threads start: fresh device memory is mapped synchronously (21 us per MB), and allocating 22 MB blocks from inside the
+        # threads while the other segments' kernels were running made two such segments 2.5 times slower each (6.8 against
+        # 3.5 ms per epoch at d = 1681).
+        # (in pieces of at most 1 GB rather than one tensor of 16 GB -- 729 blocks at d = 1681 -- so that the pieces fit the holes
+        # the caching allocator has)
+        for sg in self.segs:
+            if sg['kind'] == 'middle':
+                sg['fill'] = fill = [None]
+                piece, used = None, 0
+                for q in range(1, sg['ni']):
+                    dq = sizes[sg['lo'] + q]
+                    if piece is None or used + dq > piece.shape[0]:
+                        rows = max(dq, min(int((1 << 27) // max(d, 1)), int(self.bounds[sg['hi'] - 1] - self.bounds[sg['lo'] + q])))
+                        piece, used = torch.zeros((rows, d), dtype=torch.float64, device=self.device), 0
+                    fill.append(piece[used:used + dq])
+                    used += dq
         self._factor()
 
     # ---- helpers
@@ -526,6 +543,8 @@ class _SegmentedChain:
             if q + 1 < ni:
                 M._set_device(q, q + 1, self.upper[lo + q])
         M._set_device(0, ni, left.t().contiguous())                       # N[lo, a]
+        for q in range(1, ni):                                             # fill-in W[t, a] (allocated before the threads started)
+            M._set_device(q, ni, sg['fill'][q])
         M._set_device(ni - 1, ni + 1, self.upper[hi - 2])                  # N[last interior epoch, c]
         for i, j in ((ni, ni), (ni, ni + 1), (ni + 1, ni + 1)):
             M._set_device(i, j, Z(d, d))
