@@ -64,6 +64,8 @@ PROTOTYPES = {
     'shg_scratch_release': [],
     'shg_block_potrf': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [c_double_p, ctypes.c_void_p],
     'shg_block_potrf_rows': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_block_potrf_rows_pair': [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_block_set_lookahead': [ctypes.c_int],
     'shg_block_solve': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     'shg_block_sparse_inverse': [ctypes.c_int] + [ctypes.c_void_p] * 6,
     'shg_block_solve_rows': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],

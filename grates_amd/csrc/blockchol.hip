@@ -30,7 +30,9 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
             long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, hipStream_t stream);
 int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
                 long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, int tri, hipStream_t stream);
-int potrf_inverse_upper(int n, double* A, int lda, double* X, int ldx, double* work, int* info, hipStream_t stream);
+int potrf_inverse_batch(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, double* work, long long strideW,
+                        int* info, int info_stride, int batch, hipStream_t stream);
+void potrf_inverse_set_lookahead(int enable);
 size_t potrf_inverse_work(int n);
 
 namespace {
@@ -112,60 +114,107 @@ using namespace shg;
 // Only the block rows first <= r < last are eliminated: the rows before `first` count as factored already (their updates have
 // been applied), the rows from `last` on receive the updates and are left as the Schur complement of what has been
 // eliminated.  Two chains that meet in a common last block (the two halves of a block-tridiagonal system, each walked from
-// its free end) are factored this way on two streams at once; the caller adds the two complements and finishes with the
-// last row.
-extern "C" int shg_block_potrf_rows(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
-                                    int first, int last, int* info, void* stream_) {
-    const BlockView V{nb, bounds, rowptr, colidx, blk};
-    int rc = check(V, inv, "shg_block_potrf");
-    if (rc) return rc;
-    SHG_REQUIRE(first >= 0 && first <= last && last <= nb, "shg_block_potrf_rows: rows %d .. %d outside 0 .. %d", first, last, nb);
-    hipStream_t stream = (hipStream_t)stream_;
+// its free end) are factored this way; the caller adds the two complements and finishes with the last row.
+// `count` matrices of the same structure (shg_block_potrf_rows_pair: the two chains) go through every launch together, as a
+// batch of two whose items lie (second block - first block) apart: the step of one chain is a string of launches that are too
+// small to fill the card, and the card overlaps the queues of two or three host threads only in part.
+static int potrf_rows(int count, const BlockView* V, double* const* const* blk, double* const* const* inv, int first, int last, int* info,
+                      int info_stride, hipStream_t stream) {
+    const BlockView& V0 = V[0];
+    const int* colidx = V0.colidx;
+    const int* bounds = V0.bounds;
+    auto apart = [&](const double* const* p) { return count > 1 ? (long long)(p[1] - p[0]) : 0LL; };
     Scratch scratch(stream);
-    const int dmax = V.max_size();
-    double* work = scratch.get(potrf_inverse_work(dmax));
-    double* panel = scratch.get((size_t)dmax * dmax);
-    int* info_blk = (int*)scratch.get(1);
+    const int dmax = V0.max_size();
+    const size_t wsize = potrf_inverse_work(dmax), bsize = (size_t)dmax * dmax;
+    double* work = scratch.get(wsize * count);
+    double* panel = scratch.get(bsize * count);
+    int* info_blk = (int*)scratch.get(count);
     SHG_REQUIRE(work && panel && info_blk, "shg_block_potrf: workspace allocation failed");
     // inv[r] == blk[diagonal r]: the caller keeps U_rr^-1 INSTEAD of U_rr (nothing but shg_block_multiply needs the diagonal
     // factor blocks once their inverses exist): the block is factored in a scratch copy and its inverse goes where it was
     double* diag_copy = nullptr;
-    if (info && (rc = zero_fill(info, stream)) != SHG_OK) return rc;
+    int rc = SHG_OK;
+    for (int b = 0; b < count; ++b)
+        if (info && (rc = zero_fill(info + (size_t)b * info_stride, stream)) != SHG_OK) return rc;
     for (int r = first; r < last; ++r) {
-        const int dr = V.size(r);
-        const int e0 = V.begin(r), e1 = V.end(r);
-        double* Arr = blk[e0];
-        if (inv[r] == Arr) {
-            if (!diag_copy) diag_copy = scratch.get((size_t)dmax * dmax);
+        const int dr = V0.size(r);
+        const int e0 = V0.begin(r), e1 = V0.end(r);
+        double* Arr[2] = {blk[0][e0], count > 1 ? blk[1][e0] : nullptr};
+        const double* Xrr[2] = {inv[0][r], count > 1 ? inv[1][r] : nullptr};
+        const bool in_place = Xrr[0] == Arr[0];
+        SHG_REQUIRE(count == 1 || (Xrr[1] == Arr[1]) == in_place, "shg_block_potrf_rows_pair: block row %d keeps its inverse in place in one matrix only", r);
+        if (in_place) {
+            if (!diag_copy) diag_copy = scratch.get(bsize * count);
             SHG_REQUIRE(diag_copy != nullptr, "shg_block_potrf: workspace allocation failed");
-            SHG_HIP(hipMemcpyAsync(diag_copy, Arr, (size_t)dr * dr * sizeof(double), hipMemcpyDeviceToDevice, stream));
-            Arr = diag_copy;
+            for (int b = 0; b < count; ++b) {
+                SHG_HIP(hipMemcpyAsync(diag_copy + b * bsize, Arr[b], (size_t)dr * dr * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                Arr[b] = diag_copy + b * bsize;
+            }
         }
-        rc = zero_fill(info_blk, stream);
+        for (int b = 0; b < count; ++b)
+            if ((rc = zero_fill(info_blk + b, stream)) != SHG_OK) return rc;
+        const long long sA = apart(Arr), sX = apart(Xrr);
+        rc = potrf_inverse_batch(dr, Arr[0], dr, sA, const_cast<double*>(Xrr[0]), dr, sX, work, (long long)wsize, info_blk, 1, count, stream);   // factor and inverse in one sweep
         if (rc) return rc;
-        rc = potrf_inverse_upper(dr, Arr, dr, inv[r], dr, work, info_blk, stream);      // factor and inverse in one recursive sweep
-        if (rc) return rc;
-        if (info) hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, stream, info, info_blk, bounds[r] - bounds[0]);     // first failure wins
+        if (info)
+            for (int b = 0; b < count; ++b)     // first failure wins
+                hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, stream, info + (size_t)b * info_stride, info_blk + b, bounds[r] - bounds[0]);
         // W_rc = U_rr^-T A_rc, through the panel scratch (the product cannot overwrite its own operand)
         for (int e = e0 + 1; e < e1; ++e) {
-            const int dc = V.size(colidx[e]);
-            rc = gemm_tri(true, false, dr, dc, dr, 1.0, inv[r], dr, blk[e], dc, 0.0, panel, dc, 2, stream);
+            const int dc = V0.size(colidx[e]);
+            const double* Arc[2] = {blk[0][e], count > 1 ? blk[1][e] : nullptr};
+            rc = gemm_ex_tri(true, false, dr, dc, dr, 1.0, Xrr[0], dr, sX, Arc[0], dc, apart(Arc), 0.0, panel, dc, (long long)bsize, count, false, 2, stream);
             if (rc) return rc;
-            SHG_HIP(hipMemcpyAsync(blk[e], panel, (size_t)dr * dc * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            for (int b = 0; b < count; ++b)
+                SHG_HIP(hipMemcpyAsync(blk[b][e], panel + b * bsize, (size_t)dr * dc * sizeof(double), hipMemcpyDeviceToDevice, stream));
         }
         // trailing update A_cd -= W_rc^T W_rd
         for (int e = e0 + 1; e < e1; ++e) {
             const int c = colidx[e];
             for (int f = e; f < e1; ++f) {
                 const int d = colidx[f];
-                double* Acd = V.at(c, d);
-                SHG_REQUIRE(Acd != nullptr, "shg_block_potrf: fill-in block (%d, %d) was not allocated", c, d);
-                rc = gemm(true, false, V.size(c), V.size(d), dr, -1.0, blk[e], V.size(c), blk[f], V.size(d), 1.0, Acd, V.size(d), c == d, stream);
+                const double* Acd[2] = {V[0].at(c, d), count > 1 ? V[1].at(c, d) : nullptr};
+                SHG_REQUIRE(Acd[0] != nullptr && (count == 1 || Acd[1] != nullptr), "shg_block_potrf: fill-in block (%d, %d) was not allocated", c, d);
+                const double* Wc[2] = {blk[0][e], count > 1 ? blk[1][e] : nullptr};
+                const double* Wd[2] = {blk[0][f], count > 1 ? blk[1][f] : nullptr};
+                rc = gemm_ex(true, false, V0.size(c), V0.size(d), dr, -1.0, Wc[0], V0.size(c), apart(Wc), Wd[0], V0.size(d), apart(Wd), 1.0,
+                             const_cast<double*>(Acd[0]), V0.size(d), apart(Acd), count, c == d, stream);
                 if (rc) return rc;
             }
         }
     }
     SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+extern "C" int shg_block_potrf_rows(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv,
+                                    int first, int last, int* info, void* stream_) {
+    const BlockView V{nb, bounds, rowptr, colidx, blk};
+    int rc = check(V, inv, "shg_block_potrf");
+    if (rc) return rc;
+    SHG_REQUIRE(first >= 0 && first <= last && last <= nb, "shg_block_potrf_rows: rows %d .. %d outside 0 .. %d", first, last, nb);
+    return potrf_rows(1, &V, &blk, &inv, first, last, info, 0, (hipStream_t)stream_);
+}
+
+// shg_block_potrf_rows for two matrices of the same structure (one block table, two sets of blocks), info[0] and info[1]
+extern "C" int shg_block_potrf_rows_pair(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk0, double* const* inv0,
+                                         double* const* blk1, double* const* inv1, int first, int last, int* info, void* stream_) {
+    const BlockView V[2] = {{nb, bounds, rowptr, colidx, blk0}, {nb, bounds, rowptr, colidx, blk1}};
+    int rc = check(V[0], inv0, "shg_block_potrf_rows_pair");
+    if (!rc) rc = check(V[1], inv1, "shg_block_potrf_rows_pair");
+    if (rc) return rc;
+    SHG_REQUIRE(first >= 0 && first <= last && last <= nb, "shg_block_potrf_rows_pair: rows %d .. %d outside 0 .. %d", first, last, nb);
+    double* const* blk[2] = {blk0, blk1};
+    double* const* inv[2] = {inv0, inv1};
+    return potrf_rows(2, V, blk, inv, first, last, info, 1, (hipStream_t)stream_);
+}
+
+// The factorisation of a diagonal block takes a look-ahead on two more streams (blas.hip) unless the calling thread turns it
+// off: a caller that factors several matrices from several threads at once does better without (and better still with
+// shg_block_potrf_rows_pair).  The setting belongs to the calling thread.
+extern "C" int shg_block_set_lookahead(int enable) {
+    potrf_inverse_set_lookahead(enable ? 1 : 0);
     return SHG_OK;
 }
 

@@ -32,6 +32,9 @@ public:
     ScratchLease(const ScratchLease&) = delete;
     ScratchLease& operator=(const ScratchLease&) = delete;
     void* get(int slot, size_t bytes);
+    // two more streams of the same device for work that runs beside the leased stream (the look-ahead of blas.hip's
+    // factorisation), with the events that order them; created on first use, kept with the scratch buffers
+    int side(hipStream_t streams[2], hipEvent_t* to_side, hipEvent_t from_side[2]);
 private:
     void* owner_;
 };

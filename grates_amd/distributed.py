@@ -264,7 +264,17 @@ class _TwistedChain:
     def factor(self):
         from . import engine
         nt, nbot = self.nt, self.nbot
-        self._both(lambda: self.top._cholesky_rows(0, nt - 1), lambda: self.bottom._cholesky_rows(0, nbot - 1))
+        # the two halves row by row in ONE string of launches, each launch a batch of two (shg_block_potrf_rows_pair); the longer
+        # half finishes its extra row alone.  (Blocks of different sizes: two threads on two streams as in the sweeps below.)
+        paired = min(nt, nbot) - 1
+        if paired >= 1 and len(set(self.sizes)) == 1:
+            self.top._cholesky_rows_pair(self.bottom, 0, paired)
+            if nt - 1 > paired:
+                self.top._cholesky_rows(paired, nt - 1)
+            if nbot - 1 > paired:
+                self.bottom._cholesky_rows(paired, nbot - 1)
+        else:
+            self._both(lambda: self.top._cholesky_rows(0, nt - 1), lambda: self.bottom._cholesky_rows(0, nbot - 1))
         # Schur complement of the middle block: N_mm minus the contributions of both halves
         st, sb = self.top.device_block(nt - 1, nt - 1), self.bottom.device_block(nbot - 1, nbot - 1)
         engine.axpby(1.0, sb, 1.0, st)
@@ -480,6 +490,7 @@ class _SegmentedChain:
 
         def run(sg, stream):
             torch.cuda.set_device(self.device)
+            self.engine.block_set_lookahead(False)         # several chains at once: one queue each (csrc/blas.hip)
             stream.wait_stream(main)
             with torch.cuda.stream(stream):
                 out = job(sg)
@@ -491,8 +502,13 @@ class _SegmentedChain:
             with ThreadPoolExecutor(max_workers=len(self.segs)) as pool:
                 futures = [pool.submit(run, sg, st) for sg, st in zip(self.segs, self.streams)]
                 return [f.result() for f in futures]
+        return self._in_turn(all_segments)
+
+    def _in_turn(self, work):
+        """work() -- at once on every rank, or rank after rank in a rehearsal with turns; its time goes to busy_s"""
         import time
         import torch.distributed as dist
+        torch = self.torch
         out = None
         for turn in range(self.world if self.turns else 1):
             if self.turns:
@@ -500,7 +516,7 @@ class _SegmentedChain:
                 dist.barrier(self.group)
             if not self.turns or turn == self.rank:
                 t0 = time.perf_counter()
-                out = all_segments()
+                out = work()
                 torch.cuda.synchronize(self.device)
                 self.busy_s += time.perf_counter() - t0
         if self.turns:
@@ -511,27 +527,20 @@ class _SegmentedChain:
         return _chain_matrix(self.BlockMatrix, blocks_d, blocks_u, False)
 
     # ---- step 1: every segment eliminates its interior; its separator rows collect the Schur complement
-    def _reduce(self, sg):
-        torch, engine = self.torch, self.engine
-        lo, hi, ni, d, kk = sg['lo'], sg['hi'], sg['ni'], self.d, self.kk
+    def _build(self, sg):
+        """the segment's block matrix: its interior epochs, then its separator rows"""
+        lo, hi, ni, d = sg['lo'], sg['hi'], sg['ni'], self.d
         Z = self.zeros
         if sg['kind'] == 'first':
-            M = sg['M'] = self._chain(self.diag[lo:hi], self.upper[lo:hi - 1])
-            M._cholesky_rows(0, ni)
-            y = sg['y'] = self.rhs[self._rows(lo, hi)].clone() if self.k else Z(int(self.bounds[hi] - self.bounds[lo]), 1)
-            M._solve_rows(y, True, 0, ni)
-            return [M.device_block(ni, ni).clone(), Z(d, d), Z(d, d), y[-d:].clone(), Z(d, kk)]
+            sg['M'] = self._chain(self.diag[lo:hi], self.upper[lo:hi - 1])
+            return
         left = self._left(sg)
         if sg['kind'] == 'last':
             # reversed order: position p = epoch hi - 1 - p, then the separator a on the left (zero block: it collects -S_aa)
             dd = [self.diag[t] for t in range(hi - 1, lo - 1, -1)] + [Z(d, d)]
             uu = [_transposed(self.upper[t - 1], True) for t in range(hi - 1, lo, -1)] + [left.t().contiguous()]
-            M = sg['M'] = self._chain(dd, uu)
-            M._cholesky_rows(0, ni)
-            parts = [self.rhs[self._rows(t, t + 1)] for t in range(hi - 1, lo - 1, -1)] if self.k else [Z(self.sizes[t], 1) for t in range(hi - 1, lo - 1, -1)]
-            y = sg['y'] = torch.cat(parts + [Z(d, kk)], dim=0)
-            M._solve_rows(y, True, 0, ni)
-            return [Z(d, d), M.device_block(ni, ni).clone(), Z(d, d), Z(d, kk), y[-d:].clone()]
+            sg['M'] = self._chain(dd, uu)
+            return
         # between two separators a and c: block rows [interior ..., a, c]; a and c start from zero and collect -S_aa, -S_ac, -S_cc,
         # the coupling to a is carried from row to row as fill-in (allocated by the symbolic step of the block Cholesky)
         offset = self.bounds[lo:hi] - self.bounds[lo]
@@ -548,7 +557,58 @@ class _SegmentedChain:
         M._set_device(ni - 1, ni + 1, self.upper[hi - 2])                  # N[last interior epoch, c]
         for i, j in ((ni, ni), (ni, ni + 1), (ni + 1, ni + 1)):
             M._set_device(i, j, Z(d, d))
-        M._cholesky_rows(0, ni)
+
+    def _eliminate(self):
+        """block Cholesky of the interior rows of every segment.  Two chains from the ends of the whole system (segments 'first' and
+        'last' of one rank: the single-GPU case) or two segments between separators with equally many epochs have the same
+        structure and go through the device together, every launch a batch of two (shg_block_potrf_rows_pair); the others run
+        side by side, one thread and one stream each."""
+        segs = self.segs
+        chains = [sg for sg in segs if sg['kind'] != 'middle']
+        between = [sg for sg in segs if sg['kind'] == 'middle']
+        pairs, single = [], []
+        if len(chains) == 2 and len(set(self.sizes)) == 1:
+            pairs.append((chains[0], chains[1], min(chains[0]['ni'], chains[1]['ni'])))
+        else:
+            single += chains
+        while between:
+            sg = between.pop(0)
+            mate = next((o for o in between if o['ni'] == sg['ni']), None) if len(set(self.sizes)) == 1 else None
+            if mate is None:
+                single.append(sg)
+            else:
+                between.remove(mate)
+                pairs.append((sg, mate, sg['ni']))
+        if not pairs:
+            self._each(lambda sg: sg['M']._cholesky_rows(0, sg['ni']))
+            return
+
+        def work():
+            self.engine.block_set_lookahead(True)
+            for a, b, rows in pairs:
+                a['M']._cholesky_rows_pair(b['M'], 0, rows)
+                for sg in (a, b):
+                    if sg['ni'] > rows:
+                        sg['M']._cholesky_rows(rows, sg['ni'])
+            for sg in single:
+                sg['M']._cholesky_rows(0, sg['ni'])
+        self._in_turn(work)
+
+    def _reduce(self, sg):
+        torch, engine = self.torch, self.engine
+        lo, hi, ni, d, kk = sg['lo'], sg['hi'], sg['ni'], self.d, self.kk
+        Z = self.zeros
+        M = sg['M']
+        if sg['kind'] == 'first':
+            y = sg['y'] = self.rhs[self._rows(lo, hi)].clone() if self.k else Z(int(self.bounds[hi] - self.bounds[lo]), 1)
+            M._solve_rows(y, True, 0, ni)
+            return [M.device_block(ni, ni).clone(), Z(d, d), Z(d, d), y[-d:].clone(), Z(d, kk)]
+        if sg['kind'] == 'last':
+            parts = [self.rhs[self._rows(t, t + 1)] for t in range(hi - 1, lo - 1, -1)] if self.k else [Z(self.sizes[t], 1) for t in range(hi - 1, lo - 1, -1)]
+            y = sg['y'] = torch.cat(parts + [Z(d, kk)], dim=0)
+            M._solve_rows(y, True, 0, ni)
+            return [Z(d, d), M.device_block(ni, ni).clone(), Z(d, d), Z(d, kk), y[-d:].clone()]
+        offset = self.bounds[lo:hi] - self.bounds[lo]
         y = sg['y'] = torch.cat(((self.rhs[self._rows(lo, hi - 1)] if self.k else Z(int(offset[-1]), 1)), Z(2 * d, kk)), dim=0)
         M._solve_rows(y, True, 0, ni)
         Acc = self.diag[hi - 1].clone()
@@ -560,6 +620,8 @@ class _SegmentedChain:
     # ---- step 2: the separator system, redundantly on every rank
     def _factor(self):
         engine, d, kk, K = self.engine, self.d, self.kk, self.K
+        self._each(self._build)
+        self._eliminate()
         pieces = self._each(self._reduce)
         flat = [t.contiguous() for p in pieces for t in p]
         if self.world > 1:

@@ -367,6 +367,29 @@ def block_potrf(table, inverses, first=0, last=None):
     return int(info.item())
 
 
+def block_potrf_pair(table0, inverses0, table1, inverses1, first=0, last=None):
+    """block_potrf for two matrices of the same structure (bounds, stored blocks) in one pass, every launch serving both
+    (shg_block_potrf_rows_pair); returns the two pivot flags."""
+    torch = require_gpu()
+    for a, b in ((table0.bounds - table0.bounds[0], table1.bounds - table1.bounds[0]), (table0.rowptr, table1.rowptr), (table0.colidx, table1.colidx)):
+        if a.shape != b.shape or not np.array_equal(a, b):
+            raise ValueError('block_potrf_pair: the two matrices differ in structure')
+    inverses0, p0 = _table(inverses0)
+    inverses1, p1 = _table(inverses1)
+    info = torch.zeros(2, dtype=torch.int32, device=device())
+    nb, bounds, rowptr, colidx, address0 = table0.args()
+    _lib.call('shg_block_potrf_rows_pair', nb, bounds, rowptr, colidx, address0, p0, table1.args()[4], p1, int(first),
+              int(table0.nb if last is None else last), _ptr(info), _stream())
+    flags = info.cpu()
+    return int(flags[0]), int(flags[1])
+
+
+def block_set_lookahead(enable):
+    """The factorisation of a diagonal block overlaps its panel steps on two more streams unless the calling THREAD turns that
+    off (shg_block_set_lookahead): threads that factor several matrices at once do better without."""
+    _lib.call('shg_block_set_lookahead', 1 if enable else 0)
+
+
 def block_solve(table, inverses, transpose, B):
     """B [n, k] <- W^-1 B or W^-T B in place (device tensor, contiguous last dimension)."""
     _require_row_major(B, 'block_solve')

@@ -419,6 +419,27 @@ class BlockMatrix:
         if pivot:
             raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(pivot))
 
+    def _cholesky_rows_pair(self, other, first, last):
+        """_cholesky_rows(first, last) of this matrix and of `other` in one pass (shg_block_potrf_rows_pair).  The two matrices
+        must have the same structure in the leading block rows and columns that the rows before `last` reach (two chains that
+        need not be equally long: up to block `last`; matrices with border columns: all of them)."""
+        tables, inverses = [], []
+        for m in (self, other):
+            m.__square_bounds()
+            if first == 0:
+                m.__allocate_fill()
+                m.__inverse_factor.clear()
+            reach = max([last] + [j for (i, j) in m.__data if i < last])
+            head = {k: v for k, v in m.__data.items() if k[0] <= reach and k[1] <= reach}
+            tables.append(engine.BlockTable(np.ascontiguousarray(m.__row_index[:reach + 2], dtype=np.int32), head))
+            inverses.append(m.__inverse_table()[:reach + 1])
+        pivots = engine.block_potrf_pair(tables[0], inverses[0], tables[1], inverses[1], first, last)
+        for m in (self, other):
+            m._holds_factor_inverses = m._inverse_in_place
+        for pivot in pivots:
+            if pivot:
+                raise np.linalg.LinAlgError('{0}-th leading minor of the array is not positive definite'.format(pivot))
+
     def _solve_rows(self, x, transpose, first, last):
         """in place on the device tensor x [n, k]: the sweep of solve_triangular over the block rows first <= r < last only
         (shg_block_solve_rows)"""

@@ -226,6 +226,15 @@ int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream)
 int shg_block_potrf(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int* info, void* stream);
 int shg_block_potrf_rows(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int first, int last,
                          int* info, void* stream);
+/* shg_block_potrf_rows for TWO matrices of the same structure (one table, two sets of blocks and inverses): every launch
+ * serves both, info[0] and info[1] receive the two pivot flags.  The two half chains of a two-ended elimination go through the
+ * device as one string of launches instead of two that the card overlaps only in part. */
+int shg_block_potrf_rows_pair(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk0, double* const* inv0,
+                              double* const* blk1, double* const* inv1, int first, int last, int* info, void* stream);
+/* The factorisation of a diagonal block larger than 256 overlaps its 128-column panel steps on two more streams of the device
+ * (look-ahead; the caller's stream waits for them before the call returns control of the data).  A THREAD that factors matrices
+ * beside other threads turns it off for itself: the card does not overlap that many queues (csrc/blas.hip). */
+int shg_block_set_lookahead(int enable);
 int shg_block_solve(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int transpose, double* B,
                     int k, int ldb, void* stream);
 int shg_block_sparse_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, void* stream);
