@@ -101,6 +101,8 @@ int check(const BlockView& V, double* const* inv, const char* who) {
 
 }  // namespace
 
+__global__ void mirror_upper_kernel(int n, double* __restrict__ C, int ldc);       // blas.hip: C[c][r] = C[r][c] for c > r
+
 __global__ void merge_info_kernel(int* __restrict__ dst, const int* __restrict__ src, int offset) {
     if (*dst == 0 && *src != 0) *dst = *src + offset;
 }
@@ -314,13 +316,15 @@ extern "C" int shg_block_sparse_inverse_rows(int nb, const int* bounds, const in
         }
         if (inv[r] == blk[e0]) {                                                                                       // (inverse kept in the diagonal block itself)
             double* zrr = T(e0 + 1 + most_slot, r);
-            rc = gemm_tri(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, zrr, dr, 9, stream);
+            rc = gemm_ex_tri(false, true, dr, dr, dr, 1.0, inv[r], dr, 0, inv[r], dr, 0, 0.0, zrr, dr, 0, 1, true, 9, stream);
             if (rc) return rc;
             SHG_HIP(hipMemcpyAsync(blk[e0], zrr, (size_t)dr * dr * sizeof(double), hipMemcpyDeviceToDevice, stream));
         } else {
-            rc = gemm_tri(false, true, dr, dr, dr, 1.0, inv[r], dr, inv[r], dr, 0.0, blk[e0], dr, 9, stream);            // Z_rr = U^-1 U^-T ...
+            rc = gemm_ex_tri(false, true, dr, dr, dr, 1.0, inv[r], dr, 0, inv[r], dr, 0, 0.0, blk[e0], dr, 0, 1, true, 9, stream);   // Z_rr = U^-1 U^-T ...
         }
         if (rc) return rc;
+        // (the diagonal block is symmetric: its upper triangle is computed -- half the flops of its d^3 products -- and mirrored
+        //  below, once the row is complete)
         for (int f = e1 - 1; f >= e0; --f) {                                                                           // ... and the row, last block first
             const int j = colidx[f];
             double* Zrj = blk[f];
@@ -329,11 +333,15 @@ extern "C" int shg_block_sparse_inverse_rows(int nb, const int* bounds, const in
                 const double* Zkj = k <= j ? V.at(k, j) : V.at(j, k);                                                  // Z_kj = Z_jk^T for k > j
                 if (!Zkj) continue;
                 if (k <= j)
-                    rc = gemm(false, false, dr, V.size(j), V.size(k), -1.0, T(e, r), V.size(k), Zkj, V.size(j), 1.0, Zrj, V.size(j), false, stream);
+                    rc = gemm(false, false, dr, V.size(j), V.size(k), -1.0, T(e, r), V.size(k), Zkj, V.size(j), 1.0, Zrj, V.size(j), j == r, stream);
                 else
-                    rc = gemm(false, true, dr, V.size(j), V.size(k), -1.0, T(e, r), V.size(k), Zkj, V.size(k), 1.0, Zrj, V.size(j), false, stream);
+                    rc = gemm(false, true, dr, V.size(j), V.size(k), -1.0, T(e, r), V.size(k), Zkj, V.size(k), 1.0, Zrj, V.size(j), j == r, stream);
                 if (rc) return rc;
             }
+        }
+        if (dr > 1) {
+            hipLaunchKernelGGL(mirror_upper_kernel, dim3(ceil_div(dr, 32), ceil_div(dr, 32)), dim3(256), 0, stream, dr, blk[e0], dr);
+            SHG_HIP(hipGetLastError());
         }
     }
     SHG_HIP(hipGetLastError());
