@@ -841,27 +841,10 @@ static int zero_lower(int n, double* A, int lda, long long strideA, int batch, h
     return SHG_OK;
 }
 
-// X = U^-1 for an upper triangular U [n][ldu]; X [n][ldx] (the strictly lower part of X is set to zero); work: n * 128 doubles
-int trtri_upper(int n, const double* U, int ldu, double* X, int ldx, double* work, hipStream_t stream) {
-    if (n <= 0) return SHG_OK;
-    if (int zrc = zero_fill(X, ldx, n, n, stream)) return zrc;
-    // leaves: X_kk = U_kk^-1 for all diagonal blocks at once (the ragged last one separately)
-    const int nfullb = n / LEAF, rest = n % LEAF;
+// X = U^-1 from the inverses of the 128 x 128 diagonal blocks (already in X) by recursive doubling: units of size s are
+// complete; neighbours (a, a + s) merge into units of 2 s with X12 = -X11 (U12 X22).  work: n * n / 4 doubles.
+static int trtri_doubling(int n, const double* U, int ldu, double* X, int ldx, double* work, hipStream_t stream) {
     int rc;
-    // the leaf kernel reads its block from "A" and writes the inverse to "X": copy U's diagonal blocks through X itself
-    // (mode 2 reads A = U diagonal block, which it does not modify)
-    if (nfullb > 0) {
-        rc = launch_leaf(LEAF, const_cast<double*>(U), ldu, (long long)LEAF * (ldu + 1), X, ldx, (long long)LEAF * (ldx + 1), nfullb, 2, nullptr, 0,
-                         stream);
-        if (rc) return rc;
-    }
-    if (rest > 0) {
-        const size_t o = (size_t)nfullb * LEAF;
-        rc = launch_leaf(rest, const_cast<double*>(U) + o * (ldu + 1), ldu, 0, X + o * (ldx + 1), ldx, 0, 1, 2, nullptr, 0, stream);
-        if (rc) return rc;
-    }
-    // recursive doubling: units of size s are complete; merge neighbours (a, a + s) into units of 2 s:
-    //   X12 = -X11 (U12 X22)
     for (int s = LEAF; s < n; s *= 2) {
         // pairs with a full right unit: one batched launch per product (uniform strides along the diagonal)
         const int nfullpairs = n / (2 * s);
@@ -887,6 +870,28 @@ int trtri_upper(int n, const double* U, int ldu, double* X, int ldx, double* wor
         }
     }
     return SHG_OK;
+}
+
+// X = U^-1 for an upper triangular U [n][ldu]; X [n][ldx] (the strictly lower part of X is set to zero); work: n * 128 doubles
+int trtri_upper(int n, const double* U, int ldu, double* X, int ldx, double* work, hipStream_t stream) {
+    if (n <= 0) return SHG_OK;
+    if (int zrc = zero_fill(X, ldx, n, n, stream)) return zrc;
+    // leaves: X_kk = U_kk^-1 for all diagonal blocks at once (the ragged last one separately)
+    const int nfullb = n / LEAF, rest = n % LEAF;
+    int rc;
+    // the leaf kernel reads its block from "A" and writes the inverse to "X": copy U's diagonal blocks through X itself
+    // (mode 2 reads A = U diagonal block, which it does not modify)
+    if (nfullb > 0) {
+        rc = launch_leaf(LEAF, const_cast<double*>(U), ldu, (long long)LEAF * (ldu + 1), X, ldx, (long long)LEAF * (ldx + 1), nfullb, 2, nullptr, 0,
+                         stream);
+        if (rc) return rc;
+    }
+    if (rest > 0) {
+        const size_t o = (size_t)nfullb * LEAF;
+        rc = launch_leaf(rest, const_cast<double*>(U) + o * (ldu + 1), ldu, 0, X + o * (ldx + 1), ldx, 0, 1, 2, nullptr, 0, stream);
+        if (rc) return rc;
+    }
+    return trtri_doubling(n, U, ldu, X, ldx, work, stream);
 }
 
 // A = U^T U in place (upper triangle referenced, strictly lower triangle zeroed); work: 128 * 128 doubles; info (device int,
@@ -925,6 +930,7 @@ struct FactorBatch {
     long long strideA, strideX, strideW;
     int info_stride;
 };
+
 
 static int potrf_inverse_rec(int n, double* A, int lda, double* X, int ldx, double* work, int* info, int info_base, const FactorBatch& fb,
                              hipStream_t stream) {
@@ -968,7 +974,8 @@ size_t potrf_inverse_work(int n) { return (size_t)(n / 2 + LEAF) * (n / 2 + LEAF
 // host threads at once: the card overlaps the kernels of two to three queues, not of four or six (two threads: 2.2 ms per matrix
 // each, against 2.0 ms with the recursive sweep; three: 3.5 against 2.2) -- concurrent chains are factored as a BATCH instead
 // (FactorBatch: every launch serves all of them), which keeps the two queues and halves the launches per matrix.
-static int potrf_inverse_lookahead(int n, double* A, int lda, double* X, int ldx, double* work, int* info, const FactorBatch& fb, hipStream_t stream) {
+static int potrf_inverse_lookahead(int n, double* A, int lda, double* X, int ldx, double* work, int* info, const FactorBatch& fb,
+                                   const Coupling* cp, hipStream_t stream) {
     ScratchLease lease(stream);
     hipStream_t side[2];
     hipEvent_t to_side, from_side[2];
@@ -977,6 +984,10 @@ static int potrf_inverse_lookahead(int n, double* A, int lda, double* X, int ldx
     // (one side stream: two of them landed on the same hardware queue as often as not, and the trailing update then waited for
     //  the inverse; behind the event that the caller's stream waits for, the inverse delays nobody but the next trailing update)
     hipStream_t trail = side[0], inverse = side[0];
+    // the columns to the right of A (Coupling) on a queue of their own if there is one
+    hipStream_t couple = lease.sides_apart() >= 2 ? side[1] : side[0];
+    hipEvent_t row_ready = nullptr;
+    if (cp && (rc = lease.event(2, &row_ready)) != SHG_OK) return rc;
     const int nb = ceil_div(n, LEAF), nbatch = fb.count;
     const long long sA = fb.strideA, sX = fb.strideX, sW = fb.strideW;
     auto at = [&](double* P, int ld, int i, int j) { return P + (size_t)i * LEAF * ld + (size_t)j * LEAF; };
@@ -1003,15 +1014,41 @@ static int potrf_inverse_lookahead(int n, double* A, int lda, double* X, int ldx
             if (rc) return rc;
         }
         SHG_HIP(hipEventRecord(to_side, stream));
+        if (rest2 > 0 || cp) SHG_HIP(hipStreamWaitEvent(trail, to_side, 0));
         if (rest2 > 0) {
-            SHG_HIP(hipStreamWaitEvent(trail, to_side, 0));
             double *Ak1 = at(A, lda, k, k + 1), *Ak2 = at(A, lda, k, k + 2);
             rc = gemm_ex_tri(true, false, kb, rest2, kb, 1.0, Xkk, ldx, sX, Ak2, lda, sA, 0.0, Ak2, lda, sA, nbatch, false, 2, trail);   // in place: kb <= 128 rows
             if (rc) return rc;
+            if (cp && couple != trail) SHG_HIP(hipEventRecord(row_ready, trail));               // row panel k of U is complete
             rc = gemm_ex(true, false, kb1, rest2, kb, -1.0, Ak1, lda, sA, Ak2, lda, sA, 1.0, at(A, lda, k + 1, k + 2), lda, sA, nbatch, false, trail);
             if (rc) return rc;
             rc = gemm_ex(true, false, rest2, rest2, kb, -1.0, Ak2, lda, sA, Ak2, lda, sA, 1.0, at(A, lda, k + 2, k + 2), lda, sA, nbatch, true, trail);
             if (rc) return rc;
+        }
+        if (cp) {
+            // the same three products for the columns to the right of A: rows k of B, the rows of B below, and S
+            if (couple != trail) {
+                SHG_HIP(hipStreamWaitEvent(couple, to_side, 0));
+                if (rest2 > 0) SHG_HIP(hipStreamWaitEvent(couple, row_ready, 0));
+            }
+            double* Bk = cp->B + (size_t)k0 * cp->ldb;
+            rc = gemm_ex_tri(true, false, kb, cp->nc, kb, 1.0, Xkk, ldx, sX, Bk, cp->ldb, cp->strideB, 0.0, Bk, cp->ldb, cp->strideB, nbatch, false, 2, couple);
+            if (rc) return rc;
+            if (n - k1 > 0) {
+                rc = gemm_ex(true, false, n - k1, cp->nc, kb, -1.0, at(A, lda, k, k + 1), lda, sA, Bk, cp->ldb, cp->strideB, 1.0, cp->B + (size_t)k1 * cp->ldb,
+                             cp->ldb, cp->strideB, nbatch, false, couple);
+                if (rc) return rc;
+            }
+            // S -= W^T W for the rows of W that have become final, in two pieces (after half of the panels and after the last one):
+            // a rank-128 update per step reads and writes all of S for 8 K-steps of work
+            const int half = nb / 2;                                 // (nb >= 3 here)
+            if (k == half - 1 || k == nb - 1) {
+                const int r0 = k == nb - 1 ? half * LEAF : 0;        // rows r0 .. k1 - 1 of W
+                double* Wr = cp->B + (size_t)r0 * cp->ldb;
+                rc = gemm_ex(true, false, cp->nc, cp->nc, k1 - r0, -1.0, Wr, cp->ldb, cp->strideB, Wr, cp->ldb, cp->strideB, 1.0, cp->S, cp->lds, cp->strideS, nbatch,
+                             true, couple);
+                if (rc) return rc;
+            }
         }
         SHG_HIP(hipEventRecord(from_side[0], trail));
         if (k > 0) {
@@ -1024,6 +1061,15 @@ static int potrf_inverse_lookahead(int n, double* A, int lda, double* X, int ldx
             if (rc) return rc;
         }
     }
+    SHG_HIP(hipStreamWaitEvent(stream, from_side[0], 0));
+    if (cp && couple != trail) {
+        SHG_HIP(hipEventRecord(from_side[1], couple));
+        SHG_HIP(hipStreamWaitEvent(stream, from_side[1], 0));
+    }
+    if (cp && cp->inverse_done) {
+        SHG_HIP(hipEventRecord(cp->inverse_done, inverse));          // B and S are complete; the last block column of the inverse may still be growing
+        return SHG_OK;
+    }
     SHG_HIP(hipEventRecord(from_side[1], inverse));
     SHG_HIP(hipStreamWaitEvent(stream, from_side[1], 0));
     return SHG_OK;
@@ -1032,11 +1078,25 @@ static int potrf_inverse_lookahead(int n, double* A, int lda, double* X, int ldx
 static thread_local int g_lookahead = 1;
 void potrf_inverse_set_lookahead(int enable) { g_lookahead = enable; }
 
+// whether potrf_inverse_batch takes the coupling block and the next diagonal block along (Coupling)
+static bool takes_lookahead(int n) { return n > 2 * LEAF && g_lookahead; }
+
+bool potrf_inverse_carries_coupling(int n, hipStream_t stream) {
+    if (!takes_lookahead(n)) return false;
+    // only with a hardware queue of its own for the coupling columns: on the stream of the trailing update they make it the
+    // pace-maker of the sweep (2.24 against 1.87 ms per pair of d = 1681 blocks)
+    ScratchLease lease(stream);
+    hipStream_t side[2];
+    hipEvent_t to_side, from_side[2];
+    return lease.side(side, &to_side, from_side) == SHG_OK && lease.sides_apart() >= 2;
+}
+
 int potrf_inverse_batch(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, double* work, long long strideW,
-                        int* info, int info_stride, int batch, hipStream_t stream) {
+                        int* info, int info_stride, int batch, const Coupling* cp, hipStream_t stream) {
     if (n <= 0 || batch <= 0) return SHG_OK;
     const FactorBatch fb{batch, strideA, strideX, strideW, info_stride};
-    if (n > 2 * LEAF && g_lookahead) return potrf_inverse_lookahead(n, A, lda, X, ldx, work, info, fb, stream);
+    if (takes_lookahead(n)) return potrf_inverse_lookahead(n, A, lda, X, ldx, work, info, fb, cp, stream);
+    if (cp) return fail(SHG_ERR_INVALID, "potrf_inverse_batch: a coupling block needs the look-ahead sweep");
     for (int b = 0; b < batch; ++b)
         if (int zrc = zero_fill(X + b * strideX, ldx, n, n, stream)) return zrc;
     const int rc = potrf_inverse_rec(n, A, lda, X, ldx, work, info, 0, fb, stream);
@@ -1045,7 +1105,7 @@ int potrf_inverse_batch(int n, double* A, int lda, long long strideA, double* X,
 }
 
 int potrf_inverse_upper(int n, double* A, int lda, double* X, int ldx, double* work, int* info, hipStream_t stream) {
-    return potrf_inverse_batch(n, A, lda, 0, X, ldx, 0, work, 0, info, 0, 1, stream);
+    return potrf_inverse_batch(n, A, lda, 0, X, ldx, 0, work, 0, info, 0, 1, nullptr, stream);
 }
 
 }  // namespace shg

@@ -31,7 +31,8 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
 int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
                 long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, int tri, hipStream_t stream);
 int potrf_inverse_batch(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, double* work, long long strideW,
-                        int* info, int info_stride, int batch, hipStream_t stream);
+                        int* info, int info_stride, int batch, const Coupling* cp, hipStream_t stream);
+bool potrf_inverse_carries_coupling(int n, hipStream_t stream);
 void potrf_inverse_set_lookahead(int enable);
 size_t potrf_inverse_work(int n);
 
@@ -135,33 +136,61 @@ static int potrf_rows(int count, const BlockView* V, double* const* const* blk, 
     SHG_REQUIRE(work && panel && info_blk, "shg_block_potrf: workspace allocation failed");
     // inv[r] == blk[diagonal r]: the caller keeps U_rr^-1 INSTEAD of U_rr (nothing but shg_block_multiply needs the diagonal
     // factor blocks once their inverses exist): the block is factored in a scratch copy and its inverse goes where it was
-    double* diag_copy = nullptr;
+    // (two copies in turn: the inverse of row r is still being completed from copy r % 2, on the side stream of the look-ahead,
+    //  while row r + 1 is factored in the other one; `inverse_done` says when a copy is free again)
+    double* diag_copy[2] = {nullptr, nullptr};
+    hipEvent_t inverse_done[2] = {nullptr, nullptr};
+    bool pending[2] = {false, false};
     int rc = SHG_OK;
+    if ((rc = scratch.lease.event(0, &inverse_done[0])) != SHG_OK || (rc = scratch.lease.event(1, &inverse_done[1])) != SHG_OK) return rc;
+    auto join = [&](int which) -> int {            // the caller's stream waits for the inverse that was left growing
+        if (pending[which]) SHG_HIP(hipStreamWaitEvent(stream, inverse_done[which], 0));
+        pending[which] = false;
+        return SHG_OK;
+    };
     for (int b = 0; b < count; ++b)
         if (info && (rc = zero_fill(info + (size_t)b * info_stride, stream)) != SHG_OK) return rc;
     for (int r = first; r < last; ++r) {
         const int dr = V0.size(r);
         const int e0 = V0.begin(r), e1 = V0.end(r);
+        const int turn = (r - first) & 1;
         double* Arr[2] = {blk[0][e0], count > 1 ? blk[1][e0] : nullptr};
         const double* Xrr[2] = {inv[0][r], count > 1 ? inv[1][r] : nullptr};
         const bool in_place = Xrr[0] == Arr[0];
         SHG_REQUIRE(count == 1 || (Xrr[1] == Arr[1]) == in_place, "shg_block_potrf_rows_pair: block row %d keeps its inverse in place in one matrix only", r);
+        if ((rc = join(turn)) != SHG_OK) return rc;
         if (in_place) {
-            if (!diag_copy) diag_copy = scratch.get(bsize * count);
-            SHG_REQUIRE(diag_copy != nullptr, "shg_block_potrf: workspace allocation failed");
+            if (!diag_copy[turn]) diag_copy[turn] = scratch.get(bsize * count);
+            SHG_REQUIRE(diag_copy[turn] != nullptr, "shg_block_potrf: workspace allocation failed");
             for (int b = 0; b < count; ++b) {
-                SHG_HIP(hipMemcpyAsync(diag_copy + b * bsize, Arr[b], (size_t)dr * dr * sizeof(double), hipMemcpyDeviceToDevice, stream));
-                Arr[b] = diag_copy + b * bsize;
+                SHG_HIP(hipMemcpyAsync(diag_copy[turn] + b * bsize, Arr[b], (size_t)dr * dr * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                Arr[b] = diag_copy[turn] + b * bsize;
             }
         }
         for (int b = 0; b < count; ++b)
             if ((rc = zero_fill(info_blk + b, stream)) != SHG_OK) return rc;
         const long long sA = apart(Arr), sX = apart(Xrr);
-        rc = potrf_inverse_batch(dr, Arr[0], dr, sA, const_cast<double*>(Xrr[0]), dr, sX, work, (long long)wsize, info_blk, 1, count, stream);   // factor and inverse in one sweep
+        // a chain row (one coupling block, to the next block row): W_r,r+1 and the Schur complement of the next diagonal block come
+        // out of the panel sweep over the diagonal block itself (Coupling, common.h), and the next row starts while the inverse of
+        // this one is still being completed
+        const bool chain_row = e1 - e0 == 2 && colidx[e0 + 1] == r + 1 && potrf_inverse_carries_coupling(dr, stream);
+        Coupling cp{};
+        if (chain_row) {
+            const int dc = V0.size(r + 1);
+            const double* Wn[2] = {blk[0][e0 + 1], count > 1 ? blk[1][e0 + 1] : nullptr};
+            const double* Sn[2] = {V[0].at(r + 1, r + 1), count > 1 ? V[1].at(r + 1, r + 1) : nullptr};
+            cp = Coupling{const_cast<double*>(Wn[0]), dc, dc, apart(Wn), const_cast<double*>(Sn[0]), dc, apart(Sn), inverse_done[turn]};
+        }
+        rc = potrf_inverse_batch(dr, Arr[0], dr, sA, const_cast<double*>(Xrr[0]), dr, sX, work, (long long)wsize, info_blk, 1, count, chain_row ? &cp : nullptr,
+                                 stream);   // factor and inverse in one sweep
         if (rc) return rc;
         if (info)
             for (int b = 0; b < count; ++b)     // first failure wins
                 hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, stream, info + (size_t)b * info_stride, info_blk + b, bounds[r] - bounds[0]);
+        if (chain_row) {
+            pending[turn] = true;
+            continue;
+        }
         // W_rc = U_rr^-T A_rc, through the panel scratch (the product cannot overwrite its own operand)
         for (int e = e0 + 1; e < e1; ++e) {
             const int dc = V0.size(colidx[e]);
@@ -186,6 +215,7 @@ static int potrf_rows(int count, const BlockView* V, double* const* const* blk, 
             }
         }
     }
+    if ((rc = join(0)) != SHG_OK || (rc = join(1)) != SHG_OK) return rc;
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }

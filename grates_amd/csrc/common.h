@@ -35,9 +35,26 @@ public:
     // two more streams of the same device for work that runs beside the leased stream (the look-ahead of blas.hip's
     // factorisation), with the events that order them; created on first use, kept with the scratch buffers
     int side(hipStream_t streams[2], hipEvent_t* to_side, hipEvent_t from_side[2]);
+    int event(int i, hipEvent_t* ev);       // further events of the stream (0 .. 7), created on first use
+    int sides_apart() const;                // how many of the side streams have a hardware queue of their own (0 .. 2)
 private:
     void* owner_;
 };
+// The block row of a chain continues to the right of its diagonal block A [n x n] with ONE coupling block B [n x nc] (which
+// becomes W = U^-T B) above the next diagonal block S [nc x nc] (which becomes the Schur complement S - W^T W).  The panel
+// sweep over A simply carries on through B and S: step k solves its 128 rows of B, subtracts their products from the rows of B
+// below and from S -- on the side stream, under the leaves, instead of two d^3 products (and their launches) after the sweep.
+struct Coupling {
+    double* B;
+    int ldb, nc;
+    long long strideB;
+    double* S;
+    int lds;
+    long long strideS;
+    hipEvent_t inverse_done;      // recorded on the side stream behind the last product of the inverse; the caller's stream does
+                                  // not wait for it (lookahead_join does)
+};
+
 void stream_scratch_release();
 hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream);    // hipMallocAsync from a pool that keeps freed memory cached
 

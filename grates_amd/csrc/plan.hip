@@ -9,6 +9,7 @@
 #include <memory>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "common.h"
 
@@ -81,9 +82,12 @@ struct ScratchBuffer {
 struct StreamScratch {
     std::recursive_mutex mtx;
     int device = 0;
+    hipStream_t stream = nullptr;
     std::map<int, ScratchBuffer> slots;
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t to_side = nullptr, from_side[2] = {nullptr, nullptr};
+    hipEvent_t more[8] = {};
+    int side_apart = 0;              // how many of the side streams run on hardware queues of their own (found by experiment)
 };
 // Keyed by (device, stream): the default stream is the null handle on every device, and a buffer allocated on one device must
 // never be handed to a kernel of another.  Entries are created once and never erased, so a pointer to one stays valid.
@@ -102,6 +106,7 @@ ScratchLease::ScratchLease(hipStream_t stream) {
         if (!e) {
             e.reset(new StreamScratch);
             e->device = dev;
+            e->stream = stream;
         }
         owner_ = e.get();
     }
@@ -127,13 +132,64 @@ void* ScratchLease::get(int slot, size_t bytes) {
     return e.ptr;
 }
 
+// Side streams that really run beside the leased stream.  The runtime spreads its streams over a few hardware queues (four by
+// default; the streams of one queue run one after the other), PyTorch alone has created dozens before this library is first
+// called, and nothing in the API says which queue a stream got -- two streams created here one after the other shared one as
+// often as not, and the look-ahead they were meant to carry ran in series.  So the queues are told apart by experiment, once per
+// leased stream: a one-thread kernel that spins for 0.2 ms on one stream, a time stamp on the other; the stamp is earlier than
+// the end of the spin exactly when the two streams do not share a queue.  (Priorities would separate the queues too, but with
+// one stream above and one below the ordinary priority every kernel of the leased stream took 40 - 55 us on this card.)
+__global__ void spin_kernel(long long ticks, long long* __restrict__ out) {
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < 100000 && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(8);       // (bounded whatever the counter does)
+    out[0] = wall_clock64();
+}
+
+__global__ void stamp_kernel(long long* __restrict__ out) { out[0] = wall_clock64(); }
+
+static bool queues_apart(hipStream_t a, hipStream_t b, long long* probe) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, a, 20000LL, probe);         // 0.2 ms of the 100 MHz counter
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, b, probe + 1);
+    long long host[2] = {0, 0};
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
+        hipMemcpy(host, probe, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return host[1] < host[0];
+}
+
 int ScratchLease::side(hipStream_t streams[2], hipEvent_t* to_side, hipEvent_t from_side[2]) {
     StreamScratch* e = static_cast<StreamScratch*>(owner_);
     if (!e->to_side) {
-        // (ordinary priority: with one stream above and one below it, every kernel of the caller's stream -- a one-thread
-        //  kernel included -- took 40 - 55 us on this card)
+        long long* probe = nullptr;
+        SHG_HIP(hipMalloc((void**)&probe, 2 * sizeof(long long)));
+        hipStream_t found[2] = {nullptr, nullptr};
+        int nfound = 0;
+        std::vector<hipStream_t> rejected;
+        for (int attempt = 0; attempt < 12 && nfound < 2; ++attempt) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+            const bool ok = queues_apart(e->stream, s, probe) && (nfound == 0 || (queues_apart(found[0], s, probe) && queues_apart(s, found[0], probe)));
+            if (ok)
+                found[nfound++] = s;
+            else
+                rejected.push_back(s);
+        }
+        // (fewer than two such streams: the result is the same, the streams just take turns)
+        for (int i = nfound; i < 2; ++i) {
+            if (rejected.empty()) {
+                (void)hipFree(probe);
+                return fail(SHG_ERR_HIP, "side streams could not be created");
+            }
+            found[i] = rejected.back();
+            rejected.pop_back();
+        }
+        for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+        (void)hipFree(probe);
+        e->side_apart = nfound;
         for (int i = 0; i < 2; ++i) {
-            SHG_HIP(hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking));
+            e->side[i] = found[i];
             SHG_HIP(hipEventCreateWithFlags(&e->from_side[i], hipEventDisableTiming));
         }
         SHG_HIP(hipEventCreateWithFlags(&e->to_side, hipEventDisableTiming));
@@ -143,6 +199,16 @@ int ScratchLease::side(hipStream_t streams[2], hipEvent_t* to_side, hipEvent_t f
         from_side[i] = e->from_side[i];
     }
     *to_side = e->to_side;
+    return SHG_OK;
+}
+
+int ScratchLease::sides_apart() const { return static_cast<StreamScratch*>(owner_)->side_apart; }
+
+int ScratchLease::event(int i, hipEvent_t* ev) {
+    StreamScratch* e = static_cast<StreamScratch*>(owner_);
+    SHG_REQUIRE(i >= 0 && i < 8, "ScratchLease::event: index %d", i);
+    if (!e->more[i]) SHG_HIP(hipEventCreateWithFlags(&e->more[i], hipEventDisableTiming));
+    *ev = e->more[i];
     return SHG_OK;
 }
 
