@@ -20,6 +20,7 @@
 //   Z = (W^T W)^-1 on the pattern of W (Takahashi), r descending with T_rk = U_rr^-1 W_rk:
 //            Z_rj = -sum_{k > r} T_rk Z_kj (j > r),   Z_rr = U_rr^-1 U_rr^-T - sum_{k > r} T_rk Z_rk^T
 #include <algorithm>
+#include <cstdint>
 #include <vector>
 
 #include "common.h"
@@ -126,7 +127,8 @@ static int potrf_rows(int count, const BlockView* V, double* const* const* blk, 
     const BlockView& V0 = V[0];
     const int* colidx = V0.colidx;
     const int* bounds = V0.bounds;
-    auto apart = [&](const double* const* p) { return count > 1 ? (long long)(p[1] - p[0]) : 0LL; };
+    // (doubles between the two items of a batch: the blocks are separate allocations, so the distance is taken between addresses)
+    auto apart = [&](const double* const* p) { return count > 1 ? (long long)(((intptr_t)p[1] - (intptr_t)p[0]) / (intptr_t)sizeof(double)) : 0LL; };
     Scratch scratch(stream);
     const int dmax = V0.max_size();
     const size_t wsize = potrf_inverse_work(dmax), bsize = (size_t)dmax * dmax;
