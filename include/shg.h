@@ -233,7 +233,9 @@ int shg_block_potrf_rows_pair(int nb, const int* bounds, const int* rowptr, cons
                               double* const* blk1, double* const* inv1, int first, int last, int* info, void* stream);
 /* The factorisation of a diagonal block larger than 256 overlaps its 128-column panel steps on two more streams of the device
  * (look-ahead; the caller's stream waits for them before the call returns control of the data).  A THREAD that factors matrices
- * beside other threads turns it off for itself: the card does not overlap that many queues (csrc/blas.hip). */
+ * beside other threads turns it off for itself: the card does not overlap that many queues (csrc/blas.hip).  The first such
+ * factorisation on a stream synchronises that stream once: the side streams are chosen by a timing experiment so that they do
+ * not share a hardware queue with it or with each other (csrc/plan.hip); every later call only enqueues. */
 int shg_block_set_lookahead(int enable);
 int shg_block_solve(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int transpose, double* B,
                     int k, int ldb, void* stream);
