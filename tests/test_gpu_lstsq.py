@@ -386,3 +386,107 @@ def test_blocks_with_foreign_strides_and_in_place_factor_state():
     Z = np.linalg.inv(N)
     assert relerr(chain[0, 0], Z[:d, :d]) < TOL_INV and relerr(chain[0, 1], Z[:d, d:]) < TOL_INV
     chain._scale(2.0)                                                     # an ordinary matrix again
+
+
+# ---- the block-row entry points behind the partitioned smoother: look-ahead, batches of two, short-K products -------------------
+def _chain(seed, epochs, d, torch):
+    """a symmetric positive definite block-tridiagonal chain on the device (diagonal blocks, coupling blocks) and its dense form"""
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(seed)
+    diag, upper = [], []
+    for t in range(epochs):
+        G = torch.randn((d, d + 8), dtype=torch.float64, device='cuda', generator=gen)
+        diag.append(G @ G.T / d + 4.0 * torch.eye(d, dtype=torch.float64, device='cuda'))
+        if t + 1 < epochs:
+            upper.append(torch.randn((d, d), dtype=torch.float64, device='cuda', generator=gen) / d)
+    dense = torch.zeros((epochs * d, epochs * d), dtype=torch.float64, device='cuda')
+    for t in range(epochs):
+        dense[t * d:(t + 1) * d, t * d:(t + 1) * d] = diag[t]
+        if t + 1 < epochs:
+            dense[t * d:(t + 1) * d, (t + 1) * d:(t + 2) * d] = upper[t]
+            dense[(t + 1) * d:(t + 2) * d, t * d:(t + 1) * d] = upper[t].T
+    return diag, upper, dense
+
+
+def _chain_matrix(diag, upper, in_place):
+    d = diag[0].shape[0]
+    idx = np.arange(0, (len(diag) + 1) * d, d)
+    bm = ls.BlockMatrix(idx, idx)
+    bm._inverse_in_place = in_place
+    for t, b in enumerate(diag):
+        bm._set_device(t, t, b.clone())
+    for t, b in enumerate(upper):
+        bm._set_device(t, t + 1, b.clone())
+    return bm
+
+
+@pytest.mark.parametrize('d', [96, 300, 385])          # one leaf | look-ahead with three panels | with a ragged fourth one
+def test_factorisation_with_and_without_lookahead(d):
+    """shg_block_potrf_rows: the panel sweep with its side streams (chain rows carry W and the Schur complement along) against the
+    recursive sweep (shg_block_set_lookahead(0)) and against the dense Cholesky factor, 1e-12"""
+    import torch
+    from grates_amd import engine
+    epochs = 4
+    diag, upper, dense = _chain(11, epochs, d, torch)
+    reference = torch.linalg.cholesky(dense, upper=True)
+    factors = []
+    for lookahead in (True, False):
+        engine.block_set_lookahead(lookahead)
+        try:
+            bm = _chain_matrix(diag, upper, False)
+            bm.cholesky()
+        finally:
+            engine.block_set_lookahead(True)
+        blocks = [bm.device_block(t, t) for t in range(epochs)] + [bm.device_block(t, t + 1) for t in range(epochs - 1)]
+        factors.append(blocks)
+        for t in range(epochs):
+            assert relerr(bm.device_block(t, t).cpu().numpy(), reference[t * d:(t + 1) * d, t * d:(t + 1) * d].cpu().numpy()) < 1e-12
+            if t + 1 < epochs:
+                assert relerr(bm.device_block(t, t + 1).cpu().numpy(), reference[t * d:(t + 1) * d, (t + 1) * d:(t + 2) * d].cpu().numpy()) < 1e-12
+    for a, b in zip(*factors):
+        assert relerr(a.cpu().numpy(), b.cpu().numpy()) < 1e-12
+
+
+@pytest.mark.parametrize('d,in_place', [(300, True), (300, False), (64, True)])
+def test_pair_factorisation_matches_single(d, in_place):
+    """shg_block_potrf_rows_pair: two chains of one structure in one pass (every launch a batch of two) against the same two chains
+    factored one after the other; the longer chain finishes its further row alone"""
+    import torch
+    pairs = [_chain(21, 5, d, torch), _chain(22, 4, d, torch)]
+    single = []
+    for diag, upper, _ in pairs:
+        bm = _chain_matrix(diag, upper, in_place)
+        bm._cholesky_rows(0, len(diag))
+        single.append(bm)
+    a, b = (_chain_matrix(diag, upper, in_place) for diag, upper, _ in pairs)
+    a._cholesky_rows_pair(b, 0, 3)                       # rows 0 .. 2 of both; block 3 of each is left as Schur complement
+    a._cholesky_rows(3, 5)
+    b._cholesky_rows(3, 4)
+    for one, two, n in ((single[0], a, 5), (single[1], b, 4)):
+        for t in range(n):
+            assert relerr(two.device_block(t, t).cpu().numpy(), one.device_block(t, t).cpu().numpy()) < 1e-12
+            if t + 1 < n:
+                assert relerr(two.device_block(t, t + 1).cpu().numpy(), one.device_block(t, t + 1).cpu().numpy()) < 1e-12
+    # and the factor is a factor: W^T W = N through the solve of the in-place form
+    diag, upper, dense = pairs[0]
+    rhs = torch.ones((5 * d, 1), dtype=torch.float64, device='cuda')
+    x = a.solve_triangular(a.solve_triangular(rhs.clone(), transpose=True))
+    x = x if hasattr(x, 'cpu') else torch.as_tensor(x, device='cuda')
+    assert float((dense @ x.reshape(-1, 1) - rhs).abs().max()) < 1e-10
+
+
+@pytest.mark.parametrize('shape', [(128, 128, 128), (17, 1553, 128), (1553, 128, 96), (128, 300, 64), (100, 100, 100)])
+def test_short_k_products(shape):
+    """products with K <= 128 and a thin output go through the panel kernel (csrc/blas.hip): against torch, 1e-13"""
+    import torch
+    from grates_amd import engine
+    M, N, K = shape
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(5)
+    for transa in (False, True):
+        A = torch.randn((K, M) if transa else (M, K), dtype=torch.float64, device='cuda', generator=gen)
+        B = torch.randn((K, N), dtype=torch.float64, device='cuda', generator=gen)
+        C = torch.randn((M, N), dtype=torch.float64, device='cuda', generator=gen)
+        expected = 0.5 * C - 2.0 * ((A.T if transa else A) @ B)
+        engine.gemm(A, B, transa=transa, alpha=-2.0, beta=0.5, out=C)
+        assert relerr(C.cpu().numpy(), expected.cpu().numpy()) < 1e-13
