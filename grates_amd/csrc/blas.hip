@@ -970,6 +970,9 @@ size_t potrf_inverse_work(int n) { return (size_t)(n / 2 + LEAF) * (n / 2 + LEAF
 // Events order the two: the side stream starts step k when leaf k and U_k,k+1 exist, the caller's stream forms U_k+1,k+2 when
 // the side stream has finished the trailing update of step k, and joins it at the end.  Every block receives its updates in a
 // fixed order, so the result does not depend on how the streams interleave.
+// With a Coupling (a chain row: the block row continues to the right of A) a second side stream, on a hardware queue of its own,
+// carries the same steps through the coupling block and the next diagonal block; it needs row panel k of U (an event of the
+// first side stream) and is joined at the end of the sweep only.
 // One matrix alone: 1.27 - 1.40 ms instead of 1.89 ms (n = 1681).  It does NOT pay for matrices that are factored from several
 // host threads at once: the card overlaps the kernels of two to three queues, not of four or six (two threads: 2.2 ms per matrix
 // each, against 2.0 ms with the recursive sweep; three: 3.5 against 2.2) -- concurrent chains are factored as a BATCH instead
@@ -981,8 +984,8 @@ static int potrf_inverse_lookahead(int n, double* A, int lda, double* X, int ldx
     hipEvent_t to_side, from_side[2];
     int rc = lease.side(side, &to_side, from_side);
     if (rc) return rc;
-    // (one side stream: two of them landed on the same hardware queue as often as not, and the trailing update then waited for
-    //  the inverse; behind the event that the caller's stream waits for, the inverse delays nobody but the next trailing update)
+    // (trailing update and inverse on ONE side stream: behind the event that the caller's stream waits for, the inverse delays
+    //  nobody but the next trailing update)
     hipStream_t trail = side[0], inverse = side[0];
     // the columns to the right of A (Coupling) on a queue of their own if there is one
     hipStream_t couple = lease.sides_apart() >= 2 ? side[1] : side[0];
