@@ -1,12 +1,12 @@
 #!/bin/bash
 # HBM traffic of the synthesis kernel from rocprofv3 PMC counters (two separate passes: FETCH_SIZE and WRITE_SIZE do not
 # fit one pass on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots") and the kernel-trace statistics of the same command.
-# Run on a GPU box from the repository root: writes gpurun_out/r02_kernel_stats.csv and gpurun_out/r02_pmc_traffic.json.
+# Run on a GPU box from the repository root: writes gpurun_out/r03_kernel_stats.csv and gpurun_out/r03_pmc_traffic.json.
 out=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-args="--cpu-sample 0 --cov-parallels 0 --steps 20 --warmup 5"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_r02 -o run -- python3 $GRAFT_REPO_ROOT/bench.py $args > $out/prof_r02.log 2>&1
-cp $(find $out/prof_r02 -name "*kernel_stats.csv" | head -1) $out/r02_kernel_stats.csv
+args="--legs synthesis --cpu-sample 0 --steps 20 --warmup 5 --ramp 300"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_r03 -o run -- python3 $GRAFT_REPO_ROOT/bench.py $args > $out/prof_r03.log 2>&1
+cp $(find $out/prof_r03 -name "*kernel_stats.csv" | head -1) $out/r03_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o run -- python3 $GRAFT_REPO_ROOT/bench.py $args > $out/pmc_$c.log 2>&1
 done
@@ -27,6 +27,6 @@ summary = {
     "lon_stage_bytes_per_launch": write_kb * 1024.0 + fetch_kb * 1024.0 * 2.0,
     "algorithmic_bytes_per_launch": 240 * 8 * (97 * 97 + 720 * 1440),
 }
-open("$out/r02_pmc_traffic.json", "w").write(json.dumps(summary, indent=1))
+open("$out/r03_pmc_traffic.json", "w").write(json.dumps(summary, indent=1))
 print(json.dumps(summary))
 PY
