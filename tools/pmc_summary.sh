@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ / TCP / TCC counters of the two headline kernels, one rocprofv3 --pmc pass per counter group (never combined with a trace
 # domain other than --kernel-trace).  Run on a GPU box from the repository root:
-#   tools/pmc_summary.sh            -> gpurun_out/r02_synthesis_pmc.txt, gpurun_out/r02_covprop_pmc.txt
+#   tools/pmc_summary.sh            -> gpurun_out/r03_synthesis_pmc.txt, gpurun_out/r03_covprop_pmc.txt
 out=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 groups=(
@@ -35,5 +35,5 @@ for c, v in sorted(agg.items()):
 PY
   done
 }
-run_group r02_synthesis_pmc synthesis_rot_kernel python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --cov-parallels 0 --steps 20 --warmup 5 --ramp 50
-run_group r02_covprop_pmc gemm_f64_kernel python3 $GRAFT_REPO_ROOT/tools/gemm_phases.py --release-library 8
+run_group r03_synthesis_pmc synthesis_rot_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs synthesis --cpu-sample 0 --steps 20 --warmup 5 --ramp 50
+run_group r03_covprop_pmc gemm_f64_kernel python3 $GRAFT_REPO_ROOT/tools/gemm_phases.py --release-library 24
