@@ -429,6 +429,69 @@ __global__ __launch_bounds__(512) void panel_kernel(PanelParams P) {
     }
 }
 
+// A block times a handful of right-hand sides, op(A) = A (the backward sweep W x = y of the smoother with one solution vector: N = 1):
+// the block is read once from memory and the product is bound by that.  The tiled kernel made 27 workgroups with a K loop of 1681,
+// or a split-K launch plus its reduction, out of it (15 us); here one wave takes one output row, its lanes stream along the
+// contiguous index k of the block and are summed at the end (sweep of config 5: 0.27 -> 0.08 s).  The transposed product (forward
+// sweep) stays with the tiled kernel: with the lanes along the output rows every wave walks down a column strip one row per load,
+// and a version with eight waves per 64 rows was three times slower than the split-K launch.
+// tri as in GemmExParams (square operands): the structurally zero part of A is not read.
+constexpr int kGemvColumns = 8;
+
+struct GemvParams {
+    int M, N, K;
+    const double* A;
+    int lda;
+    const double* X;
+    int ldx;
+    double* Y;
+    int ldy;
+    double alpha, beta;
+    int tri;
+};
+
+__global__ __launch_bounds__(256) void gemv_rows_kernel(GemvParams P) {              // op(A) = A
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= P.M) return;
+    int kb = 0, ke = P.K;
+    if (P.tri & 1) kb = i & ~63;                     // op(A)[i][k] = 0 for k < i
+    if (P.tri & 2) ke = min(ke, i + 1);              // ... for k > i
+    double s[kGemvColumns];
+#pragma unroll
+    for (int c = 0; c < kGemvColumns; ++c) s[c] = 0.0;
+    const double* a = P.A + (size_t)i * P.lda;
+    for (int k = kb + lane; k < ke; k += 64) {
+        const double v = ((P.tri & 1) && k < i) ? 0.0 : a[k];
+#pragma unroll
+        for (int c = 0; c < kGemvColumns; ++c)
+            if (c < P.N) s[c] = fma(v, P.X[(size_t)k * P.ldx + c], s[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < kGemvColumns; ++c) {
+        if (c >= P.N) break;
+        double v = s[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) {
+            double* y = P.Y + (size_t)i * P.ldy + c;
+            *y = P.beta == 0.0 ? P.alpha * v : fma(P.beta, *y, P.alpha * v);
+        }
+    }
+}
+
+static bool gemv_shape(bool ta, bool tb, int M, int N, int K, int batch, bool upper_only, int tri, const double* A, const double* B, const double* C) {
+    return !ta && !tb && batch == 1 && !upper_only && N <= kGemvColumns && M >= 256 && K >= 256 && C != A && C != B && (tri & ~3) == 0 &&
+           (tri == 0 || M == K);
+}
+
+static int gemv(int M, int N, int K, double alpha, const double* A, int lda, const double* X, int ldx, double beta, double* Y, int ldy, int tri,
+                hipStream_t stream) {
+    GemvParams P{M, N, K, A, lda, X, ldx, Y, ldy, alpha, beta, tri};
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, stream, P);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
 static bool panel_shape(bool tb, int M, int N, int K, int batch, const double* A, const double* B, const double* C) {
     if (tb || batch > 4 || K > 128 || C == A) return false;
     if (C == B) return M <= 128;
@@ -460,6 +523,7 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
 int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
                 long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, int tri, hipStream_t stream) {
     if (M <= 0 || N <= 0 || batch <= 0) return SHG_OK;
+    if (K > 0 && gemv_shape(ta, tb, M, N, K, batch, upper_only, tri, A, B, C)) return gemv(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, stream);
     if (K > 0 && panel_shape(tb, M, N, K, batch, A, B, C) && !(upper_only && M != N))
         return panel_gemm(ta, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, upper_only, (tri & 2) != 0 && M == K,
                           (tri & 4) != 0 && K == N, stream);

@@ -475,9 +475,11 @@ def test_pair_factorisation_matches_single(d, in_place):
     assert float((dense @ x.reshape(-1, 1) - rhs).abs().max()) < 1e-10
 
 
-@pytest.mark.parametrize('shape', [(128, 128, 128), (17, 1553, 128), (1553, 128, 96), (128, 300, 64), (100, 100, 100)])
+@pytest.mark.parametrize('shape', [(128, 128, 128), (17, 1553, 128), (1553, 128, 96), (128, 300, 64), (100, 100, 100), (1681, 1, 1681), (300, 3, 700),
+                                   (700, 8, 257)])
 def test_short_k_products(shape):
-    """products with K <= 128 and a thin output go through the panel kernel (csrc/blas.hip): against torch, 1e-13"""
+    """products with K <= 128 and a thin output go through the panel kernel, products with a handful of columns through the streaming
+    kernels (csrc/blas.hip): against torch, 1e-13"""
     import torch
     from grates_amd import engine
     M, N, K = shape
