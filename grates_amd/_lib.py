@@ -56,6 +56,7 @@ PROTOTYPES = {
     'shg_gemm': [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int,
                  ctypes.c_double, c_double_p, ctypes.c_int, ctypes.c_void_p],
     'shg_axpby': [ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_int, ctypes.c_void_p],
+    'shg_transpose_in_place': [ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
     'shg_potrf': [ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
     'shg_trtri': [ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
     'shg_analysis': [c_plan_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],

@@ -209,8 +209,8 @@ def _chain_matrix(BlockMatrix, blocks_d, blocks_u, copy=True):
 def _transposed(block, in_place):
     """block^T as a contiguous tensor; a square block can be transposed in its own storage"""
     if in_place and block.shape[0] == block.shape[1] and block.is_contiguous():
-        block.copy_(block.t().clone())
-        return block
+        from . import engine
+        return engine.transpose_in_place(block)
     return block.t().contiguous()
 
 

@@ -623,6 +623,15 @@ def trtri(U):
     return X
 
 
+def transpose_in_place(A):
+    """A <- A^T for a square 2-d device tensor with a contiguous last dimension, in its own storage"""
+    require_gpu()
+    if A.dim() != 2 or A.shape[0] != A.shape[1] or (A.shape[1] > 1 and A.stride(1) != 1):
+        raise ValueError('transpose_in_place: a square matrix with a contiguous last dimension is expected')
+    _lib.call('shg_transpose_in_place', A.shape[0], _ptr(A), max(A.stride(0), 1), _stream())
+    return A
+
+
 def axpby(alpha, X, beta, Y):
     """Y = alpha X + beta Y in place for 2-d device tensors of equal shape (row strides honoured)."""
     require_gpu()

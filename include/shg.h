@@ -205,6 +205,7 @@ int shg_gemm(int transa, int transb, int M, int N, int K, double alpha, const do
 int shg_potrf(int n, double* A, int lda, int* info, void* stream);
 /* Y = alpha X + beta Y on [rows][cols] blocks: _scale / _axpy of blocks and vectors (grates/lstsq.py:889-903, 1107-1117) */
 int shg_axpby(int rows, int cols, double alpha, const double* X, int ldx, double beta, double* Y, int ldy, void* stream);
+int shg_transpose_in_place(int n, double* A, int lda, void* stream);      /* A <- A^T, square, in its own storage */
 int shg_trtri(int n, const double* U, int ldu, double* X, int ldx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

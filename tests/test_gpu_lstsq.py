@@ -492,3 +492,17 @@ def test_short_k_products(shape):
         expected = 0.5 * C - 2.0 * ((A.T if transa else A) @ B)
         engine.gemm(A, B, transa=transa, alpha=-2.0, beta=0.5, out=C)
         assert relerr(C.cpu().numpy(), expected.cpu().numpy()) < 1e-13
+
+
+@pytest.mark.parametrize('n', [1, 31, 32, 33, 100, 1681])
+def test_transpose_in_place(n):
+    """shg_transpose_in_place (the coupling blocks of a chain walked backwards): bit-exact against torch, also inside a wider array"""
+    import torch
+    from grates_amd import engine
+    A = torch.randn((n, n), dtype=torch.float64, device='cuda')
+    expected = A.t().clone()
+    assert torch.equal(engine.transpose_in_place(A), expected)
+    wide = torch.randn((n, n + 5), dtype=torch.float64, device='cuda')
+    before = wide.clone()
+    engine.transpose_in_place(wide[:, :n])
+    assert torch.equal(wide[:, :n], before[:, :n].t()) and torch.equal(wide[:, n:], before[:, n:])
