@@ -144,6 +144,7 @@ __device__ inline double swap_half_row(double x) {
     return __builtin_bit_cast(double, ((long long)hi2 << 32) | (unsigned int)lo2);
 }
 
+constexpr int kRotMaxClasses = 6; // classes r = 0 .. R / 2 of the rotation-folded synthesis kernel, R <= 10
 constexpr int kEpochTile = 8;    // epochs handled together by one wave of the Legendre stage
 constexpr int kLatTile = 64;     // parallels per wave of the Legendre stage (lane <-> parallel)
 
@@ -155,7 +156,8 @@ struct shg_plan {
     int N = 0, nlat = 0, nlon = 0;
     int ldlat = 0;          // nlat rounded up to 64: leading dimension of per-parallel tables / F
     bool sym4 = false;      // 4-fold longitude symmetry path
-    int rotR = 0;           // rotations of the meridian set used by the rotation-folded kernel (synthesis_rot.hip): 6, 3 or 0 = not applicable
+    int rotR = 0;           // rotations of the meridian set used by the rotation-folded kernel (synthesis_rot.hip): 10, 9, 6, 3 or 0 = not applicable
+    std::vector<double> lon_host;   // meridians as given (the trig stream of that kernel is rebuilt when shg_plan_set_rotations changes R)
     double* rot_trig = nullptr; // [column tiles][k-steps][64 lanes][2] cos / signed sin stream of that kernel
     bool sym_ns = false;    // parallels (colatitude and kn rows) symmetric about the equator
     int ngroups = 1;        // 4 (sym4) or 1
@@ -249,7 +251,8 @@ int build_blockmap(shg_plan* p, int nbt, int nit, hipStream_t stream);
 int pack_coefficients_fused(shg_plan* p, bool ns, int rotR, const double* anm, int B, hipStream_t stream);
 int synthesis_fused(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 bool has_rotation_symmetry(int nlon, const double* lon, int R);
-int rot_layout(int R, int N, int nk[4], int cnt[4], std::vector<int>* order_slot);
+int rot_layout(int R, int N, int nk[kRotMaxClasses], int cnt[kRotMaxClasses], std::vector<int>* order_slot);
+int rot_choose(int nlon, const double* lon_h, int N);
 int rot_applicable(const shg_plan* p);
 int build_rot_trig(shg_plan* p, const double* lon_h);
 int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);

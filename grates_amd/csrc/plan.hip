@@ -399,8 +399,9 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
     p->ldlat = round_up(nlat, kLatTile);
     p->sym4 = has_fourfold_symmetry(nlon, lon_h);
     p->sym_ns = has_north_south_symmetry(N, nlat, colat_h, kn_h, p->ns_badmap, p->ns_nbad, p->ns_badrow);
-    // rotation-folded kernel: R = 6 where nlon / 6 is a multiple of 16 (0.25 degree grid), else R = 3 (0.5 degree grid)
-    p->rotR = has_rotation_symmetry(nlon, lon_h, 6) ? 6 : has_rotation_symmetry(nlon, lon_h, 3) ? 3 : 0;
+    // rotation-folded kernel: the largest rotation count the meridians allow (0.25 degree grid: 10, 0.5 degree grid: 3)
+    p->rotR = rot_choose(nlon, lon_h, N);
+    p->lon_host.assign(lon_h, lon_h + nlon);
 
     // ---- K slots of the longitude stage
     if (p->sym4) {
@@ -540,6 +541,27 @@ extern "C" int shg_plan_set_path(shg_plan* p, int path) {
     return SHG_OK;
 }
 
+extern "C" int shg_plan_set_rotations(shg_plan* p, int R) {
+    SHG_REQUIRE(p != nullptr, "shg_plan_set_rotations: NULL plan");
+    std::unique_lock<std::mutex> lock(p->mtx);
+    const int want = R == 0 ? rot_choose(p->nlon, p->lon_host.data(), p->N) : R;
+    SHG_REQUIRE(R == 0 || ((R == 3 || R == 6 || R == 9 || R == 10) && has_rotation_symmetry(p->nlon, p->lon_host.data(), R)),
+                "shg_plan_set_rotations: the meridians are not invariant under %d rotations in whole 128-byte lines (R in {3, 6, 9, 10}, nlon %% 2R == 0, (nlon / R) %% 16 == 0)", R);
+    if (want == p->rotR) return SHG_OK;
+    const int before = p->rotR;
+    p->rotR = want;
+    if (want != 0 && !rot_applicable(p)) {
+        p->rotR = before;
+        return fail(SHG_ERR_UNSUPPORTED, "shg_plan_set_rotations: the panel of %d rotations at degree %d does not fit the LDS", want, p->N);
+    }
+    SHG_HIP(hipDeviceSynchronize());               // the trig stream of the old count may still be in use
+    if (rot_applicable(p)) {
+        const int rc = build_rot_trig(p, p->lon_host.data());
+        if (rc) return rc;
+    }
+    return SHG_OK;
+}
+
 extern "C" int shg_plan_info(const shg_plan* p, int64_t which[8]) {
     SHG_REQUIRE(p != nullptr && which != nullptr, "shg_plan_info: NULL argument");
     which[0] = p->N;
@@ -549,6 +571,6 @@ extern "C" int shg_plan_info(const shg_plan* p, int64_t which[8]) {
     which[4] = p->chunk;
     which[5] = p->K;
     which[6] = (p->path >= 2 || (p->path == 0 && (rot_applicable(p) || fused_chunk_for(p) != 0 || fused32_applicable(p)))) ? 1 : 0;
-    which[7] = p->path;
+    which[7] = p->path | (rot_applicable(p) ? p->rotR << 8 : 0);
     return SHG_OK;
 }

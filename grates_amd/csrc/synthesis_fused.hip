@@ -624,7 +624,7 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, i
     const int N = p->N;
     std::vector<int> slot16;
     if (rotR) {
-        int nk[4], cn[4];
+        int nk[kRotMaxClasses], cn[kRotMaxClasses];
         rot_layout(rotR, N, nk, cn, &slot16);
     }
     const int nw = rotR ? rot_kernel_waves() : 8;        // waves that share the orders of a tile

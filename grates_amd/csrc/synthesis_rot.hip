@@ -43,6 +43,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
+#ifndef SHG_ROT_PREFERENCE
+#define SHG_ROT_PREFERENCE 10, 6, 3
+#endif
 #ifndef SHG_ROT_WAVES
 #define SHG_ROT_WAVES 8          // waves per workgroup.  12 (three per SIMD; the kernel needs 143 registers, no spill at 168; ring
 #endif                           // depth 3 to fit the LDS) measured the same 0.525 ms: the fp64 issue pipe is the bound, not occupancy
@@ -54,20 +57,16 @@ constexpr int kColStride = kWaves / 4;              // column tiles of a wave: w
 constexpr int kRingDepth = SHG_RING_DEPTH;         // trig pieces in flight per wave
 constexpr int kRingSlots = kRingDepth + 1;          // ring slots (1 KB each) per wave
 constexpr int kRingDoubles = kWaves * kRingSlots * 128;  // the rings of the waves sit at the start of the LDS (DMA offsets < 64 KB)
-constexpr int kMaxClasses = 4;
+constexpr int kMaxClasses = kRotMaxClasses;
 
-// class layout for R rotations: position of class r in the K sequence (two-sum classes first), and whether it has four sums
+// class layout for R rotations: classes r = 0 .. R / 2; in the K sequence the two-sum classes come first (r = 0, and r = R / 2 for
+// even R), then r = 1, 2, ... with four sums each: 2 R accumulators per 16 rows x 16 columns, which the epilogue turns into the
+// 2 R images in place
 template <int R>
-struct RotTraits;
-template <>
-struct RotTraits<6> {                               // r = 0, 3 (two sums), 1, 2 (four sums)
-    static constexpr int kClasses = 4, kTwo = 2, kAcc = 12;
-    static constexpr int kOrder[4] = {0, 3, 1, 2};
-};
-template <>
-struct RotTraits<3> {                               // r = 0 (two sums), 1 (four sums)
-    static constexpr int kClasses = 2, kTwo = 1, kAcc = 6;
-    static constexpr int kOrder[2] = {0, 1};
+struct RotTraits {
+    static constexpr int kClasses = R / 2 + 1, kTwo = R % 2 == 0 ? 2 : 1, kAcc = 2 * R;
+    // accumulators of class r: (CA, SB) at a(r) for the two-sum classes, (CA, SA, CB, SB) at a(r) for the others
+    static constexpr int acc_of(int r) { return r == 0 ? 0 : (R % 2 == 0 && 2 * r == R) ? 2 : 2 * kTwo + 4 * (r - 1); }
 };
 
 struct RotParams {
@@ -176,6 +175,103 @@ __device__ __forceinline__ void rot_images<3>(double4_t* acc, int r) {
         acc[3 * sgn + 0][r] = x0 + x1;
         acc[3 * sgn + 1][r] = fma(g, y1, t);
         acc[3 * sgn + 2][r] = fma(-g, y1, t);
+    }
+}
+
+// R = 9, accumulators 0 CA_0, 1 SB_0, 2 + 4 (r - 1) .. (CA, SA, CB, SB)_r, r = 1 .. 4.  With c_j = cos(40 j deg), s_j = sin(40 j deg)
+// (c_3 = -1/2, s_3 = sqrt(3) / 2) and C_k = X_0 + sum_r c_(rk mod 9) X_r, S_k = sum_r s_(rk mod 9) Y_r:
+//   f_0 = X_0 + X_1 + X_2 + X_3 + X_4,   f_k = C_k + S_k,   f_(9-k) = C_k - S_k,   k = 1 .. 4.
+template <>
+__device__ __forceinline__ void rot_images<9>(double4_t* acc, int r) {
+    constexpr double c1 = 0.76604444311897803520, c2 = 0.17364817766693034885, c4 = -0.93969262078590838405;
+    constexpr double s1 = 0.64278760968653932632, s2 = 0.98480775301220805937, s3 = 0.86602540378443864676, s4 = 0.34202014332566873304;
+    const double ca0 = acc[0][r], sb0 = acc[1][r];
+    double ca[4], sa[4], cb[4], sb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ca[j] = acc[2 + 4 * j][r];
+        sa[j] = acc[3 + 4 * j][r];
+        cb[j] = acc[4 + 4 * j][r];
+        sb[j] = acc[5 + 4 * j][r];
+    }
+#pragma unroll
+    for (int sgn = 0; sgn < 2; ++sgn) {
+        const double x0 = sgn ? ca0 - sb0 : ca0 + sb0;
+        double x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = sgn ? ca[j] - sb[j] : ca[j] + sb[j];
+            y[j] = sgn ? cb[j] + sa[j] : cb[j] - sa[j];
+        }
+        const double x1 = x[0], x2 = x[1], x3 = x[2], x4 = x[3], y1 = y[0], y2 = y[1], y3 = y[2], y4 = y[3];
+        const double t = (x1 + x2) + x4, x03 = x0 + x3;
+        const double h = fma(-0.5, x3, x0), u = s3 * y3;
+        const double C1 = fma(c1, x1, fma(c2, x2, fma(c4, x4, h)));
+        const double C2 = fma(c2, x1, fma(c4, x2, fma(c1, x4, h)));
+        const double C3 = fma(-0.5, t, x03);
+        const double C4 = fma(c4, x1, fma(c1, x2, fma(c2, x4, h)));
+        const double S1 = fma(s1, y1, fma(s2, y2, fma(s4, y4, u)));
+        const double S2 = fma(s2, y1, fma(s4, y2, fma(-s1, y4, -u)));
+        const double S3 = s3 * ((y1 - y2) + y4);
+        const double S4 = fma(s4, y1, fma(-s1, y2, fma(-s2, y4, u)));
+        acc[9 * sgn + 0][r] = x03 + t;
+        acc[9 * sgn + 1][r] = C1 + S1;
+        acc[9 * sgn + 8][r] = C1 - S1;
+        acc[9 * sgn + 2][r] = C2 + S2;
+        acc[9 * sgn + 7][r] = C2 - S2;
+        acc[9 * sgn + 3][r] = C3 + S3;
+        acc[9 * sgn + 6][r] = C3 - S3;
+        acc[9 * sgn + 4][r] = C4 + S4;
+        acc[9 * sgn + 5][r] = C4 - S4;
+    }
+}
+
+// R = 10, accumulators 0 CA_0, 1 SB_0, 2 CA_5, 3 SB_5, 4 + 4 (r - 1) .. (CA, SA, CB, SB)_r, r = 1 .. 4.  With c1 = cos 36, c2 = cos 72,
+// s1 = sin 36, s2 = sin 72 (degrees): the even classes have period 5 in k, the odd ones change sign after 5 steps,
+//   E_0 = X_0 + X_2 + X_4,  E_1,4 = (X_0 + c2 X_2 - c1 X_4) +- (s2 Y_2 + s1 Y_4),  E_2,3 = (X_0 - c1 X_2 + c2 X_4) +- (s1 Y_2 - s2 Y_4)
+//   O_0 = X_1 + X_3 + X_5,  O_1,4 = (s1 Y_1 + s2 Y_3) +- (c1 X_1 - c2 X_3 - X_5),  O_2,3 = (s2 Y_1 - s1 Y_3) +- (c2 X_1 - c1 X_3 + X_5)
+//   f_k = E_k + O_k,  f_(k+5) = E_k - O_k,  k = 0 .. 4.
+template <>
+__device__ __forceinline__ void rot_images<10>(double4_t* acc, int r) {
+    constexpr double c1 = 0.80901699437494742410, c2 = 0.30901699437494742410;
+    constexpr double s1 = 0.58778525229247312917, s2 = 0.95105651629515357212;
+    const double ca0 = acc[0][r], sb0 = acc[1][r], ca5 = acc[2][r], sb5 = acc[3][r];
+    double ca[4], sa[4], cb[4], sb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ca[j] = acc[4 + 4 * j][r];
+        sa[j] = acc[5 + 4 * j][r];
+        cb[j] = acc[6 + 4 * j][r];
+        sb[j] = acc[7 + 4 * j][r];
+    }
+#pragma unroll
+    for (int sgn = 0; sgn < 2; ++sgn) {
+        const double x0 = sgn ? ca0 - sb0 : ca0 + sb0, x5 = sgn ? ca5 - sb5 : ca5 + sb5;
+        double x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = sgn ? ca[j] - sb[j] : ca[j] + sb[j];
+            y[j] = sgn ? cb[j] + sa[j] : cb[j] - sa[j];
+        }
+        const double x1 = x[0], x2 = x[1], x3 = x[2], x4 = x[3], y1 = y[0], y2 = y[1], y3 = y[2], y4 = y[3];
+        const double e0 = (x0 + x2) + x4;
+        const double a1 = fma(c2, x2, fma(-c1, x4, x0)), b1 = fma(s2, y2, s1 * y4);
+        const double a2 = fma(-c1, x2, fma(c2, x4, x0)), b2 = fma(s1, y2, -(s2 * y4));
+        const double e1 = a1 + b1, e4 = a1 - b1, e2 = a2 + b2, e3 = a2 - b2;
+        const double o0 = (x1 + x3) + x5;
+        const double p = fma(c1, x1, fma(-c2, x3, -x5)), q = fma(s1, y1, s2 * y3);
+        const double u = fma(c2, x1, fma(-c1, x3, x5)), v = fma(s2, y1, -(s1 * y3));
+        const double o1 = q + p, o4 = q - p, o2 = v + u, o3 = v - u;
+        acc[10 * sgn + 0][r] = e0 + o0;
+        acc[10 * sgn + 5][r] = e0 - o0;
+        acc[10 * sgn + 1][r] = e1 + o1;
+        acc[10 * sgn + 6][r] = e1 - o1;
+        acc[10 * sgn + 2][r] = e2 + o2;
+        acc[10 * sgn + 7][r] = e2 - o2;
+        acc[10 * sgn + 3][r] = e3 + o3;
+        acc[10 * sgn + 8][r] = e3 - o3;
+        acc[10 * sgn + 4][r] = e4 + o4;
+        acc[10 * sgn + 9][r] = e4 - o4;
     }
 }
 
@@ -584,19 +680,18 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
 // host side
 // ------------------------------------------------------------------------------------------------
 
-// class position in the K sequence (two-sum classes first) and sign of order m >= 1 for R rotations
+// class position in the K sequence (two-sum classes first: r = 0, then r = R / 2 for even R, then r = 1, 2, ...) and sign of
+// order m >= 1 for R rotations
 static inline void order_class(int R, int m, int& cls, int& sign) {
     const int rho = m % R;
     const int r = 2 * rho <= R ? rho : R - rho;
     sign = 2 * rho <= R ? 1 : -1;
-    if (R == 6) {
-        static const int pos[4] = {0, 2, 3, 1};         // r -> position in (0, 3, 1, 2)
-        cls = pos[r];
-    } else {                                            // R == 3: (0, 1)
+    if (R % 2 == 0)
+        cls = r == 0 ? 0 : 2 * r == R ? 1 : r + 1;
+    else
         cls = r;
-    }
 }
-static inline int rot_classes(int R) { return R == 6 ? 4 : 2; }
+static inline int rot_classes(int R) { return R / 2 + 1; }
 
 // sign of the sine coefficients of order m in the repacked coefficient table (0 = no rotation kernel)
 int rot_sigma_negative(int R, int m) { return R > 0 && 2 * (m % R) > R ? 1 : 0; }
@@ -655,16 +750,37 @@ int rot_kernel_waves() { return kWaves; }
 
 static size_t rot_lds_bytes(int nslot) { return (size_t)kRingDoubles * 8 + (size_t)(nslot + 1) * 1024; }      // rings, panel
 
+static bool rot_fits(int R, int N) {
+    int nk[kMaxClasses], cnt[kMaxClasses];
+    return rot_lds_bytes(rot_layout(R, N, nk, cnt, nullptr)) <= 160 * 1024;
+}
+
 int rot_applicable(const shg_plan* p) {
     if (p->rotR == 0 || p->N < 1) return 0;
     if ((long long)p->nlat * p->nlon * 8 >= (1LL << 31)) return 0;
-    int nk[kMaxClasses], cnt[kMaxClasses];
-    const int nslot = rot_layout(p->rotR, p->N, nk, cnt, nullptr);
-    return rot_lds_bytes(nslot) <= 160 * 1024 ? 1 : 0;
+    return rot_fits(p->rotR, p->N) ? 1 : 0;
+}
+
+// The rotation count of a plan: the first of kRotPreference that the meridians allow and whose panel fits the LDS at degree N.
+// 10 rotations (20 images; the 0.25 degree grid: 72 columns in the fundamental domain) need 92 MFMAs per 16 rows x 16 columns x 20
+// images at d/o 96, 9 rotations (18 images, 80 columns) 102, 6 rotations (12 images, 120 columns) 80.
+int rot_choose(int nlon, const double* lon_h, int N) {
+    static const int kRotPreference[] = {SHG_ROT_PREFERENCE};
+    int fallback = 0;
+    for (int R : kRotPreference)
+        if (has_rotation_symmetry(nlon, lon_h, R)) {
+            if (N < 1 || rot_fits(R, N)) return R;
+            if (!fallback) fallback = R;
+        }
+    return fallback;
 }
 
 // trig stream [nct][npieces][64][2] (+ one spare piece), built on the host like the other cos/sin tables (grates/utilities.py:272-273)
 int build_rot_trig(shg_plan* p, const double* lon_h) {
+    if (p->rot_trig) {
+        (void)hipFree(p->rot_trig);
+        p->rot_trig = nullptr;
+    }
     const int R = p->rotR, N = p->N, nlon = p->nlon, nd = nlon / (2 * R), nct = ceil_div(nd, 16);
     int nk[kMaxClasses], cnt[kMaxClasses];
     std::vector<int> order_slot;
@@ -747,7 +863,13 @@ int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream
     const size_t lds = rot_lds_bytes(P.nslot);
     const dim3 grid_dim((unsigned)(nbt * nit));
     ProfileScope ps(p, 2, stream);
-    rc = R == 6 ? launch_rot<6>(p, ns, P, lds, grid_dim, stream) : launch_rot<3>(p, ns, P, lds, grid_dim, stream);
+    switch (R) {
+        case 10: rc = launch_rot<10>(p, ns, P, lds, grid_dim, stream); break;
+        case 9: rc = launch_rot<9>(p, ns, P, lds, grid_dim, stream); break;
+        case 6: rc = launch_rot<6>(p, ns, P, lds, grid_dim, stream); break;
+        case 3: rc = launch_rot<3>(p, ns, P, lds, grid_dim, stream); break;
+        default: return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel: no kernel for %d rotations", R);
+    }
 
     if (rc) return rc;
     SHG_HIP(hipGetLastError());

@@ -90,13 +90,18 @@ class Plan:
         arr = (ctypes.c_int64 * 8)()
         _lib.call('shg_plan_info', self._handle, arr)
         return {'max_degree': arr[0], 'nlat': arr[1], 'nlon': arr[2], 'fourfold_symmetry': bool(arr[3] & 1), 'north_south_symmetry': bool(arr[3] & 2),
-                'rotation_symmetry': bool(arr[3] & 4), 'epochs_per_pass': arr[4], 'k_slots': arr[5], 'fused': bool(arr[6]), 'path': int(arr[7])}
+                'rotation_symmetry': bool(arr[3] & 4), 'epochs_per_pass': arr[4], 'k_slots': arr[5], 'fused': bool(arr[6]), 'path': int(arr[7]) & 0xff, 'rotations': int(arr[7]) >> 8}
 
     def set_path(self, path):
         """'auto', 'staged' (three kernels, any grid), 'fused' (single kernel on 4-fold symmetric meridians), 'fused32' (32-row
         panels) or 'rot' (rotation-folded kernel on equi-angular meridians with nlon % 96 == 0 or nlon % 48 == 0).  The fused
         kernels use the north-south symmetry of the parallels when the grid has it (their plain variants otherwise)."""
         _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'fused32': 5, 'rot': 6}[path])
+
+    def set_rotations(self, R):
+        """Rotation count of the rotation-folded kernel: 0 (the plan's own choice), 3, 6, 9 or 10; the meridians must be invariant
+        under R rotations with nlon / R a multiple of 16 (`info()['rotations']` tells the count in use)."""
+        _lib.call('shg_plan_set_rotations', self._handle, int(R))
 
     def set_chunk(self, epochs_per_pass):
         _lib.call('shg_plan_set_chunk', self._handle, int(epochs_per_pass))

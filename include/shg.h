@@ -64,8 +64,15 @@ int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
  * parallels when the grid has it and their plain variant otherwise; the variant is not a choice of the caller. */
 int shg_plan_set_path(shg_plan* plan, int path);
 
+/* Rotation count R of kernel 6: the longitude sums are evaluated on nlon / (2 R) columns and the 2 R images of every column are
+ * formed in registers.  0 = the plan's own choice (the default: 10 where nlon / 10 is a multiple of 16 -- the 0.25 degree grid --,
+ * else 6, else 3), or one of 3, 6, 9, 10; the meridians must be equi-angular and cell-centred with nlon a multiple of 2 R and
+ * nlon / R a multiple of 16, and the panel of that count must fit the LDS.  Waits for the device (the tables are rebuilt).
+ * shg_plan_info reports the count in use in bits 8.. of which[7]. */
+int shg_plan_set_rotations(shg_plan* plan, int R);
+
 /* Introspection: which[0]=N, [1]=nlat, [2]=nlon, [3]=bit 0: 4-fold longitude symmetry, bit 1: parallels symmetric about the
- * equator, bit 2: the rotation-folded kernel (path 6) applies, [4]=epochs per pass, [5]=K slots of the longitude stage, [6]=1 if synthesis uses the fused kernel, [7]=path. */
+ * equator, bit 2: the rotation-folded kernel (path 6) applies, [4]=epochs per pass, [5]=K slots of the longitude stage, [6]=1 if synthesis uses the fused kernel, [7]=path | rotation count of kernel 6 << 8. */
 int shg_plan_info(const shg_plan* plan, int64_t which[8]);
 
 /* Per-kernel timing with HIP events recorded on the caller's stream around every kernel a plan launches.

@@ -219,7 +219,7 @@ def test_fused_and_staged_paths(N, dlon, dlat):
 @pytest.mark.parametrize('N,nlon,nlat,B', [(96, 1440, 720, 5), (96, 1440, 18, 9), (31, 1440, 36, 4), (6, 1440, 16, 1), (1, 2880, 8, 2), (2, 192, 6, 3),
                                           (45, 192, 90, 6), (60, 720, 360, 5), (96, 720, 10, 8), (17, 240, 120, 3), (100, 480, 24, 4)])
 def test_rotation_folded_kernel(N, nlon, nlat, B):
-    """The rotation-folded kernel (12 images per column where nlon % 96 == 0, 6 where nlon % 48 == 0) against the oracle: long and
+    """The rotation-folded kernel (20 images per column where nlon % 160 == 0, 12 where nlon % 96 == 0, 6 where nlon % 48 == 0) against the oracle: long and
     short class lists (padding slots), partial column tiles, a single column tile (waves without work), ragged batch sizes."""
     grid = ga.grid.GeographicGrid(360.0 / nlon, 180.0 / nlat)
     ker = orc.KernelTable('ewh', love())
@@ -240,6 +240,38 @@ def test_rotation_folded_kernel(N, nlon, nlat, B):
     for nb in (1, 2, 3):                                                # partial epoch tiles: bit-identical to the full batch
         if nb < B:
             assert np.array_equal(ga.engine.to_host(plan.synthesis(batch[0:nb])), outs['rot'][0:nb])
+
+
+@pytest.mark.parametrize('N,nlon,nlat,B', [(96, 1440, 720, 5), (96, 1440, 18, 9), (31, 1440, 36, 4), (6, 1440, 16, 1), (1, 2880, 8, 2),
+                                          (45, 720, 90, 6), (17, 1440, 10, 3), (100, 1440, 24, 4), (9, 1440, 4, 2), (10, 1440, 4, 5)])
+def test_rotation_counts(N, nlon, nlat, B):
+    """Every rotation count the meridians allow (3, 6, 9, 10: 6, 12, 18 and 20 images per column of the fundamental domain) against
+    the oracle and against each other; counts the meridians do not allow are refused, 0 restores the plan's own choice."""
+    grid = ga.grid.GeographicGrid(360.0 / nlon, 180.0 / nlat)
+    ker = orc.KernelTable('ewh', love())
+    batch = np.stack([inputs.coefficients(7000 + N * 10 + e, N) for e in range(B)])
+    nref = min(B, 2)
+    ref = np.stack([orc.synthesis_regular(batch[e], grid.meridians, grid.parallels, ker) for e in range(nref)])
+    plan = ga.engine.Plan(N, *_tables(grid, N, 'ewh'))
+    own = plan.info()['rotations']
+    allowed = [R for R in (3, 6, 9, 10) if nlon % (2 * R) == 0 and (nlon // R) % 16 == 0]
+    assert own == ([R for R in (10, 6, 3) if R in allowed] + [0])[0]
+    outs = {}
+    for R in (3, 6, 9, 10, 4, 12):
+        if R not in allowed:
+            with pytest.raises(ga._lib.ShgError):
+                plan.set_rotations(R)
+            continue
+        plan.set_rotations(R)
+        assert plan.info()['rotations'] == R and plan.info()['rotation_symmetry']
+        outs[R] = ga.engine.to_host(plan.synthesis(batch))
+        assert relerr(outs[R][0:nref], ref) < TOL, R
+        assert relerr(outs[R], outs[allowed[0]]) < TOL, R
+        if B > 1:
+            assert np.array_equal(ga.engine.to_host(plan.synthesis(batch[0:1])), outs[R][0:1])
+    plan.set_rotations(0)
+    assert plan.info()['rotations'] == own
+    assert np.array_equal(ga.engine.to_host(plan.synthesis(batch)), outs[own])
 
 
 def test_rotation_folded_kernel_applicability():
