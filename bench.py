@@ -77,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument('--ramp', type=int, default=300, help='untimed launches before the second measurement of the headline (device clock ramp)')
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass of the staged path (0 = library default)')
+    ap.add_argument('--launch-timeout', type=float, default=1500.0, help='seconds after which `--gpus N` run without a launcher kills its ranks (0 = never)')
     ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'fused32', 'rot'], help='synthesis kernel path')
     ap.add_argument('--cpu-sample', type=int, default=16, help='solutions timed on the CPU baseline (0 = skip all CPU baselines)')
     ap.add_argument('--cov-parallels', type=int, default=-1,
@@ -121,12 +122,41 @@ def free_port():
 
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run as a child process.
-    Nothing in this process has touched the GPU (no torch import so far)."""
+    Nothing in this process has touched the GPU (no torch import so far).  The child runs in a session of its own; when it has
+    not ended after --launch-timeout seconds the whole session is killed and the exit code is 124.  A rank that fails prints
+    its number and traceback (run_rank_reported) and exits non-zero, torch.distributed.run then ends the other ranks and
+    returns non-zero itself."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    return subprocess.call(cmd, env=env)
+    return run_child(cmd, env, args.launch_timeout, '{0} ranks'.format(args.gpus))
+
+
+def run_child(cmd, env, timeout, what):
+    """Run `cmd` in a session of its own and return its exit code; 124 after killing the whole session when it has not ended
+    within `timeout` seconds (0 or less: no limit)."""
+    import signal
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=timeout if timeout > 0 else None)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write('bench.py: the {0} did not finish within {1:.0f} s (--launch-timeout): killing them\n'.format(what, timeout))
+        sys.stderr.flush()
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+    except KeyboardInterrupt:
+        os.killpg(child.pid, signal.SIGTERM)
+        raise
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -625,31 +655,36 @@ class RankContext:
         from grates_amd import distributed as gd
         self.all_counts = [b - a for a, b in (gd.shard_range(args.smoother_epochs, r, world) for r in range(world))]
 
+    @property
+    def collective(self):
+        """collectives run whenever a process group exists -- also for a world of one rank started under a launcher"""
+        return self.world > 1 or self.dist.is_initialized()
+
     def barrier(self):
         self.wl.synchronize()
-        if self.world > 1:
+        if self.collective:
             self.dist.barrier()
         self.wl.synchronize()
 
     def _reduce(self, values, op):
-        if self.world == 1:
+        if not self.collective:
             return list(values)
         t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.reduce_device)
         self.dist.all_reduce(t, op=op)
         return [float(v) for v in t.tolist()]
 
     def max_over_ranks(self, x):
-        return self._reduce([x], self.dist.ReduceOp.MAX)[0] if self.world > 1 else x
+        return self._reduce([x], self.dist.ReduceOp.MAX)[0]
 
     def sum_over_ranks(self, values):
-        return self._reduce(values, self.dist.ReduceOp.SUM) if self.world > 1 else list(values)
+        return self._reduce(values, self.dist.ReduceOp.SUM)
 
     def all_ranks_agree(self, flag):
-        return self._reduce([1.0 if flag else 0.0], self.dist.ReduceOp.MIN)[0] > 0.5 if self.world > 1 else bool(flag)
+        return self._reduce([1.0 if flag else 0.0], self.dist.ReduceOp.MIN)[0] > 0.5
 
     def gather_rows(self, tensors):
         """per-rank lists of the given (equally shaped, small) device tensors of every rank"""
-        if self.world == 1:
+        if not self.collective:
             return [list(tensors)]
         from grates_amd import distributed as gd
         return gd.gather_blocks(tensors)
@@ -698,7 +733,7 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE={0} does not match --gpus {1}'.format(world, args.gpus))
     wl = workload_factory(args, rank, world, local_rank)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or 'RANK' in os.environ) and not dist.is_initialized():       # under a launcher also a world of one rank gets its group
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
@@ -770,6 +805,8 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
             'leg_order': leg_order + (['covariance extensions + CPU baseline'] if cov_state is not None else []) +
                          [n for n in ('analysis', 'filters', 'smoother') if n in args.leg_set]}
         config.update(wl.config)
+        if dist.is_initialized():
+            config['process_group'] = {'backend': dist.get_backend(), 'world': dist.get_world_size()}
         line = {
             'metric': METRIC,
             'value': world * B * args.steps / elapsed,
@@ -823,7 +860,7 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
         checks = [line.get('check')] + [legs[k].get('check') for k in legs if isinstance(legs[k], dict)]
         line['all_checks_ok'] = all(c.get('ok', True) for c in checks if isinstance(c, dict))
         emit(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     return line
@@ -924,7 +961,23 @@ def main(argv=None):
     refuse_experiment_environment()
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
         raise SystemExit(launch_ranks(args, argv))
-    run_rank(args)
+    run_rank_reported(args)
+
+
+def run_rank_reported(args, run=None):
+    """run_rank; a rank that fails says which one it is, prints its traceback and ends its process with code 1 without waiting for
+    collectives that will never complete (the launcher then ends the other ranks and the job returns non-zero)."""
+    import traceback
+    try:
+        return (run or run_rank)(args)
+    except Exception as err:                                            # noqa: BLE001 -- (SystemExit passes: it carries its own message)
+        rank = os.environ.get('RANK', '0')
+        sys.stderr.write('bench.py: rank {0} of {1} FAILED: {2!r}\n{3}'.format(rank, os.environ.get('WORLD_SIZE', '1'), err, traceback.format_exc()))
+        sys.stderr.flush()
+        sys.stdout.flush()
+        if 'RANK' in os.environ:
+            os._exit(1)
+        raise SystemExit(1)
 
 
 if __name__ == '__main__':

@@ -17,14 +17,17 @@ import numpy as np
 
 
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  Without that
+    environment the process is a single rank without a process group (every sharded entry point then skips its collectives);
+    under a launcher a process group is created even for a world of one rank, and the collectives run (over RCCL: communicator
+    set-up, device-buffer all_gather -- what tests/test_gpu_rccl.py exercises on a one-GPU box)."""
     import torch
     import torch.distributed as dist
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    if world == 1:
+    if world == 1 and 'RANK' not in os.environ:
         return 0, 1
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
@@ -60,9 +63,9 @@ def all_gather_bands(local, band_sizes, group=None):
     """
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return local
+    world = dist.get_world_size(group)
     if len(band_sizes) != world:
         raise ValueError('band_sizes must have one entry per rank')
     longest = max(band_sizes)
@@ -413,14 +416,19 @@ class _SegmentedChain:
             diag, upper = [b.clone() for b in diag], [b.clone() if b is not None else None for b in upper]
         self.diag, self.upper = list(diag), list(upper)
         self.rhs = None if rhs is None else rhs.clone()
-        # the same number of segments on every rank (the gathered lists must have the same length)
-        n_min = n_loc
-        if world > 1:
-            t = torch.tensor([n_loc], dtype=torch.int64, device=self.device if dist.get_backend(group) != 'gloo' else 'cpu')
+        # the same number of segments on every rank (the gathered lists must have the same length): the shortest rank decides, ragged
+        # block sizes on ANY rank mean separators at the rank boundaries only, and a caller-given count must be the same everywhere
+        self.collective = collective = dist.is_initialized()
+        want = int(segments) if segments is not None else -max(int(os.environ.get('GRATES_AMD_SEGMENTS', '0') or 0), 0)    # < 0: the default rule with that wish
+        n_min, ragged, seg_lo, seg_hi = n_loc, len(set(sizes)) > 1, want, want
+        if collective:
+            t = torch.tensor([n_loc, -int(ragged), seg_lo, -seg_hi], dtype=torch.int64, device=self.device if dist.get_backend(group) != 'gloo' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-            n_min = int(t.item())
+            n_min, ragged, seg_lo, seg_hi = int(t[0].item()), bool(-int(t[1].item())), int(t[2].item()), -int(t[3].item())
+        if seg_lo != seg_hi:
+            raise ValueError('the ranks were given different segment counts (or GRATES_AMD_SEGMENTS differs between them): {0} .. {1}'.format(seg_lo, seg_hi))
         self.count = count = default_segments(n_min, world) if segments is None else int(segments)
-        if len(set(sizes)) > 1 and count > 1:
+        if ragged and count > 1:
             self.count = count = 1                                   # ragged blocks: separators only at the rank boundaries
         self.K = world * count
         if self.K < 2:
@@ -435,7 +443,7 @@ class _SegmentedChain:
         # separator size (equal everywhere) and the coupling of the previous rank's last epoch to this rank's first one
         self.d = d = sizes[self.segs[0]['hi'] - 1] if not (last_rank and count == 1) else None
         boundary = upper[n_loc - 1] if not last_rank else None
-        if world > 1:
+        if collective:
             shape = (sizes[-1], sizes[-1])
             gathered = _gather_blocks([boundary.contiguous() if boundary is not None else torch.zeros(shape, dtype=torch.float64, device=self.device)], group)
             self.left_of_rank = gathered[rank - 1][0] if rank > 0 else None
@@ -624,7 +632,7 @@ class _SegmentedChain:
         self._eliminate()
         pieces = self._each(self._reduce)
         flat = [t.contiguous() for p in pieces for t in p]
-        if self.world > 1:
+        if self.collective:
             everyone = _gather_blocks(flat, self.group)
             flat_all = [t for part in everyone for t in part]
         else:
@@ -704,7 +712,7 @@ class _SegmentedChain:
             zdiag += zd
             zupper += zu
         first_left = results[0][2]
-        if self.world > 1:
+        if self.collective:
             send = first_left if first_left is not None else self.zeros(d, self.sizes[0])
             from_right = _gather_blocks([send.contiguous()], self.group)
             if self.rank < self.world - 1:

@@ -19,6 +19,19 @@ def main(result_dir):
     import grates_amd as ga
     from grates_amd import distributed as gd
     rank, world = gd.init('nccl')
+    dist = torch.distributed
+    assert dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() == world
+    counts = {'backend': dist.get_backend(), 'world': world, 'all_gather': 0, 'all_reduce': 0, 'on_device': 0, 'on_host': 0}
+
+    def counted(name, real):
+        def call(*a, **k):
+            counts[name] += 1
+            tensors = [t for x in a for t in (x if isinstance(x, (list, tuple)) else [x]) if torch.is_tensor(t)]
+            counts['on_device' if all(t.is_cuda for t in tensors) else 'on_host'] += 1
+            return real(*a, **k)
+        return call
+    dist.all_gather = counted('all_gather', dist.all_gather)
+    dist.all_reduce = counted('all_reduce', dist.all_reduce)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()          # noqa: E731
 
     N, nmin = 24, 2
@@ -47,6 +60,9 @@ def main(result_dir):
     np.save(os.path.join(result_dir, 'x_{0}.npy'.format(rank)), x.cpu().numpy())
     np.save(os.path.join(result_dir, 'zd_{0}.npy'.format(rank)), np.stack([b.cpu().numpy() for b in Zd]))
     np.save(os.path.join(result_dir, 'zu_{0}.npy'.format(rank)), np.stack([b.cpu().numpy() for b in Zu]))
+    import json
+    with open(os.path.join(result_dir, 'collectives_{0}.json'.format(rank)), 'w') as f:
+        json.dump(counts, f)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

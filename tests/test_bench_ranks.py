@@ -163,7 +163,7 @@ def test_bare_multi_gpu_invocation_launches_ranks(monkeypatch):
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         monkeypatch.delenv(k, raising=False)
     calls = []
-    monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(bench, 'run_child', lambda cmd, env, timeout, what: calls.append((cmd, env)) or 0)
     with pytest.raises(SystemExit) as e:
         bench.main(['--gpus', '2', '--steps', '5', '--warmup', '1'])
     assert e.value.code == 0 and len(calls) == 1
@@ -184,6 +184,47 @@ def test_bare_multi_gpu_invocation_launches_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main(['--gpus', '2'])
     assert 'WORLD_SIZE' in str(e.value.code) and len(calls) == 1
+
+
+def _rank_world_of_one(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    args = bench.parse_args(['--gpus', '1', '--steps', '2', '--warmup', '1', '--ramp', '0', '--epochs', '4', '--backend', 'gloo',
+                             '--cov-repeats', '1', '--smoother-epochs', '9'])
+    import torch.distributed as dist
+    seen = []
+    real = dist.all_gather
+
+    def spy(*a, **k):
+        seen.append('all_gather')
+        return real(*a, **k)
+    dist.all_gather = spy
+    line = bench.run_rank(args, workload_factory=StubWorkload, emit=lambda text: None)
+    assert line['n_gpus'] == 1 and line['all_checks_ok'] and not dist.is_initialized()
+    assert seen, 'a world of one rank under a launcher runs its collectives (covariance leg: all_gather of the bands)'
+    with open(os.path.join(out_dir, 'ok'), 'w') as f:
+        f.write('ok')
+
+
+def test_world_of_one_under_a_launcher_runs_the_collectives(tmp_path):
+    """RANK / WORLD_SIZE = 1 in the environment (torch.distributed.run --nproc-per-node 1): a process group is created and every
+    collective of the rank function runs -- the path tests/test_gpu_rccl.py takes over RCCL on the one-GPU box."""
+    mp.spawn(_rank_world_of_one, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / 'ok').exists()
+
+
+def test_launcher_timeout_and_failing_rank(tmp_path):
+    import subprocess
+    import time
+    t0 = time.time()
+    rc = bench.run_child([sys.executable, '-c', 'import time; time.sleep(120)'], dict(os.environ), 1.0, 'sleepers')
+    assert rc == 124 and time.time() - t0 < 30
+    assert bench.run_child([sys.executable, '-c', 'raise SystemExit(3)'], dict(os.environ), 30.0, 'x') == 3
+    code = ('import sys; sys.path.insert(0, {0!r}); import bench\n'
+            'def boom(args):\n    raise RuntimeError("kernel launch failed")\n'
+            'bench.run_rank_reported(bench.parse_args(["--gpus", "2"]), run=boom)\n').format(ROOT)
+    done = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, RANK='1', WORLD_SIZE='2'), capture_output=True, text=True, timeout=120)
+    assert done.returncode == 1
+    assert 'rank 1 of 2 FAILED' in done.stderr and 'kernel launch failed' in done.stderr and 'Traceback' in done.stderr
 
 
 def test_block_table_compressed_rows():
