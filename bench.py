@@ -565,7 +565,10 @@ class GpuWorkload:
                        'epochs_per_rank': ctx.all_counts, 'parallelism': 'epochs in {0} contiguous range(s), all_gather of separator blocks'.format(ctx.world),
                        'flops_per_epoch': {'factor (potrf d^3/3 + U^-T A d^3 + Schur update d^3)': flops_factor,
                                            'sparse inverse (U^-1 W d^3 + T Z 2 d^3 + U^-1 U^-T d^3/3 + T Z^T d^3)': flops_inverse},
-                       'flops': flops},
+                       'flops': flops,
+                       # which factorisation path the main thread's chain took: chain rows carry their coupling block through the panel
+                       # sweep only when the queue experiment found two side streams with hardware queues of their own (csrc/plan.hip)
+                       'lookahead': ga.engine.block_lookahead_info()},
             'roofline': {'kernel': 'gemm_ex_kernel + leaf_kernel (block Cholesky, sweeps and Takahashi recursion of one chain)', 'bound': 'mfma',
                          'achieved': flops / elapsed / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': flops / elapsed / 1e12 / MFMA_F64_PEAK_TFLOPS, 'traffic': None,

@@ -68,6 +68,7 @@ PROTOTYPES = {
     'shg_block_potrf_rows': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_block_potrf_rows_pair': [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_block_set_lookahead': [ctypes.c_int],
+    'shg_block_lookahead_info': [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)],
     'shg_block_solve': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     'shg_block_sparse_inverse': [ctypes.c_int] + [ctypes.c_void_p] * 6,
     'shg_block_solve_rows': [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],

@@ -1023,6 +1023,13 @@ static int potrf_inverse_rec(int n, double* A, int lda, double* X, int ldx, doub
 
 size_t potrf_inverse_work(int n) { return (size_t)(n / 2 + LEAF) * (n / 2 + LEAF); }
 
+// 0: recursive sweep on the caller's stream; 1: panel sweep with look-ahead, chain rows carry their coupling block along when the
+// two side streams have hardware queues of their own (a timing experiment, plan.hip); 2: ... carry it along in any case (on the
+// stream of the trailing update if there is no second queue); 3: ... never.  Setting of the calling thread.
+static thread_local int g_lookahead = 1;
+void potrf_inverse_set_lookahead(int mode) { g_lookahead = mode; }
+int potrf_inverse_lookahead_mode() { return g_lookahead; }
+
 // The same factor and inverse by 128-column panels with a look-ahead of one panel.  The serial chain of the recursive sweep is
 // 14 leaves AND every product between them (1.89 ms at n = 1681: 0.79 ms of leaves, 1.0 ms of products that are too small to
 // fill the chip).  Here the caller's stream carries only what the next leaf waits for,
@@ -1052,7 +1059,7 @@ static int potrf_inverse_lookahead(int n, double* A, int lda, double* X, int ldx
     //  nobody but the next trailing update)
     hipStream_t trail = side[0], inverse = side[0];
     // the columns to the right of A (Coupling) on a queue of their own if there is one
-    hipStream_t couple = lease.sides_apart() >= 2 ? side[1] : side[0];
+    hipStream_t couple = lease.sides_apart() >= 2 || g_lookahead == 2 ? side[1] : side[0];
     hipEvent_t row_ready = nullptr;
     if (cp && (rc = lease.event(2, &row_ready)) != SHG_OK) return rc;
     const int nb = ceil_div(n, LEAF), nbatch = fb.count;
@@ -1142,20 +1149,17 @@ static int potrf_inverse_lookahead(int n, double* A, int lda, double* X, int ldx
     return SHG_OK;
 }
 
-static thread_local int g_lookahead = 1;
-void potrf_inverse_set_lookahead(int enable) { g_lookahead = enable; }
-
 // whether potrf_inverse_batch takes the coupling block and the next diagonal block along (Coupling)
 static bool takes_lookahead(int n) { return n > 2 * LEAF && g_lookahead; }
 
 bool potrf_inverse_carries_coupling(int n, hipStream_t stream) {
-    if (!takes_lookahead(n)) return false;
+    if (!takes_lookahead(n) || g_lookahead == 3) return false;
     // only with a hardware queue of its own for the coupling columns: on the stream of the trailing update they make it the
-    // pace-maker of the sweep (2.24 against 1.87 ms per pair of d = 1681 blocks)
+    // pace-maker of the sweep (2.24 against 1.87 ms per pair of d = 1681 blocks) -- unless the caller insists (mode 2)
     ScratchLease lease(stream);
     hipStream_t side[2];
     hipEvent_t to_side, from_side[2];
-    return lease.side(side, &to_side, from_side) == SHG_OK && lease.sides_apart() >= 2;
+    return lease.side(side, &to_side, from_side) == SHG_OK && (lease.sides_apart() >= 2 || g_lookahead == 2);
 }
 
 int potrf_inverse_batch(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, double* work, long long strideW,

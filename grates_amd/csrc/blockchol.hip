@@ -34,7 +34,8 @@ int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const doubl
 int potrf_inverse_batch(int n, double* A, int lda, long long strideA, double* X, int ldx, long long strideX, double* work, long long strideW,
                         int* info, int info_stride, int batch, const Coupling* cp, hipStream_t stream);
 bool potrf_inverse_carries_coupling(int n, hipStream_t stream);
-void potrf_inverse_set_lookahead(int enable);
+void potrf_inverse_set_lookahead(int mode);
+int potrf_inverse_lookahead_mode();
 size_t potrf_inverse_work(int n);
 
 namespace {
@@ -132,10 +133,13 @@ static int potrf_rows(int count, const BlockView* V, double* const* const* blk, 
     Scratch scratch(stream);
     const int dmax = V0.max_size();
     const size_t wsize = potrf_inverse_work(dmax), bsize = (size_t)dmax * dmax;
-    double* work = scratch.get(wsize * count);
+    // two work areas in turn, like the copies of the diagonal block below: after a chain row the side stream of the look-ahead is
+    // still growing the last block column of that row's inverse THROUGH its work area when the next row starts -- and a next row
+    // that does not take the look-ahead (128 < d <= 256, or no chain row) works on the caller's stream
+    double* work_of[2] = {scratch.get(wsize * count), scratch.get(wsize * count)};
     double* panel = scratch.get(bsize * count);
     int* info_blk = (int*)scratch.get(count);
-    SHG_REQUIRE(work && panel && info_blk, "shg_block_potrf: workspace allocation failed");
+    SHG_REQUIRE(work_of[0] && work_of[1] && panel && info_blk, "shg_block_potrf: workspace allocation failed");
     // inv[r] == blk[diagonal r]: the caller keeps U_rr^-1 INSTEAD of U_rr (nothing but shg_block_multiply needs the diagonal
     // factor blocks once their inverses exist): the block is factored in a scratch copy and its inverse goes where it was
     // (two copies in turn: the inverse of row r is still being completed from copy r % 2, on the side stream of the look-ahead,
@@ -183,7 +187,7 @@ static int potrf_rows(int count, const BlockView* V, double* const* const* blk, 
             const double* Sn[2] = {V[0].at(r + 1, r + 1), count > 1 ? V[1].at(r + 1, r + 1) : nullptr};
             cp = Coupling{const_cast<double*>(Wn[0]), dc, dc, apart(Wn), const_cast<double*>(Sn[0]), dc, apart(Sn), inverse_done[turn]};
         }
-        rc = potrf_inverse_batch(dr, Arr[0], dr, sA, const_cast<double*>(Xrr[0]), dr, sX, work, (long long)wsize, info_blk, 1, count, chain_row ? &cp : nullptr,
+        rc = potrf_inverse_batch(dr, Arr[0], dr, sA, const_cast<double*>(Xrr[0]), dr, sX, work_of[turn], (long long)wsize, info_blk, 1, count, chain_row ? &cp : nullptr,
                                  stream);   // factor and inverse in one sweep
         if (rc) return rc;
         if (info)
@@ -247,8 +251,24 @@ extern "C" int shg_block_potrf_rows_pair(int nb, const int* bounds, const int* r
 // The factorisation of a diagonal block takes a look-ahead on two more streams (blas.hip) unless the calling thread turns it
 // off: a caller that factors several matrices from several threads at once does better without (and better still with
 // shg_block_potrf_rows_pair).  The setting belongs to the calling thread.
-extern "C" int shg_block_set_lookahead(int enable) {
-    potrf_inverse_set_lookahead(enable ? 1 : 0);
+extern "C" int shg_block_set_lookahead(int mode) {
+    SHG_REQUIRE(mode >= 0 && mode <= 3, "shg_block_set_lookahead: mode %d not in 0 .. 3", mode);
+    potrf_inverse_set_lookahead(mode);
+    return SHG_OK;
+}
+
+extern "C" int shg_block_lookahead_info(void* stream_, int which[4]) {
+    SHG_REQUIRE(which != nullptr, "shg_block_lookahead_info: NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    ScratchLease lease(stream);
+    hipStream_t side[2];
+    hipEvent_t to_side, from_side[2];
+    const int rc = lease.side(side, &to_side, from_side);
+    if (rc) return rc;
+    which[0] = potrf_inverse_lookahead_mode();
+    which[1] = lease.sides_apart();
+    which[2] = potrf_inverse_carries_coupling(1 << 20, stream) ? 1 : 0;       // what a chain row of a large block does under this setting
+    which[3] = 0;
     return SHG_OK;
 }
 

@@ -389,10 +389,22 @@ def block_potrf_pair(table0, inverses0, table1, inverses1, first=0, last=None):
     return int(flags[0]), int(flags[1])
 
 
-def block_set_lookahead(enable):
+LOOKAHEAD_MODES = {False: 0, True: 1, 'off': 0, 'on': 1, 'carry': 2, 'plain': 3}
+
+
+def block_set_lookahead(mode):
     """The factorisation of a diagonal block overlaps its panel steps on two more streams unless the calling THREAD turns that
-    off (shg_block_set_lookahead): threads that factor several matrices at once do better without."""
-    _lib.call('shg_block_set_lookahead', 1 if enable else 0)
+    off (shg_block_set_lookahead): threads that factor several matrices at once do better without.  mode: False / 'off', True /
+    'on' (chain rows carry their coupling block through the sweep when a second hardware queue was found), 'carry' (always),
+    'plain' (never)."""
+    _lib.call('shg_block_set_lookahead', LOOKAHEAD_MODES[mode])
+
+
+def block_lookahead_info():
+    """{'mode', 'side_queues_apart', 'chain_rows_carry_coupling'} of the calling thread on the current stream."""
+    arr = (ctypes.c_int * 4)()
+    _lib.call('shg_block_lookahead_info', _stream(), arr)
+    return {'mode': int(arr[0]), 'side_queues_apart': int(arr[1]), 'chain_rows_carry_coupling': bool(arr[2])}
 
 
 def block_solve(table, inverses, transpose, B):

@@ -244,7 +244,16 @@ int shg_block_potrf_rows_pair(int nb, const int* bounds, const int* rowptr, cons
  * beside other threads turns it off for itself: the card does not overlap that many queues (csrc/blas.hip).  The first such
  * factorisation on a stream synchronises that stream once: the side streams are chosen by a timing experiment so that they do
  * not share a hardware queue with it or with each other (csrc/plan.hip); every later call only enqueues. */
-int shg_block_set_lookahead(int enable);
+int shg_block_set_lookahead(int mode);
+/* mode (of the calling thread): 0 = off (recursive sweep on the caller's stream), 1 = on (the default): panel sweep with look-ahead;
+ * a chain row -- a block row whose only coupling is to the next one, as in the block-tridiagonal normal equations of a smoother,
+ * grates/lstsq.py:364-392 -- carries its coupling block and the next diagonal block through the sweep on the second side stream
+ * WHEN that stream has a hardware queue of its own (found by the timing experiment); 2 = on, chain rows always carry them;
+ * 3 = on, chain rows never do (the coupling block is formed after the sweep, by one product).  The results of the variants agree to
+ * rounding (different summation orders); which one mode 1 takes on this stream is reported by
+ * shg_block_lookahead_info: which[0] = mode, [1] = side streams with a hardware queue of their own (0 .. 2), [2] = 1 if chain
+ * rows carry their coupling along under the current mode.  (Synchronises the stream once, like the first factorisation.) */
+int shg_block_lookahead_info(void* stream, int which[4]);
 int shg_block_solve(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, int transpose, double* B,
                     int k, int ldb, void* stream);
 int shg_block_sparse_inverse(int nb, const int* bounds, const int* rowptr, const int* colidx, double* const* blk, double* const* inv, void* stream);
