@@ -7,76 +7,225 @@
 
 namespace shg {
 
-constexpr int kFiltEpochs = 64;     // epochs per workgroup = lanes of a wave
+#ifndef SHG_FILT_X
+#define SHG_FILT_X 0      // experiment switches (timing only, profiling builds): 1 no gather, 2 no products, 4 no scatter
+#endif
+#ifndef SHG_FILT_GROUP
+#define SHG_FILT_GROUP 0  // orders per workgroup: 0 = the largest of 8, 4, 2 whose LDS stage fits
+#endif
 
-// One workgroup = one order block x 64 epochs, 16 waves (the work per block is small and made of dependent scalar-load /
-// LDS round trips: many waves per SIMD hide them).  The coefficient vectors of the 64 epochs are gathered into LDS
-// (xs[k][epoch]); every wave then takes groups of four block rows: the row index is wave-uniform, so the block entries come
-// through scalar loads and feed the FMAs as scalar operands, and one LDS read of xs[c][epoch] serves four FMAs.
-// HBM/L2 bound: bytes = 8 (sum of block sizes x epoch groups + 2 P B).
-__global__ __launch_bounds__(1024) void orderwise_filter_kernel(int Nb, int N, int B, const double* __restrict__ blocks,
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kOwEpochs = 16;       // epochs per workgroup = one MFMA column tile
+constexpr int kOwPitch = 17;        // doubles per LDS row xs[k][epoch]: lanes along k (sine gather / scatter) and lanes along the epochs
+                                    // (cosine gather / scatter, MFMA fragments) both spread over the banks
+#ifndef SHG_FILT_WAVES
+#define SHG_FILT_WAVES 16
+#endif
+constexpr int kOwWaves = SHG_FILT_WAVES;    // waves per workgroup
+constexpr int kOwThreads = 64 * kOwWaves;
+constexpr int kOwMaxUnits = 96 / kOwWaves;  // (order, row tile) units per wave
+#ifndef SHG_FILT_DEPTH
+#define SHG_FILT_DEPTH 16
+#endif
+constexpr int kOwDepth = SHG_FILT_DEPTH;    // loads of a thread in flight in the gather
+#ifndef SHG_FILT_SPLIT
+#define SHG_FILT_SPLIT 1
+#endif
+constexpr int kOwSplit = SHG_FILT_SPLIT;    // workgroups that share the (order, row tile) units of an (order group, epoch group): unit u belongs to part u % split
+__device__ __host__ inline int ow_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// One workgroup = G consecutive orders (all cosine or all sine blocks) x 16 epochs, 16 waves.
+//   Why G orders together: in the coefficient array of an epoch ([n][m]: C_nm at [n][m], S_nm at [m-1][n], utilities.py:310-411) the
+//   cosine coefficients of an order are a COLUMN piece, 8 (N+1) bytes apart -- one 64-byte sector per element whichever way the
+//   lanes run (round 3: 3.6 cycles per element and CU for the gather and again for the scatter, 0.84 TB/s; every sector fetched
+//   and written back once per order that has 8 bytes in it).  The same sectors hold the cosine coefficients of the neighbouring
+//   orders: with G = 8 orders per workgroup the lanes run along the orders and a sector is touched once.
+//   gather   cosine: lanes (order, epoch): 64-byte runs [n][m0 .. m0+7]; sine: lanes along the degree, whole runs [m-1][m .. N];
+//            staged in LDS as xs[order][k][epoch]
+//   product  Y_m [n x 16 epochs] = W_m [n x n] X_m on the fp64 MFMA: unit = (order, tile of 16 rows), dealt to the waves;
+//            A fragments (block entries) straight from L2 with one 16-byte buffer load per lane and pair of k-steps (16 rows x 64
+//            bytes per wave-instruction, rows clamped, beyond the packed blocks the range check returns 0), B fragments from xs;
+//            the rows k >= n of xs are zero, so that whatever the A fragments hold beyond their block's columns does not count.
+//            (Round 3 formed the products with v_fma_f64 and scalar loads of the block entries: 40 of its 74 us.)
+//   scatter  the results replace the input in xs once every wave has finished reading it; then like the gather.
+// HBM/L2 bound: bytes = 8 (sum of block sizes x epoch groups from L2 + 2 P B).
+template <int G>
+__global__ __launch_bounds__(kOwThreads) void orderwise_filter_kernel(int Nb, int N, int B, int ngc, int ngs, int negroups, int plane, const double* __restrict__ blocks,
                                                                const long long* __restrict__ block_off,
                                                                const double* __restrict__ in, double* __restrict__ out) {
-    extern __shared__ double xs[];                 // [n][kFiltEpochs]
-    const int kb = blockIdx.x;                     // 0: order 0 cos, 2m-1: order m cos, 2m: order m sin
-    const int m = (kb + 1) >> 1;
-    const bool sine = kb > 0 && (kb & 1) == 0;
-    const int n = N + 1 - m;                       // coefficients of this order in the field
-    const int ld = Nb + 1 - m;                     // leading dimension of the stored block
-    const int e = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y * kFiltEpochs + e;
+    extern __shared__ double xs[];                 // [G][plane]: plane j holds xs[k][epoch] of order m0 + j, k < npad, pitch 17
+    // Workgroup -> (order group, epoch group).  Every epoch group of an order group reads the same blocks (G blocks, ~1 MB at d/o 120),
+    // and all blocks together (9.4 MB) do not fit the L2 of an XCD (4 MB): dealt out group-major over all XCDs (the first version of
+    // this kernel) the blocks streamed in from beyond the L2 once per epoch group -- 141 MB for 240 epochs, 40 of its 80 us.
+    // Workgroups go to the XCDs round robin by their linear index: XCD x = blockIdx % 8 takes the order groups x, x + 8, ... one
+    // after the other, all epoch groups of one before the next, so that its L2 holds the blocks of the one or two order groups
+    // its CUs are working on.
+    const int ngrp = ngc + ngs;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int part = seq % kOwSplit;               // (the parts of a pair gather the same input: neighbours on one XCD)
+    const int grp = 8 * (seq / (kOwSplit * negroups)) + xcd, eg = (seq / kOwSplit) % negroups;
+    if (grp >= ngrp) return;
+    // groups in the order c0, s0, c1, s1, ...: the long blocks first
+    const bool sine = grp < 2 * ngs ? (grp & 1) != 0 : false;
+    const int gi = grp < 2 * ngs ? grp >> 1 : grp - ngs;
+    const int m0 = sine ? 1 + G * gi : G * gi;     // first order of the group
+    const int n0 = N + 1 - m0;                     // coefficients of order m0 in the field
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = eg * kOwEpochs;
     const size_t E = (size_t)(N + 1) * (N + 1);
-    const double* W = blocks + block_off[kb];
+    const int ld_in = N + 1;
 
-    // element k (degree m + k) of this order: cos at [m+k][m], sin at [m-1][m+k]
-    auto pos = [&](int k) -> size_t { return sine ? (size_t)(m - 1) * (N + 1) + (m + k) : (size_t)(m + k) * (N + 1) + m; };
-    // gather: 8 elements per thread in flight at a time (the addresses are a whole coefficient array apart from lane to lane,
-    // so every element is its own memory transaction: a loop that waits for each one is bound by their latency)
-    for (int k0 = 0; k0 < n; k0 += 128) {
-        double v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + wave + 16 * j;                     // indices clamped, not tested: no branch around the loads
-            v[j] = in[(size_t)min(b, B - 1) * E + pos(min(k, n - 1))];
+    // the rows k >= n of every plane are zero (the gather fills the others): at most 7 + j of them below the padded length
+    {
+        const int npad = 8 * ow_ceil_div(n0, 8);
+        for (int i = tid; i < G * 16 * kOwPitch; i += kOwThreads) {
+            const int j = i / (16 * kOwPitch), k = npad - 1 - (i / kOwPitch) % 16, e = i % kOwPitch;
+            if (k >= n0 - j && k >= 0) xs[j * plane + k * kOwPitch + e] = 0.0;
         }
+    }
+
+    // ---- gather
+    if (!(SHG_FILT_X & 1)) {
+        if (!sine) {
+            // (row n, epoch e, order j), j fastest: C_n,m0+j at [n][m0 + j]
+            const int total = n0 * kOwEpochs * G;
+            for (int i0 = 0; i0 < total; i0 += kOwDepth * kOwThreads) {
+                double v[kOwDepth];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + wave + 16 * j;
-            if (k < n) xs[k * kFiltEpochs + e] = b < B ? v[j] : 0.0;
+                for (int u = 0; u < kOwDepth; ++u) {
+                    const int i = min(i0 + u * kOwThreads + tid, total - 1);
+                    const int j = i % G, e = (i / G) % kOwEpochs, n = m0 + i / (G * kOwEpochs);
+                    v[u] = in[(size_t)min(b0 + e, B - 1) * E + (size_t)n * ld_in + min(m0 + j, n)];      // (clamped, not tested: no branch around the loads)
+                }
+#pragma unroll
+                for (int u = 0; u < kOwDepth; ++u) {
+                    const int i = i0 + u * kOwThreads + tid;
+                    const int j = i % G, e = (i / G) % kOwEpochs, n = m0 + i / (G * kOwEpochs);
+                    if (i < total && m0 + j <= n) xs[j * plane + (n - m0 - j) * kOwPitch + e] = b0 + e < B ? v[u] : 0.0;
+                }
+            }
+        } else {
+            // (order j, epoch e, degree k), k fastest: S_m+k,m at [m - 1][m + k], m = m0 + j
+            const int total = G * kOwEpochs * n0;
+            for (int i0 = 0; i0 < total; i0 += kOwDepth * kOwThreads) {
+                double v[kOwDepth];
+#pragma unroll
+                for (int u = 0; u < kOwDepth; ++u) {
+                    const int i = min(i0 + u * kOwThreads + tid, total - 1);
+                    const int k = i % n0, e = (i / n0) % kOwEpochs, m = min(m0 + i / (n0 * kOwEpochs), N);
+                    v[u] = in[(size_t)min(b0 + e, B - 1) * E + (size_t)(m - 1) * ld_in + min(m + k, N)];
+                }
+#pragma unroll
+                for (int u = 0; u < kOwDepth; ++u) {
+                    const int i = i0 + u * kOwThreads + tid;
+                    const int k = i % n0, e = (i / n0) % kOwEpochs, j = i / (n0 * kOwEpochs);
+                    if (i < total && m0 + j + k <= N) xs[j * plane + k * kOwPitch + e] = b0 + e < B ? v[u] : 0.0;
+                }
+            }
         }
     }
     __syncthreads();
-    for (int r0 = 4 * wave; r0 < n; r0 += 64) {       // rows r0 .. r0 + 3 (clamped: a duplicate row is computed, not stored)
-        const double* w0 = W + (size_t)r0 * ld;
-        const double* w1 = W + (size_t)min(r0 + 1, n - 1) * ld;
-        const double* w2 = W + (size_t)min(r0 + 2, n - 1) * ld;
-        const double* w3 = W + (size_t)min(r0 + 3, n - 1) * ld;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int c = 0;
-        for (; c + 4 <= n; c += 4) {
+
+    // ---- products
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(blocks), 0, (int)((block_off[2 * Nb] + 1) * 8), 0x00020000);
+    const int fr = lane & 15, fk = lane >> 4;
+    double4_t res[kOwMaxUnits];
+    int unit_j[kOwMaxUnits], unit_r0[kOwMaxUnits];
+    {
+        // unit u of the group = (order j, row tile rt) in order of j; this wave takes the units wave, wave + waves, ...  The orders
+        // of a group have T or T - 1 row tiles (n_j = n0 - j, G <= 16): the first jf orders T, the others T - 1.
+        const int T = ow_ceil_div(n0, 16), jf = min((n0 - 1) % 16 + 1, G);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double x = xs[(c + u) * kFiltEpochs + e];
-                s0 = fma(w0[c + u], x, s0);
-                s1 = fma(w1[c + u], x, s1);
-                s2 = fma(w2[c + u], x, s2);
-                s3 = fma(w3[c + u], x, s3);
+        for (int q = 0; q < kOwMaxUnits; ++q) {
+            const int u = part + kOwSplit * (wave + kOwWaves * q);
+            int j, rt;
+            if (u < jf * T) {
+                j = u / T;
+                rt = u % T;
+            } else if (T > 1) {
+                j = jf + (u - jf * T) / (T - 1);
+                rt = (u - jf * T) % (T - 1);
+            } else {
+                j = G;
+                rt = 0;
+            }
+            const bool ok = j < G && j < n0 && 16 * rt < n0 - j;
+            unit_j[q] = ok ? j : -1;
+            unit_r0[q] = 16 * rt;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kOwMaxUnits; ++q) {
+        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const int j = unit_j[q];
+        if (j >= 0 && !(SHG_FILT_X & 2)) {
+            const int m = m0 + j, nj = n0 - j, ld = Nb + 1 - m;
+            const int kb = m == 0 ? 0 : 2 * m - (sine ? 0 : 1);                     // 0: order 0 cos, 2m-1: order m cos, 2m: order m sin
+            // (the whole offset in the vector operand: the range check of a raw buffer does not cover the scalar offset)
+            const unsigned voff = (unsigned)(block_off[kb] * 8) + (unsigned)((min(unit_r0[q] + fr, nj - 1) * ld + 2 * fk) * 8);
+            const double* xb = xs + j * plane + 2 * fk * kOwPitch + fr;
+            // columns c + 2 fk, c + 2 fk + 1 of the block rows (A fragments of two k-steps), rows c + 2 fk, c + 2 fk + 1 of xs; the A
+            // fragments come from L2 four pairs of k-steps ahead of their use (a ring of four registers pairs)
+            auto lda = [&](int c) { return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff + (unsigned)c * 8u, 0, 0)); };
+            auto step = [&](const double2_t a, int c) {
+                const double x0 = xb[c * kOwPitch], x1 = xb[(c + 1) * kOwPitch];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x1, acc1, 0, 0, 0);
+            };
+            double2_t a0 = lda(0), a1 = lda(8), a2 = lda(16), a3 = lda(24);
+            for (int c = 0; c < nj; c += 32) {
+                step(a0, c);
+                a0 = lda(c + 32);
+                if (c + 8 < nj) step(a1, c + 8);
+                a1 = lda(c + 40);
+                if (c + 16 < nj) step(a2, c + 16);
+                a2 = lda(c + 48);
+                if (c + 24 < nj) step(a3, c + 24);
+                a3 = lda(c + 56);
             }
         }
-        for (; c < n; ++c) {
-            const double x = xs[c * kFiltEpochs + e];
-            s0 = fma(w0[c], x, s0);
-            s1 = fma(w1[c], x, s1);
-            s2 = fma(w2[c], x, s2);
-            s3 = fma(w3[c], x, s3);
-        }
-        if (b < B) {
-            const double s[4] = {s0, s1, s2, s3};
+        res[q] = acc0 + acc1;
+    }
+    __syncthreads();                                  // every wave has read what it needs of xs
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + i;
-                if (r < n) out[(size_t)b * E + pos(r)] = (m + r <= 1) ? xs[r * kFiltEpochs + e] : s[i];    // filter.py:189
+    for (int q = 0; q < kOwMaxUnits; ++q) {
+        const int j = unit_j[q];
+        if (j >= 0) {
+            const int m = m0 + j, nj = n0 - j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = unit_r0[q] + fk + 4 * r;                            // C/D layout: row = fk + 4 reg, column = fr
+                if (row < nj && m + row > 1) xs[j * plane + row * kOwPitch + fr] = res[q][r];     // degrees 0 and 1 keep the input (filter.py:189)
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- scatter (every part the rows of its own units)
+    auto owner = [&](int j, int k) {
+        if (kOwSplit == 1) return true;
+        const int T = ow_ceil_div(n0, 16), jf = min((n0 - 1) % 16 + 1, G);
+        const int u = (j < jf ? j * T : jf * T + (j - jf) * (T - 1)) + k / 16;
+        return u % kOwSplit == part;
+    };
+    if (!(SHG_FILT_X & 4)) {
+        if (!sine) {
+            const int total = n0 * kOwEpochs * G;
+            for (int i = tid; i < total; i += kOwThreads) {
+                const int j = i % G, e = (i / G) % kOwEpochs, n = m0 + i / (G * kOwEpochs);
+                if (m0 + j <= n && b0 + e < B && owner(j, n - m0 - j)) out[(size_t)(b0 + e) * E + (size_t)n * ld_in + m0 + j] = xs[j * plane + (n - m0 - j) * kOwPitch + e];
+            }
+        } else {
+            const int total = G * kOwEpochs * n0;
+            for (int i = tid; i < total; i += kOwThreads) {
+                const int k = i % n0, e = (i / n0) % kOwEpochs, j = i / (n0 * kOwEpochs);
+                const int m = m0 + j;
+                if (m + k <= N && b0 + e < B && owner(j, k)) out[(size_t)(b0 + e) * E + (size_t)(m - 1) * ld_in + m + k] = xs[j * plane + k * kOwPitch + e];
             }
         }
     }
@@ -86,6 +235,26 @@ __global__ __launch_bounds__(1024) void orderwise_filter_kernel(int Nb, int N, i
 
 using namespace shg;
 
+// LDS plane of one order: round_up(N + 1, 8) rows of 17 doubles, padded so that planes lie 16 / G + 1 (mod 16) doubles apart:
+// the lanes (order, epoch) of the cosine gather then hit distinct banks
+static int orderwise_plane(int N, int G) {
+    const int rows = round_up(N + 1, 8) * kOwPitch;
+    return rows + ((1 + 16 / G - rows) % 16 + 16) % 16;
+}
+
+template <int G>
+static int launch_orderwise(int Nb, int N, int B, const double* blocks, const long long* block_off, const double* in, double* out, hipStream_t stream) {
+    const int plane = orderwise_plane(N, G);
+    const size_t lds = (size_t)G * plane * sizeof(double);
+    if (lds > 64 * 1024) SHG_HIP(hipFuncSetAttribute((const void*)orderwise_filter_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int ngc = ceil_div(N + 1, G), ngs = ceil_div(N, G);       // groups of cosine (orders 0 .. N) and sine (1 .. N) blocks
+    const int negroups = ceil_div(B, kOwEpochs);
+    hipLaunchKernelGGL(orderwise_filter_kernel<G>, dim3((unsigned)(8 * ceil_div(ngc + ngs, 8) * negroups * kOwSplit)), dim3(kOwThreads), lds, stream, Nb, N, B, ngc, ngs, negroups, plane,
+                       blocks, block_off, in, out);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
 extern "C" int shg_orderwise_filter(const double* blocks_packed, const int64_t* block_off, int Nb, int N, const double* anm_in, int B,
                                     double* anm_out, void* stream_) {
     SHG_REQUIRE(Nb >= 0 && N >= 0 && B >= 0, "shg_orderwise_filter: negative size");
@@ -93,14 +262,18 @@ extern "C" int shg_orderwise_filter(const double* blocks_packed, const int64_t* 
     if (B == 0) return SHG_OK;
     SHG_REQUIRE(blocks_packed && block_off && anm_in && anm_out, "shg_orderwise_filter: NULL pointer");
     SHG_REQUIRE(anm_in != anm_out, "shg_orderwise_filter: in-place operation is not supported");
-    const size_t lds = (size_t)(N + 1) * kFiltEpochs * sizeof(double);
-    // the coefficient vectors of an order for 64 epochs sit in LDS: 64 KB by default, up to the 160 KB of a CU on request
-    SHG_REQUIRE(lds <= 160 * 1024, "shg_orderwise_filter: degree %d exceeds the LDS staging of the block kernel (max degree 319)", N);
-    if (lds > 64 * 1024) SHG_HIP(hipFuncSetAttribute((const void*)orderwise_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(orderwise_filter_kernel, dim3(2 * N + 1, ceil_div(B, kFiltEpochs)), dim3(1024), lds, (hipStream_t)stream_, Nb, N, B,
-                       blocks_packed, (const long long*)block_off, anm_in, anm_out);
-    SHG_HIP(hipGetLastError());
-    return SHG_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long* off = (const long long*)block_off;
+    // orders per workgroup: as many as the LDS stage allows (8: degree <= 143, 4: <= 295, 2: <= 591); every wave holds the results of
+    // its (order, row tile) units in registers
+    auto fits = [&](int G) {
+        return (size_t)G * orderwise_plane(N, G) * sizeof(double) <= 160 * 1024 && ceil_div(ceil_div(G * ceil_div(N + 1, 16), kOwSplit), kOwWaves) <= kOwMaxUnits;
+    };
+    const int want = SHG_FILT_GROUP;
+    if ((want == 0 || want == 8) && fits(8)) return launch_orderwise<8>(Nb, N, B, blocks_packed, off, anm_in, anm_out, stream);
+    if ((want == 0 || want == 4) && fits(4)) return launch_orderwise<4>(Nb, N, B, blocks_packed, off, anm_in, anm_out, stream);
+    if (fits(2)) return launch_orderwise<2>(Nb, N, B, blocks_packed, off, anm_in, anm_out, stream);
+    return fail(SHG_ERR_UNSUPPORTED, "shg_orderwise_filter: degree %d exceeds the LDS staging of the block kernel (max degree 591)", N);
 }
 
 // ------------------------------------------------------------------------------------------------

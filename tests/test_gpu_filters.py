@@ -84,8 +84,8 @@ def test_general_matrix_filter(golden):
 
 
 def test_orderwise_filter_above_degree_127():
-    """Blocks up to d/o 180: the 64-epoch LDS staging of the block kernel exceeds the 64 KB default (up to degree 319 it fits
-    the 160 KB of a CU; beyond that the kernel refuses)."""
+    """Blocks up to d/o 180: the LDS stage of the block kernel holds 8 orders x 16 epochs up to degree 143, 4 orders up to 295 and 2
+    up to 591 (beyond that the kernel refuses); a field of lower degree than the blocks."""
     nmax, T = 180, 70
     normals = inputs.orderwise_normal_blocks(48, nmax)
     blocks = orc.ddk_blocks(normals, 5)
