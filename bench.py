@@ -83,7 +83,7 @@ def parse_args(argv=None):
     ap.add_argument('--cov-parallels', type=int, default=-1,
                     help='parallels of the covariance leg over all ranks (-1 = the whole 0.5 degree grid, 360; 0 = skip the leg)')
     ap.add_argument('--cov-repeats', type=int, default=3, help='timed passes of the covariance leg')
-    ap.add_argument('--cov-cpu-parallels', type=int, default=1, help='parallels of the covariance CPU baseline (0 = skip)')
+    ap.add_argument('--cov-cpu-parallels', type=int, default=8, help='parallels of the covariance CPU baseline (0 = skip)')
     ap.add_argument('--cov-extensions', type=int, default=1, help='1: also time the symmetric and separable variants (N = 1 only)')
     ap.add_argument('--smoother-epochs', type=int, default=SMOOTHER_EPOCHS, help='epochs of the smoother leg over all ranks (BASELINE config 5: 3650)')
     ap.add_argument('--smoother-repeats', type=int, default=2, help='timed passes of the smoother leg (first call, repeated call)')
@@ -359,7 +359,9 @@ class GpuWorkload:
             'config': {'workload': '{0} epochs per GPU, grids resident in HBM, kernel {1}, min_degree 0'.format(B, KERNEL), 'max_degree': N,
                        'grid': [nlat, nlon], 'epochs_per_gpu': B},
             'roofline': {'kernel': 'analysis_transform_kernel + analysis_operator_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None,
+                         'traffic': pmc_traffic('analysis', ['analysis_transform_kernel', 'analysis_operator_kernel'])[0],
+                         'traffic_source': pmc_traffic('analysis', ['analysis_transform_kernel', 'analysis_operator_kernel'])[1],
                          'algorithmic_bytes_per_launch': per_epoch * B, 'avg_launch_ms': per_call_ms,
                          'kernels': {'analysis_transform_kernel': {'avg_us': 1e3 * k_lon[0] / max(k_lon[1], 1), 'launches': int(k_lon[1])},
                                      'analysis_operator_kernel': {'avg_us': 1e3 * k_solve[0] / max(k_solve[1], 1), 'launches': int(k_solve[1])}},
@@ -428,7 +430,8 @@ class GpuWorkload:
                 'unit': 'epochs/s', 'n_gpus': ctx.world, 'scaling': 'weak', 'ms_per_step': 1e3 * el_block / args.steps, 'dtype': 'f64',
                 'config': {'workload': '{0} epochs per GPU, {1} blocks, weights 1e11 n^4'.format(T, len(blocks)), 'max_degree': nmax, 'epochs_per_gpu': T},
                 'roofline': {'kernel': 'orderwise_filter_kernel', 'bound': 'hbm', 'achieved': block_bytes / (ev_block * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                             'unit': 'GB/s', 'frac': block_bytes / (ev_block * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                             'unit': 'GB/s', 'frac': block_bytes / (ev_block * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'traffic': pmc_traffic('filters', ['orderwise_filter_kernel'])[0], 'traffic_source': pmc_traffic('filters', ['orderwise_filter_kernel'])[1],
                              'algorithmic_bytes_per_launch': block_bytes, 'avg_launch_ms': ev_block},
             },
             'dense': {
@@ -439,7 +442,9 @@ class GpuWorkload:
                            'epochs_per_gpu': T, 'flops_per_step': dense_flops},
                 'roofline': {'kernel': 'gemm_ex_kernel (shg_dense_filter; the step also holds the ravel / unravel kernels)', 'bound': 'mfma',
                              'achieved': dense_flops / (ev_dense * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                             'frac': dense_flops / (ev_dense * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': ev_dense},
+                             'frac': dense_flops / (ev_dense * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS,
+                             'traffic': pmc_traffic('filters', ['gemm_ex_kernel'])[0], 'traffic_source': pmc_traffic('filters', ['gemm_ex_kernel'])[1],
+                             'avg_launch_ms': ev_dense},
             },
             'check': {'dense_vs_block_max_rel_diff': agree, 'tolerance': 1e-12, 'ok': bool(agree < 1e-12),
                       'what': 'timed output buffers of the two forms against each other (all epochs)'},
@@ -571,7 +576,8 @@ class GpuWorkload:
                        'lookahead': ga.engine.block_lookahead_info()},
             'roofline': {'kernel': 'gemm_ex_kernel + leaf_kernel (block Cholesky, sweeps and Takahashi recursion of one chain)', 'bound': 'mfma',
                          'achieved': flops / elapsed / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': flops / elapsed / 1e12 / MFMA_F64_PEAK_TFLOPS, 'traffic': None,
+                         'frac': flops / elapsed / 1e12 / MFMA_F64_PEAK_TFLOPS,
+                         'traffic': None, 'traffic_note': 'MFMA-bound leg of ~650 000 launches; per-kernel HBM-side bytes of a 64-epoch chain: profiles/r04_pmc_traffic.json (legs.smoother)',
                          'factor_TFLOPs': T * flops_factor / ph['factor_s'] / 1e12 if ph.get('factor_s') else None,
                          'factor_frac': T * flops_factor / ph['factor_s'] / 1e12 / MFMA_F64_PEAK_TFLOPS if ph.get('factor_s') else None,
                          'sparse_inverse_TFLOPs': T * flops_inverse / ph['covariance_s'] / 1e12 if ph.get('covariance_s') else None,
@@ -627,19 +633,27 @@ def blas_threads():
         return int(os.cpu_count() or 1)
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (profiles/), with its origin:
-    counters cannot be collected inside a timed run."""
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
-        path = os.path.join(ROOT, 'profiles', name)
-        try:
-            with open(path) as f:
-                d = json.load(f)
-        except Exception:
-            continue
-        if kernel_name.split('<')[0] in d.get('kernel', ''):
-            return d.get('lon_stage_bytes_per_launch'), 'profiles/' + name + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of ' + d.get('commit', 'an earlier build') + ')'
-    return None, None
+def pmc_traffic(leg, kernels):
+    """HBM-side bytes per launch of the named kernels of a leg (summed) from the committed rocprofv3 --pmc summary of the same workload
+    (profiles/r04_pmc_traffic.json, tools/pmc_legs.sh), with its origin: counters cannot be collected inside a timed run.  A kernel
+    name matches when the recorded name starts with it.  -> (bytes or None, source or None)"""
+    path = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        rows = table['legs'][leg]
+    except Exception:
+        return None, None
+    total, found = 0.0, []
+    for want in kernels:
+        hit = [(name, r) for name, r in rows.items() if name.startswith(want)]
+        if not hit:
+            return None, None
+        name, r = max(hit, key=lambda kv: kv[1]['dispatches'])
+        total += r['bytes']
+        found.append(name.split('<')[0])
+    return total, 'profiles/r04_pmc_traffic.json ({0}; {1}; build of {2}): {3}'.format(table.get('source', ''), table.get('correction', ''),
+                                                                                  table.get('commit', 'round 4'), ' + '.join(found))
 
 
 def algorithmic_bytes_per_solution(max_degree, nlat, nlon):
@@ -798,7 +812,7 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
             return rate, avg_ms, epochs_per_launch
         achieved, lon_avg_ms, epochs_per_launch = kernel_rate(prof)
         ramp_achieved, ramp_avg_ms, _ = kernel_rate(ramp_prof)
-        traffic, traffic_source = pmc_traffic(wl.kernel_name)
+        traffic, traffic_source = pmc_traffic('synthesis', [wl.kernel_name])
         kernels = {k: {'ms_total': round(v[0], 4), 'launches': int(v[1]), 'avg_us': round(1e3 * v[0] / max(v[1], 1), 3)} for k, v in prof.items()}
         config = {'workload': 'batch of {0} monthly solutions d/o {1} -> {2} deg GeographicGrid ({3}x{4}), kernel {5}, per GPU'.format(
             B, MAX_DEGREE, GRID_STEP, wl.nlat, wl.nlon, KERNEL),
@@ -924,6 +938,7 @@ def covariance_leg_report(args, wl, rank, world, state):
         'seconds_median': median, 'seconds_min': best, 'seconds_all': times, 'GFLOPs_best': flops / best / 1e9,
         'roofline': {'kernel': 'gemm_f64_kernel<MODE_COVPROP>', 'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F64_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': (achieved / MFMA_F64_PEAK_TFLOPS) if achieved else None, 'traffic': None,
+                     'traffic_note': 'MFMA-bound; HBM-side bytes of a band of 8 parallels (Sigma read once per 128 rows): profiles/r04_pmc_traffic.json (legs.covariance)',
                      'avg_launch_ms': k_ms / max(k_n, 1), 'launches': int(k_n)},
         'sigma_checksum': float(host.sum()), 'sigma_crc32': zlib.crc32(host.tobytes()) & 0xffffffff,
     }

@@ -187,12 +187,22 @@ int ScratchLease::side(hipStream_t streams[2], hipEvent_t* to_side, hipEvent_t f
         }
         for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
         (void)hipFree(probe);
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        bool created = true;
+        for (int i = 0; i < 3 && created; ++i) created = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!created) {                                  // nothing is kept: the next call starts over
+            for (hipEvent_t x : ev)
+                if (x) (void)hipEventDestroy(x);
+            for (hipStream_t s : found) (void)hipStreamDestroy(s);
+            (void)hipGetLastError();
+            return fail(SHG_ERR_HIP, "events of the side streams could not be created");
+        }
         e->side_apart = nfound;
         for (int i = 0; i < 2; ++i) {
             e->side[i] = found[i];
-            SHG_HIP(hipEventCreateWithFlags(&e->from_side[i], hipEventDisableTiming));
+            e->from_side[i] = ev[i];
         }
-        SHG_HIP(hipEventCreateWithFlags(&e->to_side, hipEventDisableTiming));
+        e->to_side = ev[2];
     }
     for (int i = 0; i < 2; ++i) {
         streams[i] = e->side[i];
@@ -222,11 +232,26 @@ void stream_scratch_release() {
     (void)hipGetDevice(&current);
     for (StreamScratch* e : entries) {
         std::lock_guard<std::recursive_mutex> hold(e->mtx);
-        if (e->slots.empty()) continue;
+        if (e->slots.empty() && !e->to_side) continue;
         (void)hipSetDevice(e->device);
         for (auto& b : e->slots)
             if (b.second.ptr) (void)hipFree(b.second.ptr);
         e->slots.clear();
+        // the side streams of the look-ahead and every event of the entry (the caller has drained the device): the next
+        // factorisation on this stream repeats the queue experiment
+        for (int i = 0; i < 2; ++i) {
+            if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
+            if (e->from_side[i]) (void)hipEventDestroy(e->from_side[i]);
+            e->side[i] = nullptr;
+            e->from_side[i] = nullptr;
+        }
+        if (e->to_side) (void)hipEventDestroy(e->to_side);
+        e->to_side = nullptr;
+        for (hipEvent_t& x : e->more) {
+            if (x) (void)hipEventDestroy(x);
+            x = nullptr;
+        }
+        e->side_apart = 0;
     }
     (void)hipSetDevice(current);
 }

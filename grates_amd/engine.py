@@ -134,6 +134,7 @@ class Plan:
             out = torch.empty((B, self.nlat, self.nlon), dtype=torch.float64, device=self.device)
         elif tuple(out.shape) != (B, self.nlat, self.nlon) or out.dtype != torch.float64 or not out.is_contiguous():
             raise ValueError('out must be a contiguous fp64 tensor of shape {0}'.format((B, self.nlat, self.nlon)))
+        Plan._written(out)
         with torch.cuda.device(self.device):
             _lib.call('shg_synthesis', self._handle, _ptr(x), B, _ptr(out), _stream())
         return out[0] if single else out
@@ -169,13 +170,33 @@ class Plan:
                       _ptr(out), _stream())
         return out
 
-    def analysis(self, grid, area, min_degree):
+    _trusting = None          # weak set of the plans that hold a weight token (class attribute, created on first use)
+
+    @classmethod
+    def _written(cls, tensor):
+        """A library call is about to write into `tensor` through its raw pointer (torch's version counter does not see that): plans
+        that trust weights living in the same storage forget their token and validate the weights again on their next analysis."""
+        if not cls._trusting:
+            return
+        try:
+            storage = tensor.untyped_storage().data_ptr()
+        except Exception:
+            return
+        for plan in list(cls._trusting):
+            w = plan._analysis_weights
+            if w is not None and w.untyped_storage().data_ptr() == storage:
+                plan._analysis_token = None
+
+    def analysis(self, grid, area, min_degree, trusted_weights=None):
         """grid [B, nlat, nlon], area [nlat, nlon] -> anm [B, N+1, N+1].
 
         The library validates `area` against the weights its cached operators were built for on every call (a device compare and
         one host synchronisation).  A device tensor that is the very tensor of the previous call (same storage, same torch
         version counter: not written to since) need not be compared again -- the call then passes area = NULL ("the weights of
-        the previous call", include/shg.h) and nothing waits for the device."""
+        the previous call", include/shg.h) and nothing waits for the device.  Writes through `.data` or through raw pointers outside
+        this module are invisible to the version counter: `trusted_weights=False` always validates, `True` skips the validation
+        whatever the tensor's history (the caller vouches for it); this module's own raw-pointer writes (`gemm(out=)`, `axpby`,
+        `Plan.synthesis(out=)`) into the storage of trusted weights withdraw the trust."""
         torch = _torch()
         g = to_device(grid, self.device)
         single = g.dim() == 2
@@ -187,7 +208,9 @@ class Plan:
         if torch.is_tensor(area) and area.is_cuda and area.dtype == torch.float64 and area.is_contiguous():
             token = (area.data_ptr(), area._version, tuple(area.shape), int(min_degree))
         with torch.cuda.device(self.device):
-            if g.shape[0] > 0 and token is not None and token == self._analysis_token:
+            trusted = token is not None and (token == self._analysis_token if trusted_weights is None else
+                                             (bool(trusted_weights) and self._analysis_token is not None and token[2:] == self._analysis_token[2:]))
+            if g.shape[0] > 0 and trusted and trusted_weights is not False:
                 _lib.call('shg_analysis', self._handle, _ptr(g), None, int(min_degree), g.shape[0], _ptr(out), _stream())
             else:
                 a = to_device(area, self.device).reshape(self.nlat, self.nlon)
@@ -195,6 +218,11 @@ class Plan:
                 _lib.call('shg_analysis', self._handle, _ptr(g), _ptr(a), int(min_degree), g.shape[0], _ptr(out), _stream())
                 if g.shape[0] > 0:       # (the tensor is kept alive: its address cannot be handed to another one meanwhile)
                     self._analysis_token, self._analysis_weights = token, (area if token is not None else None)
+                    if token is not None:
+                        import weakref
+                        if Plan._trusting is None:
+                            Plan._trusting = weakref.WeakSet()
+                        Plan._trusting.add(self)
         return out[0] if single else out
 
     _analysis_token = None
@@ -607,7 +635,9 @@ def gemm(A, B, transa=False, transb=False, alpha=1.0, beta=0.0, out=None):
         if beta != 0.0:
             raise ValueError('gemm: beta != 0 needs an output tensor')
         out = torch.empty((M, N), dtype=torch.float64, device=A.device)
-    elif tuple(out.shape) != (M, N) or (N > 1 and out.stride(1) != 1):
+    elif tuple(out.shape) == (M, N) and not (N > 1 and out.stride(1) != 1):
+        Plan._written(out)
+    if tuple(out.shape) != (M, N) or (N > 1 and out.stride(1) != 1):
         raise ValueError('gemm: output must be ({0}, {1}) with a contiguous last dimension'.format(M, N))
     _lib.call('shg_gemm', int(transa), int(transb), M, N, K, float(alpha), _ptr(A), max(A.stride(0), 1), _ptr(B), max(B.stride(0), 1),
               float(beta), _ptr(out), max(out.stride(0), 1), _stream())
@@ -658,5 +688,6 @@ def axpby(alpha, X, beta, Y):
         return Y
     if (X.shape[1] > 1 and X.stride(1) != 1) or (Y.shape[1] > 1 and Y.stride(1) != 1):
         raise ValueError('axpby: contiguous last dimension expected')
+    Plan._written(Y)
     _lib.call('shg_axpby', X.shape[0], X.shape[1], float(alpha), _ptr(X), max(X.stride(0), 1), float(beta), _ptr(Y), max(Y.stride(0), 1), _stream())
     return Y

@@ -452,11 +452,12 @@ class TimeSeries:
             d.values = residuals[k, :]
         return engine.to_host(trend)
 
-    def bin(self, bin_center_epochs, func=np.mean):
+    def bin(self, bin_center_epochs, func=np.mean, no_data=np.nan):
         """
         Aggregate the series in bins: every element goes to the nearest bin centre, `func` (default: mean) is applied to the
         elements of a bin, the result carries the centre as epoch (grates/gravityfield.py:1014-1045).  An empty bin is an
-        error (upstream fails on it while assigning the epoch).  As upstream, numpy.mean of PotentialCoefficients ends in a
+        error (upstream fails on it while assigning the epoch; its `no_data` argument is accepted here as there and, as there,
+        never used).  As upstream, numpy.mean of PotentialCoefficients ends in a
         TypeError (division by a numpy integer): pass e.g. ``lambda v: sum(v[1:], v[0]) * (1.0 / len(v))``.
         """
         centers = list(bin_center_epochs)
@@ -796,3 +797,15 @@ class ReferenceField(PotentialCoefficients):
 
 WGS84 = ReferenceField(GM=3986004.418e8, omega=7292115.0e-11, a=6378137.0, f=1 / 298.257223563)
 GRS80 = ReferenceField(GM=3986005e8, omega=7292115.0e-11, a=6378137.0, J2=108263e-8)
+
+
+from .timevariable import Oscillation, TimeVariableGravityField, Trend  # noqa: E402,F401  (reference import paths)
+
+
+def __getattr__(name):
+    """`gravityfield.SurfaceMasCons` / `AnisotropicBasisFunctions` resolve like in the reference; the classes live in
+    grates_amd.extras (outside the hot path's scope) and are imported on first use."""
+    if name in ('SurfaceMasCons', 'AnisotropicBasisFunctions'):
+        from . import extras
+        return getattr(extras, name)
+    raise AttributeError('module {0!r} has no attribute {1!r}'.format(__name__, name))

@@ -546,3 +546,11 @@ def cartesian2geodetic(xyz, a=6378137.0, f=298.2572221010**-1, max_iter=10, thre
             break
         h_previous = h
     return np.arctan2(xyz[:, 1], xyz[:, 0]), np.arctan2(k * z, np.sqrt(p2)), h
+
+
+def __getattr__(name):
+    """`grid.ReuterGrid` resolves like in the reference; the class lives in grates_amd.extras (outside the hot path's scope)."""
+    if name == 'ReuterGrid':
+        from . import extras
+        return extras.ReuterGrid
+    raise AttributeError('module {0!r} has no attribute {1!r}'.format(__name__, name))

@@ -217,6 +217,19 @@ def test_same_weight_tensor_skips_the_comparison_and_stays_correct():
     # another minimum degree is another set of operators
     assert not torch.equal(plan.analysis(vals, area, 2), changed)
     assert torch.equal(plan.analysis(vals, area, 0), changed)
+    # raw-pointer writes of this module into the weights (invisible to torch's version counter) withdraw the trust (advisor r03)
+    assert plan._analysis_token is not None
+    ga.engine.axpby(0.0, area, 2.0, area)                                         # weights doubled through shg_axpby
+    assert plan._analysis_token is None
+    doubled = plan.analysis(vals, area, 0)
+    assert torch.equal(doubled, ga.engine.Plan(N, colat, kn, grid.meridians).analysis(vals, area.clone(), 0))
+    # trusted_weights=False always validates (a write through .data is invisible to everything else), True vouches for the tensor
+    area.data[0:3] *= 0.5
+    assert torch.equal(plan.analysis(vals, area, 0), doubled)                     # stale operators: the documented trap ...
+    halved = plan.analysis(vals, area, 0, trusted_weights=False)                  # ... that the explicit validation avoids
+    assert not torch.equal(halved, doubled)
+    assert torch.equal(halved, ga.engine.Plan(N, colat, kn, grid.meridians).analysis(vals, area.clone(), 0))
+    assert torch.equal(plan.analysis(vals, area, 0, trusted_weights=True), halved)
     # a NULL weight pointer on a plan without cached operators is an error, not a fault
     empty = ga.engine.Plan(N, colat, kn, grid.meridians)
     with pytest.raises(Exception):

@@ -193,6 +193,34 @@ def test_smoother_against_oracle(dim, order, epochs):
     assert relerr(combined.matrix.to_array(), lo.to_array(ref['matrix'])) < tol_inv
 
 
+def test_config5_chain_of_12_epochs_against_oracle():
+    """The bench's spot check as a test: 12 epochs of the seeded config-5 system (d = 1681, N_tt = G G^T / d + 4 I, well conditioned)
+    through the partitioned smoother -- solution, every diagonal and every coupling block of the inverse -- against the oracle's
+    block Cholesky / sweeps / Takahashi recursion (grates/lstsq.py:698-846), 1e-12."""
+    import torch
+    import bench
+    from grates_amd import distributed as gd
+    n, d = 12, 1681
+    gen = torch.Generator(device='cuda')
+    sets = [bench.smoother_blocks(t, d, gen, torch, ga.engine) for t in range(n)]
+    host = [(D.cpu().numpy(), R.cpu().numpy(), b.cpu().numpy()) for D, R, b in sets]
+    x, zd, zu = gd.smooth_block_tridiagonal_partitioned([s[0] for s in sets], [s[1] for s in sets[:-1]], torch.cat([s[2] for s in sets], dim=0))
+    bm = lo.block_matrix(np.arange(0, (n + 1) * d, d))
+    for t, (D, R, _) in enumerate(host):
+        bm['blocks'][(t, t)] = D.copy()
+        if t + 1 < n:
+            bm['blocks'][(t, t + 1)] = R.copy()
+    rhs = np.vstack([h[2] for h in host])
+    lo.cholesky(bm)
+    ref_x = lo.solve_triangular(bm, lo.solve_triangular(bm, rhs, transpose=True))
+    lo.sparse_inverse(bm)
+    assert relerr(x.cpu().numpy(), ref_x) < 1e-12
+    for t in range(n):
+        assert relerr(zd[t].cpu().numpy(), bm['blocks'][(t, t)]) < 1e-12, t
+        if t + 1 < n:
+            assert relerr(zu[t].cpu().numpy(), bm['blocks'][(t, t + 1)]) < 1e-12, t
+
+
 def test_sinex_normals_solved_on_device(golden, tmp_path):
     """SINEX file -> NormalEquations -> blocked Cholesky solve on the GPU (SURVEY 8f rank 3 feeding rank 1): the solution
     against numpy.linalg.solve of the matrix the reference read from the same file (tests/golden/g14_sinex.npz)."""

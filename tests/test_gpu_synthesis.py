@@ -447,18 +447,10 @@ def test_time_variable_field_and_gridded_rms_golden(golden):
         series.append(gf)
     gfm = ga.gravityfield
 
-    class Model:
-        """a time-variable field for gridded_rms (anything with evaluate_at): linear trend per year + annual oscillation + the
-        interpolated series -- the constituents the fixture was generated with (grates/gravityfield.py:788-812, 1054-1140)"""
-        trend, cosine, sine, interpolated = field(110), field(111), field(112), gfm.TimeSeries(series)
-
-        def evaluate_at(self, epoch):
-            days = (epoch - t0).total_seconds() / 86400
-            phase = 2 * np.pi * days / 365.25
-            out = np.sum([self.trend * (days / 365.25), self.cosine * np.cos(phase) + self.sine * np.sin(phase), self.interpolated.evaluate_at(epoch)])
-            out.epoch = epoch
-            return out
-    model = Model()
+    # linear trend per year + annual oscillation + the interpolated series: the constituents the fixture was generated with
+    # (grates/gravityfield.py:788-812, 1054-1140)
+    model = gfm.TimeVariableGravityField([gfm.Trend(field(110), t0), gfm.Oscillation(field(111), field(112), 365.25, t0), gfm.TimeSeries(series)])
+    assert ga.grid.ReuterGrid is ga.extras.ReuterGrid and gfm.SurfaceMasCons is ga.extras.SurfaceMasCons       # reference import paths
     epochs = [t0 + datetime.timedelta(days=9.5 * k) for k in range(30)]
     at7 = model.evaluate_at(epochs[7])
     assert at7.epoch == epochs[7]
