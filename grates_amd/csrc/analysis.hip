@@ -360,11 +360,16 @@ __global__ void analysis_scatter_kernel(int N, int nmin, int nb, int b0, const d
 // anm[b][n][m] / anm[b][m-1][n] by the lanes that hold them (the scatter kernel's pattern, without the round trip through X).
 constexpr int kOpKC = 16, kOpCols = 64, kOpRows = 128;
 
-__global__ __launch_bounds__(256) void analysis_operator_kernel(int N, int nmin, int nlat, int nb, int b0, const double* __restrict__ H,
+__global__ __launch_bounds__(256) void analysis_operator_kernel(int N, int nmin, int nlat, int nb, int b0, int ngroups, const double* __restrict__ H,
                                                                 const double* __restrict__ gt, double* __restrict__ anm) {
     __shared__ double AL[2][kOpKC][kOpRows + 2];
     __shared__ double BL[2][kOpKC][kOpCols + 2];
-    const int s = blockIdx.x, cb = blockIdx.y * kOpCols;
+    // Workgroups go to the 8 XCDs round robin by their linear index.  All epoch groups of a slot read the same operator H_s: XCD x takes
+    // the slots x, x + 8, ... with their epoch groups next to each other, so that H_s comes in from memory once per XCD's L2 (slot-major
+    // over all XCDs, the order of round 3, every epoch group fetched it again: 108 instead of 27 MB at d/o 96, 240 epochs).
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int s = 8 * (seq / ngroups) + xcd, cb = (seq % ngroups) * kOpCols;
+    if (s > 2 * N) return;
     const int m = (s + 1) >> 1;
     const bool sine = s > 0 && (s & 1) == 0;
     const int n0 = max(m, nmin), R = N + 1;
@@ -705,7 +710,8 @@ static int analysis_pass(shg_plan* p, const double* grid, const double* area, in
         if (rc) return rc;
         ProfileScope ps(p, 5, stream);
         if (R <= kOpRows && nlat % 2 == 0) {
-            hipLaunchKernelGGL(analysis_operator_kernel, dim3(S, ceil_div(nb, kOpCols)), dim3(256), 0, stream, N, nmin, nlat, nb, b0, p->ana_H, gt, anm);
+            hipLaunchKernelGGL(analysis_operator_kernel, dim3((unsigned)(8 * ceil_div(S, 8) * ceil_div(nb, kOpCols))), dim3(256), 0, stream, N, nmin, nlat, nb, b0,
+                               ceil_div(nb, kOpCols), p->ana_H, gt, anm);
         } else {
             // X_s [R][nb] = H_s [R][nlat] gt_s^T   (gt_s is [nb][nlat])
             rc = gemm_ex(false, true, R, nb, nlat, 1.0, p->ana_H, nlat, (long long)R * nlat, gt, nlat, rows, 0.0, X, nb, (long long)R * nb, S, false, stream);
