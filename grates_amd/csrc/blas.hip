@@ -43,13 +43,6 @@ struct GemmExParams {
     int slices;               // split-K launch of a batch: blockIdx.z = item * slices + slice; strideA/B step the slices,
     long long itemA, itemB;   //   itemA/B the items of the batch (C: the partial products of all of them are contiguous)
     int tri;                  // triangular operands (square, M = K resp. K = N): 1 op(A) upper, 2 op(A) lower, 4 op(B) upper, 8 op(B) lower
-    // Output tile of a workgroup.  Workgroups go to the 8 XCDs round robin by their linear index and every XCD has an L2 of its own:
-    // with tiles numbered row by row every XCD sees every row strip of op(A) and every column strip of op(B) -- both operands
-    // come in from beyond the L2 eight times (the dense filter W [14637^2] X [14637 x 240] in 64-tiles: four column tiles, W read
-    // 4.3 times, 7.3 GB per product by the fabric counters = the 2 ms it took).  Here the XCDs form a gr x gc grid (gr gc = 8) and
-    // XCD (xr, xc) owns the tiles (xr + gr i, xc + gc j): a row strip is fetched by gc XCDs, a column strip by gr of them, and the host
-    // picks the grid that moves the fewest bytes.  blockIdx.x = 8 (nj i + j) + xcd, tiles beyond the matrix return at once.
-    int gr, gc, ni, nj;
 };
 
 // TA: A is stored [K][M] (op(A) = A^T);  TB: B is stored [N][K] (op(B) = B^T).  Row-major everywhere.
@@ -60,9 +53,7 @@ __global__ __launch_bounds__(256, T == 128 ? 2 : 3) void gemm_ex_kernel(GemmExPa
     double* As0 = gemm_ex_lds;                  // [2][XBUF]
     double* Bs0 = gemm_ex_lds + 2 * XBUF;       // [2][XBUF]
 
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    const int m0 = ((xcd / P.gc) + P.gr * (seq / P.nj)) * XM, n0 = ((xcd % P.gc) + P.gc * (seq % P.nj)) * XN;
-    if (m0 >= P.M || n0 >= P.N) return;
+    const int m0 = blockIdx.y * XM, n0 = blockIdx.x * XN;
     if (P.upper_only && m0 >= n0 + XN) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -576,30 +567,11 @@ int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const doubl
     const bool narrow = M <= 64 && !upper_only && tiles64 >= 512;
     const bool small_tiles = (work_tiles < 512 || narrow) && !split_candidate && (const double*)C != A && (const double*)C != B;
     const int XT = small_tiles ? 64 : 128;
-    const int tiles_x = ceil_div(N, XT), tiles_y = ceil_div(M, XT);
-    {
-        // XCD grid gr x gc: bytes from beyond the L2 ~ gc |op(A)| + gr |op(B)| = gc M K + gr K N (a strip is fetched once per XCD that needs it)
-        double best = 0.0;
-        P.gr = 8;
-        P.gc = 1;
-        for (int gc = 1; gc <= 8; gc *= 2) {
-            const int gr = 8 / gc;
-            if ((gc > 1 && gc > tiles_x) || (gr > 1 && gr > tiles_y)) continue;
-            const double cost = (double)gc * M + (double)gr * N;
-            if (best == 0.0 || cost < best) {
-                best = cost;
-                P.gr = gr;
-                P.gc = gc;
-            }
-        }
-        P.ni = ceil_div(tiles_y, P.gr);
-        P.nj = ceil_div(tiles_x, P.gc);
-    }
-    dim3 grid((unsigned)(8 * P.ni * P.nj), 1, batch);
+    dim3 grid(ceil_div(N, XT), ceil_div(M, XT), batch);
     const size_t lds = (size_t)4 * (small_tiles ? GemmExTile<64>::BUF : GemmExTile<128>::BUF) * sizeof(double);   // 73.7 KB (two workgroups per CU) / 41 KB
     // Few output tiles and a long K (block times a handful of right-hand sides): split K over grid.z into a workspace of
     // partial products that a second kernel sums in a fixed order (deterministic, unlike atomics).
-    const int tiles = tiles_x * tiles_y * batch;
+    const int tiles = (int)(grid.x * grid.y) * batch;
     double* partial = nullptr;
     int slices = 1;
     std::unique_ptr<ScratchLease> lease;            // held until the kernel that sums the partial products is enqueued
