@@ -966,10 +966,10 @@ def covariance_leg_report(args, wl, rank, world, state):
                 out[key]['max_rel_diff_vs_general'] = float(((sep - sigma).abs().max() / sigma.abs().max()).item())
             del sep
     if world == 1 and args.cov_cpu_parallels > 0 and args.cpu_sample > 0 and hasattr(wl, 'covariance_cpu'):
-        out['cpu_baseline'] = wl.covariance_cpu(0, args.cov_cpu_parallels, sigma)
+        out['cpu_baseline'] = wl.covariance_cpu(0, min(args.cov_cpu_parallels, total), sigma)
         err = out['cpu_baseline']['max_rel_diff_vs_gpu']
         out['check'] = {'max_rel_err_vs_oracle': err, 'tolerance': 1e-11, 'ok': bool(err < 1e-11),
-                        'what': 'sigma of the first {0} parallel(s) of the timed, gathered output against the NumPy oracle'.format(args.cov_cpu_parallels)}
+                        'what': 'sigma of the first {0} parallel(s) of the timed, gathered output against the NumPy oracle'.format(min(args.cov_cpu_parallels, total))}
     return out
 
 
