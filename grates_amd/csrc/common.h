@@ -81,8 +81,8 @@ inline int experiment_switches() {
 }
 #else
 #define SHG_DBG(P, bits) 0
-#if (defined(SHG_ROT_X) && SHG_ROT_X) || (defined(SHG_GEMM_X) && SHG_GEMM_X) || (defined(SHG_ANA_X) && SHG_ANA_X)
-#error "SHG_ROT_X / SHG_GEMM_X / SHG_ANA_X are timing experiments: build with -DSHG_EXPERIMENT (make timeline)"
+#if (defined(SHG_ROT_X) && SHG_ROT_X) || (defined(SHG_GEMM_X) && SHG_GEMM_X) || (defined(SHG_ANA_X) && SHG_ANA_X) || (defined(SHG_FILT_X) && SHG_FILT_X)
+#error "SHG_ROT_X / SHG_GEMM_X / SHG_ANA_X / SHG_FILT_X are timing experiments: build with -DSHG_EXPERIMENT (make timeline)"
 #endif
 #endif
 

@@ -8,7 +8,7 @@
 namespace shg {
 
 #ifndef SHG_FILT_X
-#define SHG_FILT_X 0      // experiment switches (timing only, profiling builds): 1 no gather, 2 no products, 4 no scatter
+#define SHG_FILT_X 0      // experiment switches (timing only, -DSHG_EXPERIMENT builds): 1 no gather, 2 no products, 4 no scatter
 #endif
 #ifndef SHG_FILT_GROUP
 #define SHG_FILT_GROUP 0  // orders per workgroup: 0 = the largest of 8, 4, 2 whose LDS stage fits
@@ -31,10 +31,6 @@ constexpr int kOwMaxUnits = 96 / kOwWaves;  // (order, row tile) units per wave
 #define SHG_FILT_DEPTH 16
 #endif
 constexpr int kOwDepth = SHG_FILT_DEPTH;    // loads of a thread in flight in the gather
-#ifndef SHG_FILT_SPLIT
-#define SHG_FILT_SPLIT 1
-#endif
-constexpr int kOwSplit = SHG_FILT_SPLIT;    // workgroups that share the (order, row tile) units of an (order group, epoch group): unit u belongs to part u % split
 __device__ __host__ inline int ow_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // One workgroup = G consecutive orders (all cosine or all sine blocks) x 16 epochs, 16 waves.
@@ -65,8 +61,7 @@ __global__ __launch_bounds__(kOwThreads) void orderwise_filter_kernel(int Nb, in
     // its CUs are working on.
     const int ngrp = ngc + ngs;
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    const int part = seq % kOwSplit;               // (the parts of a pair gather the same input: neighbours on one XCD)
-    const int grp = 8 * (seq / (kOwSplit * negroups)) + xcd, eg = (seq / kOwSplit) % negroups;
+    const int grp = 8 * (seq / negroups) + xcd, eg = seq % negroups;
     if (grp >= ngrp) return;
     // groups in the order c0, s0, c1, s1, ...: the long blocks first
     const bool sine = grp < 2 * ngs ? (grp & 1) != 0 : false;
@@ -142,7 +137,7 @@ __global__ __launch_bounds__(kOwThreads) void orderwise_filter_kernel(int Nb, in
         const int T = ow_ceil_div(n0, 16), jf = min((n0 - 1) % 16 + 1, G);
 #pragma unroll
         for (int q = 0; q < kOwMaxUnits; ++q) {
-            const int u = part + kOwSplit * (wave + kOwWaves * q);
+            const int u = wave + kOwWaves * q;
             int j, rt;
             if (u < jf * T) {
                 j = u / T;
@@ -206,26 +201,20 @@ __global__ __launch_bounds__(kOwThreads) void orderwise_filter_kernel(int Nb, in
     }
     __syncthreads();
 
-    // ---- scatter (every part the rows of its own units)
-    auto owner = [&](int j, int k) {
-        if (kOwSplit == 1) return true;
-        const int T = ow_ceil_div(n0, 16), jf = min((n0 - 1) % 16 + 1, G);
-        const int u = (j < jf ? j * T : jf * T + (j - jf) * (T - 1)) + k / 16;
-        return u % kOwSplit == part;
-    };
+    // ---- scatter
     if (!(SHG_FILT_X & 4)) {
         if (!sine) {
             const int total = n0 * kOwEpochs * G;
             for (int i = tid; i < total; i += kOwThreads) {
                 const int j = i % G, e = (i / G) % kOwEpochs, n = m0 + i / (G * kOwEpochs);
-                if (m0 + j <= n && b0 + e < B && owner(j, n - m0 - j)) out[(size_t)(b0 + e) * E + (size_t)n * ld_in + m0 + j] = xs[j * plane + (n - m0 - j) * kOwPitch + e];
+                if (m0 + j <= n && b0 + e < B) out[(size_t)(b0 + e) * E + (size_t)n * ld_in + m0 + j] = xs[j * plane + (n - m0 - j) * kOwPitch + e];
             }
         } else {
             const int total = G * kOwEpochs * n0;
             for (int i = tid; i < total; i += kOwThreads) {
                 const int k = i % n0, e = (i / n0) % kOwEpochs, j = i / (n0 * kOwEpochs);
                 const int m = m0 + j;
-                if (m + k <= N && b0 + e < B && owner(j, k)) out[(size_t)(b0 + e) * E + (size_t)(m - 1) * ld_in + m + k] = xs[j * plane + k * kOwPitch + e];
+                if (m + k <= N && b0 + e < B) out[(size_t)(b0 + e) * E + (size_t)(m - 1) * ld_in + m + k] = xs[j * plane + k * kOwPitch + e];
             }
         }
     }
@@ -249,7 +238,7 @@ static int launch_orderwise(int Nb, int N, int B, const double* blocks, const lo
     if (lds > 64 * 1024) SHG_HIP(hipFuncSetAttribute((const void*)orderwise_filter_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ngc = ceil_div(N + 1, G), ngs = ceil_div(N, G);       // groups of cosine (orders 0 .. N) and sine (1 .. N) blocks
     const int negroups = ceil_div(B, kOwEpochs);
-    hipLaunchKernelGGL(orderwise_filter_kernel<G>, dim3((unsigned)(8 * ceil_div(ngc + ngs, 8) * negroups * kOwSplit)), dim3(kOwThreads), lds, stream, Nb, N, B, ngc, ngs, negroups, plane,
+    hipLaunchKernelGGL(orderwise_filter_kernel<G>, dim3((unsigned)(8 * ceil_div(ngc + ngs, 8) * negroups)), dim3(kOwThreads), lds, stream, Nb, N, B, ngc, ngs, negroups, plane,
                        blocks, block_off, in, out);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
@@ -267,7 +256,7 @@ extern "C" int shg_orderwise_filter(const double* blocks_packed, const int64_t* 
     // orders per workgroup: as many as the LDS stage allows (8: degree <= 143, 4: <= 295, 2: <= 591); every wave holds the results of
     // its (order, row tile) units in registers
     auto fits = [&](int G) {
-        return (size_t)G * orderwise_plane(N, G) * sizeof(double) <= 160 * 1024 && ceil_div(ceil_div(G * ceil_div(N + 1, 16), kOwSplit), kOwWaves) <= kOwMaxUnits;
+        return (size_t)G * orderwise_plane(N, G) * sizeof(double) <= 160 * 1024 && ceil_div(G * ceil_div(N + 1, 16), kOwWaves) <= kOwMaxUnits;
     };
     const int want = SHG_FILT_GROUP;
     if ((want == 0 || want == 8) && fits(8)) return launch_orderwise<8>(Nb, N, B, blocks_packed, off, anm_in, anm_out, stream);
