@@ -15,10 +15,12 @@ GeographicGrid (kernel 'ewh') on MI355X; beside it one leg per remaining BASELIN
 One "step" of the headline = one pass of the hot path over one batch: 240 coefficient sets already resident in HBM ->
 240 grids in HBM (shg_synthesis through the C ABI).  `value` is measured exactly as the contract says: W warm-up steps, then K
 timed steps between barrier + synchronize pairs, max over ranks.  Leg order (also in `config.leg_order`): synthesis setup, the timed
-repeats of the covariance leg, THEN the synthesis contract pass -- device clocks ramp up over the first ~100 ms of fp64 MFMA work
-after an idle period, and the covariance leg is ~25 s of declared, reported fp64 MFMA work; nothing runs unreported.
-`value_after_ramp` repeats the measurement behind `--ramp` further untimed launches (with `--legs synthesis` alone it is the only
-figure taken on ramped clocks).
+repeats of the covariance leg, the timed steps of the filters leg (block form, then the dense form: config 3's full-matrix products), THEN
+the synthesis contract pass.  Why: behind an idle period -- or behind work that loads only the MFMA units or only the HBM -- launches
+6 .. 25 of the synthesis kernel run 4 .. 13 % slower than its steady state (the card's power management settling on the new load;
+tools/ramp_probe.py); behind a few products that load both, as the dense filter's do, they run at the steady time.  All of it is
+declared, reported work of other BASELINE configurations; nothing runs unreported.  `value_after_ramp` repeats the measurement
+behind `--ramp` further untimed launches (with `--legs synthesis` alone it is the only figure taken in the steady state).
 
 N > 1: one process per GPU.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment) the script is a
 rank; started bare (`python bench.py --gpus 4`) it launches `python -m torch.distributed.run --nproc-per-node N` on
@@ -393,6 +395,11 @@ class GpuWorkload:
 
     # ---- filters: OrderWiseFilter / DDK and GeneralMatrix, grates/filter.py:153-222, 456-479
     def leg_filters(self, ctx):
+        return self.leg_filters_report(ctx, self.leg_filters_timed(ctx))
+
+    def leg_filters_timed(self, ctx):
+        """The device part of the filters leg: setup, the timed steps of the block form, then those of the dense form (the last thing it
+        does on the device).  Returns what the report needs."""
         import numpy as np
         ga, torch, args = self.ga, self.torch, self.args
         nmax, T = DDK_DEGREE, args.epochs
@@ -419,8 +426,17 @@ class GpuWorkload:
         step_dense()
         dense_steps = max(args.steps // 2, 1)
         el_dense, _, ev_dense = ctx.timed(step_dense, max(args.warmup // 2, 1), dense_steps, events=True)
+        return dict(nmax=nmax, T=T, nmin=nmin, P=P, blocks=blocks, batch_host=batch_host, dense=dense, state=state, el_block=el_block, ev_block=ev_block,
+                    el_dense=el_dense, ev_dense=ev_dense, dense_steps=dense_steps)
+
+    def leg_filters_report(self, ctx, st):
+        """The line of the filters leg from the timed part's record, the two forms against each other and against the oracle, the CPU baselines."""
+        import numpy as np
+        args = self.args
         if ctx.rank != 0:
             return None
+        nmax, T, nmin, P, blocks, batch_host, dense, state = (st[k] for k in ('nmax', 'T', 'nmin', 'P', 'blocks', 'batch_host', 'dense', 'state'))
+        el_block, ev_block, el_dense, ev_dense, dense_steps = (st[k] for k in ('el_block', 'ev_block', 'el_dense', 'ev_dense', 'dense_steps'))
         block_bytes = 8.0 * (sum(b.size for b in blocks) + 2.0 * (nmax + 1) ** 2 * T)
         dense_flops = 2.0 * P * P * T
         agree = float(((state['dense'] - state['block']).abs().max() / state['block'].abs().max()).item())
@@ -791,6 +807,15 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
         barrier()
         cov_state = covariance_leg_timed(args, wl, rank, world, barrier, max_over_ranks, gd)
         leg_order.append('covariance (timed repeats)')
+    # ... and behind it the timed steps of the filters leg (BASELINE config 3), whose last part is the dense form: ten products that load
+    # the fp64 MFMA AND the HBM like the synthesis kernel does.  tools/ramp_probe.py: launches 6 .. 25 of the synthesis kernel take
+    # +13 % behind an idle period, +8 % behind covariance propagation (MFMA only), +4 % behind plain copies (HBM only) and their
+    # steady time behind as little as three such products (6 ms) -- the card's power management settles on the mix of the load.
+    flt_state = None
+    if 'filters' in args.leg_set and hasattr(wl, 'leg_filters_timed'):
+        barrier()
+        flt_state = wl.leg_filters_timed(ctx)
+        leg_order.append('filters (timed steps: block form, then dense form)')
     leg_order += ['synthesis contract pass', 'synthesis pass behind {0} more launches'.format(args.ramp), 'synthesis check + CPU baseline']
     barrier()
     elapsed, prof = timed_steps(args.warmup, args.steps)
@@ -820,7 +845,8 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
             'parallelism': 'epochs sharded over {0} GPU(s), no collective'.format(world),
             'legs': sorted(args.leg_set), 'ramp_launches_before_value_after_ramp': args.ramp,
             'leg_order': leg_order + (['covariance extensions + CPU baseline'] if cov_state is not None else []) +
-                         [n for n in ('analysis', 'filters', 'smoother') if n in args.leg_set]}
+                         (['filters checks + CPU baselines'] if flt_state is not None else []) +
+                         [n for n in ('analysis', 'filters', 'smoother') if n in args.leg_set and not (n == 'filters' and flt_state is not None)]}
         config.update(wl.config)
         if dist.is_initialized():
             config['process_group'] = {'backend': dist.get_backend(), 'world': dist.get_world_size()}
@@ -867,9 +893,12 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
         cov_state = None
         if hasattr(wl, 'release_covariance'):
             wl.release_covariance()
+    if flt_state is not None:
+        legs['filters'] = wl.leg_filters_report(ctx, flt_state)
+        flt_state = None
     for name in ('analysis', 'filters', 'smoother'):
         runner = getattr(wl, 'leg_' + name, None)
-        if name in args.leg_set and runner is not None:
+        if name in args.leg_set and runner is not None and name not in legs:
             barrier()
             legs[name] = runner(ctx)
     if rank == 0:

@@ -57,6 +57,38 @@ def main():
     print('covariance stretch {0:.2f} s'.format(time.perf_counter() - t0))
     series('after covariance    ')
     series('after itself        ')
+    other = torch.empty_like(out)
+    for _ in range(100):                                     # ~80 ms of plain HBM traffic (2 GB read + 2 GB written per copy)
+        other.copy_(out)
+    torch.cuda.synchronize()
+    series('after HBM copies    ')
+    del other
+    big = torch.randn((8192, 8192), dtype=torch.float64, device='cuda')
+    for _ in range(6):                                       # ~100 ms of plain fp64 MFMA work (square products, L2-resident operands)
+        ga.engine.gemm(big, big)
+    torch.cuda.synchronize()
+    series('after fp64 products ')
+    del big
+    big = torch.randn((8192, 8192), dtype=torch.float64, device='cuda')
+    ga.engine.gemm(big, big)                                 # ~17 ms
+    torch.cuda.synchronize()
+    series('after ONE product   ')
+    del big
+    Pn = 14637
+    W = torch.randn((Pn, Pn), dtype=torch.float64, device='cuda')
+    X = torch.randn((Pn, 240), dtype=torch.float64, device='cuda')
+    for _ in range(10):                                      # the dense filter of config 3: 10 x 2 ms
+        ga.engine.dense_filter(W, X)
+    torch.cuda.synchronize()
+    series('after dense filter  ')
+    for _ in range(3):
+        ga.engine.dense_filter(W, X)
+    torch.cuda.synchronize()
+    series('after 3 dense filt. ')
+    del W, X
+    cplan.covariance_propagation(cov, 0, 0, 60)
+    torch.cuda.synchronize()
+    series('after cov 0.25 s    ')
     time.sleep(0.2)
     series('after 0.2 s idle    ')
     time.sleep(1.0)
