@@ -44,7 +44,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
 #ifndef SHG_ROT_PREFERENCE
-#define SHG_ROT_PREFERENCE 10, 6, 3
+#define SHG_ROT_PREFERENCE 10, 9, 6, 3
 #endif
 #ifndef SHG_ROT_WAVES
 #define SHG_ROT_WAVES 8          // waves per workgroup.  12 (three per SIMD; the kernel needs 143 registers, no spill at 168; ring
@@ -763,7 +763,8 @@ int rot_applicable(const shg_plan* p) {
 
 // The rotation count of a plan: the first of kRotPreference that the meridians allow and whose panel fits the LDS at degree N.
 // 10 rotations (20 images; the 0.25 degree grid: 72 columns in the fundamental domain) need 92 MFMAs per 16 rows x 16 columns x 20
-// images at d/o 96, 9 rotations (18 images, 80 columns) 102, 6 rotations (12 images, 120 columns) 80.
+// images at d/o 96, 9 rotations (18 images, 80 columns) 102, 6 rotations (12 images, 120 columns) 80.  The 0.5 degree grid (nlon = 720) allows 9
+// and 3: 0.167 against 0.222 ms per 240 epochs at d/o 96.
 int rot_choose(int nlon, const double* lon_h, int N) {
     static const int kRotPreference[] = {SHG_ROT_PREFERENCE};
     int fallback = 0;

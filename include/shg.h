@@ -66,7 +66,7 @@ int shg_plan_set_path(shg_plan* plan, int path);
 
 /* Rotation count R of kernel 6: the longitude sums are evaluated on nlon / (2 R) columns and the 2 R images of every column are
  * formed in registers.  0 = the plan's own choice (the default: 10 where nlon / 10 is a multiple of 16 -- the 0.25 degree grid --,
- * else 6, else 3), or one of 3, 6, 9, 10; the meridians must be equi-angular and cell-centred with nlon a multiple of 2 R and
+ * else 9 -- the 0.5 degree grid --, else 6, else 3), or one of 3, 6, 9, 10; the meridians must be equi-angular and cell-centred with nlon a multiple of 2 R and
  * nlon / R a multiple of 16, and the panel of that count must fit the LDS.  Waits for the device (the tables are rebuilt).
  * shg_plan_info reports the count in use in bits 8.. of which[7]. */
 int shg_plan_set_rotations(shg_plan* plan, int R);

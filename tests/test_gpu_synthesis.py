@@ -255,7 +255,7 @@ def test_rotation_counts(N, nlon, nlat, B):
     plan = ga.engine.Plan(N, *_tables(grid, N, 'ewh'))
     own = plan.info()['rotations']
     allowed = [R for R in (3, 6, 9, 10) if nlon % (2 * R) == 0 and (nlon // R) % 16 == 0]
-    assert own == ([R for R in (10, 6, 3) if R in allowed] + [0])[0]
+    assert own == ([R for R in (10, 9, 6, 3) if R in allowed] + [0])[0]
     outs = {}
     for R in (3, 6, 9, 10, 4, 12):
         if R not in allowed:
