@@ -398,6 +398,43 @@ def test_temporal_basis_functions(golden):
         ga.utilities.TemporalBasisFunction(None)
 
 
+def test_time_variable_field_constituents(golden):
+    """Trend + annual oscillation + interpolated series (grates/gravityfield.py:784-812, 1054-1140) against the reference's own evaluation
+    (g16: the model at epoch 7 of 30), the constituents one by one against their formulas, and the reference import paths of the classes
+    that live in grates_amd.extras."""
+    g = golden('g16_time_variable')
+    gfm = ga.gravityfield
+
+    def field(seed):
+        gf = gfm.PotentialCoefficients()
+        gf.anm = inputs.coefficients(seed, 20)
+        return gf
+    t0 = datetime.datetime(2005, 1, 1)
+    series = []
+    for k in range(6):
+        gf = field(120 + k)
+        gf.epoch = t0 + datetime.timedelta(days=61 * k)
+        series.append(gf)
+    trend, cosine, sine = field(110), field(111), field(112)
+    model = gfm.TimeVariableGravityField([gfm.Trend(trend, t0), gfm.Oscillation(cosine, sine, 365.25, t0), gfm.TimeSeries(series)])
+    epoch = t0 + datetime.timedelta(days=9.5 * 7)
+    at7 = model.evaluate_at(epoch)
+    assert at7.epoch == epoch
+    np.testing.assert_allclose(at7.anm, g['model_anm_at_7'], rtol=0, atol=1e-24)       # values ~1e-10
+    days = 66.5
+    np.testing.assert_array_equal(gfm.Trend(trend, t0).evaluate_at(epoch).anm, (trend * (days / 365.25)).anm)
+    np.testing.assert_array_equal(gfm.Trend(trend, t0, time_scale=1.0).evaluate_at(epoch).anm, (trend * days).anm)
+    phase = 2 * np.pi * days / 365.25
+    np.testing.assert_allclose(gfm.Oscillation(cosine, sine, 365.25, t0).evaluate_at(epoch).anm, cosine.anm * np.cos(phase) + sine.anm * np.sin(phase),
+                               rtol=0, atol=1e-26)
+    trend.anm[:] = 0.0                                                                  # the constituents hold copies
+    assert np.abs(gfm.Trend(field(110), t0).evaluate_at(epoch).anm).max() > 0
+    assert ga.grid.ReuterGrid is ga.extras.ReuterGrid and gfm.SurfaceMasCons is ga.extras.SurfaceMasCons
+    assert gfm.AnisotropicBasisFunctions is ga.extras.AnisotropicBasisFunctions
+    with pytest.raises(AttributeError):
+        gfm.NoSuchClass
+
+
 def test_reuter_grid_and_latitude_mappings(golden):
     """ReuterGrid point distribution (grates/grid.py:1207-1278) for the three latitude mappings and the ellipsoid <-> sphere
     latitude mappings themselves (:2047-2110) against the reference (tests/golden/g17_reuter.npz)."""
