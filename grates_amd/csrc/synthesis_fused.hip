@@ -172,11 +172,16 @@ __global__ __launch_bounds__(256) void pack_coefficients4_ns_kernel(int N, int B
 // Gather form of the NS repack: one thread per 16-byte element of the fragment-ordered table (fully coalesced writes, every
 // element written, padding included: no zero-fill of the workspace); the two degrees of an element are read from the epoch's
 // coefficient triangle, which stays in L2.  octinfo[octet] = order | (octet index inside the order) << 8.
-__global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N, int B, int Qtot, int rotR, const int* __restrict__ octinfo,
+// Workgroups go to the 8 XCDs round robin by their linear index: XCD x takes the epoch tiles x, x + 8, ... with all their octets one after
+// the other, so that the coefficient triangles of an epoch tile (4 x 75 KB at d/o 96; every 64-byte sector of their cosine columns is
+// shared by eight orders) are fetched into one L2 only.
+__global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N, int B, int Qtot, int rotR, int nbt, const int* __restrict__ octinfo,
                                                                             const double* __restrict__ anm, double* __restrict__ cpk4) {
-    const int t = blockIdx.x * 256 + threadIdx.x;                  // (octet, lane)
-    if (t >= Qtot * 64) return;
-    const int bt = blockIdx.y;
+    const int nx = (Qtot * 64 + 255) / 256;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int bt = 8 * (seq / nx) + xcd;
+    const int t = (seq % nx) * 256 + threadIdx.x;                  // (octet, lane)
+    if (bt >= nbt || t >= Qtot * 64) return;
     const int oct = t >> 6, lane = t & 63;
     const int info = octinfo[oct];
     const int m = info & 255, ol = info >> 8;
@@ -751,8 +756,8 @@ int pack_coefficients_fused(shg_plan* p, bool ns, int rotR, const double* anm, i
     const int E = (p->N + 1) * (p->N + 1);
     ProfileScope ps(p, 0, stream);
     if (ns)
-        hipLaunchKernelGGL(pack_coefficients4_ns_gather_kernel, dim3(ceil_div(p->Qtot * 64, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot,
-                           rotR, p->octinfo_d, anm, p->cpk4);
+        hipLaunchKernelGGL(pack_coefficients4_ns_gather_kernel, dim3((unsigned)(8 * ceil_div(nbt, 8) * ceil_div(p->Qtot * 64, 256))), dim3(256), 0, stream, p->N, B,
+                           p->Qtot, rotR, nbt, p->octinfo_d, anm, p->cpk4);
     else
         hipLaunchKernelGGL(pack_coefficients4_kernel, dim3(ceil_div(E, 256), nbt), dim3(256), 0, stream, p->N, B, p->Qtot, rotR, p->qoff, anm,
                            p->cpk4);
