@@ -243,7 +243,8 @@ class GpuWorkload:
         self.plan.synthesis(self.batch, out=self.out)
 
     def profile(self, enable):
-        self.plan.profile(enable)
+        # events around the dominant kernel only: the pair around the 16 us coefficient repack would cost every step another ~5 us
+        self.plan.profile(enable, kinds=('lon_stage',) if self.plan.info()['fused'] else None)
 
     def profile_read(self):
         return self.plan.profile_read()

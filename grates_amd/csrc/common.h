@@ -237,6 +237,7 @@ struct shg_plan {
 
     // optional per-kernel event timing (shg_plan_profile)
     bool profiling = false;
+    unsigned profile_mask = ~0u;            // kinds that are timed while profiling is on
     std::vector<hipEvent_t> prof_events;    // pairs (start, stop)
     std::vector<int> prof_kinds;
     size_t prof_used = 0;                   // number of pairs in use

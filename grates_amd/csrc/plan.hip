@@ -350,7 +350,7 @@ int plan_alloc_workspace(shg_plan* p) {
 }
 
 ProfileScope::ProfileScope(shg_plan* plan, int kind, hipStream_t s) : p(plan), stream(s) {
-    if (!p || !p->profiling) return;
+    if (!p || !p->profiling || !((p->profile_mask >> kind) & 1)) return;
     if (p->prof_used * 2 + 2 > p->prof_events.size()) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -374,7 +374,9 @@ using namespace shg;
 
 extern "C" int shg_plan_profile(shg_plan* p, int enable) {
     SHG_REQUIRE(p != nullptr, "shg_plan_profile: NULL plan");
+    // enable: 0 off, 1 every kind, otherwise a mask of kinds shifted by one (bit k + 1 = kind k): an event pair costs the stream ~5 us
     p->profiling = enable != 0;
+    p->profile_mask = enable == 1 ? ~0u : (unsigned)enable >> 1;
     return SHG_OK;
 }
 

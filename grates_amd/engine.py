@@ -108,9 +108,16 @@ class Plan:
 
     PROFILE_KINDS = ('pack_coefficients', 'legendre_stage', 'lon_stage', 'covprop', 'analysis_lon', 'analysis_solve', 'k6', 'k7')
 
-    def profile(self, enable=True):
-        """Record HIP events around every kernel this plan launches (on the launching stream)."""
-        _lib.call('shg_plan_profile', self._handle, 1 if enable else 0)
+    def profile(self, enable=True, kinds=None):
+        """Record HIP events around every kernel this plan launches (on the launching stream), or around the kernels of the named
+        `kinds` only (PROFILE_KINDS; an event pair costs the stream ~5 us)."""
+        if enable and kinds:
+            mask = 0
+            for name in kinds:
+                mask |= 1 << (self.PROFILE_KINDS.index(name) + 1)
+            _lib.call('shg_plan_profile', self._handle, mask)
+        else:
+            _lib.call('shg_plan_profile', self._handle, 1 if enable else 0)
 
     def profile_read(self):
         """{kernel: (total_ms, launches)} since the last read; synchronises the recorded events."""

@@ -77,6 +77,7 @@ int shg_plan_info(const shg_plan* plan, int64_t which[8]);
 
 /* Per-kernel timing with HIP events recorded on the caller's stream around every kernel a plan launches.
  * kinds: 0 pack_coefficients, 1 legendre_stage, 2 lon_stage, 3 covprop, 4 analysis_lon, 5 analysis_solve.
+ * enable: 0 = off, 1 = every kind, otherwise a mask of kinds shifted by one (bit k + 1 = kind k; an event pair costs the stream ~5 us).
  * shg_plan_profile_read synchronises the recorded events, returns accumulated milliseconds and launch
  * counts per kind since the last read, and resets the accumulators. */
 #define SHG_PROFILE_KINDS 8
