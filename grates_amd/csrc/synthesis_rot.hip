@@ -79,6 +79,8 @@ struct RotParams {
     int nslot;                // panel slots of the orders >= 1 = 4 * npieces; order 0 sits in slot nslot
 #ifdef SHG_EXPERIMENT
     int dbg;                  // experiment switches (SHG_DEBUG): 1 no stores, 2 no Legendre stage, 4 no longitude stage
+    int stagger;              // SHG_STAGGER: the first 256 workgroups start up to this many 10 ns ticks late (spread in 32 steps)
+    int stagger2;             // SHG_STAGGER2: waves 4 .. 7 enter the longitude stage this many 10 ns ticks behind waves 0 .. 3
 #endif
     int Qtot;
     const double* cpk4;       // repacked coefficients (see synthesis_fused.hip), S_nm negated where s_m = -1
@@ -98,6 +100,8 @@ struct RotParams {
 #define ROT_STAMP(ev)                                                                                         \
     do {                                                                                                      \
         if (P.tl && lane == 0) P.tl[((size_t)blockIdx.x * kWaves + wave) * 16 + (ev)] = wall_clock64();            \
+        if (P.tl && lane == 0 && ((ev) == 0 || (ev) == 12))                                                   \
+            P.tl[((size_t)blockIdx.x * kWaves + wave) * 16 + ((ev) == 0 ? 13 : 14)] = __builtin_amdgcn_s_memtime();  \
     } while (0)
 #else
 #define ROT_STAMP(ev)
@@ -520,9 +524,10 @@ __device__ __forceinline__ void rot_phase1(const RotParams& P, PanelPtr panel, c
         return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(table, voff, soff, 0));
     };
     const int bad = NS ? P.badmap[it] : -1;
-    __amdgpu_buffer_rsrc_t pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)it * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
+    const int it_tab = SHG_DBG(P, 16) ? 7 : it, bt_tab = SHG_DBG(P, 32) ? 0 : bt;       // experiment: every workgroup reads the same tables
+    __amdgpu_buffer_rsrc_t pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)it_tab * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
     const __amdgpu_buffer_rsrc_t cfu =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(NS ? P.cpk4 + (size_t)bt * P.Qtot * 128 : P.cpk4 + (size_t)bt * P.Qtot * 64), 0, 0xffffffffu, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(NS ? P.cpk4 + (size_t)bt_tab * P.Qtot * 128 : P.cpk4 + (size_t)bt_tab * P.Qtot * 64), 0, 0xffffffffu, 0x00020000);
     const unsigned pk_voff = (unsigned)lane * 16u;
     const unsigned cf_voff = NS ? (unsigned)lane * 16u : (unsigned)(fk * 8 + (fr & 7)) * 16u;
     int mode = NS && bad >= 0 ? 1 : 0;
@@ -628,6 +633,13 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
     const int bt = P.blockmap ? P.blockmap[2 * blockIdx.x] : (int)(blockIdx.x % nbt);
     const int it = P.blockmap ? P.blockmap[2 * blockIdx.x + 1] : (int)(blockIdx.x / nbt);
     const int fr = lane & 15, fk = lane >> 4;
+#ifdef SHG_EXPERIMENT
+    if (P.stagger > 0 && blockIdx.x < 256) {
+        const long long ticks = (long long)P.stagger * (long long)(((blockIdx.x >> 3) * 13) & 31) / 32;
+        const long long t0 = wall_clock64();
+        for (int i = 0; i < 100000 && (long long)wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     ROT_STAMP(0);
 
     double2_t* const panel = reinterpret_cast<double2_t*>(As + kRingDoubles);      // [(slot * 64 + row)]
@@ -654,6 +666,12 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
     ROT_STAMP(1);
     __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
     ROT_STAMP(2);
+#ifdef SHG_EXPERIMENT
+    if (P.stagger2 > 0 && wave >= 4) {
+        const long long t0 = wall_clock64();
+        for (int i = 0; i < 100000 && (long long)wall_clock64() - t0 < P.stagger2; ++i) __builtin_amdgcn_s_sleep(4);
+    }
+#endif
 
     // ---- phase 2: longitude stage
     if ((wave >> 2) < P.nct && !SHG_DBG(P, 4)) {
@@ -842,6 +860,8 @@ int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream
     P.npieces = P.nslot / 4;
 #ifdef SHG_EXPERIMENT
     P.dbg = experiment_switches();
+    P.stagger = getenv("SHG_STAGGER") ? atoi(getenv("SHG_STAGGER")) : 0;
+    P.stagger2 = getenv("SHG_STAGGER2") ? atoi(getenv("SHG_STAGGER2")) : 0;
 #endif
     P.Qtot = p->Qtot;
     P.cpk4 = p->cpk4;

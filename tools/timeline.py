@@ -36,6 +36,15 @@ torch.cuda.synchronize()
 print('avg ms per call (30 calls)', e0.elapsed_time(e1) / 30)
 del os.environ['SHG_TIMELINE_PTR']
 t = tl.cpu().numpy().astype(np.float64)
+if os.environ.get('SHG_TIMELINE_SAVE'):
+    np.save(os.environ['SHG_TIMELINE_SAVE'], tl.cpu().numpy())
+if (t[:, :, 13] > 0).any():    # shader-clock stamps beside the wall-clock ones at tile start / end: the clock the kernel runs at
+    dc = t[:, :, 14] - t[:, :, 13]
+    dw = (t[:, :, 12] - t[:, :, 0]) / 100.0
+    ok = (t[:, :, 13] > 0) & (t[:, :, 14] > 0) & (dw > 5)
+    mhz = dc[ok] / dw[ok]
+    print('in-kernel clock MHz: median %.0f p10 %.0f p90 %.0f' % (np.median(mhz), np.percentile(mhz, 10), np.percentile(mhz, 90)))
+    t[:, :, 13:] = 0
 t0 = t[t > 0].min()
 us = (t - t0) / 100.0          # 100 MHz counter
 us[t == 0] = np.nan
