@@ -67,7 +67,7 @@ ANA_DEGREE, ANA_GRID_STEP = 96, 0.5
 DDK_DEGREE, DDK_LEVEL_SCALE = 120, 1e11          # config 3: DDK5 weights 1e11 n^4 (grates/filter.py:334-349)
 SMOOTHER_DIM, SMOOTHER_EPOCHS = 1681, 3650       # config 5: d/o 40 state, ten years of daily solutions
 LEGS = ('synthesis', 'covariance', 'analysis', 'filters', 'smoother')
-FORBIDDEN_ENVIRONMENT = ('SHG_LIBRARY', 'SHG_DEBUG', 'SHG_TIMELINE_PTR')
+FORBIDDEN_ENVIRONMENT = ('SHG_LIBRARY', 'SHG_DEBUG', 'SHG_TIMELINE_PTR', 'SHG_STAGGER', 'SHG_STAGGER2')
 
 
 def parse_args(argv=None):
@@ -77,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--legs', default='all', help='comma separated subset of ' + ','.join(LEGS) + " (default: all; 'synthesis' always runs)")
     ap.add_argument('--ramp', type=int, default=300, help='untimed launches before the second measurement of the headline (device clock ramp)')
+    ap.add_argument('--idle-pass', type=int, default=1, help='1: also time the contract pass straight behind the idle setup (roofline.value_idle_start)')
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass of the staged path (0 = library default)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='seconds after which `--gpus N` run without a launcher kills its ranks (0 = never)')
@@ -673,6 +674,123 @@ def pmc_traffic(leg, kernels):
                                                                                   table.get('commit', 'round 4'), ' + '.join(found))
 
 
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or d.get(k) is None:
+            return None
+        d = d[k]
+    return d
+
+
+LEG_CODES = (('synthesis setup', 'setup'), ('synthesis pass behind the idle setup', 'idle_pass'), ('covariance (timed repeats)', 'covariance'),
+             ('filters (timed steps: block form, then dense form)', 'filters'), ('synthesis contract pass', 'CONTRACT_PASS'),
+             ('synthesis pass behind', 'ramp+pass'), ('synthesis check + CPU baseline', 'check+cpu'),
+             ('covariance extensions + CPU baseline', 'cov_ext+cpu'), ('filters checks + CPU baselines', 'filt_check+cpu'))
+
+
+def summarise(line):
+    """The driver's record keeps the contract's scalar fields and the scalars of `config`, `roofline` and `cpu_baseline` (strings cut
+    at ~140 characters); nested objects and further top-level keys are dropped.  So the figures of every leg that the metric names or the
+    review reads -- the second half of the metric first: covariance GFLOP/s with its fraction of the fp64 MFMA peak -- are repeated as
+    scalars of those three objects, the leg order as ONE short string, the grid as 'nlat x nlon'."""
+    cfg, roof = line['config'], line['roofline']
+    order = []
+    for item in cfg.get('leg_order', []):
+        order.append(next((code for text, code in LEG_CODES if item.startswith(text)), item))
+    cfg['leg_order'] = '>'.join(order)
+    if isinstance(cfg.get('grid'), (list, tuple)):
+        cfg['grid'] = 'x'.join(str(v) for v in cfg['grid'])
+    cfg['legs'] = ','.join(cfg.get('legs', [])) if isinstance(cfg.get('legs'), (list, tuple)) else cfg.get('legs')
+    if isinstance(cfg.get('process_group'), dict):
+        cfg['process_group'] = '{backend} world {world}'.format(**cfg['process_group'])
+    after = roof.pop('after_ramp', None) or {}
+    roof['frac_after_ramp'] = after.get('frac')
+    roof['avg_launch_ms_after_ramp'] = after.get('avg_launch_ms')
+    roof['value_after_ramp'] = line.get('value_after_ramp')
+    cov, ana, flt, smo = (line.get(k) if isinstance(line.get(k), dict) else None for k in ('covariance', 'analysis', 'filters', 'smoother'))
+    if cov:
+        cfg['covariance_workload'] = 'd/o {0} (P={1}) -> {2} deg grid, {3} of {4} parallels, {5} band(s)'.format(
+            COV_DEGREE, _get(cov, 'config', 'P'), COV_GRID_STEP, _get(cov, 'config', 'parallels'), _get(cov, 'config', 'nlat'), cov.get('n_gpus'))
+        roof['covariance_GFLOPs'] = cov.get('value')
+        roof['covariance_seconds'] = cov.get('seconds_median')
+        roof['covariance_kernel_TFLOPs'] = _get(cov, 'roofline', 'achieved')
+        roof['covariance_frac'] = _get(cov, 'roofline', 'frac')
+        roof['covariance_whole_leg_frac'] = (cov['value'] / 1e3 / MFMA_F64_PEAK_TFLOPS / max(cov.get('n_gpus') or 1, 1)) if cov.get('value') else None
+        roof['covariance_mfma_busy'] = _get(cov, 'roofline', 'mfma_busy')
+        if isinstance(line.get('cpu_baseline'), dict) and isinstance(cov.get('cpu_baseline'), dict):
+            line['cpu_baseline']['covariance_GFLOPs'] = cov['cpu_baseline'].get('value')
+            line['cpu_baseline']['covariance_sample'] = cov['cpu_baseline'].get('sample')
+    if ana:
+        roof['analysis_frac'] = _get(ana, 'roofline', 'frac')
+        roof['analysis_epochs_per_s'] = ana.get('value')
+        t_, a_ = _get(ana, 'roofline', 'traffic'), _get(ana, 'roofline', 'algorithmic_bytes_per_launch')
+        roof['analysis_traffic_ratio'] = (t_ / a_) if t_ and a_ else None
+        roof['analysis_ms_per_call'] = _get(ana, 'roofline', 'avg_launch_ms')
+    if flt:
+        roof['filters_block_frac'] = _get(flt, 'block', 'roofline', 'frac')
+        ms_ = _get(flt, 'block', 'roofline', 'avg_launch_ms')
+        roof['filters_block_us_per_step'] = 1e3 * ms_ if ms_ else None
+        roof['filters_dense_frac'] = _get(flt, 'dense', 'roofline', 'frac')
+        roof['filters_dense_TFLOPs'] = _get(flt, 'dense', 'roofline', 'achieved')
+        roof['filters_dense_mfma_busy'] = _get(flt, 'dense', 'roofline', 'mfma_busy')
+    if smo:
+        roof['smoother_epochs_per_s'] = smo.get('value')
+        roof['smoother_frac'] = _get(smo, 'roofline', 'frac')
+        roof['smoother_factor_frac'] = _get(smo, 'roofline', 'factor_frac')
+    roof['all_checks_ok'] = line.get('all_checks_ok')
+    return line
+
+
+LINE_LIMIT = 7900          # bytes: the driver keeps the last 8 KB of the output
+
+
+def compact_line(line, limit=LINE_LIMIT):
+    """The printed line within `limit` bytes: floats to 6 significant digits (`value`, `ms_per_step` to 9), one top-level
+    `traffic_source` instead of one per leg, strings of the leg objects cut at 72 characters, their notes left out; if that is not
+    enough the legs' per-repeat lists, `config` texts, CPU baselines and checks go, in that order (named in `dropped_for_line_limit`).  Contract fields, `config`, `roofline`, `cpu_baseline` are never dropped."""
+    keep9 = {'value', 'ms_per_step'}
+
+    def tidy(o, key=None, depth=0):
+        if isinstance(o, float):
+            if key and 'checksum' in key:
+                return o                                    # reproducibility checksums keep every digit
+            return float('{0:.{1}g}'.format(o, 9 if key in keep9 and depth <= 1 else 6))
+        if isinstance(o, dict):
+            return {k: tidy(v, k, depth + 1) for k, v in o.items() if not (depth >= 1 and k in ('traffic_note', 'note', 'phases_all', 'flops_per_epoch'))}
+        if isinstance(o, (list, tuple)):
+            return [tidy(v, key, depth + 1) for v in o]
+        if isinstance(o, str) and depth > 1 and len(o) > 72:
+            return o[:69] + '...'
+        return o
+
+    sources = []
+
+    def strip_sources(o):
+        if isinstance(o, dict):
+            src = o.pop('traffic_source', None)
+            if src and src not in sources:
+                sources.append(src)
+            for v in o.values():
+                strip_sources(v)
+    strip_sources(line)
+    if sources:
+        line['traffic_source'] = sources[0].split(': ')[0][:140]
+    line = tidy(line)
+    size = lambda o: len(json.dumps(o, separators=(',', ':')))          # noqa: E731
+    droppable = [(leg, key) for leg in ('smoother', 'filters', 'analysis', 'covariance') if isinstance(line.get(leg), dict)
+                 for key in ('seconds_all', 'config')]
+    droppable += [(leg, key) for leg in ('smoother', 'filters', 'analysis', 'covariance') if isinstance(line.get(leg), dict) for key in ('cpu_baseline', 'check')]
+    droppable += [(None, 'kernels'), (None, 'traffic_source')]
+    for leg, key in droppable:
+        if size(line) <= limit:
+            break
+        target = line if leg is None else line[leg]
+        if key in target:
+            target.pop(key)
+            line.setdefault('dropped_for_line_limit', []).append(key if leg is None else leg + '.' + key)
+    return line
+
+
 def algorithmic_bytes_per_solution(max_degree, nlat, nlon):
     """coefficients read once + grid written once; plan tables amortised over the batch."""
     return 8 * ((max_degree + 1) ** 2 + nlat * nlon)
@@ -802,6 +920,13 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
     wl.setup_synthesis()
     B = args.epochs
     leg_order = ['synthesis setup']
+    # the contract pass straight behind the (idle) setup, before any other leg: reported as `roofline.value_idle_start`, so that what the
+    # leg order is worth is a number of the record and not a paragraph of DESIGN.md
+    idle_elapsed, idle_prof = (None, None)
+    if args.idle_pass:
+        barrier()
+        idle_elapsed, idle_prof = timed_steps(args.warmup, args.steps)
+        leg_order.append('synthesis pass behind the idle setup')
     cov_state = None
     if 'covariance' in args.leg_set:
         from grates_amd import distributed as gd
@@ -838,6 +963,7 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
             return rate, avg_ms, epochs_per_launch
         achieved, lon_avg_ms, epochs_per_launch = kernel_rate(prof)
         ramp_achieved, ramp_avg_ms, _ = kernel_rate(ramp_prof)
+        idle_achieved, idle_avg_ms, _ = kernel_rate(idle_prof) if idle_prof is not None else (None, None, None)
         traffic, traffic_source = pmc_traffic('synthesis', [wl.kernel_name])
         kernels = {k: {'ms_total': round(v[0], 4), 'launches': int(v[1]), 'avg_us': round(1e3 * v[0] / max(v[1], 1), 3)} for k, v in prof.items()}
         config = {'workload': 'batch of {0} monthly solutions d/o {1} -> {2} deg GeographicGrid ({3}x{4}), kernel {5}, per GPU'.format(
@@ -877,6 +1003,9 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
                 'whole_path_GBs': per_solution * B * args.steps / elapsed / 1e9,
                 'after_ramp': {'achieved': ramp_achieved, 'frac': (ramp_achieved / HBM_PEAK_GBS) if ramp_achieved else None, 'avg_launch_ms': ramp_avg_ms,
                                'whole_path_GBs': per_solution * B * args.steps / ramp_elapsed / 1e9},
+                'value_idle_start': (world * B * args.steps / idle_elapsed) if idle_elapsed else None,
+                'frac_idle_start': (idle_achieved / HBM_PEAK_GBS) if idle_achieved else None,
+                'avg_launch_ms_idle_start': idle_avg_ms,
             },
             'kernels': kernels,
         }
@@ -906,7 +1035,8 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
         line.update(legs)
         checks = [line.get('check')] + [legs[k].get('check') for k in legs if isinstance(legs[k], dict)]
         line['all_checks_ok'] = all(c.get('ok', True) for c in checks if isinstance(c, dict))
-        emit(json.dumps(line))
+        line = compact_line(summarise(line))
+        emit(json.dumps(line, separators=(',', ':')))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -964,7 +1094,7 @@ def covariance_leg_report(args, wl, rank, world, state):
         'n_gpus': world, 'scaling': 'strong',
         'config': {'workload': 'd/o {0} (P = {1}, Sigma {2:.2f} GB replicated), parallels 0..{3} of {4} x {5} meridians in {6} latitude band(s) of {7} parallels, all_gather of sigma'.format(
             COV_DEGREE, P, P * P * 8 / 1e9, total, nlat, nlon, world, [b1 - b0 for b0, b1 in bands]),
-            'sigma_recipe': wl.cov_recipe, 'flops': flops, 'full_grid_flops': 2.0 * nlat * nlon * P * (P + 1.0), 'repeats': len(times)},
+            'P': P, 'parallels': total, 'nlat': nlat, 'sigma_recipe': wl.cov_recipe, 'flops': flops, 'full_grid_flops': 2.0 * nlat * nlon * P * (P + 1.0), 'repeats': len(times)},
         'seconds_median': median, 'seconds_min': best, 'seconds_all': times, 'GFLOPs_best': flops / best / 1e9,
         'roofline': {'kernel': 'gemm_f64_kernel<MODE_COVPROP>', 'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F64_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': (achieved / MFMA_F64_PEAK_TFLOPS) if achieved else None, 'traffic': None,

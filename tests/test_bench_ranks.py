@@ -118,12 +118,38 @@ def _rank(rank, world, port, out_dir):
             f.write(lines[0])
 
 
+def _check_record(line, world):
+    """What the driver's record keeps: the contract's scalars and the SCALARS of config / roofline / cpu_baseline.  The whole metric must
+    be readable from those: both halves (solutions/s, covariance GFLOP/s with its fraction of the MFMA peak), the leg order as one
+    string, the grid, the world -- and the line must fit the 8 KB the driver keeps of the output."""
+    text = json.dumps(line, separators=(',', ':'))
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    cfg, roof = line['config'], line['roofline']
+    for obj in (cfg, roof) + ((line['cpu_baseline'],) if line['cpu_baseline'] else ()):
+        for k, v in obj.items():
+            if k == 'kernels':
+                continue
+            assert v is None or isinstance(v, (int, float, str, bool)), (k, v)
+            assert not isinstance(v, str) or len(v) <= 140, (k, len(v))
+    assert cfg['leg_order'].startswith('setup>idle_pass>covariance>') and '>CONTRACT_PASS>' in cfg['leg_order']
+    assert cfg['grid'] == '12x24' and 'parallels' in cfg['covariance_workload'] and cfg['legs'].startswith('analysis,covariance')
+    if world > 1 or 'process_group' in cfg:
+        assert cfg['process_group'] == 'gloo world {0}'.format(world)
+    cov = line['covariance']
+    assert roof['covariance_GFLOPs'] == pytest.approx(cov['value']) and roof['covariance_seconds'] == pytest.approx(cov['seconds_median'])
+    assert roof['covariance_frac'] == pytest.approx(cov['roofline']['frac']) and roof['covariance_kernel_TFLOPs'] > 0
+    assert roof['smoother_epochs_per_s'] == pytest.approx(line['smoother']['value']) and roof['all_checks_ok'] is True
+    assert 'traffic_source' not in roof
+
+
 def _expected_sigma():
     return torch.sqrt(1.0 + torch.arange(7 * 5, dtype=torch.float64)).numpy()       # the stand-in's own arithmetic
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 7, 8])
 def test_rank_function_gloo(world, tmp_path):
+    """worlds 7 and 8: the pre-flight of the driver's 8-GPU run -- ragged latitude bands (7 parallels over 7 / 8 ranks: bands of one
+    parallel and, for 8 ranks, an EMPTY band), 11 smoother epochs over 8 ranks, the line says n_gpus 8 and the world of its group"""
     mp.spawn(_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     line = json.loads(open(tmp_path / 'line.json').read())
     assert line['metric'] == bench.METRIC and line['unit'] == 'solutions/s' and line['n_gpus'] == world
@@ -132,7 +158,9 @@ def test_rank_function_gloo(world, tmp_path):
     assert line['value_after_ramp'] > 0 and line['cpu_baseline'] is None                      # the CPU baseline runs at N = 1 only
     assert line['check']['epochs_checked'] == 1                                               # ... the oracle check of the output does not
     assert line['roofline']['bound'] == 'hbm' and line['roofline']['avg_launch_ms'] == pytest.approx(0.5)
-    assert line['roofline']['after_ramp']['avg_launch_ms'] == pytest.approx(0.5)
+    assert line['roofline']['avg_launch_ms_after_ramp'] == pytest.approx(0.5) and line['roofline']['value_after_ramp'] == line['value_after_ramp']
+    assert line['roofline']['value_idle_start'] > 0 and line['roofline']['avg_launch_ms_idle_start'] == pytest.approx(0.5)
+    _check_record(line, world)
     sm = line['smoother']
     assert sm['n_gpus'] == world and sum(sm['epochs_per_rank']) == 11 and sm['check']['ok'] and line['all_checks_ok']
     assert sm['check']['longest_shard'] == max(sm['epochs_per_rank'])
@@ -153,6 +181,7 @@ def test_rank_function_single_process(monkeypatch):
     line = bench.run_rank(args, workload_factory=StubWorkload, emit=lines.append)
     assert json.loads(lines[0]) == json.loads(json.dumps(line))
     assert line['n_gpus'] == 1 and line['cpu_baseline']['kind'] == 'port' and line['check']['epochs_checked'] == 5
+    _check_record(line, 1)
     assert line['smoother']['epochs_per_rank'] == [bench.SMOOTHER_EPOCHS] and line['all_checks_ok']
     assert line['covariance']['sigma_checksum'] == pytest.approx(_expected_sigma().sum(), rel=0, abs=1e-12)
     assert line['covariance']['seconds_min'] <= line['covariance']['seconds_median']

@@ -100,5 +100,5 @@ def test_bench_rank_function_over_rccl():
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
     line = json.loads([ln for ln in done.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['all_checks_ok'] and line['check']['ok']
-    assert line['config']['process_group'] == {'backend': 'nccl', 'world': 1}
+    assert line['config']['process_group'] == 'nccl world 1'
     assert line['covariance']['check']['ok'] and line['smoother']['check']['ok']
