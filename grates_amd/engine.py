@@ -265,12 +265,12 @@ def cached_plan(max_degree, colat, kn, meridians):
     for a in (np.int64(max_degree), np.int64(torch.cuda.current_device()), colat, kn, meridians):
         h.update(np.ascontiguousarray(a).tobytes())
     key = h.hexdigest()
-    plan = _plan_cache.get(key)
+    plan = _plan_cache.pop(key, None)
     if plan is None:
         if len(_plan_cache) >= _PLAN_CACHE_LIMIT:
-            _plan_cache.pop(next(iter(_plan_cache)))
+            _plan_cache.pop(next(iter(_plan_cache)))           # least recently used: a hit moves its plan to the end
         plan = Plan(max_degree, colat, kn, meridians)
-        _plan_cache[key] = plan
+    _plan_cache[key] = plan
     return plan
 
 

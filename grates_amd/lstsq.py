@@ -633,20 +633,20 @@ class TikhonovRegularization(NormalEquations):
 
 
 def accumulate_normals(normal_equations, variance_factors):
-    """Accumulate normal equations with given variance factors (grates/lstsq.py:1091-1119)."""
-    def host(v):
-        return engine.to_host(v) if _is_tensor(v) else v
-    output_matrix = normal_equations[0].matrix.copy()
-    output_matrix._scale(1 / variance_factors[0])
-    output_rhs = host(normal_equations[0].right_hand_side).copy() / variance_factors[0]
-    lPl = normal_equations[0].observation_square_sum / variance_factors[0]
-    obs_count = normal_equations[0].observation_count
-    for k in range(1, len(normal_equations)):
-        output_matrix._axpy(1 / variance_factors[k], normal_equations[k].matrix)
-        output_rhs += host(normal_equations[k].right_hand_side).copy() / variance_factors[k]
-        lPl += normal_equations[k].observation_square_sum / variance_factors[k]
-        obs_count += normal_equations[k].observation_count
-    return NormalEquations(output_matrix, output_rhs, lPl, obs_count)
+    """Weighted sum of normal equation systems, N = sum_k N_k / s_k^2 (same for the right-hand side and l^T P l); the observation
+    counts add up unweighted (grates/lstsq.py:1091-1119)."""
+    if len(normal_equations) != len(variance_factors) or len(normal_equations) == 0:
+        raise ValueError('accumulate_normals: one variance factor per system expected')
+    weights = [1.0 / factor for factor in variance_factors]
+    matrix = normal_equations[0].matrix.copy()
+    matrix._scale(weights[0])
+    for part, weight in zip(normal_equations[1:], weights[1:]):
+        matrix._axpy(weight, part.matrix)
+    sides = [engine.to_host(part.right_hand_side) if _is_tensor(part.right_hand_side) else part.right_hand_side for part in normal_equations]
+    right_hand_side = sum(side * weight for side, weight in zip(sides[1:], weights[1:]), sides[0] * weights[0])
+    square_sum = sum(part.observation_square_sum * weight for part, weight in zip(normal_equations, weights))
+    count = sum(part.observation_count for part in normal_equations)
+    return NormalEquations(matrix, right_hand_side, square_sum, count)
 
 
 def compute_variance_factors(normal_equations, combined_normals, solution, variance_factors):
