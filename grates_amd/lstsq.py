@@ -643,7 +643,7 @@ def accumulate_normals(normal_equations, variance_factors):
     for part, weight in zip(normal_equations[1:], weights[1:]):
         matrix._axpy(weight, part.matrix)
     sides = [engine.to_host(part.right_hand_side) if _is_tensor(part.right_hand_side) else part.right_hand_side for part in normal_equations]
-    right_hand_side = sum(side * weight for side, weight in zip(sides[1:], weights[1:]), sides[0] * weights[0])
+    right_hand_side = sum((side * weight for side, weight in zip(sides[1:], weights[1:])), sides[0] * weights[0])
     square_sum = sum(part.observation_square_sum * weight for part, weight in zip(normal_equations, weights))
     count = sum(part.observation_count for part in normal_equations)
     return NormalEquations(matrix, right_hand_side, square_sum, count)
