@@ -81,7 +81,7 @@ inline int experiment_switches() {
 }
 #else
 #define SHG_DBG(P, bits) 0
-#if (defined(SHG_ROT_X) && SHG_ROT_X) || (defined(SHG_GEMM_X) && SHG_GEMM_X) || (defined(SHG_ANA_X) && SHG_ANA_X) || (defined(SHG_FILT_X) && SHG_FILT_X)
+#if (defined(SHG_ROT_X) && SHG_ROT_X) || (defined(SHG_PIPE_X) && SHG_PIPE_X) || (defined(SHG_GEMM_X) && SHG_GEMM_X) || (defined(SHG_ANA_X) && SHG_ANA_X) || (defined(SHG_FILT_X) && SHG_FILT_X)
 #error "SHG_ROT_X / SHG_GEMM_X / SHG_ANA_X / SHG_FILT_X are timing experiments: build with -DSHG_EXPERIMENT (make timeline)"
 #endif
 #endif
@@ -207,6 +207,8 @@ struct shg_plan {
     int* itemtab_d = nullptr;   // work items of the fused kernel's Legendre stage, [8 waves][nrec][4]
     int itemtab_nrec = 0, itemtab_ntrip = 0;
     int itemtab_rot = -1;       // panel slot convention of the work items: 0 = 4-fold kernel, R = rotation-folded kernel
+    int* itemtab2_d = nullptr;  // the same items for the four waves of the pipelined rotation-folded kernel, packed records
+    int itemtab2_nrec = 0, itemtab2_ntrip = 0;
     int* blockmap_d = nullptr;  // XCD-aware (epoch tile, parallel tile) order of the fused kernel's workgroups
     int blockmap_nbt = 0, blockmap_nit = 0;
     std::vector<char> ns_badrow;    // per northern parallel: mirror image deviates too much to share the northern table
@@ -227,7 +229,7 @@ struct shg_plan {
     bool ana_rowconst = false;  // the weights of the cached operator are constant along every parallel (geographic and Gauss grids)
     double* ana_trig = nullptr; // trig table of the fused transform kernel in chunk order [chunk][8 columns][4 groups x MT x 16 orders], zero padded
     int ana_trig_mt = 0;
-    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 5 fused kernel with 32-row panels (two workgroups per CU), 6 rotation-folded fused kernel
+    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 5 fused kernel with 32-row panels (two workgroups per CU), 6 rotation-folded fused kernel, 7 its pipelined variant (one wave per SIMD)
 
     // users of the plan are serialised (PlanGuard): its tables are built lazily and its workspaces are per plan, not per stream
     std::mutex mtx;
@@ -257,6 +259,8 @@ int rot_choose(int nlon, const double* lon_h, int N);
 int rot_applicable(const shg_plan* p);
 int build_rot_trig(shg_plan* p, const double* lon_h);
 int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
+int pipe_applicable(const shg_plan* p);          // the pipelined variant of the rotation-folded kernel (synthesis_rot.hip, path 7)
+int synthesis_pipe(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 int fused32_applicable(const shg_plan* p);
 int synthesis_fused32(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 

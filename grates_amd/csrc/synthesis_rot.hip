@@ -87,6 +87,8 @@ struct RotParams {
     const double* pkf;
     const int4* itemtab;
     int nrec, ntrip;
+    const int2* itemtab2;     // pipelined kernel: packed work items of its four waves (see build_item_table)
+    int nrec2, ntrip2;
 #ifdef SHG_TIMELINE
     unsigned long long* tl;
 #endif
@@ -125,6 +127,20 @@ __device__ __forceinline__ void glds16(const double* gbase, unsigned lane_off, u
 #ifndef SHG_ROT_X
 #define SHG_ROT_X 0          // experiment switches (timing only): 1 no issue-side stream bookkeeping, 2 no consumer-side bookkeeping
 #endif
+
+typedef int int4_s __attribute__((ext_vector_type(4)));
+
+// 8-byte non-temporal buffer store with the wave-uniform part of the address in the SCALAR offset (no vector add per store), as
+// inline asm.  The scalar offset travels through M0, written by an SALU instruction of the statement itself: hipcc reloads
+// spilled scalars with v_readlane right in front of an asm statement, and an SGPR written by the VALU needs five wait states
+// before a vector memory instruction may read it -- an SALU read does not.  (M0 is free: gfx9 LDS instructions do not read it,
+// and every LDS-DMA of the trig stream sets it in its own statement.)  Stores of at most 8 bytes have no store-data hazard.
+__device__ __forceinline__ void store_b64_soff(double v, int4_s rsrc, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_store_dwordx2 %0, %1, %2, m0 offen nt"
+                 :
+                 : "v"(v), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -594,9 +610,13 @@ do {                                                                            
         }
         int4_v c0 = recs[0], c1 = recs[1], c2 = recs[2];
         int4_v n0 = recs[3], n1 = recs[4], n2 = recs[5], n3 = recs[6];
+        // (scheduling barriers: the order of the first loads must be the order the loop consumes them in, see pipe_phase1)
         ROT_P1_ISSUE(c0, xal, xah, xbl, xbh);
+        __builtin_amdgcn_sched_barrier(0);
         ROT_P1_ISSUE(c1, yal, yah, ybl, ybh);
+        __builtin_amdgcn_sched_barrier(0);
         ROT_P1_ISSUE(c2, zal, zah, zbl, zbh);
+        __builtin_amdgcn_sched_barrier(0);
         for (int trip = 0; trip < P.ntrip; ++trip) {
             const int4_v a3 = n0, a4 = n1, a5 = n2, a6 = n3;
             crec_t* nr = recs + 4 * trip + 7;
@@ -692,6 +712,405 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
         wait_vmcnt<0>();
     }
     ROT_STAMP(12);
+}
+
+// =====================================================================================================================
+// Pipelined variant (round 5): ONE wave per SIMD, the accumulators of a unit twice.
+//
+// What bounds synthesis_rot_kernel is not its instruction count but when it stores: every wave issues the 40 stores of a
+// unit in one burst at the end of the unit, all eight waves of a workgroup at about the same time, no wave stores anything
+// during the Legendre stage or the k-loop of a unit, and a wave's next k-loop waits for the acknowledgement of its burst
+// (one in-order vmcnt for stores and trig pieces).  Measured (tools/timeline.py, round 5): the no-store kernel takes 0.38 ms,
+// the stores alone 0.37 ms, together 0.50 ms; staggering workgroups or waves moves nothing (the chip falls back into step).
+//
+// Here a wave owns 512 registers: the 2 R images of unit u stay in registers while unit u + 1 accumulates into a second set,
+// and leave during that k-loop, a group of images behind every class of the K sequence (8-byte stores straight from the
+// accumulator registers, 4 rows x 128 bytes per instruction, wave-uniform address part in the scalar offset: no lane exchange
+// and no vector address arithmetic).  The trig stream no longer shares the in-order counter with the stores inside the
+// k-loop: the four waves of a workgroup (one row tile = one epoch each) walk the column tiles together, the pieces of column tile
+// ct + 1 are copied into the second half of a double buffer by LDS-DMA at the start of unit ct, and the only wait for them
+// stands at the end of the unit (all of the unit's stores are younger than they: vmcnt(63) never waits for a recent store),
+// followed by the workgroup's one barrier per unit.
+// =====================================================================================================================
+constexpr int kPipeWaves = 4;
+#ifndef SHG_PIPE_X
+#define SHG_PIPE_X 0           // experiment switches of the pipelined kernel's Legendre stage (timing only): 1 no arithmetic, 2 no operand loads
+#endif
+
+typedef int int8_v __attribute__((ext_vector_type(8)));
+
+// Legendre stage of the pipelined kernel.  With one wave per SIMD nothing hides the end of an order -- the last MFMA's latency, the
+// exchange between the hemispheres, the write of the panel row -- unless the wave itself has other work: every wave runs TWO
+// independent item lists (streams A and B, the lists of waves w and w + 4 of an eight-wave dealing) interleaved item by item,
+// each with its own accumulator pair and four operand sets (three items in flight per stream).  Records are packed into two words
+// (x = first octet | second octet << 16, y = panel slot | flags << 16; four records per 32-byte scalar load).
+template <bool NS>
+__device__ __forceinline__ void pipe_phase1(const RotParams& P, double2_t* panel, const int2* recs_a, const int2* recs_b, int bt, int it, int lane) {
+    const int fr = lane & 15, fk = lane >> 4;
+    constexpr int ASTRIDE = NS ? 128 : 64;
+    typedef const int8_v __attribute__((address_space(4))) crec_t;
+    auto ld16 = [](__amdgpu_buffer_rsrc_t table, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(table, voff, soff, 0));
+    };
+    const int bad = NS ? P.badmap[it] : -1;
+    __amdgpu_buffer_rsrc_t pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)it * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cfu =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(NS ? P.cpk4 + (size_t)bt * P.Qtot * 128 : P.cpk4 + (size_t)bt * P.Qtot * 64), 0, 0xffffffffu, 0x00020000);
+    const unsigned pk_voff = (unsigned)lane * 16u;
+    const unsigned cf_voff = NS ? (unsigned)lane * 16u : (unsigned)(fk * 8 + (fr & 7)) * 16u;
+    int mode = NS && bad >= 0 ? 1 : 0;
+    int prow = lane;
+    const bool arow = NS || fr < 8;
+    double4_t accA0 = {0.0, 0.0, 0.0, 0.0}, accA1 = accA0, accB0 = accA0, accB1 = accA0;
+    const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+    double sgm = (mode == 0 && fr >= 8) ? -1.0 : 1.0;
+    bool freshA = true, freshB = true;
+
+#define PIPE_P1_ISSUE(rx, S)                                                                      \
+    do {                                                                                          \
+        const unsigned lo_ = (unsigned)(rx) & 0xffffu, hi_ = (unsigned)(rx) >> 16;                \
+        if (SHG_PIPE_X & 2) break;          /* experiment: no operand loads */                     \
+        al##S = ld16(cfu, cf_voff, lo_ * (ASTRIDE * 8u));                                         \
+        bl##S = ld16(pku, pk_voff, lo_ * 1024u);                                                  \
+        ah##S = ld16(cfu, cf_voff, hi_ * (ASTRIDE * 8u));                                         \
+        bh##S = ld16(pku, pk_voff, hi_ * 1024u);                                                  \
+    } while (0)
+
+#define PIPE_P1_CONSUME(ry, S, Q)                                                                                   \
+    do {                                                                                                            \
+        const int fl_ = (ry) >> 16;                                                                                 \
+        if (SHG_PIPE_X & 1) {               /* experiment: loads only */                                            \
+            asm volatile("" ::"v"(al##S.x), "v"(al##S.y), "v"(ah##S.x), "v"(ah##S.y), "v"(bl##S.x), "v"(bl##S.y), "v"(bh##S.x), "v"(bh##S.y)); \
+            break;                                                                                                  \
+        }                                                                                                           \
+        if (fl_ & 1) {                                                                                              \
+            const double ax_ = NS ? al##S.x : (arow ? al##S.x : 0.0), ay_ = NS ? al##S.y : (arow ? al##S.y : 0.0);  \
+            if (fresh##Q) {                                                                                         \
+                acc##Q##0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, bl##S.x, zero4, 0, 0, 0);                     \
+                acc##Q##1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, bl##S.y, zero4, 0, 0, 0);                     \
+            } else {                                                                                                \
+                acc##Q##0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, bl##S.x, acc##Q##0, 0, 0, 0);                 \
+                acc##Q##1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, bl##S.y, acc##Q##1, 0, 0, 0);                 \
+            }                                                                                                       \
+            fresh##Q = false;                                                                                       \
+        }                                                                                                           \
+        if (fl_ & 2) {                                                                                              \
+            const double ax_ = NS ? ah##S.x : (arow ? ah##S.x : 0.0), ay_ = NS ? ah##S.y : (arow ? ah##S.y : 0.0);  \
+            acc##Q##0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, bh##S.x, acc##Q##0, 0, 0, 0);                     \
+            acc##Q##1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, bh##S.y, acc##Q##1, 0, 0, 0);                     \
+        }                                                                                                           \
+        if (fl_ & 4) {                                  /* last item of an order: see rot_phase1 */                  \
+            double vc_ = acc##Q##0[0] + acc##Q##1[0], vs_ = acc##Q##0[1] + acc##Q##1[1];                            \
+            if (NS) {                                                                                               \
+                const double oc_ = acc##Q##0[2] + acc##Q##1[2], os_ = acc##Q##0[3] + acc##Q##1[3];                  \
+                const double xc_ = fr < 8 ? vc_ : oc_, xs_ = fr < 8 ? vs_ : os_;                                   \
+                const double rc_ = swap_half_row(xc_), rs_ = swap_half_row(xs_);                                   \
+                vc_ = fma(sgm, xc_, rc_);                                                                           \
+                vs_ = fma(sgm, xs_, rs_);                                                                           \
+            }                                                                                                       \
+            if (!NS || mode == 0 || fr < 8) panel[((ry) & 0xffff) * 64 + prow] = (double2_t){vc_, vs_};             \
+            fresh##Q = true;                                                                                        \
+        }                                                                                                           \
+    } while (0)
+
+    double2 al0 = {0, 0}, ah0 = {0, 0}, bl0 = {0, 0}, bh0 = {0, 0}, al1 = {0, 0}, ah1 = {0, 0}, bl1 = {0, 0}, bh1 = {0, 0};
+    double2 al2 = {0, 0}, ah2 = {0, 0}, bl2 = {0, 0}, bh2 = {0, 0}, al3 = {0, 0}, ah3 = {0, 0}, bl3 = {0, 0}, bh3 = {0, 0};
+    double2 al4 = {0, 0}, ah4 = {0, 0}, bl4 = {0, 0}, bh4 = {0, 0}, al5 = {0, 0}, ah5 = {0, 0}, bl5 = {0, 0}, bh5 = {0, 0};
+    double2 al6 = {0, 0}, ah6 = {0, 0}, bl6 = {0, 0}, bh6 = {0, 0}, al7 = {0, 0}, ah7 = {0, 0}, bl7 = {0, 0}, bh7 = {0, 0};
+    crec_t* ra = reinterpret_cast<crec_t*>(reinterpret_cast<unsigned long long>(recs_a));
+    crec_t* rb = reinterpret_cast<crec_t*>(reinterpret_cast<unsigned long long>(recs_b));
+    for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
+        if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
+            mode = 2;
+            sgm = 1.0;
+            prow = lane + 8;
+            pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
+        }
+        // per stream: records of the current trip (items 0 .. 3; items 0 .. 2 are in flight in sets 0 .. 2 / 4 .. 6) and of the next one
+        int8_v ca = ra[0], cb = rb[0], na = ra[1], nb = rb[1];
+        // (the scheduling barriers keep the order of the first loads: left alone hipcc sorts them so that the set the loop consumes first is
+        //  loaded LAST, and its wait-count analysis then drains every load at the head of every trip -- s_waitcnt vmcnt(4) instead of (24))
+        PIPE_P1_ISSUE(ca[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_P1_ISSUE(cb[0], 4);
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_P1_ISSUE(ca[2], 1);
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_P1_ISSUE(cb[2], 5);
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_P1_ISSUE(ca[4], 2);
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_P1_ISSUE(cb[4], 6);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int trip = 0; trip < P.ntrip2; ++trip) {
+            PIPE_P1_ISSUE(ca[6], 3);
+            PIPE_P1_CONSUME(ca[1], 0, A);
+            PIPE_P1_ISSUE(cb[6], 7);
+            PIPE_P1_CONSUME(cb[1], 4, B);
+            PIPE_P1_ISSUE(na[0], 0);
+            PIPE_P1_CONSUME(ca[3], 1, A);
+            PIPE_P1_ISSUE(nb[0], 4);
+            PIPE_P1_CONSUME(cb[3], 5, B);
+            PIPE_P1_ISSUE(na[2], 1);
+            PIPE_P1_CONSUME(ca[5], 2, A);
+            PIPE_P1_ISSUE(nb[2], 5);
+            PIPE_P1_CONSUME(cb[5], 6, B);
+            PIPE_P1_ISSUE(na[4], 2);
+            PIPE_P1_CONSUME(ca[7], 3, A);
+            PIPE_P1_ISSUE(nb[4], 6);
+            PIPE_P1_CONSUME(cb[7], 7, B);
+            ca = na;
+            cb = nb;
+            na = ra[trip + 2];
+            nb = rb[trip + 2];
+        }
+    }
+#undef PIPE_P1_ISSUE
+#undef PIPE_P1_CONSUME
+}
+
+// A value parked in the accumulator half of the register file.  gfx950 gives a wave 512 registers, but vector ALU instructions
+// address only the first 256 (the architectural VGPRs); the others (AGPRs) can be MFMA accumulators and the DATA of loads and
+// stores.  The images of a unit wait for their stores there: the empty statement ties its result to an AGPR, hipcc moves the
+// value across with v_accvgpr_write and the architectural registers are free for the next unit's sums.
+__device__ __forceinline__ double park(double v) {
+    double a;
+    asm volatile("; park" : "=a"(a) : "0"(v));
+    return a;
+}
+// 8-byte store as store_b64_soff with its data in AGPRs
+__device__ __forceinline__ void store_b64_soff_acc(double v, int4_s rsrc, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_store_dwordx2 %0, %1, %2, m0 offen nt"
+                 :
+                 : "a"(v), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+template <bool NS, int R>
+__device__ __forceinline__ void pipe_unit(const RotParams& P, double (&Y)[2 * R][4], const double2_t* tb, const double2_t* prow,
+                                          double4_t z4, bool pending, int4_s rs, const unsigned (&va)[4], const unsigned (&vd)[4], int ct_prev) {
+    double4_t X[2 * R];
+    using T = RotTraits<R>;
+    const double4_t kZero4 = {0.0, 0.0, 0.0, 0.0};
+    const int n2 = P.nlon >> 1, nR = P.nlon / R;
+    int pf = 0;
+    double2_t tx, abx, ty = {0.0, 0.0}, aby = {0.0, 0.0};
+#define PIPE_FETCH(T_, AB_)                        \
+    do {                                           \
+        T_ = tb[pf * 64];                          \
+        AB_ = prow[pf * 256];                      \
+        pf = pf + 1 < P.npieces ? pf + 1 : pf;     /* (the fetch behind the last k-step re-reads the last one) */ \
+    } while (0)
+#define PIPE_MFMA2(A0, T_, AB_)                                                                     \
+    X[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, X[A0], 0, 0, 0);                      \
+    X[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, X[A0 + 1], 0, 0, 0)
+#define PIPE_MFMA4(A0, T_, AB_)                                                                     \
+    X[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, X[A0], 0, 0, 0);                      \
+    X[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.y, X[A0 + 1], 0, 0, 0);              \
+    X[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, X[A0 + 2], 0, 0, 0);              \
+    X[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, X[A0 + 3], 0, 0, 0)
+#define PIPE_MFMA2_FIRST(A0, T_, AB_)                                                               \
+    X[A0] = (A0) == 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, X[A0], 0, 0, 0)            \
+                      : __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, kZero4, 0, 0, 0);         \
+    X[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, kZero4, 0, 0, 0)
+#define PIPE_MFMA4_FIRST(A0, T_, AB_)                                                               \
+    X[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, kZero4, 0, 0, 0);                     \
+    X[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.y, kZero4, 0, 0, 0);                 \
+    X[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, kZero4, 0, 0, 0);                 \
+    X[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, kZero4, 0, 0, 0)
+    // one class: k-steps in pairs on the register sets (tx, abx) / (ty, aby), as in rot_phase2
+#define PIPE_CLASS(C, MF, A0, NACC)                                                                       \
+    {                                                                                                     \
+        const int nk_ = P.cls_nk[C];                                                                      \
+        int i_ = 0;                                                                                       \
+        if (nk_ >= 2) {                                                                                   \
+            PIPE_FETCH(ty, aby);                                                                          \
+            MF##_FIRST(A0, tx, abx);                                                                      \
+            PIPE_FETCH(tx, abx);                                                                          \
+            MF(A0, ty, aby);                                                                              \
+            i_ = 2;                                                                                       \
+        } else if (nk_ == 1) {                                                                            \
+            PIPE_FETCH(ty, aby);                                                                          \
+            MF##_FIRST(A0, tx, abx);                                                                      \
+            tx = ty;                                                                                      \
+            abx = aby;                                                                                    \
+            i_ = 1;                                                                                       \
+        } else {                                                                                          \
+            _Pragma("unroll") for (int z_ = ((A0) == 0 ? 1 : 0); z_ < (NACC); ++z_) X[(A0) + z_] = kZero4; \
+        }                                                                                                 \
+        for (; i_ + 2 <= nk_; i_ += 2) {                                                                  \
+            PIPE_FETCH(ty, aby);                                                                          \
+            MF(A0, tx, abx);                                                                              \
+            PIPE_FETCH(tx, abx);                                                                          \
+            MF(A0, ty, aby);                                                                              \
+        }                                                                                                 \
+        if (i_ < nk_) {                                                                                   \
+            PIPE_FETCH(ty, aby);                                                                          \
+            MF(A0, tx, abx);                                                                              \
+            tx = ty;                                                                                      \
+            abx = aby;                                                                                    \
+        }                                                                                                 \
+    }
+    PIPE_FETCH(tx, abx);                                     // fragments of the first k-step
+    X[0] = z4;                                               // order 0 does not depend on the longitude: start value of CA_0 (rows fk + 4 reg)
+#pragma unroll
+    for (int c = 0; c < T::kClasses; ++c) {
+        if (c < T::kTwo) {
+            PIPE_CLASS(c, PIPE_MFMA2, 2 * c, 2)
+        } else {
+            PIPE_CLASS(c, PIPE_MFMA4, 2 * T::kTwo + 4 * (c - T::kTwo), 4)
+        }
+        if (pending) {
+            // the images t = c, c + classes, ... of the previous unit leave
+#pragma unroll
+            for (int t = c; t < 2 * R; t += T::kClasses) {
+                const int k = t < R ? t : t - R;
+                const bool ascending = t < R;
+                int w = n2 + k * nR - (ascending ? 0 : P.nd);
+                w = w >= P.nlon ? w - P.nlon : w;
+                const unsigned soff = (unsigned)(ascending ? w + 16 * ct_prev : w + P.nd - 16 * ct_prev - 16) * 8u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) store_b64_soff_acc(Y[t][r], rs, ascending ? va[r] : vd[r], soff);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rot_images<R>(X, r);
+    // the images wait for their stores in the accumulator registers
+#pragma unroll
+    for (int t = 0; t < 2 * R; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[t][r] = park(X[t][r]);
+#undef PIPE_CLASS
+#undef PIPE_MFMA2
+#undef PIPE_MFMA4
+#undef PIPE_MFMA2_FIRST
+#undef PIPE_MFMA4_FIRST
+#undef PIPE_FETCH
+}
+
+// the 2 R images of a unit as 8-byte stores (ncol = 16, or 8 for a half tile at the end of the fundamental domain)
+template <int R>
+__device__ __forceinline__ void pipe_flush(const double (&Y)[2 * R][4], int4_s rs, const unsigned (&va)[4], const unsigned (&vd)[4], int nlon, int nd, int ct, int ncol) {
+    const int n2 = nlon >> 1, nR = nlon / R;
+#pragma unroll
+    for (int t = 0; t < 2 * R; ++t) {
+        const int k = t < R ? t : t - R;
+        const bool ascending = t < R;
+        int w = n2 + k * nR - (ascending ? 0 : nd);
+        w = w >= nlon ? w - nlon : w;
+        const unsigned soff = (unsigned)(ascending ? w + 16 * ct : w + nd - 16 * ct - ncol) * 8u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store_b64_soff_acc(Y[t][r], rs, ascending ? va[r] : vd[r], soff);
+    }
+}
+
+template <bool NS, int R>
+__global__ __launch_bounds__(64 * kPipeWaves, 1) void synthesis_pipe_kernel(RotParams P) {
+    using T = RotTraits<R>;
+    extern __shared__ __attribute__((aligned(16))) double As[];   // trig buffers [2][npieces][64][2], then panel [nslot + 1][64 rows][2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = row tile = epoch of the tile
+    const int nbt = (P.B + 3) >> 2;
+    const int bt = P.blockmap ? P.blockmap[2 * blockIdx.x] : (int)(blockIdx.x % nbt);
+    const int it = P.blockmap ? P.blockmap[2 * blockIdx.x + 1] : (int)(blockIdx.x / nbt);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int tb_doubles = P.npieces * 128;
+    double2_t* const panel = reinterpret_cast<double2_t*>(As + 2 * tb_doubles);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)As;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    ROT_STAMP(0);
+
+    // trig pieces of column tile ct -> buffer (ct & 1), dealt to the four waves
+    auto issue_trig = [&](int ct) {
+        const double* src = P.trig + (size_t)ct * P.npieces * 128;
+        const unsigned dst = lds0 + (unsigned)(ct & 1) * (unsigned)tb_doubles * 8u;
+        for (int j = wave; j < P.npieces; j += kPipeWaves) glds16(src + (size_t)j * 128, lane_off, dst + (unsigned)j * 1024u);
+    };
+    issue_trig(0);
+
+    // ---- zero the padding slots of the panel
+    {
+        int s0 = 0;
+        for (int c = 0; c < T::kClasses; ++c) {
+            for (int s = s0 + P.cls_cnt[c]; s < s0 + 4 * P.cls_nk[c]; ++s)
+                if (tid < 64) panel[s * 64 + tid] = (double2_t){0.0, 0.0};
+            s0 += 4 * P.cls_nk[c];
+        }
+    }
+
+    // ---- phase 1: Legendre stage, the orders dealt to the four waves
+    if (!SHG_DBG(P, 2)) pipe_phase1<NS>(P, panel, P.itemtab2 + (size_t)wave * P.nrec2, P.itemtab2 + (size_t)(wave + kPipeWaves) * P.nrec2, bt, it, lane);
+    ROT_STAMP(1);
+    wait_vmcnt<0>();          // the trig pieces of column tile 0 (and every load of the stage)
+    __syncthreads();          // panel and trig buffer 0 complete
+    ROT_STAMP(2);
+
+    // ---- phase 2: longitude stage, wave = row tile
+    const int rt = wave;
+    const int i0 = it * 16, i0n = it * 8;
+    auto grid_row = [&](int s) { return NS ? (s < 8 ? i0n + s : P.nlat - 1 - (i0n + s - 8)) : i0 + s; };
+    auto slot_valid = [&](int s) { return NS ? i0n + (s & 7) < P.nh : i0 + s < P.nlat; };
+    const int b = bt * 4 + rt;
+    const bool epoch_ok = b < P.B && !SHG_DBG(P, 1);
+    double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
+    const unsigned long long gaddr = (unsigned long long)Gb;
+    const int grid_bytes = P.nlat * P.nlon * 8;
+    const int4_s rs = {(int)(unsigned)gaddr, (int)(unsigned)((gaddr >> 32) & 0xffffu), grid_bytes, 0x00020000};
+    // lane parts of the store offsets: rows fk + 4 reg, column fr of a whole tile (ascending / mirrored images)
+    unsigned va[4], vd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int sl = fk + 4 * r;
+        const unsigned ro = (unsigned)grid_row(sl) * (unsigned)P.nlon * 8u;
+        va[r] = slot_valid(sl) ? ro + (unsigned)fr * 8u : 0x80000000u;
+        vd[r] = slot_valid(sl) ? ro + (unsigned)(15 - fr) * 8u : 0x80000000u;
+    }
+    const double2_t* const prow = panel + rt * 16 + fr + fk * 64;          // + 256 p: k-step p
+    const double2_t* const tb0 = reinterpret_cast<const double2_t*>(As) + lane;
+    const double2_t* const tb1 = tb0 + P.npieces * 64;
+    double4_t z4;
+    {
+        const double2_t* z = panel + P.nslot * 64 + rt * 16 + fk;         // order 0: rows fk + 4 reg
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z4[r] = z[4 * r].x;
+    }
+
+    // The trig pieces of a unit are issued before the unit's 8 R stores: "at most min(8 R, 63) operations outstanding" means they have landed
+    constexpr int kYounger = 8 * R < 63 ? 8 * R : 63;
+    double Y[T::kAcc][4];            // images of the previous unit (parked in AGPRs)
+#pragma unroll
+    for (int t = 0; t < T::kAcc; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[t][r] = park(0.0);
+    if (!SHG_DBG(P, 4)) {
+        for (int ct = 0; ct < P.nct; ++ct) {
+            // unit ct: its sums accumulate while the images of unit ct - 1 leave; the trig pieces of unit ct + 1 arrive in the other buffer
+            if (ct + 1 < P.nct) issue_trig(ct + 1);
+            pipe_unit<NS, R>(P, Y, (ct & 1) ? tb1 : tb0, prow, z4, epoch_ok && ct > 0, rs, va, vd, ct - 1);
+            ROT_STAMP(3 + min(ct, 4));
+            if (epoch_ok && ct > 0) wait_vmcnt<kYounger>(); else wait_vmcnt<0>();
+            __syncthreads();
+        }
+        // ---- the images of the last unit (a half tile at the end of the fundamental domain has 8 columns)
+        if (epoch_ok) {
+            const int ctl = P.nct - 1;
+            const int ncol = min(16, P.nd - 16 * ctl);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sl = fk + 4 * r;
+                const bool ok = slot_valid(sl) && fr < ncol;
+                const unsigned ro = (unsigned)grid_row(sl) * (unsigned)P.nlon * 8u;
+                va[r] = ok ? ro + (unsigned)fr * 8u : 0x80000000u;
+                vd[r] = ok ? ro + (unsigned)(ncol - 1 - fr) * 8u : 0x80000000u;
+            }
+            pipe_flush<R>(Y, rs, va, vd, P.nlon, P.nd, ctl, ncol);
+        }
+    }
+    ROT_STAMP(12);
+    // every LDS-DMA of this wave was waited for at the end of its unit; the stores may still be in flight when the wave ends
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -826,8 +1245,16 @@ int build_rot_trig(shg_plan* p, const double* lon_h) {
 }
 
 template <int R>
-static int launch_rot(shg_plan* p, bool ns, const RotParams& P, size_t lds, dim3 grid_dim, hipStream_t stream) {
-    if (ns) {
+static int launch_rot(shg_plan* p, bool ns, bool pipe, const RotParams& P, size_t lds, dim3 grid_dim, hipStream_t stream) {
+    if (pipe) {
+        if (ns) {
+            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_pipe_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((synthesis_pipe_kernel<true, R>), grid_dim, dim3(64 * kPipeWaves), lds, stream, P);
+        } else {
+            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_pipe_kernel<false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((synthesis_pipe_kernel<false, R>), grid_dim, dim3(64 * kPipeWaves), lds, stream, P);
+        }
+    } else if (ns) {
         SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((synthesis_rot_kernel<true, R>), grid_dim, dim3(64 * kWaves), lds, stream, P);
     } else {
@@ -837,8 +1264,17 @@ static int launch_rot(shg_plan* p, bool ns, const RotParams& P, size_t lds, dim3
     return SHG_OK;
 }
 
-int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
-    if (!rot_applicable(p)) return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel not applicable to this plan");
+// LDS of the pipelined kernel: two trig buffers of one column tile each, then the panel
+static size_t pipe_lds_bytes(int nslot) { return (size_t)(2 * (nslot / 4) + nslot + 1) * 1024; }
+
+int pipe_applicable(const shg_plan* p) {
+    if (!rot_applicable(p)) return 0;
+    int nk[kMaxClasses], cnt[kMaxClasses];
+    return pipe_lds_bytes(rot_layout(p->rotR, p->N, nk, cnt, nullptr)) <= 160 * 1024 ? 1 : 0;
+}
+
+static int synthesis_rot_launch(shg_plan* p, bool pipe, const double* anm, int B, double* grid, hipStream_t stream) {
+    if (!(pipe ? pipe_applicable(p) : rot_applicable(p))) return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel not applicable to this plan");
     const int R = p->rotR;
     const bool ns = p->sym_ns;
     int rc = build_pkf_table(p, ns, R, stream);
@@ -869,6 +1305,9 @@ int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream
     P.itemtab = reinterpret_cast<const int4*>(p->itemtab_d);
     P.nrec = p->itemtab_nrec;
     P.ntrip = p->itemtab_ntrip;
+    P.itemtab2 = reinterpret_cast<const int2*>(p->itemtab2_d);
+    P.nrec2 = p->itemtab2_nrec;
+    P.ntrip2 = p->itemtab2_ntrip;
     P.badmap = p->badmap_d;
     P.blockmap = nullptr;
     if (!SHG_DBG(P, 2048)) {
@@ -881,14 +1320,14 @@ int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream
 #ifdef SHG_TIMELINE
     P.tl = getenv("SHG_TIMELINE_PTR") ? (unsigned long long*)strtoull(getenv("SHG_TIMELINE_PTR"), nullptr, 0) : nullptr;
 #endif
-    const size_t lds = rot_lds_bytes(P.nslot);
+    const size_t lds = pipe ? pipe_lds_bytes(P.nslot) : rot_lds_bytes(P.nslot);
     const dim3 grid_dim((unsigned)(nbt * nit));
     ProfileScope ps(p, 2, stream);
     switch (R) {
-        case 10: rc = launch_rot<10>(p, ns, P, lds, grid_dim, stream); break;
-        case 9: rc = launch_rot<9>(p, ns, P, lds, grid_dim, stream); break;
-        case 6: rc = launch_rot<6>(p, ns, P, lds, grid_dim, stream); break;
-        case 3: rc = launch_rot<3>(p, ns, P, lds, grid_dim, stream); break;
+        case 10: rc = launch_rot<10>(p, ns, pipe, P, lds, grid_dim, stream); break;
+        case 9: rc = launch_rot<9>(p, ns, pipe, P, lds, grid_dim, stream); break;
+        case 6: rc = launch_rot<6>(p, ns, pipe, P, lds, grid_dim, stream); break;
+        case 3: rc = launch_rot<3>(p, ns, pipe, P, lds, grid_dim, stream); break;
         default: return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel: no kernel for %d rotations", R);
     }
 
@@ -896,5 +1335,8 @@ int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
+
+int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, false, anm, B, grid, stream); }
+int synthesis_pipe(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, true, anm, B, grid, stream); }
 
 }  // namespace shg

@@ -6,7 +6,7 @@ name=$1; src=$2; shift; shift
 cd "$(dirname "$0")/../grates_amd/csrc"
 mkdir -p build ../lib/exp
 base=$(basename $src .hip)
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function "$@" -c $src -o build/${base}_$name.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $( [ "$base" = synthesis_rot ] && echo "-mllvm -amdgpu-mfma-vgpr-form=1" ) "$@" -c $src -o build/${base}_$name.o
 objs=$(ls build/*.o | grep -v "_timeline.o" | grep -v "build/${base}\.o" | grep -v "build/${base}_" | grep -v "_[a-zA-Z0-9]*\.o$" || true)
 # plain objects of the library (one per source), the variant in place of its source's object
 plain=""

@@ -11,6 +11,7 @@ ap.add_argument('--rounds', type=int, default=4)
 ap.add_argument('--launches', type=int, default=30)
 ap.add_argument('--library', default=os.path.join(ROOT, 'grates_amd', 'lib', 'libshg_timeline.so'))
 ap.add_argument('--out', default=None)
+ap.add_argument('--path', default='auto')
 args = ap.parse_args()
 _lib.use_library(args.library)
 import numpy as np, torch
@@ -19,6 +20,7 @@ grid = ga.grid.GeographicGrid(0.25, 0.25)
 colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel('ewh'), 96, grid.parallels, 3.9860044150e+14, 6.3781363000e+06,
                                                grid.semimajor_axis, grid.flattening)
 plan = ga.engine.Plan(96, colat, kn, grid.meridians)
+plan.set_path(args.path)
 batch = torch.from_numpy(np.random.default_rng(0).standard_normal((240, 97, 97)) * 1e-10).cuda()
 out = torch.empty((240, 720, 1440), dtype=torch.float64, device='cuda')
 for _ in range(200):
