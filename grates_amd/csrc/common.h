@@ -209,6 +209,7 @@ struct shg_plan {
     int itemtab_rot = -1;       // panel slot convention of the work items: 0 = 4-fold kernel, R = rotation-folded kernel
     int* itemtab2_d = nullptr;  // the same items for the four waves of the pipelined rotation-folded kernel, packed records
     int itemtab2_nrec = 0, itemtab2_ntrip = 0;
+    int* sem_d = nullptr;       // token counter of the rotation-folded kernels' Legendre stage (synthesis_rot.hip)
     int* blockmap_d = nullptr;  // XCD-aware (epoch tile, parallel tile) order of the fused kernel's workgroups
     int blockmap_nbt = 0, blockmap_nit = 0;
     std::vector<char> ns_badrow;    // per northern parallel: mirror image deviates too much to share the northern table

@@ -539,6 +539,7 @@ extern "C" int shg_plan_destroy(shg_plan* p) {
     if (p->qoff) (void)hipFree(p->qoff);
     if (p->badmap_d) (void)hipFree(p->badmap_d);
     if (p->blockmap_d) (void)hipFree(p->blockmap_d);
+    if (p->sem_d) (void)hipFree(p->sem_d);
     if (p->itemtab_d) (void)hipFree(p->itemtab_d);
     if (p->itemtab2_d) (void)hipFree(p->itemtab2_d);
     if (p->octinfo_d) (void)hipFree(p->octinfo_d);

@@ -87,6 +87,8 @@ struct RotParams {
     const double* pkf;
     const int4* itemtab;
     int nrec, ntrip;
+    int* sem;                 // tokens of the Legendre stage in use (device-wide counter, 0 between launches)
+    int sem_limit;            // at most this many workgroups run their Legendre stage at the same time (0 = no limit)
     const int2* itemtab2;     // pipelined kernel: packed work items of its four waves (see build_item_table)
     int nrec2, ntrip2;
 #ifdef SHG_TIMELINE
@@ -641,6 +643,29 @@ do {                                                                            
 #undef ROT_P1_CONSUME
 }
 
+// Tokens of the Legendre stage.  A workgroup does not store while it runs its Legendre stage, and workgroups that share the HBM fall
+// into step (tools/timeline.py: the whole chip in the Legendre stage at once, the HBM idle, then the whole chip storing at twice the
+// rate the HBM takes).  A quarter of the CUs saturate the HBM's write path (tools/store_bench.hip), so it is enough that never more
+// than `limit` workgroups are in the stage at once: one lane takes a token before the stage and returns it behind it.  The wait is
+// bounded to a few milliseconds (a counter left non-zero by an aborted launch must not hang the next one); the counter is 0 again
+// when the grid has drained.
+__device__ __forceinline__ void legendre_token_acquire(int* sem, int limit) {
+    // Take with an atomic add (any number of workgroups get their token in the same round trip; a compare-and-swap lets one through
+    // per round trip: measured 250 us for the first 128), give back when the add shows that the limit was passed.  A waiter only LOOKS
+    // (an add of 0: atomics execute at the memory side, a plain agent-scope load is served by this XCD's L2 and saw a returned token
+    // ~100 us late) and adds again when it has seen a free token, so that the counter is not inflated by the waiters.
+    for (int spin = 0; spin < 600; ++spin) {
+        if (__hip_atomic_fetch_add(sem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < limit) return;
+        (void)__hip_atomic_fetch_add(sem, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        do {                               // (long naps: a few hundred waiters polling one word every microsecond keep the releases from it)
+            __builtin_amdgcn_s_sleep(127);
+            ++spin;
+        } while (spin < 600 && __hip_atomic_fetch_add(sem, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= limit);
+    }
+    (void)__hip_atomic_fetch_add(sem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (gave up waiting: the release still pairs)
+}
+__device__ __forceinline__ void legendre_token_release(int* sem) { (void)__hip_atomic_fetch_add(sem, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <bool NS, int R>
 __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P) {
     using T = RotTraits<R>;
@@ -682,9 +707,14 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
     for (int d = 0; d < kRingDepth; ++d) rot_issue_piece(S, P, (unsigned)lane * 16u);
 
     // ---- phase 1: Legendre stage.  Orders are distributed over the waves of the workgroup.
+    if (P.sem_limit > 0) {
+        if (tid == 0) legendre_token_acquire(P.sem, P.sem_limit);
+        __syncthreads();
+    }
     if (!SHG_DBG(P, 2)) rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
     ROT_STAMP(1);
     __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
+    if (P.sem_limit > 0 && tid == 0) legendre_token_release(P.sem);
     ROT_STAMP(2);
 #ifdef SHG_EXPERIMENT
     if (P.stagger2 > 0 && wave >= 4) {
@@ -732,6 +762,10 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
 // stands at the end of the unit (all of the unit's stores are younger than they: vmcnt(63) never waits for a recent store),
 // followed by the workgroup's one barrier per unit.
 // =====================================================================================================================
+#ifndef SHG_LEGENDRE_TOKENS
+#define SHG_LEGENDRE_TOKENS 0
+#endif
+constexpr int kLegendreTokens = SHG_LEGENDRE_TOKENS;     // workgroups that may run their Legendre stage at once (0 = no limit)
 constexpr int kPipeWaves = 4;
 #ifndef SHG_PIPE_X
 #define SHG_PIPE_X 0           // experiment switches of the pipelined kernel's Legendre stage (timing only): 1 no arithmetic, 2 no operand loads
@@ -744,8 +778,11 @@ typedef int int8_v __attribute__((ext_vector_type(8)));
 // independent item lists (streams A and B, the lists of waves w and w + 4 of an eight-wave dealing) interleaved item by item,
 // each with its own accumulator pair and four operand sets (three items in flight per stream).  Records are packed into two words
 // (x = first octet | second octet << 16, y = panel slot | flags << 16; four records per 32-byte scalar load).
-template <bool NS>
-__device__ __forceinline__ void pipe_phase1(const RotParams& P, double2_t* panel, const int2* recs_a, const int2* recs_b, int bt, int it, int lane) {
+constexpr int kPipeChunks = 8;          // the images still parked when a tile begins leave in this many groups during its Legendre stage
+
+template <bool NS, class Flush>
+__device__ __forceinline__ void pipe_phase1(const RotParams& P, double2_t* panel, const int2* recs_a, const int2* recs_b, int bt, int it, int lane,
+                                            bool pending, Flush&& flush_chunk) {
     const int fr = lane & 15, fk = lane >> 4;
     constexpr int ASTRIDE = NS ? 128 : 64;
     typedef const int8_v __attribute__((address_space(4))) crec_t;
@@ -828,6 +865,7 @@ __device__ __forceinline__ void pipe_phase1(const RotParams& P, double2_t* panel
         }
         // per stream: records of the current trip (items 0 .. 3; items 0 .. 2 are in flight in sets 0 .. 2 / 4 .. 6) and of the next one
         int8_v ca = ra[0], cb = rb[0], na = ra[1], nb = rb[1];
+        int chunk = pass == 0 && pending ? 0 : kPipeChunks, next_at = 0;
         // (the scheduling barriers keep the order of the first loads: left alone hipcc sorts them so that the set the loop consumes first is
         //  loaded LAST, and its wait-count analysis then drains every load at the head of every trip -- s_waitcnt vmcnt(4) instead of (24))
         PIPE_P1_ISSUE(ca[0], 0);
@@ -843,6 +881,11 @@ __device__ __forceinline__ void pipe_phase1(const RotParams& P, double2_t* panel
         PIPE_P1_ISSUE(cb[4], 6);
         __builtin_amdgcn_sched_barrier(0);
         for (int trip = 0; trip < P.ntrip2; ++trip) {
+            if (chunk < kPipeChunks && trip >= next_at) {          // (uniform) the next group of parked images leaves
+                flush_chunk(chunk);
+                ++chunk;
+                next_at = (chunk * P.ntrip2) / kPipeChunks;
+            }
             PIPE_P1_ISSUE(ca[6], 3);
             PIPE_P1_CONSUME(ca[1], 0, A);
             PIPE_P1_ISSUE(cb[6], 7);
@@ -864,6 +907,7 @@ __device__ __forceinline__ void pipe_phase1(const RotParams& P, double2_t* panel
             na = ra[trip + 2];
             nb = rb[trip + 2];
         }
+        for (; chunk < kPipeChunks; ++chunk) flush_chunk(chunk);
     }
 #undef PIPE_P1_ISSUE
 #undef PIPE_P1_CONSUME
@@ -880,7 +924,9 @@ __device__ __forceinline__ double park(double v) {
 }
 // 8-byte store as store_b64_soff with its data in AGPRs
 __device__ __forceinline__ void store_b64_soff_acc(double v, int4_s rsrc, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_store_dwordx2 %0, %1, %2, m0 offen nt"
+    // (s_mov + s_nop 3 = five wait states: hipcc may reload the DESCRIPTOR from a spill lane with v_readlane right in front of the
+    //  statement too, and a VALU-written SGPR must not be read by a vector memory instruction earlier)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_store_dwordx2 %0, %1, %2, m0 offen nt"
                  :
                  : "a"(v), "v"(voff), "s"(rsrc), "s"(soff)
                  : "memory");
@@ -920,7 +966,7 @@ __device__ __forceinline__ void pipe_unit(const RotParams& P, double (&Y)[2 * R]
     X[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, kZero4, 0, 0, 0)
     // one class: k-steps in pairs on the register sets (tx, abx) / (ty, aby), as in rot_phase2
 #define PIPE_CLASS(C, MF, A0, NACC)                                                                       \
-    {                                                                                                     \
+    if (!SHG_DBG(P, 8)) {                                                                                 \
         const int nk_ = P.cls_nk[C];                                                                      \
         int i_ = 0;                                                                                       \
         if (nk_ >= 2) {                                                                                   \
@@ -974,13 +1020,15 @@ __device__ __forceinline__ void pipe_unit(const RotParams& P, double (&Y)[2 * R]
             }
         }
     }
+    if (!SHG_DBG(P, 8)) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rot_images<R>(X, r);
-    // the images wait for their stores in the accumulator registers
+        for (int r = 0; r < 4; ++r) rot_images<R>(X, r);
+        // the images wait for their stores in the accumulator registers
 #pragma unroll
-    for (int t = 0; t < 2 * R; ++t)
+        for (int t = 0; t < 2 * R; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Y[t][r] = park(X[t][r]);
+            for (int r = 0; r < 4; ++r) Y[t][r] = park(X[t][r]);
+    }
 #undef PIPE_CLASS
 #undef PIPE_MFMA2
 #undef PIPE_MFMA4
@@ -989,12 +1037,12 @@ __device__ __forceinline__ void pipe_unit(const RotParams& P, double (&Y)[2 * R]
 #undef PIPE_FETCH
 }
 
-// the 2 R images of a unit as 8-byte stores (ncol = 16, or 8 for a half tile at the end of the fundamental domain)
-template <int R>
+// the images t = T0, T0 + STEP, ... of a unit as 8-byte stores (ncol = 16, or 8 for a half tile at the end of the fundamental domain)
+template <int R, int T0, int STEP>
 __device__ __forceinline__ void pipe_flush(const double (&Y)[2 * R][4], int4_s rs, const unsigned (&va)[4], const unsigned (&vd)[4], int nlon, int nd, int ct, int ncol) {
     const int n2 = nlon >> 1, nR = nlon / R;
 #pragma unroll
-    for (int t = 0; t < 2 * R; ++t) {
+    for (int t = T0; t < 2 * R; t += STEP) {
         const int k = t < R ? t : t - R;
         const bool ascending = t < R;
         int w = n2 + k * nR - (ascending ? 0 : nd);
@@ -1005,6 +1053,17 @@ __device__ __forceinline__ void pipe_flush(const double (&Y)[2 * R][4], int4_s r
     }
 }
 
+#ifdef SHG_TIMELINE
+#define PIPE_STAMP(ev)                                                                                        \
+    do {                                                                                                      \
+        if (P.tl && lane == 0) P.tl[((size_t)tile * kWaves + wave) * 16 + (ev)] = wall_clock64();                  \
+        if (P.tl && lane == 0 && ((ev) == 0 || (ev) == 12))                                                   \
+            P.tl[((size_t)tile * kWaves + wave) * 16 + ((ev) == 0 ? 13 : 14)] = __builtin_amdgcn_s_memtime();       \
+    } while (0)
+#else
+#define PIPE_STAMP(ev)
+#endif
+
 template <bool NS, int R>
 __global__ __launch_bounds__(64 * kPipeWaves, 1) void synthesis_pipe_kernel(RotParams P) {
     using T = RotTraits<R>;
@@ -1013,15 +1072,22 @@ __global__ __launch_bounds__(64 * kPipeWaves, 1) void synthesis_pipe_kernel(RotP
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = row tile = epoch of the tile
+    const int rt = wave;
     const int nbt = (P.B + 3) >> 2;
-    const int bt = P.blockmap ? P.blockmap[2 * blockIdx.x] : (int)(blockIdx.x % nbt);
-    const int it = P.blockmap ? P.blockmap[2 * blockIdx.x + 1] : (int)(blockIdx.x / nbt);
+    const int ntiles = nbt * P.nit;
     const int fr = lane & 15, fk = lane >> 4;
     const int tb_doubles = P.npieces * 128;
     double2_t* const panel = reinterpret_cast<double2_t*>(As + 2 * tb_doubles);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)As;
     const unsigned lane_off = (unsigned)lane * 16u;
-    ROT_STAMP(0);
+    const int grid_bytes = P.nlat * P.nlon * 8;
+    const int nct = P.nct, ctl = nct - 1;
+    const int ncol_last = min(16, P.nd - 16 * ctl);                 // columns of the last column tile: 16, or 8 (half tile)
+    const double2_t* const prow = panel + rt * 16 + fr + fk * 64;  // + 256 p: k-step p
+    const double2_t* const tb0 = reinterpret_cast<const double2_t*>(As) + lane;
+    const double2_t* const tb1 = tb0 + P.npieces * 64;
+    // The trig pieces of a unit are issued before the unit's 8 R stores: "at most min(8 R, 63) operations outstanding" means they have landed
+    constexpr int kYounger = 8 * R < 63 ? 8 * R : 63;
 
     // trig pieces of column tile ct -> buffer (ct & 1), dealt to the four waves
     auto issue_trig = [&](int ct) {
@@ -1029,9 +1095,8 @@ __global__ __launch_bounds__(64 * kPipeWaves, 1) void synthesis_pipe_kernel(RotP
         const unsigned dst = lds0 + (unsigned)(ct & 1) * (unsigned)tb_doubles * 8u;
         for (int j = wave; j < P.npieces; j += kPipeWaves) glds16(src + (size_t)j * 128, lane_off, dst + (unsigned)j * 1024u);
     };
-    issue_trig(0);
 
-    // ---- zero the padding slots of the panel
+    // ---- zero the padding slots of the panel (the Legendre stage never writes them)
     {
         int s0 = 0;
         for (int c = 0; c < T::kClasses; ++c) {
@@ -1041,75 +1106,131 @@ __global__ __launch_bounds__(64 * kPipeWaves, 1) void synthesis_pipe_kernel(RotP
         }
     }
 
-    // ---- phase 1: Legendre stage, the orders dealt to the four waves
-    if (!SHG_DBG(P, 2)) pipe_phase1<NS>(P, panel, P.itemtab2 + (size_t)wave * P.nrec2, P.itemtab2 + (size_t)(wave + kPipeWaves) * P.nrec2, bt, it, lane);
-    ROT_STAMP(1);
-    wait_vmcnt<0>();          // the trig pieces of column tile 0 (and every load of the stage)
-    __syncthreads();          // panel and trig buffer 0 complete
-    ROT_STAMP(2);
-
-    // ---- phase 2: longitude stage, wave = row tile
-    const int rt = wave;
-    const int i0 = it * 16, i0n = it * 8;
-    auto grid_row = [&](int s) { return NS ? (s < 8 ? i0n + s : P.nlat - 1 - (i0n + s - 8)) : i0 + s; };
-    auto slot_valid = [&](int s) { return NS ? i0n + (s & 7) < P.nh : i0 + s < P.nlat; };
-    const int b = bt * 4 + rt;
-    const bool epoch_ok = b < P.B && !SHG_DBG(P, 1);
-    double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
-    const unsigned long long gaddr = (unsigned long long)Gb;
-    const int grid_bytes = P.nlat * P.nlon * 8;
-    const int4_s rs = {(int)(unsigned)gaddr, (int)(unsigned)((gaddr >> 32) & 0xffffu), grid_bytes, 0x00020000};
-    // lane parts of the store offsets: rows fk + 4 reg, column fr of a whole tile (ascending / mirrored images)
-    unsigned va[4], vd[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int sl = fk + 4 * r;
-        const unsigned ro = (unsigned)grid_row(sl) * (unsigned)P.nlon * 8u;
-        va[r] = slot_valid(sl) ? ro + (unsigned)fr * 8u : 0x80000000u;
-        vd[r] = slot_valid(sl) ? ro + (unsigned)(15 - fr) * 8u : 0x80000000u;
+#ifdef SHG_EXPERIMENT
+    if (P.stagger > 0) {             // experiment: the workgroups start up to P.stagger ticks apart (32 steps)
+        const long long ticks = (long long)P.stagger * (long long)(((blockIdx.x >> 3) * 13) & 31) / 32;
+        const long long t0 = wall_clock64();
+        for (int i = 0; i < 100000 && (long long)wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(8);
     }
-    const double2_t* const prow = panel + rt * 16 + fr + fk * 64;          // + 256 p: k-step p
-    const double2_t* const tb0 = reinterpret_cast<const double2_t*>(As) + lane;
-    const double2_t* const tb1 = tb0 + P.npieces * 64;
-    double4_t z4;
-    {
-        const double2_t* z = panel + P.nslot * 64 + rt * 16 + fk;         // order 0: rows fk + 4 reg
-#pragma unroll
-        for (int r = 0; r < 4; ++r) z4[r] = z[4 * r].x;
-    }
-
-    // The trig pieces of a unit are issued before the unit's 8 R stores: "at most min(8 R, 63) operations outstanding" means they have landed
-    constexpr int kYounger = 8 * R < 63 ? 8 * R : 63;
-    double Y[T::kAcc][4];            // images of the previous unit (parked in AGPRs)
+#endif
+    double Y[T::kAcc][4];            // images of the previous unit, parked in AGPRs
 #pragma unroll
     for (int t = 0; t < T::kAcc; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Y[t][r] = park(0.0);
-    if (!SHG_DBG(P, 4)) {
-        for (int ct = 0; ct < P.nct; ++ct) {
-            // unit ct: its sums accumulate while the images of unit ct - 1 leave; the trig pieces of unit ct + 1 arrive in the other buffer
-            if (ct + 1 < P.nct) issue_trig(ct + 1);
-            pipe_unit<NS, R>(P, Y, (ct & 1) ? tb1 : tb0, prow, z4, epoch_ok && ct > 0, rs, va, vd, ct - 1);
-            ROT_STAMP(3 + min(ct, 4));
-            if (epoch_ok && ct > 0) wait_vmcnt<kYounger>(); else wait_vmcnt<0>();
+    bool have_last = false;          // the images of the previous tile's last unit are still parked
+
+    // The workgroup is persistent: it takes the tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the (XCD-aware) tile order, so that the
+    // images of a tile's last unit can leave during the Legendre stage of the next tile: the chip's store stream never stops.
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int bt = P.blockmap ? P.blockmap[2 * tile] : tile % nbt;
+        const int it = P.blockmap ? P.blockmap[2 * tile + 1] : tile / nbt;
+        PIPE_STAMP(0);
+        issue_trig(0);            // (buffer 0 is free: every wave has passed the barrier behind the last unit that read it)
+        auto grid_row_of = [&](int it_, int s_) { return NS ? (s_ < 8 ? it_ * 8 + s_ : P.nlat - 1 - (it_ * 8 + s_ - 8)) : it_ * 16 + s_; };
+        auto slot_valid_of = [&](int it_, int s_) { return NS ? it_ * 8 + (s_ & 7) < P.nh : it_ * 16 + s_ < P.nlat; };
+        auto descriptor_of = [&](int bt_) {
+            const int b_ = min(bt_ * 4 + rt, P.B - 1);
+            const unsigned long long g_ = (unsigned long long)(P.G + (size_t)b_ * P.nlat * P.nlon);
+            return (int4_s){(int)(unsigned)g_, (int)(unsigned)((g_ >> 32) & 0xffffu), grid_bytes, 0x00020000};
+        };
+        // what the parked images of the previous tile's last unit need to leave: its grid (descriptor) and its rows, from the tile order again
+        // (scalars carried around the tile loop end up in vector registers, which the store's descriptor operand cannot be)
+        const int tile_prev = max(tile - (int)gridDim.x, 0);
+        const int bt_prev = P.blockmap ? P.blockmap[2 * tile_prev] : tile_prev % nbt;
+        const int it_prev = P.blockmap ? P.blockmap[2 * tile_prev + 1] : tile_prev / nbt;
+        const int4_s rs_last = descriptor_of(bt_prev);
+        unsigned va_last[4], vd_last[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int sl = fk + 4 * r;
+            const unsigned ro = (unsigned)grid_row_of(it_prev, sl) * (unsigned)P.nlon * 8u;
+            const bool ok = slot_valid_of(it_prev, sl) && fr < ncol_last;
+            va_last[r] = ok ? ro + (unsigned)fr * 8u : 0x80000000u;
+            vd_last[r] = ok ? ro + (unsigned)(ncol_last - 1 - fr) * 8u : 0x80000000u;
+        }
+
+        // ---- phase 1: Legendre stage, the orders dealt to the four waves (two lists each); the parked images leave in groups meanwhile
+        auto flush_chunk = [&](int c) {
+            switch (c) {
+                case 0: pipe_flush<R, 0, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
+                case 1: pipe_flush<R, 1, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
+                case 2: pipe_flush<R, 2, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
+                case 3: pipe_flush<R, 3, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
+                case 4: pipe_flush<R, 4, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
+                case 5: pipe_flush<R, 5, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
+                case 6: pipe_flush<R, 6, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
+                default: pipe_flush<R, 7, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
+            }
+        };
+        if (P.sem_limit > 0) {
+            if (tid == 0) legendre_token_acquire(P.sem, P.sem_limit);
             __syncthreads();
         }
-        // ---- the images of the last unit (a half tile at the end of the fundamental domain has 8 columns)
-        if (epoch_ok) {
-            const int ctl = P.nct - 1;
-            const int ncol = min(16, P.nd - 16 * ctl);
+        if (!SHG_DBG(P, 2))
+            pipe_phase1<NS>(P, panel, P.itemtab2 + (size_t)wave * P.nrec2, P.itemtab2 + (size_t)(wave + kPipeWaves) * P.nrec2, bt, it, lane, have_last, flush_chunk);
+        else if (have_last)
+            for (int c = 0; c < kPipeChunks; ++c) flush_chunk(c);
+        PIPE_STAMP(1);
+        // the trig pieces of column tile 0 were issued before the 8 R stores of the parked images (if there were any)
+        if (have_last) wait_vmcnt<kYounger>(); else wait_vmcnt<0>();
+        __syncthreads();          // panel and trig buffer 0 complete
+        if (P.sem_limit > 0 && tid == 0) legendre_token_release(P.sem);
+        PIPE_STAMP(2);
+
+        // ---- phase 2: longitude stage, wave = row tile
+        const bool epoch_ok = bt * 4 + rt < P.B && !SHG_DBG(P, 1);
+        const int4_s rs = descriptor_of(bt);
+        // lane parts of the store offsets: rows fk + 4 reg, column fr of a whole tile (ascending / mirrored images)
+        unsigned va[4], vd[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int sl = fk + 4 * r;
-                const bool ok = slot_valid(sl) && fr < ncol;
-                const unsigned ro = (unsigned)grid_row(sl) * (unsigned)P.nlon * 8u;
-                va[r] = ok ? ro + (unsigned)fr * 8u : 0x80000000u;
-                vd[r] = ok ? ro + (unsigned)(ncol - 1 - fr) * 8u : 0x80000000u;
-            }
-            pipe_flush<R>(Y, rs, va, vd, P.nlon, P.nd, ctl, ncol);
+        for (int r = 0; r < 4; ++r) {
+            const int sl = fk + 4 * r;
+            const unsigned ro = (unsigned)grid_row_of(it, sl) * (unsigned)P.nlon * 8u;
+            const bool ok = slot_valid_of(it, sl);
+            va[r] = ok ? ro + (unsigned)fr * 8u : 0x80000000u;
+            vd[r] = ok ? ro + (unsigned)(15 - fr) * 8u : 0x80000000u;
         }
+        double4_t z4;
+        {
+            const double2_t* z = panel + P.nslot * 64 + rt * 16 + fk;         // order 0: rows fk + 4 reg
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z4[r] = z[4 * r].x;
+        }
+        if (!SHG_DBG(P, 4)) {
+            for (int ct = 0; ct < nct; ++ct) {
+                // unit ct: its sums accumulate while the images of unit ct - 1 leave; the trig pieces of unit ct + 1 arrive in the other buffer
+                if (ct + 1 < nct) issue_trig(ct + 1);
+                pipe_unit<NS, R>(P, Y, (ct & 1) ? tb1 : tb0, prow, z4, epoch_ok && ct > 0, rs, va, vd, ct - 1);
+                PIPE_STAMP(3 + min(ct, 4));
+                if (epoch_ok && ct > 0) wait_vmcnt<kYounger>(); else wait_vmcnt<0>();
+                __syncthreads();          // every wave is done with this unit's trig buffer (and, behind the last unit, with the panel)
+            }
+        }
+        have_last = epoch_ok && !SHG_DBG(P, 4);
+        PIPE_STAMP(12);
     }
-    ROT_STAMP(12);
+    // ---- the images of the very last unit
+    if (have_last) {
+        const int done = (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x;           // tiles of this workgroup - 1
+        const int tile_last = (int)blockIdx.x + done * (int)gridDim.x;
+        const int bt_l = P.blockmap ? P.blockmap[2 * tile_last] : tile_last % nbt;
+        const int it_l = P.blockmap ? P.blockmap[2 * tile_last + 1] : tile_last / nbt;
+        const int b_ = min(bt_l * 4 + rt, P.B - 1);
+        const unsigned long long g_ = (unsigned long long)(P.G + (size_t)b_ * P.nlat * P.nlon);
+        const int4_s rs_l = {(int)(unsigned)g_, (int)(unsigned)((g_ >> 32) & 0xffffu), grid_bytes, 0x00020000};
+        unsigned va_l[4], vd_l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int sl = fk + 4 * r;
+            const int row = NS ? (sl < 8 ? it_l * 8 + sl : P.nlat - 1 - (it_l * 8 + sl - 8)) : it_l * 16 + sl;
+            const bool ok = (NS ? it_l * 8 + (sl & 7) < P.nh : it_l * 16 + sl < P.nlat) && fr < ncol_last;
+            const unsigned ro = (unsigned)row * (unsigned)P.nlon * 8u;
+            va_l[r] = ok ? ro + (unsigned)fr * 8u : 0x80000000u;
+            vd_l[r] = ok ? ro + (unsigned)(ncol_last - 1 - fr) * 8u : 0x80000000u;
+        }
+        pipe_flush<R, 0, 1>(Y, rs_l, va_l, vd_l, P.nlon, P.nd, ctl, ncol_last);
+    }
     // every LDS-DMA of this wave was waited for at the end of its unit; the stores may still be in flight when the wave ends
 }
 
@@ -1305,6 +1426,15 @@ static int synthesis_rot_launch(shg_plan* p, bool pipe, const double* anm, int B
     P.itemtab = reinterpret_cast<const int4*>(p->itemtab_d);
     P.nrec = p->itemtab_nrec;
     P.ntrip = p->itemtab_ntrip;
+    if (!p->sem_d) {
+        if (hipMalloc((void**)&p->sem_d, 256) != hipSuccess) return fail(SHG_ERR_NOMEM, "token counter allocation failed");
+        SHG_HIP(hipMemset(p->sem_d, 0, 256));
+    }
+    P.sem = p->sem_d;
+    P.sem_limit = kLegendreTokens;
+#ifdef SHG_EXPERIMENT
+    if (getenv("SHG_SEM")) P.sem_limit = atoi(getenv("SHG_SEM"));
+#endif
     P.itemtab2 = reinterpret_cast<const int2*>(p->itemtab2_d);
     P.nrec2 = p->itemtab2_nrec;
     P.ntrip2 = p->itemtab2_ntrip;
@@ -1321,7 +1451,14 @@ static int synthesis_rot_launch(shg_plan* p, bool pipe, const double* anm, int B
     P.tl = getenv("SHG_TIMELINE_PTR") ? (unsigned long long*)strtoull(getenv("SHG_TIMELINE_PTR"), nullptr, 0) : nullptr;
 #endif
     const size_t lds = pipe ? pipe_lds_bytes(P.nslot) : rot_lds_bytes(P.nslot);
-    const dim3 grid_dim((unsigned)(nbt * nit));
+    unsigned nwg = (unsigned)(nbt * nit);
+    if (pipe) {                                       // persistent workgroups, one per CU (the kernel's LDS admits no second one)
+        int dev = 0, cus = 0;
+        SHG_HIP(hipGetDevice(&dev));
+        SHG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        nwg = std::min(nwg, (unsigned)std::max(cus, 1));
+    }
+    const dim3 grid_dim(nwg);
     ProfileScope ps(p, 2, stream);
     switch (R) {
         case 10: rc = launch_rot<10>(p, ns, pipe, P, lds, grid_dim, stream); break;

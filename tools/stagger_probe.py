@@ -32,6 +32,8 @@ for rnd in range(args.rounds):
         fields = s.split(':')
         os.environ['SHG_DEBUG'] = fields[0]
         os.environ['SHG_STAGGER'] = fields[1]
+        for k in ('SHG_SEM', 'SHG_STAGGER2'):
+            os.environ.pop(k, None)
         for extra in fields[2:]:
             k, v = extra.split('=')
             os.environ[k] = v

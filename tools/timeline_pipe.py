@@ -43,5 +43,14 @@ for u in range(5):
     prev = us[:, :, 3 + u]
 d = us[:, :, 12] - prev
 print('flush + last barrier: mean %.2f p90 %.2f' % (np.nanmean(d), np.nanpercentile(d, 90)))
+if os.environ.get('SHG_TIMELINE_SAVE'):
+    np.save(os.environ['SHG_TIMELINE_SAVE'], tl.cpu().numpy())
+start = np.nanmin(us[:, :, 0], axis=1)
+for a, b in [(0, 100), (100, 200), (200, 300), (300, 400), (400, 500)]:
+    m = (start >= a) & (start < b)
+    if m.sum():
+        p1 = (np.nanmax(us[:, :, 2], axis=1) - start)[m]
+        tt = (np.nanmax(us[:, :, 12], axis=1) - start)[m]
+        print('  tiles started in [%d, %d) us: n = %d, phase 1 + barrier %.1f, tile %.1f' % (a, b, m.sum(), p1.mean(), tt.mean()))
 tile_t = np.nanmax(us[:, :, 12], axis=1) - np.nanmin(us[:, :, 0], axis=1)
 print('tile total: mean %.2f p10 %.2f p90 %.2f' % (tile_t.mean(), np.percentile(tile_t, 10), np.percentile(tile_t, 90)))
