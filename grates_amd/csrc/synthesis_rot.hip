@@ -87,6 +87,11 @@ struct RotParams {
     const double* pkf;
     const int4* itemtab;
     int nrec, ntrip;
+    double* ring;             // fed pipeline: images of the panels of `ring_tiles` tiles ((nslot + 1) KB each, padding slots zero)
+    int ring_tiles;
+    int fed_first;            // tiles 0 .. fed_first - 1 are not produced (every consumer workgroup makes the panel of its first tile itself)
+    int* produced;            // [ring_tiles] tile + 1 once the image of that tile's panel is complete
+    int* consumed;            // [ring_tiles] tile + 1 once the consumer has the image in its LDS (-1: slot given up for this launch)
     int* sem;                 // tokens of the Legendre stage in use (device-wide counter, 0 between launches)
     int sem_limit;            // at most this many workgroups run their Legendre stage at the same time (0 = no limit)
     const int2* itemtab2;     // pipelined kernel: packed work items of its four waves (see build_item_table)
@@ -519,6 +524,21 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
 #undef ROT_FETCH
 }
 
+// Where a panel row goes: into the LDS panel of the tile, or (producer kernel of the fed pipeline) write-through into the image of a
+// tile's panel in global memory, from where another workgroup's LDS-DMA takes it (sc1 = aux 16: cdna_hip_programming.md guideline 16, R1)
+struct GlobalPanel {
+    __amdgpu_buffer_rsrc_t rsrc;
+    bool skip;
+};
+__device__ __forceinline__ void panel_put(double2_t* panel, int index, double2_t v) { panel[index] = v; }
+__device__ __forceinline__ void panel_put(const GlobalPanel& panel, int index, double2_t v) {
+    if (panel.skip) {                       // (experiment builds: the producer without its stores)
+        asm volatile("" ::"v"(v));
+        return;
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), panel.rsrc, (unsigned)index * 16u, 0, 16);
+}
+
 // Phase 1: Legendre stage of tile (bt, it) (see synthesis_fused.hip).  The orders of the tile are dealt to the waves that call this
 // (work-item records `recs`, one list per wave); the result of order m is one 16-byte pair (A_m, B'_m) per panel row, written to
 // `panel` -- the LDS panel of the tile, or (persistent kernel) the image of the NEXT tile's panel in global memory.
@@ -593,7 +613,7 @@ do {                                                                            
             vc_ = fma(sgm, xc_, rc_);                                                                           \
             vs_ = fma(sgm, xs_, rs_);                                                                           \
         }                                                                                                       \
-        if (!NS || mode == 0 || fr < 8) panel[(rec).z * 64 + prow] = (double2_t){vc_, vs_};                     \
+        if (!NS || mode == 0 || fr < 8) panel_put(panel, (rec).z * 64 + prow, (double2_t){vc_, vs_});           \
         fresh = true;                                                                                           \
     }                                                                                                           \
 } while (0)
@@ -763,9 +783,11 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
 // followed by the workgroup's one barrier per unit.
 // =====================================================================================================================
 #ifndef SHG_LEGENDRE_TOKENS
-#define SHG_LEGENDRE_TOKENS 0
+#define SHG_LEGENDRE_TOKENS -7      // > 0: that many; < 0: that many sixteenths of the device's CUs; 0: no limit
 #endif
-constexpr int kLegendreTokens = SHG_LEGENDRE_TOKENS;     // workgroups that may run their Legendre stage at once (0 = no limit)
+// Workgroups that may run their Legendre stage at once.  Measured (round 5, 240 x d/o 96 -> 0.25 degree, three boxes, alternating
+// processes): 96 .. 128 of 256 take 1.5 - 2 % off the kernel (0.497 / 0.472 / 0.497 against 0.505 / 0.480 / 0.508 ms), 64 cost 9 %.
+constexpr int kLegendreTokens = SHG_LEGENDRE_TOKENS;
 constexpr int kPipeWaves = 4;
 #ifndef SHG_PIPE_X
 #define SHG_PIPE_X 0           // experiment switches of the pipelined kernel's Legendre stage (timing only): 1 no arithmetic, 2 no operand loads
@@ -1053,6 +1075,59 @@ __device__ __forceinline__ void pipe_flush(const double (&Y)[2 * R][4], int4_s r
     }
 }
 
+// =====================================================================================================================
+// Fed pipeline (path 8): the Legendre stage as a kernel of its own that runs BESIDE the pipelined longitude kernel on every CU.
+//
+// Measured (round 5, one card): the longitude stage + stores of either rotation-folded kernel alone take 0.437 ms, 1.08 x the time the
+// HBM needs for the grids (0.405 ms, tools/store_bench.hip); the Legendre stage adds 0.07 - 0.11 ms because no wave of the workgroup
+// stores while it runs.  The pipelined kernel leaves 112 registers per SIMD free: one more wave, of another kernel.  So
+// `legendre_panel_kernel` (four waves of <= 104 registers, no LDS to speak of) computes the panels of the tiles in the consumer's
+// order into a ring of panel images in global memory (write-through stores; the ring lives in L2 / Infinity Cache), and the persistent
+// consumer takes each image into its LDS by LDS-DMA and goes straight to the longitude stage: its stores never stop, and the
+// Legendre stage's MFMAs fill the gaps of the longitude stage's on the same SIMDs.
+// Hand-off per tile, agent scope (cdna_hip_programming.md guideline 16, R1): producer -- sc1 stores, every wave drains, barrier, one
+// lane stores produced[slot] = tile + 1; consumer -- one lane polls that word, acquire, barrier, LDS-DMA, barrier, consumed[slot] =
+// tile + 1 (the ring slot may be overwritten).  Both waits are BOUNDED and nobody depends on them: a consumer that does not get its
+// image in time computes the panel itself (and poisons the slot for the rest of the launch: consumed = -1), a producer that does not
+// get its slot in time skips its tile.  Results do not depend on whether, or how far, the two kernels overlap.
+// =====================================================================================================================
+constexpr int kFedPollNaps = 400;          // x ~0.9 us: the consumer's patience for one panel image (the producer's for one ring slot)
+
+__device__ __forceinline__ bool wait_word_equals(int* word, int want, int naps) {
+    for (int i = 0; i < naps; ++i) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return true;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    return false;
+}
+
+template <bool NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(104))) void legendre_panel_kernel(RotParams P) {
+    __shared__ int go;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x + P.fed_first;            // (the consumers make the panels of their first tiles themselves: nothing to wait for at the start)
+    const int nbt = (P.B + 3) >> 2;
+    const int bt = P.blockmap ? P.blockmap[2 * tile] : tile % nbt;
+    const int it = P.blockmap ? P.blockmap[2 * tile + 1] : tile / nbt;
+    const int slot = tile % P.ring_tiles;
+    // This kernel has a third of the longitude kernel's arithmetic and should run AHEAD of it (up to the ring's length): its waves take
+    // every issue slot they can use, the longitude kernel's wave on the same SIMD fills the rest (priority, then age)
+    __builtin_amdgcn_s_setprio(3);
+    if (tid == 0) go = tile < P.ring_tiles + P.fed_first || wait_word_equals(P.consumed + slot, tile - P.ring_tiles + 1, kFedPollNaps) ? 1 : 0;
+    __syncthreads();
+    if (!go) return;                                   // (the consumer of this tile computes the panel itself)
+    const size_t image_doubles = (size_t)(P.nslot + 1) * 128;
+    GlobalPanel panel = {__builtin_amdgcn_make_buffer_rsrc(P.ring + (size_t)slot * image_doubles, 0, (unsigned)(image_doubles * 8), 0x00020000), (bool)SHG_DBG(P, 256)};
+    // the eight item lists of the rotation-folded kernel, two per wave
+    rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
+    rot_phase1<NS>(P, panel, P.itemtab + (size_t)(wave + 4) * P.nrec, bt, it, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores ...
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(P.produced + slot, tile + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before ONE lane says so
+}
+
 #ifdef SHG_TIMELINE
 #define PIPE_STAMP(ev)                                                                                        \
     do {                                                                                                      \
@@ -1064,10 +1139,11 @@ __device__ __forceinline__ void pipe_flush(const double (&Y)[2 * R][4], int4_s r
 #define PIPE_STAMP(ev)
 #endif
 
-template <bool NS, int R>
+template <bool NS, int R, bool FED>
 __global__ __launch_bounds__(64 * kPipeWaves, 1) void synthesis_pipe_kernel(RotParams P) {
     using T = RotTraits<R>;
     extern __shared__ __attribute__((aligned(16))) double As[];   // trig buffers [2][npieces][64][2], then panel [nslot + 1][64 rows][2]
+    __shared__ int fed_ready;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1163,19 +1239,48 @@ __global__ __launch_bounds__(64 * kPipeWaves, 1) void synthesis_pipe_kernel(RotP
                 default: pipe_flush<R, 7, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
             }
         };
-        if (P.sem_limit > 0) {
-            if (tid == 0) legendre_token_acquire(P.sem, P.sem_limit);
+        bool self_made = !FED;
+        if (FED) {
+            // the image of this tile's panel: wait for it (one lane, bounded), acquire, LDS-DMA; the parked images leave meanwhile
+            const int slot = tile % P.ring_tiles;
+            if (tid == 0) {
+                const bool ok = tile >= P.fed_first && wait_word_equals(P.produced + slot, tile + 1, kFedPollNaps);
+                if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                fed_ready = ok ? 1 : 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (holds the barrier until the invalidate has completed)
+            }
             __syncthreads();
+            if (fed_ready) {
+                const double* image = P.ring + (size_t)slot * (size_t)(P.nslot + 1) * 128;
+                const unsigned dst = lds0 + 2u * (unsigned)tb_doubles * 8u;
+                if (!SHG_DBG(P, 512))
+                    for (int j = wave; j <= P.nslot; j += kPipeWaves) glds16(image + (size_t)j * 128, lane_off, dst + (unsigned)j * 1024u);
+                if (have_last)
+                    for (int c = 0; c < kPipeChunks; ++c) flush_chunk(c);
+            } else {
+                self_made = true;
+#ifdef SHG_TIMELINE
+                if (P.tl && tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.tl) + ((size_t)ntiles * kWaves * 16), 1ull);       // images not in time
+#endif
+            }
         }
-        if (!SHG_DBG(P, 2))
-            pipe_phase1<NS>(P, panel, P.itemtab2 + (size_t)wave * P.nrec2, P.itemtab2 + (size_t)(wave + kPipeWaves) * P.nrec2, bt, it, lane, have_last, flush_chunk);
-        else if (have_last)
-            for (int c = 0; c < kPipeChunks; ++c) flush_chunk(c);
+        if (self_made) {
+            if (P.sem_limit > 0) {
+                if (tid == 0) legendre_token_acquire(P.sem, P.sem_limit);
+                __syncthreads();
+            }
+            if (!SHG_DBG(P, 2))
+                pipe_phase1<NS>(P, panel, P.itemtab2 + (size_t)wave * P.nrec2, P.itemtab2 + (size_t)(wave + kPipeWaves) * P.nrec2, bt, it, lane, have_last, flush_chunk);
+            else if (have_last)
+                for (int c = 0; c < kPipeChunks; ++c) flush_chunk(c);
+        }
         PIPE_STAMP(1);
-        // the trig pieces of column tile 0 were issued before the 8 R stores of the parked images (if there were any)
+        // the trig pieces of column tile 0 (and the panel image) were issued before the 8 R stores of the parked images (if there were any)
         if (have_last) wait_vmcnt<kYounger>(); else wait_vmcnt<0>();
         __syncthreads();          // panel and trig buffer 0 complete
-        if (P.sem_limit > 0 && tid == 0) legendre_token_release(P.sem);
+        if (self_made && P.sem_limit > 0 && tid == 0) legendre_token_release(P.sem);
+        if (FED && tid == 0)      // the ring slot is free again -- or given up for this launch, if its image did not arrive in time
+            __hip_atomic_store(P.consumed + tile % P.ring_tiles, fed_ready || tile < P.fed_first ? tile + 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PIPE_STAMP(2);
 
         // ---- phase 2: longitude stage, wave = row tile
@@ -1366,15 +1471,16 @@ int build_rot_trig(shg_plan* p, const double* lon_h) {
 }
 
 template <int R>
-static int launch_rot(shg_plan* p, bool ns, bool pipe, const RotParams& P, size_t lds, dim3 grid_dim, hipStream_t stream) {
-    if (pipe) {
-        if (ns) {
-            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_pipe_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((synthesis_pipe_kernel<true, R>), grid_dim, dim3(64 * kPipeWaves), lds, stream, P);
-        } else {
-            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_pipe_kernel<false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((synthesis_pipe_kernel<false, R>), grid_dim, dim3(64 * kPipeWaves), lds, stream, P);
-        }
+static int launch_rot(shg_plan* p, bool ns, int mode, const RotParams& P, size_t lds, dim3 grid_dim, hipStream_t stream) {
+#define SHG_LAUNCH_PIPE(NS_, FED_)                                                                                                        \
+    do {                                                                                                                                  \
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_pipe_kernel<NS_, R, FED_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((synthesis_pipe_kernel<NS_, R, FED_>), grid_dim, dim3(64 * kPipeWaves), lds, stream, P);                        \
+    } while (0)
+    if (mode == 2) {
+        if (ns) SHG_LAUNCH_PIPE(true, true); else SHG_LAUNCH_PIPE(false, true);
+    } else if (mode == 1) {
+        if (ns) SHG_LAUNCH_PIPE(true, false); else SHG_LAUNCH_PIPE(false, false);
     } else if (ns) {
         SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((synthesis_rot_kernel<true, R>), grid_dim, dim3(64 * kWaves), lds, stream, P);
@@ -1382,6 +1488,7 @@ static int launch_rot(shg_plan* p, bool ns, bool pipe, const RotParams& P, size_
         SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((synthesis_rot_kernel<false, R>), grid_dim, dim3(64 * kWaves), lds, stream, P);
     }
+#undef SHG_LAUNCH_PIPE
     return SHG_OK;
 }
 
@@ -1394,7 +1501,8 @@ int pipe_applicable(const shg_plan* p) {
     return pipe_lds_bytes(rot_layout(p->rotR, p->N, nk, cnt, nullptr)) <= 160 * 1024 ? 1 : 0;
 }
 
-static int synthesis_rot_launch(shg_plan* p, bool pipe, const double* anm, int B, double* grid, hipStream_t stream) {
+static int synthesis_rot_launch(shg_plan* p, int mode, const double* anm, int B, double* grid, hipStream_t stream) {
+    const bool pipe = mode != 0;
     if (!(pipe ? pipe_applicable(p) : rot_applicable(p))) return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel not applicable to this plan");
     const int R = p->rotR;
     const bool ns = p->sym_ns;
@@ -1432,6 +1540,13 @@ static int synthesis_rot_launch(shg_plan* p, bool pipe, const double* anm, int B
     }
     P.sem = p->sem_d;
     P.sem_limit = kLegendreTokens;
+    if (kLegendreTokens < 0) {
+        int dev = 0, cus = 0;
+        SHG_HIP(hipGetDevice(&dev));
+        SHG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        P.sem_limit = std::max(1, cus * -kLegendreTokens / 16);
+    }
+    if (mode != 0) P.sem_limit = 0;          // (the pipelined kernels: measured without gain)
 #ifdef SHG_EXPERIMENT
     if (getenv("SHG_SEM")) P.sem_limit = atoi(getenv("SHG_SEM"));
 #endif
@@ -1451,29 +1566,77 @@ static int synthesis_rot_launch(shg_plan* p, bool pipe, const double* anm, int B
     P.tl = getenv("SHG_TIMELINE_PTR") ? (unsigned long long*)strtoull(getenv("SHG_TIMELINE_PTR"), nullptr, 0) : nullptr;
 #endif
     const size_t lds = pipe ? pipe_lds_bytes(P.nslot) : rot_lds_bytes(P.nslot);
-    unsigned nwg = (unsigned)(nbt * nit);
+    unsigned nwg_pipe = (unsigned)(nbt * nit);
     if (pipe) {                                       // persistent workgroups, one per CU (the kernel's LDS admits no second one)
         int dev = 0, cus = 0;
         SHG_HIP(hipGetDevice(&dev));
         SHG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        nwg = std::min(nwg, (unsigned)std::max(cus, 1));
+        nwg_pipe = std::min(nwg_pipe, (unsigned)std::max(cus, 1));
     }
-    const dim3 grid_dim(nwg);
-    ProfileScope ps(p, 2, stream);
+    P.fed_first = 0;
+    P.ring = nullptr;
+    P.ring_tiles = 0;
+    P.produced = P.consumed = nullptr;
+    if (mode == 2) {
+        // the ring of panel images, the hand-off words, the producer's stream; the words are zeroed before every launch
+        constexpr int kRingTiles = 512;
+        const size_t image_bytes = (size_t)(P.nslot + 1) * 1024;
+        if (p->ring_bytes < image_bytes * kRingTiles) {
+            SHG_HIP(hipDeviceSynchronize());
+            if (p->ring_d) (void)hipFree(p->ring_d);
+            p->ring_d = nullptr;
+            p->ring_bytes = 0;
+            if (hipMalloc((void**)&p->ring_d, image_bytes * kRingTiles) != hipSuccess) return fail(SHG_ERR_NOMEM, "panel ring allocation failed");
+            p->ring_bytes = image_bytes * kRingTiles;
+        }
+        if (p->ring_image_bytes != image_bytes) {                // (the padding slots of the images are never written: they must read as zero)
+            SHG_HIP(hipMemsetAsync(p->ring_d, 0, p->ring_bytes, stream));
+            p->ring_image_bytes = image_bytes;
+        }
+        if (!p->handoff_d && hipMalloc((void**)&p->handoff_d, 2 * kRingTiles * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "hand-off words allocation failed");
+        if (!p->side_stream) {
+            SHG_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+            SHG_HIP(hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming));
+            SHG_HIP(hipEventCreateWithFlags(&p->join_event, hipEventDisableTiming));
+        }
+        P.ring = p->ring_d;
+        P.ring_tiles = kRingTiles;
+        P.produced = p->handoff_d;
+        P.consumed = p->handoff_d + kRingTiles;
+        P.fed_first = (int)std::min<unsigned>(nwg_pipe, (unsigned)(nbt * nit));
+    }
+    const dim3 grid_dim(pipe ? nwg_pipe : (unsigned)(nbt * nit));
+    ProfileScope ps(p, 2, stream);          // (fed pipeline: from the fork to the join, i.e. both kernels)
+    if (mode == 2) {
+        SHG_HIP(hipMemsetAsync(p->handoff_d, 0, 2 * P.ring_tiles * sizeof(int), stream));
+        SHG_HIP(hipEventRecord(p->fork_event, stream));
+        SHG_HIP(hipStreamWaitEvent(p->side_stream, p->fork_event, 0));
+        const int produced_tiles = nbt * nit - P.fed_first;
+        if (produced_tiles > 0) {
+            if (ns)
+                hipLaunchKernelGGL(legendre_panel_kernel<true>, dim3((unsigned)produced_tiles), dim3(256), 0, p->side_stream, P);
+            else
+                hipLaunchKernelGGL(legendre_panel_kernel<false>, dim3((unsigned)produced_tiles), dim3(256), 0, p->side_stream, P);
+            SHG_HIP(hipGetLastError());
+        }
+        SHG_HIP(hipEventRecord(p->join_event, p->side_stream));
+    }
     switch (R) {
-        case 10: rc = launch_rot<10>(p, ns, pipe, P, lds, grid_dim, stream); break;
-        case 9: rc = launch_rot<9>(p, ns, pipe, P, lds, grid_dim, stream); break;
-        case 6: rc = launch_rot<6>(p, ns, pipe, P, lds, grid_dim, stream); break;
-        case 3: rc = launch_rot<3>(p, ns, pipe, P, lds, grid_dim, stream); break;
+        case 10: rc = launch_rot<10>(p, ns, mode, P, lds, grid_dim, stream); break;
+        case 9: rc = launch_rot<9>(p, ns, mode, P, lds, grid_dim, stream); break;
+        case 6: rc = launch_rot<6>(p, ns, mode, P, lds, grid_dim, stream); break;
+        case 3: rc = launch_rot<3>(p, ns, mode, P, lds, grid_dim, stream); break;
         default: return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel: no kernel for %d rotations", R);
     }
+    if (mode == 2) SHG_HIP(hipStreamWaitEvent(stream, p->join_event, 0));
 
     if (rc) return rc;
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
 
-int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, false, anm, B, grid, stream); }
-int synthesis_pipe(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, true, anm, B, grid, stream); }
+int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 0, anm, B, grid, stream); }
+int synthesis_pipe(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 1, anm, B, grid, stream); }
+int synthesis_fed(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 2, anm, B, grid, stream); }
 
 }  // namespace shg
