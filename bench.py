@@ -81,7 +81,7 @@ def parse_args(argv=None):
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass of the staged path (0 = library default)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='seconds after which `--gpus N` run without a launcher kills its ranks (0 = never)')
-    ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'fused32', 'rot'], help='synthesis kernel path')
+    ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'fused32', 'rot', 'pipe', 'fed'], help='synthesis kernel path')
     ap.add_argument('--cpu-sample', type=int, default=16, help='solutions timed on the CPU baseline (0 = skip all CPU baselines)')
     ap.add_argument('--cov-parallels', type=int, default=-1,
                     help='parallels of the covariance leg over all ranks (-1 = the whole 0.5 degree grid, 360; 0 = skip the leg)')
@@ -235,8 +235,8 @@ class GpuWorkload:
         self.batch = torch.from_numpy(self.batch_host).cuda()
         self.out = torch.empty((B, self.nlat, self.nlon), dtype=torch.float64, device='cuda')
         info = self.plan.info()
-        rot = bool(info['rotation_symmetry']) and self.args.path in ('auto', 'rot')
-        self.kernel_name = ('synthesis_rot_kernel' if rot else 'synthesis_fused_kernel') if info['fused'] else 'lon_stage_kernel<4>'
+        rot = bool(info['rotation_symmetry']) and self.args.path in ('auto', 'rot', 'pipe', 'fed')
+        self.kernel_name = (('synthesis_pipe_kernel' if self.args.path in ('pipe', 'fed') else 'synthesis_rot_kernel') if rot else 'synthesis_fused_kernel') if info['fused'] else 'lon_stage_kernel<4>'
         self.config = {'fused_kernel': info['fused'], 'fourfold_symmetry': info['fourfold_symmetry'], 'rotation_folded_kernel': rot,
                        'rotations': info['rotations'] if rot else 0}
 
@@ -750,17 +750,21 @@ def compact_line(line, limit=LINE_LIMIT):
     enough the legs' per-repeat lists, `config` texts, CPU baselines and checks go, in that order (named in `dropped_for_line_limit`).  Contract fields, `config`, `roofline`, `cpu_baseline` are never dropped."""
     keep9 = {'value', 'ms_per_step'}
 
-    def tidy(o, key=None, depth=0):
+    kept = ('config', 'roofline', 'cpu_baseline')          # the objects whose scalars the driver keeps: their strings may have 140 characters
+
+    def tidy(o, key=None, depth=0, wide=False):
         if isinstance(o, float):
             if key and 'checksum' in key:
                 return o                                    # reproducibility checksums keep every digit
             return float('{0:.{1}g}'.format(o, 9 if key in keep9 and depth <= 1 else 6))
         if isinstance(o, dict):
-            return {k: tidy(v, k, depth + 1) for k, v in o.items() if not (depth >= 1 and k in ('traffic_note', 'note', 'phases_all', 'flops_per_epoch'))}
+            return {k: tidy(v, k, depth + 1, wide or (depth == 0 and k in kept)) for k, v in o.items()
+                    if not (depth >= 1 and k in ('traffic_note', 'note', 'phases_all', 'flops_per_epoch'))}
         if isinstance(o, (list, tuple)):
-            return [tidy(v, key, depth + 1) for v in o]
-        if isinstance(o, str) and depth > 1 and len(o) > 72:
-            return o[:69] + '...'
+            return [tidy(v, key, depth + 1, wide) for v in o]
+        limit_ = 140 if wide and depth == 2 else 72
+        if isinstance(o, str) and depth > 1 and len(o) > limit_:
+            return o[:limit_ - 3] + '...'
         return o
 
     sources = []
