@@ -267,7 +267,8 @@ int build_rot_trig(shg_plan* p, const double* lon_h);
 int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 int pipe_applicable(const shg_plan* p);          // the pipelined variant of the rotation-folded kernel (synthesis_rot.hip, path 7)
 int synthesis_pipe(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
-int synthesis_fed(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);           // path 8: Legendre stage as a second kernel beside it
+int synthesis_fed(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
+int synthesis_rot_halves(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);    // path 9: two workgroups of two epochs per CU           // path 8: Legendre stage as a second kernel beside it
 int fused32_applicable(const shg_plan* p);
 int synthesis_fused32(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 

@@ -567,8 +567,9 @@ extern "C" int shg_plan_set_chunk(shg_plan* p, int epochs_per_pass) {
 
 extern "C" int shg_plan_set_path(shg_plan* p, int path) {
     SHG_REQUIRE(p != nullptr, "shg_plan_set_path: NULL plan");
-    SHG_REQUIRE(path == 0 || path == 1 || path == 2 || path == 5 || path == 6 || path == 7 || path == 8, "shg_plan_set_path: path %d not in {0, 1, 2, 5, 6, 7, 8}", path);
-    SHG_REQUIRE(path < 7 || pipe_applicable(p), "shg_plan_set_path: pipelined rotation-folded kernel not applicable (needs what path 6 needs and two trig buffers beside the panel in the LDS)");
+    SHG_REQUIRE(path == 0 || path == 1 || path == 2 || path == 5 || path == 6 || path == 7 || path == 8 || path == 9, "shg_plan_set_path: path %d not in {0, 1, 2, 5, 6, 7, 8, 9}", path);
+    SHG_REQUIRE(path != 9 || rot_applicable(p), "shg_plan_set_path: rotation-folded kernel not applicable");
+    SHG_REQUIRE(path < 7 || path == 9 || pipe_applicable(p), "shg_plan_set_path: pipelined rotation-folded kernel not applicable (needs what path 6 needs and two trig buffers beside the panel in the LDS)");
     SHG_REQUIRE(path != 5 || fused32_applicable(p), "shg_plan_set_path: the two-workgroup fused kernel needs both grid symmetries and K <= 416 (K = %d)", p->K);
     SHG_REQUIRE(path != 2 || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
     SHG_REQUIRE(path < 6 || rot_applicable(p), "shg_plan_set_path: rotation-folded kernel not applicable (needs equi-angular meridians with nlon %% 96 == 0 or nlon %% 48 == 0, nlon >= 192, and a panel within the LDS)");

@@ -235,6 +235,7 @@ extern "C" int shg_synthesis(shg_plan* p, const double* anm, int B, double* grid
     hipStream_t stream = (hipStream_t)stream_;
     PlanGuard guard(p, stream);
     // degrees beyond the 64-row panel (d/o 127 ... ~210): the 32-row fused kernel still beats the three-kernel path
+    if (p->path == 9) return synthesis_rot_halves(p, anm, B, grid, stream);
     if (p->path == 8) return synthesis_fed(p, anm, B, grid, stream);
     if (p->path == 7) return synthesis_pipe(p, anm, B, grid, stream);
     if (p->path >= 6 || (p->path == 0 && rot_applicable(p))) return synthesis_rot(p, anm, B, grid, stream);

@@ -315,11 +315,13 @@ struct RotStream {
 };
 
 // The issue side walks the column tiles of its wave on its own: (wave >> 2), + 2, ..., then again from the start for the next tile.
+// EP = epochs (= row tiles) of the workgroup: 4 (eight waves, one workgroup per CU) or 2 (four waves, two workgroups per CU)
+template <int EP>
 __device__ __forceinline__ void rot_stream_init(RotStream& S, const RotParams& P, const double* As, int wave) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)As;
     S.ring_lds = lds0 + (unsigned)wave * (kRingSlots * 1024);
     S.im0 = S.ring_lds;
-    const int ct0 = min(wave >> 2, P.nct - 1);
+    const int ct0 = min(wave / EP, P.nct - 1);
     const int nq = (P.nct - ct0 + kColStride - 1) / kColStride;     // column tiles of this wave
     S.ifirst = P.trig + (size_t)ct0 * P.npieces * 128;
     S.ilast = S.ifirst + (size_t)(nq - 1) * kColStride * P.npieces * 128;
@@ -351,9 +353,10 @@ __device__ __forceinline__ void rot_issue_piece(RotStream& S, const RotParams& P
 // on the same column tile then drift apart and no longer share the trig pieces in the L1.)
 // On entry (S.tx, S.abx) hold the fragments of the first k-step; on exit those of the first k-step of column tile wave >> 2
 // again (trig part; the panel part is re-read by the caller once the next panel is there).
-template <bool NS, int R>
+template <bool NS, int R, int EP>
 __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As, const double2_t* panel, RotStream& S, int wave, int lane,
-                                           int bt, int it) {
+                                           int b0, int it) {
+    constexpr int PR = 16 * EP;                        // panel rows
     using T = RotTraits<R>;
     constexpr int kImages = 2 * R;
     const int fr = lane & 15, fk = lane >> 4;
@@ -365,9 +368,9 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
     const int grid_bytes = P.nlat * P.nlon * 8;        // one epoch's grid; < 2^31 (checked on the host)
     const int n2 = P.nlon >> 1, nR = P.nlon / R;
     const double2_t* const ringp = reinterpret_cast<const double2_t*>(As) + wave * (kRingSlots * 64) + lane;   // + slot * 64
-    // all units of a wave lie in the same row tile wave & 3
-    const int rt = wave & 3;
-    const double2_t* const prow = panel + rt * 16 + fr + fk * 64;        // + 256 p: k-step p of the flat class sequence
+    // all units of a wave lie in the same row tile
+    const int rt = wave % EP;
+    const double2_t* const prow = panel + rt * 16 + fr + fk * PR;        // + 4 PR p: k-step p of the flat class sequence
     // Fragments of the next k-step of the flat (unit, k-step) sequence -> (T_, AB_): one more trig piece issued, the piece of
     // this k-step waited for, ring slot and panel rows read.  Branch-free and unconditional (after the last k-step of the last
     // unit it re-reads valid memory), so that hipcc keeps exact lgkmcnt counts across the loops: the MFMAs of k-step p then
@@ -381,7 +384,7 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
         if (!(SHG_ROT_X & 8)) wait_vmcnt<kRingDepth>();                                                   \
         if (!(SHG_ROT_X & 4)) T_ = ringp[S.cslot * 64];                                                   \
         if (!(SHG_ROT_X & 2)) S.cslot = S.cslot + 1 == kRingSlots ? 0 : S.cslot + 1;                      \
-        AB_ = prow[S.pf * 256];                                                                           \
+        AB_ = prow[S.pf * (4 * PR)];                                                                           \
         if (!(SHG_ROT_X & 2)) S.pf = S.pf + 1 == P.npieces ? 0 : S.pf + 1;                                \
         __builtin_amdgcn_sched_barrier(0);                                                                \
     } while (0)
@@ -452,13 +455,13 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
     }
     const double4_t kZero4 = {0.0, 0.0, 0.0, 0.0};
     double2_t tx = S.tx, abx = S.abx, ty = {0.0, 0.0}, aby = {0.0, 0.0};
-    const int ct0 = wave >> 2;
+    const int ct0 = wave / EP;
     for (int ct = ct0, q = 0; ct < P.nct; ct += kColStride, ++q) {
         (void)q;
         double4_t acc[T::kAcc];
         {
             // order 0 does not depend on the longitude: start value of CA_0 (C/D layout: row = fk + 4 reg, all columns)
-            const double2_t* z = panel + P.nslot * 64 + rt * 16 + fk;
+            const double2_t* z = panel + P.nslot * PR + rt * 16 + fk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[0][r] = z[4 * r].x;
         }
@@ -476,7 +479,7 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
 #pragma unroll
         for (int r = 0; r < 4; ++r) rot_images<R>(acc, r);      // (unconditional: a run-time switch around an in-place update of the
                                                                 //  accumulator vectors makes hipcc copy every vector, ~60 moves per row)
-        const int b = bt * 4 + rt;
+        const int b = b0 + rt;
         const bool epoch_ok = b < P.B && !SHG_DBG(P, 1);
         double* const Gb = P.G + (size_t)min(b, P.B - 1) * P.nlat * P.nlon;
         {
@@ -531,6 +534,15 @@ struct GlobalPanel {
     bool skip;
 };
 __device__ __forceinline__ void panel_put(double2_t* panel, int index, double2_t v) { panel[index] = v; }
+// the 32-row panel of a workgroup that keeps two of the tile's four epochs (index = slot * 64 + epoch * 16 + row of the full panel)
+struct HalfPanel {
+    double2_t* rows;
+    int half;
+};
+__device__ __forceinline__ void panel_put(const HalfPanel& panel, int index, double2_t v) {
+    const int row = index & 63;
+    if ((row >> 5) == panel.half) panel.rows[(index >> 6) * 32 + (row & 31)] = v;
+}
 __device__ __forceinline__ void panel_put(const GlobalPanel& panel, int index, double2_t v) {
     if (panel.skip) {                       // (experiment builds: the producer without its stores)
         asm volatile("" ::"v"(v));
@@ -686,8 +698,9 @@ __device__ __forceinline__ void legendre_token_acquire(int* sem, int limit) {
 }
 __device__ __forceinline__ void legendre_token_release(int* sem) { (void)__hip_atomic_fetch_add(sem, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <bool NS, int R>
-__global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P) {
+template <bool NS, int R, int EP>
+__global__ __launch_bounds__(128 * EP) void synthesis_rot_kernel(RotParams P) {
+    constexpr int NW = 2 * EP, PR = 16 * EP;           // waves, panel rows
     using T = RotTraits<R>;
     extern __shared__ __attribute__((aligned(16))) double As[];   // rings [8][kRingSlots][64][2], then panel [nslot + 1][64 rows][2]
 
@@ -695,8 +708,12 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nbt = (P.B + 3) >> 2;
-    const int bt = P.blockmap ? P.blockmap[2 * blockIdx.x] : (int)(blockIdx.x % nbt);
-    const int it = P.blockmap ? P.blockmap[2 * blockIdx.x + 1] : (int)(blockIdx.x / nbt);
+    // EP == 2: the workgroups b and b + 8 (one XCD) are the two halves of a tile: epochs 0, 1 and 2, 3
+    const int tile = EP == 4 ? (int)blockIdx.x : (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7));
+    const int half = EP == 4 ? 0 : (int)((blockIdx.x >> 3) & 1);
+    if (tile >= nbt * P.nit) return;
+    const int bt = P.blockmap ? P.blockmap[2 * tile] : tile % nbt;
+    const int it = P.blockmap ? P.blockmap[2 * tile + 1] : tile / nbt;
     const int fr = lane & 15, fk = lane >> 4;
 #ifdef SHG_EXPERIMENT
     if (P.stagger > 0 && blockIdx.x < 256) {
@@ -707,14 +724,14 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
 #endif
     ROT_STAMP(0);
 
-    double2_t* const panel = reinterpret_cast<double2_t*>(As + kRingDoubles);      // [(slot * 64 + row)]
+    double2_t* const panel = reinterpret_cast<double2_t*>(As + NW * kRingSlots * 128);      // [(slot * PR + row)], behind the rings of the waves
 
     // ---- zero the padding slots of the panel
     {
         int s0 = 0;
         for (int c = 0; c < T::kClasses; ++c) {
             for (int s = s0 + P.cls_cnt[c]; s < s0 + 4 * P.cls_nk[c]; ++s)
-                if (tid < 64) panel[s * 64 + tid] = (double2_t){0.0, 0.0};
+                if (tid < PR) panel[s * PR + tid] = (double2_t){0.0, 0.0};
             s0 += 4 * P.cls_nk[c];
         }
     }
@@ -722,7 +739,7 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
     // ---- trig stream of this wave.  The issue side runs kRingDepth pieces ahead of the consumer and never stops (when a wave has
     //      no further column tile it re-reads pieces), so that the count of DMAs in flight is the same at every wait.
     RotStream S;
-    rot_stream_init(S, P, As, wave);
+    rot_stream_init<EP>(S, P, As, wave);
 #pragma unroll
     for (int d = 0; d < kRingDepth; ++d) rot_issue_piece(S, P, (unsigned)lane * 16u);
 
@@ -731,28 +748,36 @@ __global__ __launch_bounds__(64 * kWaves) void synthesis_rot_kernel(RotParams P)
         if (tid == 0) legendre_token_acquire(P.sem, P.sem_limit);
         __syncthreads();
     }
-    if (!SHG_DBG(P, 2)) rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
+    if (!SHG_DBG(P, 2)) {
+        if (EP == 4) {
+            rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
+        } else {                  // two of the eight item lists per wave; the rows of the other two epochs are computed and dropped
+            const HalfPanel hp = {panel, half};
+            rot_phase1<NS>(P, hp, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
+            rot_phase1<NS>(P, hp, P.itemtab + (size_t)(wave + 4) * P.nrec, bt, it, lane);
+        }
+    }
     ROT_STAMP(1);
     __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
     if (P.sem_limit > 0 && tid == 0) legendre_token_release(P.sem);
     ROT_STAMP(2);
 #ifdef SHG_EXPERIMENT
-    if (P.stagger2 > 0 && wave >= 4) {
+    if (P.stagger2 > 0 && wave >= EP) {
         const long long t0 = wall_clock64();
         for (int i = 0; i < 100000 && (long long)wall_clock64() - t0 < P.stagger2; ++i) __builtin_amdgcn_s_sleep(4);
     }
 #endif
 
     // ---- phase 2: longitude stage
-    if ((wave >> 2) < P.nct && !SHG_DBG(P, 4)) {
+    if (wave / EP < P.nct && !SHG_DBG(P, 4)) {
         const double2_t* const ringp = reinterpret_cast<const double2_t*>(As) + wave * (kRingSlots * 64) + lane;
         rot_issue_piece(S, P, (unsigned)lane * 16u);       // fragments of the first k-step
         wait_vmcnt<kRingDepth>();
         S.tx = ringp[0];
         S.cslot = 1;
-        S.abx = panel[(wave & 3) * 16 + fr + fk * 64];
+        S.abx = panel[(wave % EP) * 16 + fr + fk * PR];
         S.pf = P.npieces > 1 ? 1 : 0;
-        rot_phase2<NS, R>(P, As, panel, S, wave, lane, bt, it);
+        rot_phase2<NS, R, EP>(P, As, panel, S, wave, lane, bt * 4 + half * 2, it);
         // The prefetched pieces of the stream must have landed before the LDS is released -- but not the stores: the 4 R stores of
         // the last unit are the youngest operations of the wave (its last LDS-DMA was issued in the last k-step, before them), and
         // the counter runs in order, so "at most 4 R outstanding" means every DMA is done.  The wave ends with its stores in flight
@@ -1481,12 +1506,20 @@ static int launch_rot(shg_plan* p, bool ns, int mode, const RotParams& P, size_t
         if (ns) SHG_LAUNCH_PIPE(true, true); else SHG_LAUNCH_PIPE(false, true);
     } else if (mode == 1) {
         if (ns) SHG_LAUNCH_PIPE(true, false); else SHG_LAUNCH_PIPE(false, false);
+    } else if (mode == 3) {           // two workgroups of two epochs per CU
+        if (ns) {
+            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((synthesis_rot_kernel<true, R, 2>), grid_dim, dim3(256), lds, stream, P);
+        } else {
+            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<false, R, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((synthesis_rot_kernel<false, R, 2>), grid_dim, dim3(256), lds, stream, P);
+        }
     } else if (ns) {
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((synthesis_rot_kernel<true, R>), grid_dim, dim3(64 * kWaves), lds, stream, P);
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((synthesis_rot_kernel<true, R, 4>), grid_dim, dim3(64 * kWaves), lds, stream, P);
     } else {
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((synthesis_rot_kernel<false, R>), grid_dim, dim3(64 * kWaves), lds, stream, P);
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<false, R, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((synthesis_rot_kernel<false, R, 4>), grid_dim, dim3(64 * kWaves), lds, stream, P);
     }
 #undef SHG_LAUNCH_PIPE
     return SHG_OK;
@@ -1502,7 +1535,7 @@ int pipe_applicable(const shg_plan* p) {
 }
 
 static int synthesis_rot_launch(shg_plan* p, int mode, const double* anm, int B, double* grid, hipStream_t stream) {
-    const bool pipe = mode != 0;
+    const bool pipe = mode == 1 || mode == 2;
     if (!(pipe ? pipe_applicable(p) : rot_applicable(p))) return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel not applicable to this plan");
     const int R = p->rotR;
     const bool ns = p->sym_ns;
@@ -1546,7 +1579,7 @@ static int synthesis_rot_launch(shg_plan* p, int mode, const double* anm, int B,
         SHG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         P.sem_limit = std::max(1, cus * -kLegendreTokens / 16);
     }
-    if (mode != 0) P.sem_limit = 0;          // (the pipelined kernels: measured without gain)
+    if (mode != 0) P.sem_limit = 0;          // (the other kernels: measured without gain)
 #ifdef SHG_EXPERIMENT
     if (getenv("SHG_SEM")) P.sem_limit = atoi(getenv("SHG_SEM"));
 #endif
@@ -1565,7 +1598,8 @@ static int synthesis_rot_launch(shg_plan* p, int mode, const double* anm, int B,
 #ifdef SHG_TIMELINE
     P.tl = getenv("SHG_TIMELINE_PTR") ? (unsigned long long*)strtoull(getenv("SHG_TIMELINE_PTR"), nullptr, 0) : nullptr;
 #endif
-    const size_t lds = pipe ? pipe_lds_bytes(P.nslot) : rot_lds_bytes(P.nslot);
+    // mode 3: four rings of kRingSlots KB, then the 32-row panel
+    const size_t lds = pipe ? pipe_lds_bytes(P.nslot) : mode == 3 ? (size_t)4 * kRingSlots * 1024 + (size_t)(P.nslot + 1) * 512 : rot_lds_bytes(P.nslot);
     unsigned nwg_pipe = (unsigned)(nbt * nit);
     if (pipe) {                                       // persistent workgroups, one per CU (the kernel's LDS admits no second one)
         int dev = 0, cus = 0;
@@ -1605,7 +1639,8 @@ static int synthesis_rot_launch(shg_plan* p, int mode, const double* anm, int B,
         P.consumed = p->handoff_d + kRingTiles;
         P.fed_first = (int)std::min<unsigned>(nwg_pipe, (unsigned)(nbt * nit));
     }
-    const dim3 grid_dim(pipe ? nwg_pipe : (unsigned)(nbt * nit));
+    // (mode 3: the two halves of tile 8 j + x are the workgroups 16 j + x and 16 j + 8 + x)
+    const dim3 grid_dim(pipe ? nwg_pipe : mode == 3 ? (unsigned)(ceil_div(nbt * nit, 8) * 16) : (unsigned)(nbt * nit));
     ProfileScope ps(p, 2, stream);          // (fed pipeline: from the fork to the join, i.e. both kernels)
     if (mode == 2) {
         SHG_HIP(hipMemsetAsync(p->handoff_d, 0, 2 * P.ring_tiles * sizeof(int), stream));
@@ -1638,5 +1673,6 @@ static int synthesis_rot_launch(shg_plan* p, int mode, const double* anm, int B,
 int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 0, anm, B, grid, stream); }
 int synthesis_pipe(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 1, anm, B, grid, stream); }
 int synthesis_fed(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 2, anm, B, grid, stream); }
+int synthesis_rot_halves(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 3, anm, B, grid, stream); }
 
 }  // namespace shg

@@ -96,7 +96,7 @@ class Plan:
         """'auto', 'staged' (three kernels, any grid), 'fused' (single kernel on 4-fold symmetric meridians), 'fused32' (32-row
         panels) or 'rot' (rotation-folded kernel on equi-angular meridians with nlon % 96 == 0 or nlon % 48 == 0).  The fused
         kernels use the north-south symmetry of the parallels when the grid has it (their plain variants otherwise)."""
-        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'fused32': 5, 'rot': 6, 'pipe': 7, 'fed': 8}[path])
+        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'fused32': 5, 'rot': 6, 'pipe': 7, 'fed': 8, 'halves': 9}[path])
 
     def set_rotations(self, R):
         """Rotation count of the rotation-folded kernel: 0 (the plan's own choice), 3, 6, 9 or 10; the meridians must be invariant

@@ -274,11 +274,12 @@ def test_rotation_counts(N, nlon, nlat, B):
     assert np.array_equal(ga.engine.to_host(plan.synthesis(batch)), outs[own])
 
 
-@pytest.mark.parametrize('path', ['pipe', 'fed'])
+@pytest.mark.parametrize('path', ['pipe', 'fed', 'halves'])
 @pytest.mark.parametrize('N,nlon,nlat,B', [(96, 1440, 720, 5), (96, 1440, 18, 9), (31, 1440, 36, 4), (6, 1440, 16, 1), (45, 720, 90, 6), (17, 1440, 10, 3), (9, 1440, 4, 2)])
 def test_pipelined_kernels(path, N, nlon, nlat, B):
     """The pipelined variants of the rotation-folded kernel -- 'pipe': one wave per SIMD, a unit's images leave during the next unit;
-    'fed': the same, its panels computed by a second kernel on another stream and handed over through a ring in global memory -- for
+    'fed': the same, its panels computed by a second kernel on another stream and handed over through a ring in global memory;
+    'halves': the standard kernel as two workgroups of two epochs per CU (each computes the whole Legendre stage of the tile) -- for
     every rotation count against the oracle and against the standard kernel: whole and half column tiles, ragged batches (epochs beyond
     the batch in the last tile), workgroups with one tile and with many, repeated calls on one plan (hand-off words re-armed)."""
     grid = ga.grid.GeographicGrid(360.0 / nlon, 180.0 / nlat)
@@ -296,7 +297,7 @@ def test_pipelined_kernels(path, N, nlon, nlat, B):
         except ga._lib.ShgError:                      # two trig buffers beside the panel do not fit the LDS (e.g. 9 rotations at d/o 96)
             assert (R, N) != (10, 96)
             continue
-        assert plan.info()['path'] == {'pipe': 7, 'fed': 8}[path]
+        assert plan.info()['path'] == {'pipe': 7, 'fed': 8, 'halves': 9}[path]
         for call in range(2):
             out = ga.engine.to_host(plan.synthesis(batch))
             assert relerr(out[0:nref], ref) < TOL, (R, call)
@@ -314,7 +315,7 @@ def test_pipelined_kernels_plain_parallels():
     grid = ga.grid.RegularGrid(mer, par)
     plan = ga.engine.Plan(40, *_tables(grid, 40, 'potential'))
     ref = np.stack([orc.synthesis_regular(batch[e], mer, par, pot) for e in range(3)])
-    for path in ('pipe', 'fed'):
+    for path in ('pipe', 'fed', 'halves'):
         plan.set_path(path)
         assert relerr(ga.engine.to_host(plan.synthesis(batch)), ref) < TOL, path
 
