@@ -655,12 +655,17 @@ def pmc_traffic(leg, kernels):
     """HBM-side bytes per launch of the named kernels of a leg (summed) from the committed rocprofv3 --pmc summary of the same workload
     (profiles/r04_pmc_traffic.json, tools/pmc_legs.sh), with its origin: counters cannot be collected inside a timed run.  A kernel
     name matches when the recorded name starts with it.  -> (bytes or None, source or None)"""
-    path = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
-    try:
-        with open(path) as f:
-            table = json.load(f)
-        rows = table['legs'][leg]
-    except Exception:
+    table = rows = None
+    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json'):          # the newest summary that holds the leg
+        path = os.path.join(ROOT, 'profiles', name)
+        try:
+            with open(path) as f:
+                table = json.load(f)
+            rows = table['legs'][leg]
+            break
+        except Exception:
+            rows = None
+    if rows is None:
         return None, None
     total, found = 0.0, []
     for want in kernels:
@@ -670,7 +675,7 @@ def pmc_traffic(leg, kernels):
         name, r = max(hit, key=lambda kv: kv[1]['dispatches'])
         total += r['bytes']
         found.append(name.split('<')[0])
-    return total, 'profiles/r04_pmc_traffic.json ({0}; {1}; build of {2}): {3}'.format(table.get('source', ''), table.get('correction', ''),
+    return total, 'profiles/' + name + ' ({0}; {1}; build of {2}): {3}'.format(table.get('source', ''), table.get('correction', ''),
                                                                                   table.get('commit', 'round 4'), ' + '.join(found))
 
 
@@ -781,17 +786,25 @@ def compact_line(line, limit=LINE_LIMIT):
         line['traffic_source'] = sources[0].split(': ')[0][:140]
     line = tidy(line)
     size = lambda o: len(json.dumps(o, separators=(',', ':')))          # noqa: E731
-    droppable = [(leg, key) for leg in ('smoother', 'filters', 'analysis', 'covariance') if isinstance(line.get(leg), dict)
-                 for key in ('seconds_all', 'config')]
-    droppable += [(leg, key) for leg in ('smoother', 'filters', 'analysis', 'covariance') if isinstance(line.get(leg), dict) for key in ('cpu_baseline', 'check')]
-    droppable += [(None, 'kernels'), (None, 'traffic_source')]
-    for leg, key in droppable:
-        if size(line) <= limit:
-            break
-        target = line if leg is None else line[leg]
-        if key in target:
-            target.pop(key)
-            line.setdefault('dropped_for_line_limit', []).append(key if leg is None else leg + '.' + key)
+    legs_present = [leg for leg in ('smoother', 'filters', 'analysis', 'covariance') if isinstance(line.get(leg), dict)]
+
+    def nodes(leg):                                  # the leg object and, for the filters leg, its two forms
+        top = line[leg]
+        return [top] + [v for k, v in top.items() if k in ('block', 'dense') and isinstance(v, dict)]
+    # what goes first when the line is too long: per-repeat lists, descriptive texts, kernel tables; whole sub-objects only at the end
+    stages = [[(n, 'seconds_all') for leg in legs_present for n in nodes(leg)],
+              [(n.get('config'), key) for leg in legs_present for n in nodes(leg) for key in ('workload', 'sigma_recipe', 'parallelism', 'lookahead')],
+              [(n.get('roofline'), 'kernels') for leg in legs_present for n in nodes(leg)] + [(line, 'kernels')],
+              [(n.get('check'), 'what') for leg in legs_present for n in nodes(leg)] + [(n.get('cpu_baseline'), 'sample') for leg in legs_present for n in nodes(leg)],
+              [(n, key) for key in ('config', 'cpu_baseline', 'check') for leg in legs_present for n in nodes(leg)],
+              [(line, 'traffic_source')]]
+    for stage in stages:
+        for target, key in stage:
+            if size(line) <= limit:
+                break
+            if isinstance(target, dict) and key in target:
+                target.pop(key)
+                line.setdefault('dropped_for_line_limit', []).append(key)
     return line
 
 

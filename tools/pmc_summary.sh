@@ -1,8 +1,10 @@
 #!/bin/bash
 # SQ / TCP / TCC counters of the two headline kernels, one rocprofv3 --pmc pass per counter group (never combined with a trace
 # domain other than --kernel-trace).  Run on a GPU box from the repository root:
-#   tools/pmc_summary.sh            -> gpurun_out/r03_synthesis_pmc.txt, gpurun_out/r03_covprop_pmc.txt
+#   tools/pmc_summary.sh r05        -> gpurun_out/r05_synthesis_pmc.txt, r05_covprop_pmc.txt, r05_filters_block_pmc.txt, r05_filters_dense_pmc.txt
+tag=${1:-r05}
 out=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 groups=(
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY"
@@ -35,5 +37,9 @@ for c, v in sorted(agg.items()):
 PY
   done
 }
-run_group r03_synthesis_pmc synthesis_rot_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs synthesis --cpu-sample 0 --steps 20 --warmup 5 --ramp 50
-run_group r03_covprop_pmc gemm_f64_kernel python3 $GRAFT_REPO_ROOT/tools/gemm_phases.py --release-library 24
+run_group ${tag}_synthesis_pmc synthesis_rot_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs synthesis --cpu-sample 0 --steps 20 --warmup 5 --ramp 50 --idle-pass 0
+run_group ${tag}_covprop_pmc gemm_f64_kernel python3 $GRAFT_REPO_ROOT/tools/gemm_phases.py --release-library 24
+run_group ${tag}_filters_block_pmc orderwise_filter_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs filters --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0
+cp $out/${tag}_filters_block_pmc.txt $out/${tag}_filters_tmp.txt
+run_group ${tag}_filters_dense_pmc gemm_ex_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs filters --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0
+rm -f $out/${tag}_filters_tmp.txt
