@@ -419,6 +419,14 @@ class GpuWorkload:
             state['block'] = flt.filter_batch(batch)
         step_block()
         el_block, _, ev_block = ctx.timed(step_block, args.warmup, args.steps, events=True)
+        # the same operator on the series kept on the device in order-major layout (engine.OrderMajorSeries): one product per block on whole
+        # matrices, no gather / scatter; the conversion from the reference arrays happens once, outside the timed steps
+        series = ga.engine.OrderMajorSeries.from_batch(batch)
+
+        def step_series():
+            state['series'] = flt.filter_series(series)
+        step_series()
+        el_series, _, ev_series = ctx.timed(step_series, args.warmup, args.steps, events=True)
         nmin = 2
         P = (nmax + 1) ** 2 - nmin ** 2
         dense = ga.filter.GeneralMatrix(flt.matrix(nmin, nmax), nmin, nmax)   # 14637 x 14637 full normal-type matrix, 1.7 GB
@@ -429,7 +437,7 @@ class GpuWorkload:
         dense_steps = max(args.steps // 2, 1)
         el_dense, _, ev_dense = ctx.timed(step_dense, max(args.warmup // 2, 1), dense_steps, events=True)
         return dict(nmax=nmax, T=T, nmin=nmin, P=P, blocks=blocks, batch_host=batch_host, dense=dense, state=state, el_block=el_block, ev_block=ev_block,
-                    el_dense=el_dense, ev_dense=ev_dense, dense_steps=dense_steps)
+                    el_dense=el_dense, ev_dense=ev_dense, dense_steps=dense_steps, el_series=el_series, ev_series=ev_series)
 
     def leg_filters_report(self, ctx, st):
         """The line of the filters leg from the timed part's record, the two forms against each other and against the oracle, the CPU baselines."""
@@ -442,6 +450,8 @@ class GpuWorkload:
         block_bytes = 8.0 * (sum(b.size for b in blocks) + 2.0 * (nmax + 1) ** 2 * T)
         dense_flops = 2.0 * P * P * T
         agree = float(((state['dense'] - state['block']).abs().max() / state['block'].abs().max()).item())
+        agree_series = float(((state['series'].to_batch() - state['block']).abs().max() / state['block'].abs().max()).item())
+        el_series, ev_series = st['el_series'], st['ev_series']
         out = {
             'block': {
                 'metric': 'order-wise (DDK5-type) filter of a d/o-{0} series, block form'.format(nmax), 'value': ctx.world * T * args.steps / el_block,
@@ -451,6 +461,14 @@ class GpuWorkload:
                              'unit': 'GB/s', 'frac': block_bytes / (ev_block * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              'traffic': pmc_traffic('filters', ['orderwise_filter_kernel'])[0], 'traffic_source': pmc_traffic('filters', ['orderwise_filter_kernel'])[1],
                              'algorithmic_bytes_per_launch': block_bytes, 'avg_launch_ms': ev_block},
+            },
+            'order_major': {
+                'metric': 'the same filter on the series kept in order-major layout on the device (no gather / scatter)', 'value': ctx.world * T * args.steps / el_series,
+                'unit': 'epochs/s', 'n_gpus': ctx.world, 'scaling': 'weak', 'ms_per_step': 1e3 * el_series / args.steps, 'dtype': 'f64',
+                'roofline': {'kernel': 'orderwise_filter_om_kernel', 'bound': 'hbm', 'achieved': block_bytes / (ev_series * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                             'unit': 'GB/s', 'frac': block_bytes / (ev_series * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                             'algorithmic_bytes_per_launch': block_bytes, 'avg_launch_ms': ev_series},
+                'check': {'max_rel_diff_vs_block_form': agree_series, 'tolerance': 1e-12, 'ok': bool(agree_series < 1e-12)},
             },
             'dense': {
                 'metric': 'the same filter as full normal-matrix multiply W X, W {0} x {0}'.format(P), 'value': ctx.world * T * dense_steps / el_dense,
@@ -464,8 +482,8 @@ class GpuWorkload:
                              'traffic': pmc_traffic('filters', ['gemm_ex_kernel'])[0], 'traffic_source': pmc_traffic('filters', ['gemm_ex_kernel'])[1],
                              'avg_launch_ms': ev_dense},
             },
-            'check': {'dense_vs_block_max_rel_diff': agree, 'tolerance': 1e-12, 'ok': bool(agree < 1e-12),
-                      'what': 'timed output buffers of the two forms against each other (all epochs)'},
+            'check': {'dense_vs_block_max_rel_diff': agree, 'order_major_vs_block_max_rel_diff': agree_series, 'tolerance': 1e-12,
+                      'ok': bool(agree < 1e-12 and agree_series < 1e-12), 'what': 'timed output buffers of the three forms against each other (all epochs)'},
         }
         if ctx.world == 1 and args.cpu_sample > 0:
             orc, _ = self.oracle_kernel()
@@ -489,7 +507,7 @@ class GpuWorkload:
             out['dense']['cpu_baseline'] = {'value': dense_flops / dt / 1e9, 'unit': 'GFLOP/s', 'cores': blas_threads(), 'kind': 'port',
                                             'sample': 'W @ X for all {0} epochs in one dgemm (NumPy oracle, filter.py:473-477), {1:.2f} s'.format(T, dt)}
             out['check'].update({'block_max_rel_err_vs_oracle': err, 'dense_max_rel_err_vs_oracle': err_dense, 'epochs_checked_block': T,
-                                 'ok': bool(agree < 1e-12 and err < 1e-12 and err_dense < 1e-12)})
+                                 'ok': bool(agree < 1e-12 and agree_series < 1e-12 and err < 1e-12 and err_dense < 1e-12)})
         return out
 
     # ---- smoother: NormalEquations.solve + compute_covariance(sparse=True), grates/lstsq.py:950-968, 1026-1042
@@ -735,6 +753,9 @@ def summarise(line):
         roof['filters_block_frac'] = _get(flt, 'block', 'roofline', 'frac')
         ms_ = _get(flt, 'block', 'roofline', 'avg_launch_ms')
         roof['filters_block_us_per_step'] = 1e3 * ms_ if ms_ else None
+        ms_ = _get(flt, 'order_major', 'roofline', 'avg_launch_ms')
+        roof['filters_order_major_frac'] = _get(flt, 'order_major', 'roofline', 'frac')
+        roof['filters_order_major_us_per_step'] = 1e3 * ms_ if ms_ else None
         roof['filters_dense_frac'] = _get(flt, 'dense', 'roofline', 'frac')
         roof['filters_dense_TFLOPs'] = _get(flt, 'dense', 'roofline', 'achieved')
         roof['filters_dense_mfma_busy'] = _get(flt, 'dense', 'roofline', 'mfma_busy')
@@ -790,7 +811,7 @@ def compact_line(line, limit=LINE_LIMIT):
 
     def nodes(leg):                                  # the leg object and, for the filters leg, its two forms
         top = line[leg]
-        return [top] + [v for k, v in top.items() if k in ('block', 'dense') and isinstance(v, dict)]
+        return [top] + [v for k, v in top.items() if k in ('block', 'dense', 'order_major') and isinstance(v, dict)]
     # what goes first when the line is too long: per-repeat lists, descriptive texts, kernel tables; whole sub-objects only at the end
     stages = [[(n, 'seconds_all') for leg in legs_present for n in nodes(leg)],
               [(n.get('config'), key) for leg in legs_present for n in nodes(leg) for key in ('workload', 'sigma_recipe', 'parallelism', 'lookahead')],

@@ -50,6 +50,10 @@ PROTOTYPES = {
     'shg_covprop_points': [ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_degree_scale': [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_orderwise_filter': [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_order_major_pack': [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
+    'shg_order_major_unpack': [c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_orderwise_filter_om': [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_synthesis_om': [c_plan_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_ddk_blocks': [c_double_p, c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_void_p],
     'shg_dense_filter': [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_spd_solve': [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],

@@ -214,6 +214,8 @@ struct shg_plan {
     int* handoff_d = nullptr;
     hipStream_t side_stream = nullptr;
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    const double* om_src = nullptr;   // set for the duration of shg_synthesis_om: the coefficient repack reads this order-major series
+    int om_N = 0, om_Bpad = 0;
     int* sem_d = nullptr;       // token counter of the rotation-folded kernels' Legendre stage (synthesis_rot.hip)
     int* blockmap_d = nullptr;  // XCD-aware (epoch tile, parallel tile) order of the fused kernel's workgroups
     int blockmap_nbt = 0, blockmap_nit = 0;

@@ -266,6 +266,203 @@ extern "C" int shg_orderwise_filter(const double* blocks_packed, const int64_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Order-major series (round 5): a time series of coefficient sets that STAYS on the device between operators, laid out for them.
+//
+//   om [P = (N+1)^2 rows][Bpad epochs]   row of (slot s, degree offset k) = om_row(N, s) + k,   s = 0: order 0 cosine,
+//                                        2m - 1: order m cosine, 2m: order m sine (the order of the DDK block list), k = n - m
+//
+// Epochs are the fastest index (Bpad = B rounded up to 32: every row is a whole number of 256-byte runs), the coefficients of one order
+// are one contiguous [n x Bpad] matrix.  The order-wise filter is then Y_s = W_s X_s on whole matrices -- no gather, no
+// scatter (35 of the 58 us of orderwise_filter_kernel on the reference layout) --, and the coefficient repack of the fused
+// synthesis kernels reads four consecutive epochs of a degree with one 32-byte access.
+// shg_order_major_pack / _unpack convert from / to the reference layout anm [B][N+1][N+1] (C_nm at [n][m], S_nm at [m-1][n]).
+// ------------------------------------------------------------------------------------------------
+namespace shg {
+
+__host__ __device__ inline long long om_row(int N, int s) {        // first row of slot s
+    if (s == 0) return 0;
+    const int m = (s + 1) >> 1;
+    const long long cos_row = (long long)(N + 1) + 2LL * ((long long)(m - 1) * (N + 1) - (long long)m * (m - 1) / 2);
+    return (s & 1) ? cos_row : cos_row + (N + 1 - m);
+}
+
+// One workgroup = row r of the reference arrays of 16 epochs: [r][c <= r] are C_r,c (slot of order c cosine, k = r - c), [r][c > r]
+// are S_c,r+1 (slot of order r + 1 sine, k = c - r - 1).  Reads whole rows, writes 128-byte pieces (16 epochs of one coefficient).
+template <bool PACK>
+__global__ __launch_bounds__(256) void order_major_kernel(int N, int B, int Bpad, const double* __restrict__ src, double* __restrict__ dst) {
+    extern __shared__ double tile[];               // [16 epochs][N + 2]
+    const int r = blockIdx.x, b0 = blockIdx.y * 16, tid = threadIdx.x;
+    const int ld = N + 2;
+    const size_t E = (size_t)(N + 1) * (N + 1);
+    auto om_index = [&](int c) {
+        const int s = c <= r ? (c == 0 ? 0 : 2 * c - 1) : 2 * (r + 1);
+        const int k = c <= r ? r - c : c - r - 1;
+        return (size_t)(om_row(N, s) + k) * Bpad;
+    };
+    if (PACK) {
+        for (int i = tid; i < 16 * (N + 1); i += 256) {
+            const int e = i / (N + 1), c = i % (N + 1);
+            tile[e * ld + c] = b0 + e < B ? src[(size_t)(b0 + e) * E + (size_t)r * (N + 1) + c] : 0.0;
+        }
+        __syncthreads();
+        for (int i = tid; i < 16 * (N + 1); i += 256) {
+            const int c = i >> 4, e = i & 15;
+            if (b0 + e < Bpad) dst[om_index(c) + b0 + e] = tile[e * ld + c];
+        }
+    } else {
+        for (int i = tid; i < 16 * (N + 1); i += 256) {
+            const int c = i >> 4, e = i & 15;
+            tile[e * ld + c] = b0 + e < B ? src[om_index(c) + b0 + e] : 0.0;
+        }
+        __syncthreads();
+        for (int i = tid; i < 16 * (N + 1); i += 256) {
+            const int e = i / (N + 1), c = i % (N + 1);
+            if (b0 + e < B) dst[(size_t)(b0 + e) * E + (size_t)r * (N + 1) + c] = tile[e * ld + c];
+        }
+    }
+}
+
+// Y_s [n x Bpad] = W_s [n x n] X_s [n x Bpad] of one slot and one tile of 16 result rows per workgroup; the four waves share the
+// epochs, 64 each per pass.  A fragments (block entries) with one 16-byte range-checked buffer load per lane and pair of k-steps, as in
+// orderwise_filter_kernel.  B fragments straight from the series (L2: the rows of a slot are read by all its row tiles), two epochs per
+// lane and load: lane (j, k) reads X[k][32 p + 2 j .. + 1], the two values are the B operands of two MFMAs whose columns are the even
+// and the odd epochs of a group of 32 -- so that a lane also OWNS two adjacent epochs of four result rows and stores 16 bytes.
+// Degrees 0 and 1 keep the input (filter.py:189).
+constexpr int kOmPairsPerWave = 2;     // groups of 32 epochs of a wave at a time: 4 waves x 2 x 32 = 256 epochs per pass
+__global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N, int Bpad, int ntile_rows, const int* __restrict__ unit_slot, const int* __restrict__ unit_row0,
+                                                                  const double* __restrict__ blocks, const long long* __restrict__ block_off,
+                                                                  const double* __restrict__ in, double* __restrict__ out) {
+    const int unit = blockIdx.x;
+    if (unit >= ntile_rows) return;
+    const int s = unit_slot[unit], r0 = unit_row0[unit];
+    if (s < 0) return;
+    const int m = (s + 1) >> 1, n = N + 1 - m, ld = Nb + 1 - m;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(blocks), 0, (int)((block_off[2 * Nb] + 1) * 8), 0x00020000);
+    const unsigned voff = (unsigned)(block_off[s] * 8) + (unsigned)((min(r0 + fr, n - 1) * ld + 2 * fk) * 8);
+    const size_t row_first = (size_t)om_row(N, s);
+    const double2_t* X = reinterpret_cast<const double2_t*>(in + row_first * Bpad) + fr;       // + 16 p: group p of 32 epochs; + k Bpad / 2: row k
+    double2_t* Y = reinterpret_cast<double2_t*>(out + row_first * Bpad) + fr;
+    const int ldx = Bpad / 2, npair = Bpad / 32;
+    for (int p0 = wave * kOmPairsPerWave; p0 < npair; p0 += 4 * kOmPairsPerWave) {
+        double4_t acc[kOmPairsPerWave][2][2];
+#pragma unroll
+        for (int q = 0; q < kOmPairsPerWave; ++q) acc[q][0][0] = acc[q][0][1] = acc[q][1][0] = acc[q][1][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        const int nq = min(kOmPairsPerWave, npair - p0);
+        for (int c = 0; c < n; c += 8) {
+            // columns c + 2 fk, c + 2 fk + 1 of the block rows (A fragments of two k-steps: beyond the packed blocks the range check returns 0;
+            // beyond the block's own columns the rows of X are masked instead)
+            const double2_t a = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff + (unsigned)c * 8u, 0, 0));
+            const int k0 = c + 2 * fk, k1 = k0 + 1;
+            const double2_t zero2 = {0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < kOmPairsPerWave; ++q) {
+                if (q < nq) {
+                    const double2_t* xq = X + 16 * (p0 + q);
+                    const double2_t x0 = k0 < n ? xq[(size_t)k0 * ldx] : zero2, x1 = k1 < n ? xq[(size_t)k1 * ldx] : zero2;
+                    acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x0.x, acc[q][0][0], 0, 0, 0);      // even epochs, k-step 0
+                    acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x0.y, acc[q][1][0], 0, 0, 0);      // odd epochs
+                    acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x1.x, acc[q][0][1], 0, 0, 0);      // k-step 1
+                    acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x1.y, acc[q][1][1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kOmPairsPerWave; ++q) {
+            if (q < nq) {
+                const double4_t even = acc[q][0][0] + acc[q][0][1], odd = acc[q][1][0] + acc[q][1][1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r0 + fk + 4 * r;                            // C/D layout: row = fk + 4 reg, column = fr
+                    if (row < n) {
+                        const size_t at = (size_t)row * ldx + 16 * (p0 + q);
+                        Y[at] = m + row > 1 ? (double2_t){even[r], odd[r]} : X[at];
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace shg
+
+extern "C" int shg_order_major_pack(const double* anm, int N, int B, double* om, int Bpad, void* stream_) {
+    SHG_REQUIRE(N >= 0 && B >= 0 && Bpad >= B && Bpad % 32 == 0, "shg_order_major_pack: need N >= 0, 0 <= B <= Bpad, Bpad a multiple of 32");
+    if (B == 0) return SHG_OK;
+    SHG_REQUIRE(anm && om, "shg_order_major_pack: NULL pointer");
+    hipLaunchKernelGGL(shg::order_major_kernel<true>, dim3(N + 1, Bpad / 16), dim3(256), (size_t)16 * (N + 2) * sizeof(double), (hipStream_t)stream_, N, B, Bpad, anm, om);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+extern "C" int shg_order_major_unpack(const double* om, int N, int B, int Bpad, double* anm, void* stream_) {
+    SHG_REQUIRE(N >= 0 && B >= 0 && Bpad >= B && Bpad % 32 == 0, "shg_order_major_unpack: need N >= 0, 0 <= B <= Bpad, Bpad a multiple of 32");
+    if (B == 0) return SHG_OK;
+    SHG_REQUIRE(anm && om, "shg_order_major_unpack: NULL pointer");
+    hipLaunchKernelGGL(shg::order_major_kernel<false>, dim3(N + 1, Bpad / 16), dim3(256), (size_t)16 * (N + 2) * sizeof(double), (hipStream_t)stream_, N, B, Bpad, om, anm);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+extern "C" int shg_orderwise_filter_om(const double* blocks_packed, const int64_t* block_off, int Nb, int N, const double* om_in, int B, int Bpad,
+                                       double* om_out, void* stream_) {
+    SHG_REQUIRE(Nb >= 0 && N >= 0 && B >= 0 && Bpad >= B && Bpad % 32 == 0, "shg_orderwise_filter_om: negative size, or Bpad not a multiple of 32 >= B");
+    SHG_REQUIRE(N <= Nb, "DDK filter only implemented for a maximum degree of %d (max_degree=%d supplied).", Nb, N);
+    if (B == 0) return SHG_OK;
+    SHG_REQUIRE(blocks_packed && block_off && om_in && om_out, "shg_orderwise_filter_om: NULL pointer");
+    SHG_REQUIRE(om_in != om_out, "shg_orderwise_filter_om: in-place operation is not supported");
+    hipStream_t stream = (hipStream_t)stream_;
+    // (slot, tile of 16 rows) units, the long slots first; the table is tiny (~1000 entries at d/o 120) and cached per degree
+    static std::mutex mtx;
+    static int cached_N = -1, cached_units = 0, cached_dev = -1;
+    static int* table_d = nullptr;
+    std::lock_guard<std::mutex> lock(mtx);
+    int dev = 0;
+    SHG_HIP(hipGetDevice(&dev));
+    if (cached_N != N || cached_dev != dev) {
+        // The row tiles of a slot read the same rows of the series: all of them go to ONE XCD (workgroups are dealt to the XCDs round
+        // robin by their linear index: entry i of the table runs on XCD i % 8), the slots by decreasing length in a snake over the XCDs
+        // so that every XCD gets about the same arithmetic; short lists are padded with empty units (slot -1).
+        std::vector<std::vector<int>> xs(8), xr(8);
+        std::vector<int> order(2 * N + 1);
+        for (int s = 0; s <= 2 * N; ++s) order[s] = s;                       // (already by decreasing length: orders ascend)
+        for (int i = 0; i <= 2 * N; ++i) {
+            const int s = order[i], m = (s + 1) >> 1;
+            const int x = (i / 8) % 2 == 0 ? i % 8 : 7 - i % 8;
+            for (int r0 = 0; r0 < N + 1 - m; r0 += 16) {
+                xs[x].push_back(s);
+                xr[x].push_back(r0);
+            }
+        }
+        size_t longest = 0;
+        for (int x = 0; x < 8; ++x) longest = std::max(longest, xs[x].size());
+        std::vector<int> slot(8 * longest, -1), row0(8 * longest, 0);
+        for (int x = 0; x < 8; ++x)
+            for (size_t j = 0; j < xs[x].size(); ++j) {
+                slot[8 * j + x] = xs[x][j];
+                row0[8 * j + x] = xr[x][j];
+            }
+        std::vector<int> table(slot);
+        table.insert(table.end(), row0.begin(), row0.end());
+        if (table_d) {
+            SHG_HIP(hipDeviceSynchronize());
+            (void)hipFree(table_d);
+            table_d = nullptr;
+        }
+        if (hipMalloc((void**)&table_d, table.size() * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_orderwise_filter_om: unit table allocation failed");
+        SHG_HIP(hipMemcpy(table_d, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
+        cached_N = N;
+        cached_dev = dev;
+        cached_units = (int)slot.size();
+    }
+    hipLaunchKernelGGL(shg::orderwise_filter_om_kernel, dim3((unsigned)cached_units), dim3(256), 0, stream, Nb, N, Bpad, cached_units, table_d, table_d + cached_units,
+                       blocks_packed, (const long long*)block_off, om_in, om_out);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // DDK block construction:  W_k = (N_k + diag(w[m:]))^-1 N_k  for every order-wise normal block
 // (replaces the 2 Nb + 1 dense solves of DDK.__init__ / DDKGeneric.__init__, grates/filter.py:252-255, 344-347).
 // N_k + D is symmetric positive definite (normal matrix plus positive power-law weights): one workgroup per

@@ -227,6 +227,8 @@ __global__ __launch_bounds__(256) void lon_stage_kernel(LonParams P) {
 
 using namespace shg;
 
+static int synthesis_dispatch(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
+
 extern "C" int shg_synthesis(shg_plan* p, const double* anm, int B, double* grid, void* stream_) {
     SHG_REQUIRE(p != nullptr, "shg_synthesis: NULL plan");
     SHG_REQUIRE(B >= 0, "shg_synthesis: negative batch size %d", B);
@@ -234,6 +236,28 @@ extern "C" int shg_synthesis(shg_plan* p, const double* anm, int B, double* grid
     SHG_REQUIRE(anm != nullptr && grid != nullptr, "shg_synthesis: NULL array pointer");
     hipStream_t stream = (hipStream_t)stream_;
     PlanGuard guard(p, stream);
+    return synthesis_dispatch(p, anm, B, grid, stream);
+}
+
+extern "C" int shg_synthesis_om(shg_plan* p, const double* om, int Ns, int B, int Bpad, double* grid, void* stream_) {
+    SHG_REQUIRE(p != nullptr, "shg_synthesis_om: NULL plan");
+    SHG_REQUIRE(B >= 0 && Bpad >= B && Bpad % 32 == 0, "shg_synthesis_om: need 0 <= B <= Bpad, Bpad a multiple of 32");
+    SHG_REQUIRE(Ns >= p->N, "shg_synthesis_om: the series holds degrees up to %d, the plan needs %d", Ns, p->N);
+    if (B == 0) return SHG_OK;
+    SHG_REQUIRE(om != nullptr && grid != nullptr, "shg_synthesis_om: NULL array pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    PlanGuard guard(p, stream);
+    const bool fused_ns = p->sym_ns && (p->path >= 6 || p->path == 2 || (p->path == 0 && (rot_applicable(p) || fused_chunk_for(p) != 0)));
+    SHG_REQUIRE(fused_ns, "shg_synthesis_om: only the fused kernels on north-south symmetric parallels read an order-major series (unpack it for other plans)");
+    p->om_src = om;
+    p->om_N = Ns;
+    p->om_Bpad = Bpad;
+    const int rc = synthesis_dispatch(p, om, B, grid, stream);      // (the coefficient pointer is not used: the repack reads p->om_src)
+    p->om_src = nullptr;
+    return rc;
+}
+
+static int synthesis_dispatch(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
     // degrees beyond the 64-row panel (d/o 127 ... ~210): the 32-row fused kernel still beats the three-kernel path
     if (p->path == 9) return synthesis_rot_halves(p, anm, B, grid, stream);
     if (p->path == 8) return synthesis_fed(p, anm, B, grid, stream);

@@ -201,6 +201,38 @@ __global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_kernel(int N
     *reinterpret_cast<double2*>(cpk4 + ((size_t)bt * Qtot * 64 + t) * 2) = make_double2(v[0], v[1]);
 }
 
+// The same repack from an order-major series (filters.hip: om [(N_s + 1)^2 rows][Bpad epochs], N_s >= N): the four epochs of an element
+// are 32 consecutive bytes of one row.
+__host__ __device__ inline long long om_row_of(int Ns, int s) {
+    if (s == 0) return 0;
+    const int m = (s + 1) >> 1;
+    const long long cos_row = (long long)(Ns + 1) + 2LL * ((long long)(m - 1) * (Ns + 1) - (long long)m * (m - 1) / 2);
+    return (s & 1) ? cos_row : cos_row + (Ns + 1 - m);
+}
+__global__ __launch_bounds__(256) void pack_coefficients4_ns_gather_om_kernel(int N, int B, int Qtot, int rotR, int nbt, const int* __restrict__ octinfo,
+                                                                               const double* __restrict__ om, int Ns, int Bpad, double* __restrict__ cpk4) {
+    const int nx = (Qtot * 64 + 255) / 256;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int bt = 8 * (seq / nx) + xcd;
+    const int t = (seq % nx) * 256 + threadIdx.x;                  // (octet, lane)
+    if (bt >= nbt || t >= Qtot * 64) return;
+    const int oct = t >> 6, lane = t & 63;
+    const int info = octinfo[oct];
+    const int m = info & 255, ol = info >> 8;
+    const int fk = lane >> 4, row = lane & 15;
+    const int par = row >> 3, cs = (row >> 2) & 1, b = bt * 4 + (row & 3);
+    const long long slot_row = om_row_of(Ns, m == 0 ? 0 : 2 * m - 1 + cs);
+    double v[2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+        const int nl = 2 * ((2 * ol + s_) * 4 + fk) + par;         // degree offset n - m
+        const bool ok = m + nl <= N && b < B && !(cs == 1 && m == 0);
+        v[s_] = ok ? om[(size_t)(slot_row + nl) * Bpad + b] : 0.0;
+        if (rotR && cs && 2 * (m % rotR) > rotR) v[s_] = -v[s_];
+    }
+    *reinterpret_cast<double2*>(cpk4 + ((size_t)bt * Qtot * 64 + t) * 2) = make_double2(v[0], v[1]);
+}
+
 struct FusedParams {
     int N, nlat, nlon, ldlat, K, ncol, B, nit, Ppk, ncb;   // nit = 16-parallel tiles, ncb = column blocks (8 tiles each)
     int goff[5];              // first K slot of each (cos/sin, m even/odd) group; every group is a multiple of 16 slots
@@ -794,7 +826,11 @@ int pack_coefficients_fused(shg_plan* p, bool ns, int rotR, const double* anm, i
     }
     const int E = (p->N + 1) * (p->N + 1);
     ProfileScope ps(p, 0, stream);
-    if (ns)
+    if (p->om_src) {
+        if (!ns) return fail(SHG_ERR_UNSUPPORTED, "synthesis from an order-major series needs parallels symmetric about the equator (the gather repack)");
+        hipLaunchKernelGGL(pack_coefficients4_ns_gather_om_kernel, dim3((unsigned)(8 * ceil_div(nbt, 8) * ceil_div(p->Qtot * 64, 256))), dim3(256), 0, stream, p->N, B,
+                           p->Qtot, rotR, nbt, p->octinfo_d, p->om_src, p->om_N, p->om_Bpad, p->cpk4);
+    } else if (ns)
         hipLaunchKernelGGL(pack_coefficients4_ns_gather_kernel, dim3((unsigned)(8 * ceil_div(nbt, 8) * ceil_div(p->Qtot * 64, 256))), dim3(256), 0, stream, p->N, B,
                            p->Qtot, rotR, nbt, p->octinfo_d, anm, p->cpk4);
     else

@@ -127,8 +127,25 @@ class Plan:
         return {name: (ms[k], n[k]) for k, name in enumerate(self.PROFILE_KINDS) if n[k] > 0}
 
     def synthesis(self, anm, out=None):
-        """anm [B, N+1, N+1] (or [N+1, N+1]) -> grid [B, nlat, nlon] (device tensor)."""
+        """anm [B, N+1, N+1] (or [N+1, N+1]), or an OrderMajorSeries of at least the plan's degree -> grid [B, nlat, nlon] (device tensor)."""
         torch = _torch()
+        if isinstance(anm, OrderMajorSeries):
+            B = anm.epochs
+            if anm.max_degree < self.max_degree:
+                raise ValueError('the series holds degrees up to {0}, the plan needs {1}'.format(anm.max_degree, self.max_degree))
+            if out is None:
+                out = torch.empty((B, self.nlat, self.nlon), dtype=torch.float64, device=self.device)
+            elif tuple(out.shape) != (B, self.nlat, self.nlon) or out.dtype != torch.float64 or not out.is_contiguous():
+                raise ValueError('out must be a contiguous fp64 tensor of shape {0}'.format((B, self.nlat, self.nlon)))
+            Plan._written(out)
+            with torch.cuda.device(self.device):
+                try:
+                    _lib.call('shg_synthesis_om', self._handle, _ptr(anm.data), anm.max_degree, B, anm.padded_epochs, _ptr(out), _stream())
+                except _lib.ShgError:            # a plan whose kernel reads the reference arrays only: through them
+                    batch = anm.to_batch()
+                    n1 = self.max_degree + 1
+                    _lib.call('shg_synthesis', self._handle, _ptr(batch[:, :n1, :n1].contiguous()), B, _ptr(out), _stream())
+            return out
         x = to_device(anm, self.device)
         single = x.dim() == 2
         if single:
@@ -567,6 +584,49 @@ def epoch_rms(values, acc=None, count=0):
         acc = torch.empty((v.shape[1],), dtype=torch.float64, device=v.device)
     _lib.call('shg_epoch_rms', _ptr(v), v.shape[0], v.shape[1], int(accumulate), int(count), _ptr(acc), _stream())
     return acc
+
+
+class OrderMajorSeries:
+    """A time series of coefficient sets that stays on the device between operators (the batching of TimeSeries.to_array,
+    grates/gravityfield.py:964-980, in the layout the order-wise operators work on): `data` [(N+1)^2, Bpad] with the epochs fastest
+    (Bpad = epochs rounded up to 32) and the coefficients of one order and kind (the slots of the DDK block list: order 0 cosine,
+    order 1 cosine, order 1 sine, ...) in consecutive rows.  `OrderWiseFilter.filter_series` and `Plan.synthesis` take and return it
+    without passing through the reference arrays [B, N+1, N+1]; `from_batch` / `to_batch` convert."""
+
+    def __init__(self, data, max_degree, epochs):
+        self.data, self.max_degree, self.epochs = data, int(max_degree), int(epochs)
+
+    @property
+    def padded_epochs(self):
+        return int(self.data.shape[1])
+
+    @classmethod
+    def from_batch(cls, anm):
+        torch = require_gpu()
+        x = to_device(anm)
+        if x.dim() != 3 or x.shape[1] != x.shape[2]:
+            raise ValueError('coefficient batch must have shape (B, N+1, N+1), got {0}'.format(tuple(x.shape)))
+        B, N = int(x.shape[0]), int(x.shape[1]) - 1
+        bpad = -(-max(B, 1) // 32) * 32
+        data = torch.empty(((N + 1) ** 2, bpad), dtype=torch.float64, device=x.device)
+        _lib.call('shg_order_major_pack', _ptr(x), N, B, _ptr(data), bpad, _stream())
+        return cls(data, N, B)
+
+    def to_batch(self):
+        torch = require_gpu()
+        N, B = self.max_degree, self.epochs
+        out = torch.empty((B, N + 1, N + 1), dtype=torch.float64, device=self.data.device)
+        _lib.call('shg_order_major_unpack', _ptr(self.data), N, B, self.padded_epochs, _ptr(out), _stream())
+        return out
+
+
+def orderwise_filter_series(blocks_packed, block_offsets, block_max_degree, series):
+    """OrderWiseFilter.filter of every epoch of an OrderMajorSeries: one matrix product per block, nothing gathered or scattered."""
+    torch = require_gpu()
+    out = torch.empty_like(series.data)
+    _lib.call('shg_orderwise_filter_om', _ptr(blocks_packed), _ptr(block_offsets), int(block_max_degree), series.max_degree,
+              _ptr(series.data), series.epochs, series.padded_epochs, _ptr(out), _stream())
+    return OrderMajorSeries(out, series.max_degree, series.epochs)
 
 
 def orderwise_filter(blocks_packed, block_offsets, block_max_degree, anm):

@@ -134,6 +134,15 @@ class OrderWiseFilter(SpatialFilter):
         packed, offsets = self._device_blocks()
         return engine.orderwise_filter(packed, offsets, self.__nmax, anm_batch)
 
+    def filter_series(self, series):
+        """Filter every epoch of an engine.OrderMajorSeries (a time series kept on the device in order-major layout): one matrix
+        product per block on whole matrices; returns a new series.  The values are those of `filter` applied epoch by epoch
+        (grates/filter.py:153-191), degrees 0 and 1 restored from the input."""
+        if series.max_degree > self.__nmax:
+            raise ValueError('DDK filter only implemented for a maximum degree of {1:d} (max_degree={0:d} supplied).'.format(series.max_degree, self.__nmax))
+        packed, offsets = self._device_blocks()
+        return engine.orderwise_filter_series(packed, offsets, self.__nmax, series)
+
     def filter(self, gravityfield):
         """Filtered copy; degrees 0 and 1 are restored from the input; ValueError above the block degree
         (grates/filter.py:172-191)."""

@@ -61,7 +61,9 @@ int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
  * degree <= ~210; chosen automatically above degree 126), 6 = single fused kernel for equi-angular cell-centred meridians that
  * folds the longitude stage over 6 (nlon a multiple of 96) or 3 (nlon a multiple of 48) rotations and the reflection of the
  * meridian set (degree <= ~110; the automatic choice where it applies).  Kernels 2 and 6 use the north-south symmetry of the
- * parallels when the grid has it and their plain variant otherwise; the variant is not a choice of the caller. */
+ * parallels when the grid has it and their plain variant otherwise; the variant is not a choice of the caller.
+ * 7, 8, 9: variants of kernel 6 built and measured in round 5, all slower than it on MI355X: 7 one wave per SIMD with the images of
+ * a unit stored during the next unit, 8 the same fed by a Legendre-stage kernel on a second stream, 9 two workgroups of two epochs per CU. */
 int shg_plan_set_path(shg_plan* plan, int path);
 
 /* Rotation count R of kernel 6: the longitude sums are evaluated on nlon / (2 R) columns and the 2 R images of every column are
@@ -180,6 +182,21 @@ int shg_degree_scale(const double* w /* [N+1] device */, int N, int nfirst, cons
 int shg_orderwise_filter(const double* blocks_packed, const int64_t* block_off, int Nb, int N,
                          const double* anm_in, int B, double* anm_out, void* stream);
 int shg_dense_filter(const double* W, int P, const double* X, int T, double* Y, void* stream);
+
+/* Order-major series: a time series of coefficient sets kept on the device between operators -- the batching the reference does with
+ * TimeSeries.to_array (grates/gravityfield.py:964-980), in the layout the order-wise operators want:
+ *   om [(N+1)^2 rows][Bpad]   epochs fastest (Bpad = B rounded up to a multiple of 32), row of (slot s, k = n - m) = first_row(s) + k with
+ *   the slots in the order of the DDK block list (s = 0: order 0 cosine, 2m - 1: order m cosine, 2m: order m sine; grates/filter.py:153-191).
+ *   shg_order_major_pack / _unpack   from / to the reference arrays anm [B][N+1][N+1]
+ *   shg_orderwise_filter_om          OrderWiseFilter.filter of all epochs: Y_s = W_s X_s per slot on whole matrices (no gather / scatter);
+ *                                    degrees 0 and 1 keep the input, N <= Nb as in shg_orderwise_filter
+ *   shg_synthesis_om                 shg_synthesis of a series of degree Ns >= the plan's N (higher degrees are not read); fused kernels on
+ *                                    parallels symmetric about the equator only (SHG_ERR_INVALID otherwise: unpack the series) */
+int shg_order_major_pack(const double* anm, int N, int B, double* om, int Bpad, void* stream);
+int shg_order_major_unpack(const double* om, int N, int B, int Bpad, double* anm, void* stream);
+int shg_orderwise_filter_om(const double* blocks_packed, const int64_t* block_off, int Nb, int N, const double* om_in, int B, int Bpad,
+                            double* om_out, void* stream);
+int shg_synthesis_om(shg_plan* plan, const double* om, int Ns, int B, int Bpad, double* grid, void* stream);
 
 /* DDK block construction  W_k = (N_k + diag(w[m:]))^-1 N_k  for all 2Nb+1 order-wise normal blocks
  *   replaces the dense solves of DDK.__init__ / DDKGeneric.__init__      (grates/filter.py:252-255, 344-347)

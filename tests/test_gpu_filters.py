@@ -52,6 +52,71 @@ def test_orderwise_errors_and_batch():
     assert relerr(orc.ravel_coefficients(y, 2, 17), W @ orc.ravel_coefficients(x_in, 2, 17)) < TOL
 
 
+@pytest.mark.parametrize('nmax,ngf,B', [(20, 20, 5), (120, 120, 37), (120, 96, 16), (30, 7, 33), (12, 0, 3), (12, 1, 2)])
+def test_order_major_series(golden, nmax, ngf, B):
+    """A series kept on the device in order-major layout: conversion from / to the reference arrays is exact, the filter on whole
+    per-order matrices gives the values of OrderWiseFilter.filter epoch by epoch (golden fixture where one exists, oracle, and the
+    kernel on the reference layout), degrees 0 and 1 restored, padding epochs never leak."""
+    import torch
+    blocks = inputs.orderwise_random_blocks(42, nmax)
+    flt = ga.filter.OrderWiseFilter(blocks)
+    batch = np.stack([inputs.coefficients(43 + e, ngf) for e in range(B)])
+    series = ga.engine.OrderMajorSeries.from_batch(batch)
+    assert series.max_degree == ngf and series.epochs == B and series.padded_epochs % 32 == 0 and series.data.shape[0] == (ngf + 1) ** 2
+    np.testing.assert_array_equal(ga.engine.to_host(series.to_batch()), batch)
+    # row order: slot 0 = order 0 cosine (degrees 0 .. N), then order 1 cosine, order 1 sine, ...
+    host = ga.engine.to_host(series.data)
+    np.testing.assert_array_equal(host[0:ngf + 1, 0:B], batch[:, :, 0].T)
+    if ngf >= 1:
+        np.testing.assert_array_equal(host[ngf + 1:2 * ngf + 1, 0:B], batch[:, 1:, 1].T)          # C_n1, n = 1 .. N
+        np.testing.assert_array_equal(host[2 * ngf + 1:3 * ngf + 1, 0:B], batch[:, 0, 1:].T)      # S_n1 at [0][n]
+    series.data[:, B:] = 1e300                           # whatever sits in the padding epochs stays there
+    out = flt.filter_series(series)
+    assert out is not series and out.max_degree == ngf and out.epochs == B
+    got = ga.engine.to_host(out.to_batch())
+    np.testing.assert_array_equal(ga.engine.to_host(series.to_batch()), batch)                    # input untouched
+    for e in sorted({0, B // 2, B - 1}):
+        assert relerr(got[e], orc.orderwise_filter(batch[e], blocks)) < TOL
+    assert relerr(got, ga.engine.to_host(flt.filter_batch(batch))) < TOL
+    np.testing.assert_array_equal(got[:, 0:2, 0:2], batch[:, 0:2, 0:2])                           # degrees 0 and 1 restored
+    if (nmax, ngf) in ((20, 20), (120, 120), (120, 96)):
+        assert relerr(got[0], golden('g10_filter')['orderwise_{0}_{1}'.format(nmax, ngf)]) < TOL
+    if ngf > 0:
+        with pytest.raises(ValueError):              # blocks of a lower degree than the series
+            ga.filter.OrderWiseFilter(inputs.orderwise_random_blocks(42, ngf - 1)).filter_series(series)
+
+
+def test_order_major_series_to_grid():
+    """DDK-type filter -> synthesis without leaving the device layout: series of degree 120 filtered, synthesised by plans of degree 96
+    and 120 (rotation-folded kernel and the pipelined variants) and by a plan that reads the reference arrays only."""
+    blocks = inputs.orderwise_random_blocks(7, 120)
+    flt = ga.filter.OrderWiseFilter(blocks)
+    B = 9
+    batch = np.stack([inputs.coefficients(900 + e, 120) for e in range(B)])
+    filtered = flt.filter_series(ga.engine.OrderMajorSeries.from_batch(batch))
+    reference = ga.engine.to_host(flt.filter_batch(batch))
+    ker = orc.KernelTable('potential')
+    for N, step, paths in ((96, 0.25, ('auto', 'pipe', 'fed', 'halves')), (120, 0.5, ('auto',)), (60, 3.0, ('auto', 'staged'))):
+        grid = ga.grid.GeographicGrid(step, step)
+        colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel('potential'), N, grid.parallels, 3.9860044150e+14, 6.3781363000e+06,
+                                                       grid.semimajor_axis, grid.flattening)
+        plan = ga.engine.Plan(N, colat, kn, grid.meridians)
+        want = ga.engine.to_host(plan.synthesis(reference[:, :N + 1, :N + 1].copy()))
+        check = orc.synthesis_regular(reference[0][:N + 1, :N + 1], grid.meridians, grid.parallels, ker)
+        assert relerr(want[0], check) < TOL
+        for path in paths:
+            try:
+                plan.set_path(path)
+            except ga._lib.ShgError:
+                continue
+            got = ga.engine.to_host(plan.synthesis(filtered))
+            assert got.shape == want.shape and relerr(got, want) < TOL, (N, path)
+    colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel('potential'), 121, grid.parallels, 3.9860044150e+14, 6.3781363000e+06,
+                                                   grid.semimajor_axis, grid.flattening)
+    with pytest.raises(ValueError):                  # a plan of a higher degree than the series
+        ga.engine.Plan(121, colat, kn, grid.meridians).synthesis(filtered)
+
+
 def test_ddk_from_synthetic_normals(golden):
     """DDK construction + application (config 3 operator) with synthetic SPD normals; the published blocks are absent."""
     g = golden('g10_filter')
