@@ -478,7 +478,7 @@ class GpuWorkload:
                            'epochs_per_gpu': T, 'flops_per_step': dense_flops},
                 'roofline': {'kernel': 'gemm_ex_kernel (shg_dense_filter; the step also holds the ravel / unravel kernels)', 'bound': 'mfma',
                              'achieved': dense_flops / (ev_dense * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                             'frac': dense_flops / (ev_dense * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS,
+                             'frac': dense_flops / (ev_dense * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 'mfma_busy': pmc_mfma_busy('filters_dense'),
                              'traffic': pmc_traffic('filters', ['gemm_ex_kernel'])[0], 'traffic_source': pmc_traffic('filters', ['gemm_ex_kernel'])[1],
                              'avg_launch_ms': ev_dense},
             },
@@ -829,6 +829,18 @@ def compact_line(line, limit=LINE_LIMIT):
     return line
 
 
+def pmc_mfma_busy(leg):
+    """MFMA-busy share of a leg's dominant kernel from the committed SQ counter summary (tools/pmc_summary.sh, tools/pmc_mfma_busy.py):
+    counters cannot be collected inside a timed run.  -> fraction or None"""
+    for name in ('r05_mfma_busy.json',):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                return float(json.load(f)['kernels'][leg]['mfma_busy'])
+        except Exception:
+            pass
+    return None
+
+
 def algorithmic_bytes_per_solution(max_degree, nlat, nlon):
     """coefficients read once + grid written once; plan tables amortised over the batch."""
     return 8 * ((max_degree + 1) ** 2 + nlat * nlon)
@@ -1035,7 +1047,7 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
                 'kernel': wl.kernel_name, 'bound': 'hbm',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
-                'traffic': traffic, 'traffic_source': traffic_source,
+                'traffic': traffic, 'traffic_source': traffic_source, 'mfma_busy': pmc_mfma_busy('synthesis'),
                 'algorithmic_bytes_per_launch': per_solution * epochs_per_launch,
                 'avg_launch_ms': lon_avg_ms,
                 'whole_path_GBs': per_solution * B * args.steps / elapsed / 1e9,
@@ -1135,7 +1147,7 @@ def covariance_leg_report(args, wl, rank, world, state):
             'P': P, 'parallels': total, 'nlat': nlat, 'sigma_recipe': wl.cov_recipe, 'flops': flops, 'full_grid_flops': 2.0 * nlat * nlon * P * (P + 1.0), 'repeats': len(times)},
         'seconds_median': median, 'seconds_min': best, 'seconds_all': times, 'GFLOPs_best': flops / best / 1e9,
         'roofline': {'kernel': 'gemm_f64_kernel<MODE_COVPROP>', 'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F64_PEAK_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': (achieved / MFMA_F64_PEAK_TFLOPS) if achieved else None, 'traffic': None,
+                     'unit': 'TFLOP/s', 'frac': (achieved / MFMA_F64_PEAK_TFLOPS) if achieved else None, 'traffic': None, 'mfma_busy': pmc_mfma_busy('covariance'),
                      'traffic_note': 'MFMA-bound; HBM-side bytes of a band of 8 parallels (Sigma read once per 128 rows): profiles/r04_pmc_traffic.json (legs.covariance)',
                      'avg_launch_ms': k_ms / max(k_n, 1), 'launches': int(k_n)},
         'sigma_checksum': float(host.sum()), 'sigma_crc32': zlib.crc32(host.tobytes()) & 0xffffffff,

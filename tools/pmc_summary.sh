@@ -15,7 +15,7 @@ groups=(
  "TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum"
 )
 run_group() {   # tag kernel-substring command...
-  tag=$1; kern=$2; shift 2
+  local tag=$1 kern=$2; shift 2
   : > $out/$tag.txt
   for g in "${groups[@]}"; do
     d=$out/pmc_${tag}_$(echo $g | cut -d' ' -f1)
