@@ -12,6 +12,13 @@
 
 #include "common.h"
 
+#ifndef SHG_GEMM_TAIL
+#define SHG_GEMM_TAIL 1             // tall products in 64-tiles: the rows of the last, mostly empty round as a product of their own (split over K)
+#endif
+#ifndef SHG_GEMM_STRIPS
+#define SHG_GEMM_STRIPS 1          // row-strip workgroup order of tall products with 2 .. 8 column tiles (gemm_ex_kernel)
+#endif
+
 namespace shg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -43,6 +50,8 @@ struct GemmExParams {
     int slices;               // split-K launch of a batch: blockIdx.z = item * slices + slice; strideA/B step the slices,
     long long itemA, itemB;   //   itemA/B the items of the batch (C: the partial products of all of them are contiguous)
     int tri;                  // triangular operands (square, M = K resp. K = N): 1 op(A) upper, 2 op(A) lower, 4 op(B) upper, 8 op(B) lower
+    int strip_tiles;          // > 0: 1-d grid in row-strip order -- the `strip_tiles` column tiles of a row strip on ONE XCD, next to each other
+    int strip_rows;           //      row tiles of the product (the grid is padded to a multiple of 8 of them)
 };
 
 // TA: A is stored [K][M] (op(A) = A^T);  TB: B is stored [N][K] (op(B) = B^T).  Row-major everywhere.
@@ -53,7 +62,18 @@ __global__ __launch_bounds__(256, T == 128 ? 2 : 3) void gemm_ex_kernel(GemmExPa
     double* As0 = gemm_ex_lds;                  // [2][XBUF]
     double* Bs0 = gemm_ex_lds + 2 * XBUF;       // [2][XBUF]
 
-    const int m0 = blockIdx.y * XM, n0 = blockIdx.x * XN;
+    // Tall products with a few column tiles (W [14637^2] X [14637 x 240]: four tiles of 64 columns): in the plain 2-d order the column
+    // tiles of a row strip are consecutive workgroups, i.e. on DIFFERENT XCDs (round robin), and every one of them streams the strip of
+    // op(A) from HBM into its own L2 (W read 4.3 times).  Row-strip order: workgroup L runs on XCD L % 8; the workgroups L, L + 8, ...,
+    // L + 8 (c - 1) of one XCD are the c column tiles of row strip 8 (L / (8 c)) + L % 8 and start together.
+    int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    if (P.strip_tiles > 0) {
+        const int L = blockIdx.x, x = L & 7, q = L >> 3;
+        tile_x = q % P.strip_tiles;
+        tile_y = (q / P.strip_tiles) * 8 + x;
+        if (tile_y >= P.strip_rows) return;
+    }
+    const int m0 = tile_y * XM, n0 = tile_x * XN;
     if (P.upper_only && m0 >= n0 + XN) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -523,6 +543,25 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
 int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
                 long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, int tri, hipStream_t stream) {
     if (M <= 0 || N <= 0 || batch <= 0) return SHG_OK;
+    // Tall products in 64-tiles whose last round of workgroups would be mostly empty (W [14637^2] X [14637 x 240]: 916 tiles on 768 workgroup
+    // slots -- the card works for four tiles per CU where 3.6 are needed): the rows of the whole rounds first, the remaining rows as a product of
+    // their own, which the rules below run as 128-tiles split over K (every CU gets a piece; the partial products are summed in a fixed order).
+    if (SHG_GEMM_TAIL && K >= 2048 && batch == 1 && !upper_only && tri == 0 && !ta && (const double*)C != A && (const double*)C != B) {
+        const int col_tiles = ceil_div(N, 64), row_tiles = ceil_div(M, 64);
+        const long long tiles = (long long)col_tiles * row_tiles;
+        constexpr int kSlots = 768;                                      // 64-tile workgroups the card holds at once (three per CU)
+        const int rows_per_round = kSlots / std::max(col_tiles, 1);
+        if (col_tiles <= 8 && tiles >= 512 && tiles > kSlots && rows_per_round >= 8) {
+            const int whole = (row_tiles / rows_per_round) * rows_per_round, rest = row_tiles - whole;
+            if (whole > 0 && rest > 0 && rest * 2 <= rows_per_round) {
+                const int m_main = whole * 64;
+                int rc = gemm_ex_tri(ta, tb, m_main, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, upper_only, tri, stream);
+                if (rc) return rc;
+                return gemm_ex_tri(ta, tb, M - m_main, N, K, alpha, A + (size_t)m_main * lda, lda, strideA, B, ldb, strideB, beta, C + (size_t)m_main * ldc, ldc, strideC, batch,
+                                   upper_only, tri, stream);
+            }
+        }
+    }
     if (K > 0 && gemv_shape(ta, tb, M, N, K, batch, upper_only, tri, A, B, C)) return gemv(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, stream);
     if (K > 0 && panel_shape(tb, M, N, K, batch, A, B, C) && !(upper_only && M != N))
         return panel_gemm(ta, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, upper_only, (tri & 2) != 0 && M == K,
@@ -552,6 +591,7 @@ int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const doubl
     P.Ktotal = 0;
     P.slices = 1;
     P.itemA = P.itemB = 0;
+    P.strip_tiles = P.strip_rows = 0;
     // 128 x 128 output tiles; products with fewer of them than the card holds at once (512: the K = 128 panel updates of the
     // blocked factorisation, the d = 1681 block products of the smoother alone or as a batch of two) take 64 x 64 tiles, four
     // times as many workgroups: a single partial round of 128-tiles lasts as long as its longest tile (a batch of two
@@ -569,6 +609,11 @@ int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const doubl
     const int XT = small_tiles ? 64 : 128;
     dim3 grid(ceil_div(N, XT), ceil_div(M, XT), batch);
     const size_t lds = (size_t)4 * (small_tiles ? GemmExTile<64>::BUF : GemmExTile<128>::BUF) * sizeof(double);   // 73.7 KB (two workgroups per CU) / 41 KB
+    if (SHG_GEMM_STRIPS && batch == 1 && !upper_only && grid.x >= 2 && grid.x <= 8 && grid.y >= 32) {        // tall and skinny: row-strip order
+        P.strip_tiles = (int)grid.x;
+        P.strip_rows = (int)grid.y;
+        grid = dim3((unsigned)(8 * P.strip_tiles * ceil_div((int)grid.y, 8)), 1, 1);
+    }
     // Few output tiles and a long K (block times a handful of right-hand sides): split K over grid.z into a workspace of
     // partial products that a second kernel sums in a fixed order (deterministic, unlike atomics).
     const int tiles = (int)(grid.x * grid.y) * batch;
