@@ -350,22 +350,39 @@ __global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N,
 #pragma unroll
         for (int q = 0; q < kOmPairsPerWave; ++q) acc[q][0][0] = acc[q][0][1] = acc[q][1][0] = acc[q][1][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
         const int nq = min(kOmPairsPerWave, npair - p0);
+        // columns c + 2 fk, c + 2 fk + 1 of the block rows (A fragments of two k-steps: beyond the packed blocks the range check returns 0;
+        // beyond the block's own columns the rows of X are masked instead); the operands of step c + 8 are loaded before the MFMAs of step c
+        const double2_t zero2 = {0.0, 0.0};
+        auto load_a = [&](int c) { return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff + (unsigned)c * 8u, 0, 0)); };
+        auto load_x = [&](int q, int k) { return q < nq && k < n ? X[16 * (p0 + q) + (size_t)k * ldx] : zero2; };
+        double2_t a = load_a(0), x0[kOmPairsPerWave], x1[kOmPairsPerWave];
+#pragma unroll
+        for (int q = 0; q < kOmPairsPerWave; ++q) {
+            x0[q] = load_x(q, 2 * fk);
+            x1[q] = load_x(q, 2 * fk + 1);
+        }
         for (int c = 0; c < n; c += 8) {
-            // columns c + 2 fk, c + 2 fk + 1 of the block rows (A fragments of two k-steps: beyond the packed blocks the range check returns 0;
-            // beyond the block's own columns the rows of X are masked instead)
-            const double2_t a = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff + (unsigned)c * 8u, 0, 0));
-            const int k0 = c + 2 * fk, k1 = k0 + 1;
-            const double2_t zero2 = {0.0, 0.0};
+            const double2_t an = load_a(c + 8);                      // (beyond the last step: within the packed blocks or zero by the range check)
+            double2_t xn0[kOmPairsPerWave], xn1[kOmPairsPerWave];
+#pragma unroll
+            for (int q = 0; q < kOmPairsPerWave; ++q) {
+                xn0[q] = load_x(q, c + 8 + 2 * fk);
+                xn1[q] = load_x(q, c + 9 + 2 * fk);
+            }
 #pragma unroll
             for (int q = 0; q < kOmPairsPerWave; ++q) {
                 if (q < nq) {
-                    const double2_t* xq = X + 16 * (p0 + q);
-                    const double2_t x0 = k0 < n ? xq[(size_t)k0 * ldx] : zero2, x1 = k1 < n ? xq[(size_t)k1 * ldx] : zero2;
-                    acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x0.x, acc[q][0][0], 0, 0, 0);      // even epochs, k-step 0
-                    acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x0.y, acc[q][1][0], 0, 0, 0);      // odd epochs
-                    acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x1.x, acc[q][0][1], 0, 0, 0);      // k-step 1
-                    acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x1.y, acc[q][1][1], 0, 0, 0);
+                    acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x0[q].x, acc[q][0][0], 0, 0, 0);      // even epochs, k-step 0
+                    acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x0[q].y, acc[q][1][0], 0, 0, 0);      // odd epochs
+                    acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x1[q].x, acc[q][0][1], 0, 0, 0);      // k-step 1
+                    acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x1[q].y, acc[q][1][1], 0, 0, 0);
                 }
+            }
+            a = an;
+#pragma unroll
+            for (int q = 0; q < kOmPairsPerWave; ++q) {
+                x0[q] = xn0[q];
+                x1[q] = xn1[q];
             }
         }
 #pragma unroll
