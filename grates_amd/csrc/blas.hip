@@ -15,6 +15,9 @@
 #ifndef SHG_GEMM_TAIL
 #define SHG_GEMM_TAIL 1             // tall products in 64-tiles: the rows of the last, mostly empty round as a product of their own (split over K)
 #endif
+#ifndef SHG_GEMM_TALL
+#define SHG_GEMM_TALL 1             // tall products with 226 .. 240 columns: whole-width tiles dealt stream-K (gemm_tall.hip)
+#endif
 #ifndef SHG_GEMM_STRIPS
 #define SHG_GEMM_STRIPS 1          // row-strip workgroup order of tall products with 2 .. 8 column tiles (gemm_ex_kernel)
 #endif
@@ -543,10 +546,17 @@ int gemm_ex(bool ta, bool tb, int M, int N, int K, double alpha, const double* A
 int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA, const double* B, int ldb,
                 long long strideB, double beta, double* C, int ldc, long long strideC, int batch, bool upper_only, int tri, hipStream_t stream) {
     if (M <= 0 || N <= 0 || batch <= 0) return SHG_OK;
+    if (SHG_GEMM_TALL && K > 0 && gemm_tall_shape(ta, tb, M, N, K, batch, upper_only, tri, A, lda, B, ldb, C))
+        return gemm_tall(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, stream);
     // Tall products in 64-tiles whose last round of workgroups would be mostly empty (W [14637^2] X [14637 x 240]: 916 tiles on 768 workgroup
     // slots -- the card works for four tiles per CU where 3.6 are needed): the rows of the whole rounds first, the remaining rows as a product of
     // their own, which the rules below run as 128-tiles split over K (every CU gets a piece; the partial products are summed in a fixed order).
-    if (SHG_GEMM_TAIL && K >= 2048 && batch == 1 && !upper_only && tri == 0 && !ta && (const double*)C != A && (const double*)C != B) {
+#ifdef SHG_GEMM_TALL128
+    const bool tall128 = K >= 2048 && batch == 1 && !upper_only && tri == 0 && N <= 256 && M >= 8192;
+#else
+    const bool tall128 = false;
+#endif
+    if (SHG_GEMM_TAIL && !tall128 && K >= 2048 && batch == 1 && !upper_only && tri == 0 && !ta && (const double*)C != A && (const double*)C != B) {
         const int col_tiles = ceil_div(N, 64), row_tiles = ceil_div(M, 64);
         const long long tiles = (long long)col_tiles * row_tiles;
         constexpr int kSlots = 768;                                      // 64-tile workgroups the card holds at once (three per CU)
@@ -605,7 +615,7 @@ int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const doubl
     const bool split_candidate = batch <= 2 && !upper_only && K >= 512 && tiles64 < 256;
     // (and products of at most 64 rows with many column tiles: a 128-row tile would be more than half empty)
     const bool narrow = M <= 64 && !upper_only && tiles64 >= 512;
-    const bool small_tiles = (work_tiles < 512 || narrow) && !split_candidate && (const double*)C != A && (const double*)C != B;
+    const bool small_tiles = (work_tiles < 512 || narrow) && !split_candidate && !tall128 && (const double*)C != A && (const double*)C != B;
     const int XT = small_tiles ? 64 : 128;
     dim3 grid(ceil_div(N, XT), ceil_div(M, XT), batch);
     const size_t lds = (size_t)4 * (small_tiles ? GemmExTile<64>::BUF : GemmExTile<128>::BUF) * sizeof(double);   // 73.7 KB (two workgroups per CU) / 41 KB
@@ -622,6 +632,9 @@ int gemm_ex_tri(bool ta, bool tb, int M, int N, int K, double alpha, const doubl
     std::unique_ptr<ScratchLease> lease;            // held until the kernel that sums the partial products is enqueued
     if (!small_tiles && batch <= 2 && !upper_only && tiles < 384 && K >= 512) {                 // fewer than 1.5 workgroups per CU
         slices = std::min(std::min(16, K / 128), std::max(1, 512 / tiles));
+#ifdef SHG_GEMM_TALL128
+        if (tall128) slices = SHG_GEMM_TALL128;
+#endif
         if (slices > 1) {
             const int chunk = round_up(ceil_div(K, slices), XK);
             slices = ceil_div(K, chunk);

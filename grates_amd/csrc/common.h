@@ -55,6 +55,11 @@ struct Coupling {
                                   // not wait for it (lookahead_join does)
 };
 
+// gemm_tall.hip: C = alpha A B + beta C for tall A [M x K] and at most 240 columns (the dense filter product)
+bool gemm_tall_shape(bool ta, bool tb, int M, int N, int K, int batch, bool upper_only, int tri, const double* A, int lda, const double* B, int ldb,
+                     const double* C);
+int gemm_tall(int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc, hipStream_t stream);
+
 void stream_scratch_release();
 hipError_t workspace_alloc(void** ptr, size_t bytes, hipStream_t stream);    // hipMallocAsync from a pool that keeps freed memory cached
 
@@ -81,7 +86,7 @@ inline int experiment_switches() {
 }
 #else
 #define SHG_DBG(P, bits) 0
-#if (defined(SHG_ROT_X) && SHG_ROT_X) || (defined(SHG_PIPE_X) && SHG_PIPE_X) || (defined(SHG_GEMM_X) && SHG_GEMM_X) || (defined(SHG_ANA_X) && SHG_ANA_X) || (defined(SHG_FILT_X) && SHG_FILT_X)
+#if (defined(SHG_ROT_X) && SHG_ROT_X) || (defined(SHG_PIPE_X) && SHG_PIPE_X) || (defined(SHG_GEMM_X) && SHG_GEMM_X) || (defined(SHG_ANA_X) && SHG_ANA_X) || (defined(SHG_FILT_X) && SHG_FILT_X) || (defined(SHG_TALL_X) && SHG_TALL_X)
 #error "SHG_ROT_X / SHG_GEMM_X / SHG_ANA_X / SHG_FILT_X are timing experiments: build with -DSHG_EXPERIMENT (make timeline)"
 #endif
 #endif

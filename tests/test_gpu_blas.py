@@ -55,6 +55,28 @@ def test_gemm_seeded_random_shapes():
         np.testing.assert_array_equal(got[:, N:], C0[:, N:])            # the padding columns are untouched
 
 
+@pytest.mark.parametrize('M,N,K', [(2048, 240, 2048), (2049, 226, 2061), (3000, 240, 2500), (2176, 238, 2063), (4133, 232, 2048)])
+def test_gemm_tall_products(M, N, K):
+    """Tall products with 226 .. 240 columns take the whole-width stream-K kernel (gemm_tall.hip): rows and K that are no multiples of
+    the tile, a partial last K tile, alpha / beta, row strides of all three operands, and the same bits on every run (the pieces of a
+    cut tile are summed in a fixed order)."""
+    rng = np.random.default_rng(M + N + K)
+    A0 = rng.standard_normal((M, K + 5))
+    B0 = rng.standard_normal((K, N + 6))
+    C0 = rng.standard_normal((M, N + 2))
+    A, B = dev(A0)[:, 0:K], dev(B0)[:, 0:N]
+    ref = A0[:, 0:K] @ B0[:, 0:N]
+    out = eng.gemm(A, B)
+    assert relerr(out.cpu().numpy(), ref) < 1e-13
+    again = eng.gemm(A, B)
+    assert torch.equal(out, again)
+    buf = dev(C0)
+    eng.gemm(A, B, alpha=-0.5, beta=1.5, out=buf[:, 0:N])
+    got = buf.cpu().numpy()
+    assert relerr(got[:, 0:N], -0.5 * ref + 1.5 * C0[:, 0:N]) < 1e-13
+    np.testing.assert_array_equal(got[:, N:], C0[:, N:])
+
+
 def test_gemm_alpha_beta_and_views():
     rng = np.random.default_rng(5)
     A, B, C = rng.standard_normal((150, 90)), rng.standard_normal((90, 70)), rng.standard_normal((150, 70))

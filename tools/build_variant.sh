@@ -10,7 +10,7 @@ base=$(basename $src .hip)
 objs=$(ls build/*.o | grep -v "_timeline.o" | grep -v "build/${base}\.o" | grep -v "build/${base}_" | grep -v "_[a-zA-Z0-9]*\.o$" || true)
 # plain objects of the library (one per source), the variant in place of its source's object
 plain=""
-for f in plan synthesis synthesis_fused synthesis_rot synthesis_fused32 tables gemm covprop covsep filters points analysis blas blockchol timeseries; do
+for f in plan synthesis synthesis_fused synthesis_rot synthesis_fused32 tables gemm covprop covsep filters points analysis blas gemm_tall blockchol timeseries; do
   if [ "$f" = "$base" ]; then plain="$plain build/${base}_$name.o"; else plain="$plain build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../lib/exp/libshg_$name.so $plain
