@@ -31,7 +31,7 @@ constexpr int kTallK = 16;                                 // K tile
 constexpr int kTallRowsPerWave = kTallK / kTallWaves;      // rows of a B tile that one wave copies
 constexpr int kTallGroups = 256;                           // ranges of the iteration sequence = workgroups
 #ifndef SHG_TALL_X
-#define SHG_TALL_X 0          // timing experiments (wrong results): 1 the B tile is copied once per segment, 2 the A operand is loaded once per segment
+#define SHG_TALL_X 0          // timing experiments (wrong results): 1 the B tile is copied once per segment, 2 the A operand is loaded once per segment, 4 no fragment reads, 8 no barriers
 #endif
 
 struct TallParams {
@@ -131,13 +131,21 @@ __global__ __launch_bounds__(64 * kTallWaves, 1) void gemm_tall_kernel(TallParam
         double4_t acc[NF];
 #pragma unroll
         for (int b = 0; b < NF; ++b) acc[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        const double* bl = tall_lds + (2 * fk) * LS + fr;                  // the lane's corner of a B tile
+        typedef const volatile double __attribute__((address_space(3))) lds_double_t;
+        lds_double_t* bl = (lds_double_t*)tall_lds + (2 * fk) * LS + fr;   // the lane's corner of a B tile
         // the fragments of k-step s + 1 are requested before the MFMAs of k-step s are issued (two fragment sets; the scheduling
         // barriers keep hipcc from hoisting all four sets in front of the first MFMA, which does not fit the register file)
-        auto frags = [&](const double* Bs, int s, double (&bf)[NF]) {
+        auto frags = [&](lds_double_t* Bs, int s, double (&bf)[NF]) {
             const int ro = ((s & 1) + 8 * (s >> 1)) * LS;
+            if (SHG_TALL_X & 4) {
 #pragma unroll
-            for (int b = 0; b < NF; ++b) bf[b] = Bs[ro + 16 * b];
+                for (int b = 0; b < NF; ++b) asm volatile("" : "+v"(bf[b]));
+                return;
+            }
+            // (volatile: hipcc would pair the reads into ds_read2_b64 -- 8 LDS cycles per instruction on 32 banks where two
+            //  ds_read_b64 take 2 + 2 on 64 banks)
+#pragma unroll
+            for (int b = 0; b < NF; ++b) bf[b] = *(lds_double_t*)(Bs + ro + 16 * b);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto mfmas = [&](const double4_t& areg, int s, const double (&bf)[NF]) {
@@ -170,14 +178,16 @@ __global__ __launch_bounds__(64 * kTallWaves, 1) void gemm_tall_kernel(TallParam
         auto publish = [&](double4_t& next) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(next.x), "+v"(next.y), "+v"(next.z), "+v"(next.w));
-            __syncthreads();
+            if (!(SHG_TALL_X & 8)) __syncthreads();
         };
         // One whole K tile out of buffer `buf` (set 0 holds the fragments of its k-step 0), K tile tn on its way into the other buffer.
         // The loop is rotated across the barrier: the last k-step is issued behind the barrier that publishes the next tile and behind
         // the request for that tile's first fragments.  No branches: the tile after the last one of a segment is that tile again.
         double bf0[NF], bf1[NF];
+#pragma unroll
+        for (int b = 0; b < NF; ++b) bf0[b] = bf1[b] = (SHG_TALL_X & 4) ? 1.0 + 0.37 * fr + 0.11 * b : 0.0;     // (no fragment reads: operands that toggle the multipliers like real ones)
         auto tile_step = [&](int buf, const double4_t& areg, double4_t& next, int tn) {
-            const double* Bs = bl + buf * kTallK * LS;
+            lds_double_t* Bs = bl + buf * kTallK * LS;
             frags(Bs, 1, bf1);
             mfmas_deal(areg, bf0, tn, buf ^ 1, next);
             frags(Bs, 2, bf0);
@@ -252,25 +262,35 @@ __global__ __launch_bounds__(64 * kTallWaves, 1) void gemm_tall_kernel(TallParam
     }
 }
 
-// sums the pieces of every tile that was cut between ranges, in the order of the ranges.  grid (tiles, rows of a tile)
+// sums the pieces of every tile that was cut between ranges, in the order of the ranges.  grid (tiles, rows of a tile / 2): a block
+// handles two rows, a thread two adjacent columns (N is even, the pieces are 16-byte aligned); the loads of up to four pieces are in
+// flight together
 __global__ __launch_bounds__(256) void gemm_tall_fixup_kernel(TallParams P, int NC) {
-    const int tile = blockIdx.x, row = blockIdx.y, gr = tile * kTallRows + row;
-    if (gr >= P.M) return;
+    const int tile = blockIdx.x, row = 2 * blockIdx.y + (threadIdx.x >> 7), gr = tile * kTallRows + row;
+    const int col = 2 * (threadIdx.x & 127);
+    if (gr >= P.M || col >= P.N) return;
     const long long t0 = (long long)tile * P.nk, t1 = t0 + P.nk;
     const int w_first = tall_owner(t0, P.iters, P.groups), w_last = tall_owner(t1 - 1, P.iters, P.groups);
     if (w_first == w_last) return;                         // written by its only range
-    for (int col = threadIdx.x; col < P.N; col += blockDim.x) {
-        double sum = 0.0;
-        for (int w = w_first; w <= w_last; ++w) {
-            const long long start = tall_range_start(w, P.iters, P.groups);
-            if (tall_range_start(w + 1, P.iters, P.groups) == start) continue;       // an empty range
-            const double* piece = P.pieces + ((size_t)2 * w + (start < t0 ? 1 : 0)) * kTallRows * NC;
-            sum += piece[(size_t)row * NC + col];
-        }
-        double* c = P.C + (size_t)gr * P.ldc + col;
-        const double v = P.alpha * sum;
-        *c = P.beta == 0.0 ? v : fma(P.beta, *c, v);
+    const size_t at = (size_t)row * NC + col;
+    auto piece_of = [&](int w) {
+        const long long start = tall_range_start(w, P.iters, P.groups);
+        return reinterpret_cast<const double2_t*>(P.pieces + ((size_t)2 * w + (start < t0 ? 1 : 0)) * kTallRows * NC + at);
+    };
+    double2_t sum = {0.0, 0.0};
+    int w = w_first;
+    for (; w + 3 <= w_last; w += 4) {                      // (ranges are never empty here: iters >= groups)
+        const double2_t p0 = *piece_of(w), p1 = *piece_of(w + 1), p2 = *piece_of(w + 2), p3 = *piece_of(w + 3);
+        sum += p0;
+        sum += p1;
+        sum += p2;
+        sum += p3;
     }
+    for (; w <= w_last; ++w) sum += *piece_of(w);
+    double* c = P.C + (size_t)gr * P.ldc + col;
+    const double v0 = P.alpha * sum.x, v1 = P.alpha * sum.y;
+    c[0] = P.beta == 0.0 ? v0 : fma(P.beta, c[0], v0);
+    c[1] = P.beta == 0.0 ? v1 : fma(P.beta, c[1], v1);
 }
 
 bool gemm_tall_shape(bool ta, bool tb, int M, int N, int K, int batch, bool upper_only, int tri, const double* A, int lda, const double* B, int ldb,
@@ -305,7 +325,7 @@ int gemm_tall(int M, int N, int K, double alpha, const double* A, int lda, const
     const size_t lds = (size_t)2 * kTallK * (NC + 8) * sizeof(double);
     SHG_SET_LDS_ONCE((gemm_tall_kernel<NF>), lds);
     hipLaunchKernelGGL((gemm_tall_kernel<NF>), dim3(P.groups), dim3(64 * kTallWaves), lds, stream, P);
-    hipLaunchKernelGGL(gemm_tall_fixup_kernel, dim3(tiles, kTallRows), dim3(256), 0, stream, P, NC);
+    hipLaunchKernelGGL(gemm_tall_fixup_kernel, dim3(tiles, kTallRows / 2), dim3(256), 0, stream, P, NC);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
