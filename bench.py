@@ -476,10 +476,11 @@ class GpuWorkload:
                 'GFLOPs': dense_flops * dense_steps / el_dense / 1e9,
                 'config': {'workload': '{0} epochs per GPU: ravel, W [{1} x {1}] @ X [{1} x {0}], unravel'.format(T, P), 'max_degree': nmax, 'min_degree': nmin,
                            'epochs_per_gpu': T, 'flops_per_step': dense_flops},
-                'roofline': {'kernel': 'gemm_ex_kernel (shg_dense_filter; the step also holds the ravel / unravel kernels)', 'bound': 'mfma',
+                'roofline': {'kernel': 'gemm_tall_kernel + gemm_tall_fixup_kernel (shg_dense_filter; the step also holds the ravel / unravel kernels)', 'bound': 'mfma',
                              'achieved': dense_flops / (ev_dense * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                              'frac': dense_flops / (ev_dense * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 'mfma_busy': pmc_mfma_busy('filters_dense'),
-                             'traffic': pmc_traffic('filters', ['gemm_ex_kernel'])[0], 'traffic_source': pmc_traffic('filters', ['gemm_ex_kernel'])[1],
+                             'traffic': pmc_traffic('filters', ['gemm_tall_kernel', 'gemm_tall_fixup_kernel'])[0],
+                             'traffic_source': pmc_traffic('filters', ['gemm_tall_kernel', 'gemm_tall_fixup_kernel'])[1],
                              'avg_launch_ms': ev_dense},
             },
             'check': {'dense_vs_block_max_rel_diff': agree, 'order_major_vs_block_max_rel_diff': agree_series, 'tolerance': 1e-12,
