@@ -16,7 +16,7 @@
 #define SHG_GEMM_TAIL 1             // tall products in 64-tiles: the rows of the last, mostly empty round as a product of their own (split over K)
 #endif
 #ifndef SHG_GEMM_TALL
-#define SHG_GEMM_TALL 1             // tall products with 226 .. 240 columns: whole-width tiles dealt stream-K (gemm_tall.hip)
+#define SHG_GEMM_TALL 1             // tall products with 178 .. 240 columns: whole-width tiles dealt stream-K (gemm_tall.hip)
 #endif
 #ifndef SHG_GEMM_STRIPS
 #define SHG_GEMM_STRIPS 1          // row-strip workgroup order of tall products with 2 .. 8 column tiles (gemm_ex_kernel)

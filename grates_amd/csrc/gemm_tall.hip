@@ -81,7 +81,8 @@ __global__ __launch_bounds__(64 * kTallWaves, 1) void gemm_tall_kernel(TallParam
     constexpr int NC = 16 * NF, LS = NC + 8;              // LS = 8 mod 16: the rows 2 fk and 2 fk + 2 of a fragment read are 16 banks apart
     constexpr int NDMA = (8 * NF + 63) / 64;              // DMA instructions per row of the B tile (16-byte pieces, 64 per instruction)
     constexpr int NCOPY = kTallRowsPerWave * NDMA;        // DMA instructions of a wave per K tile
-    static_assert(3 * NCOPY + 1 < NF, "the copies of a K tile are dealt between the MFMAs of its first k-step");
+    static_assert(2 * NCOPY < NF, "the copies of a K tile are dealt between the MFMAs of its first k-step");
+    constexpr int LOADS_AT = 2 * NCOPY + 1 < NF ? 2 * NCOPY + 1 : NF - 1;      // the A loads behind the last copy
     extern __shared__ double tall_lds[];                  // [2][16][LS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,12 +161,12 @@ __global__ __launch_bounds__(64 * kTallWaves, 1) void gemm_tall_kernel(TallParam
 #pragma unroll
             for (int b = 0; b < NF; ++b) {
                 acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[0], bf[b], acc[b], 0, 0, 0);
-                if (b % 3 == 1 && b / 3 < NCOPY && !(SHG_TALL_X & 1)) {          // (hipcc would move the statements in front of the MFMAs)
+                if (b % 2 == 1 && b / 2 < NCOPY && !(SHG_TALL_X & 1)) {          // (hipcc would move the statements in front of the MFMAs)
                     __builtin_amdgcn_sched_barrier(0);
-                    dma_b(tn, nbuf, b / 3);
+                    dma_b(tn, nbuf, b / 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (b == 3 * NCOPY + 1 && !(SHG_TALL_X & 2)) {
+                if (b == LOADS_AT && !(SHG_TALL_X & 2)) {
                     __builtin_amdgcn_sched_barrier(0);
                     load_a(tn, next);
                     __builtin_amdgcn_sched_barrier(0);
@@ -296,13 +297,29 @@ __global__ __launch_bounds__(256) void gemm_tall_fixup_kernel(TallParams P, int 
 bool gemm_tall_shape(bool ta, bool tb, int M, int N, int K, int batch, bool upper_only, int tri, const double* A, int lda, const double* B, int ldb,
                      const double* C) {
     if (ta || tb || batch != 1 || upper_only || tri != 0) return false;
-    if (N <= 224 || N > 240 || (N & 1) || (ldb & 1) || (reinterpret_cast<size_t>(B) & 15)) return false;     // 16-byte pieces of the rows of B
+    if (N <= 176 || N > 240 || (N & 1) || (ldb & 1) || (reinterpret_cast<size_t>(B) & 15)) return false;     // 12 .. 15 column fragments; 16-byte pieces of the rows of B
     if (M < 2048 || K < 2048 || (long long)lda * kTallRows * 8 >= (1ll << 32)) return false;
     return C != A && C != B;
 }
 
+template <int NF>
+static int gemm_tall_launch(TallParams P, hipStream_t stream) {
+    constexpr int NC = 16 * NF;
+    const int tiles = ceil_div(P.M, kTallRows);
+    P.iters = (long long)tiles * P.nk;
+    P.groups = (int)std::min<long long>(kTallGroups, P.iters);
+    ScratchLease lease(stream);
+    P.pieces = (double*)lease.get(kScratchSplitK, (size_t)2 * P.groups * kTallRows * NC * sizeof(double));
+    if (P.pieces == nullptr) return fail(SHG_ERR_HIP, "gemm_tall: no workspace for the partial tiles");
+    const size_t lds = (size_t)2 * kTallK * (NC + 8) * sizeof(double);
+    SHG_SET_LDS_ONCE((gemm_tall_kernel<NF>), lds);
+    hipLaunchKernelGGL((gemm_tall_kernel<NF>), dim3(P.groups), dim3(64 * kTallWaves), lds, stream, P);
+    hipLaunchKernelGGL(gemm_tall_fixup_kernel, dim3(tiles, kTallRows / 2), dim3(256), 0, stream, P, NC);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
+
 int gemm_tall(int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc, hipStream_t stream) {
-    constexpr int NF = 15, NC = 16 * NF;
     TallParams P;
     P.M = M;
     P.N = N;
@@ -316,18 +333,16 @@ int gemm_tall(int M, int N, int K, double alpha, const double* A, int lda, const
     P.alpha = alpha;
     P.beta = beta;
     P.nk = K / kTallK;
-    const int tiles = ceil_div(M, kTallRows);
-    P.iters = (long long)tiles * P.nk;
-    P.groups = (int)std::min<long long>(kTallGroups, P.iters);
-    ScratchLease lease(stream);
-    P.pieces = (double*)lease.get(kScratchSplitK, (size_t)2 * P.groups * kTallRows * NC * sizeof(double));
-    if (P.pieces == nullptr) return fail(SHG_ERR_HIP, "gemm_tall: no workspace for the partial tiles");
-    const size_t lds = (size_t)2 * kTallK * (NC + 8) * sizeof(double);
-    SHG_SET_LDS_ONCE((gemm_tall_kernel<NF>), lds);
-    hipLaunchKernelGGL((gemm_tall_kernel<NF>), dim3(P.groups), dim3(64 * kTallWaves), lds, stream, P);
-    hipLaunchKernelGGL(gemm_tall_fixup_kernel, dim3(tiles, kTallRows / 2), dim3(256), 0, stream, P, NC);
-    SHG_HIP(hipGetLastError());
-    return SHG_OK;
+    P.pieces = nullptr;
+    P.iters = 0;
+    P.groups = 0;
+    switch (ceil_div(N, 16)) {                     // column fragments of a tile
+        case 12: return gemm_tall_launch<12>(P, stream);
+        case 13: return gemm_tall_launch<13>(P, stream);
+        case 14: return gemm_tall_launch<14>(P, stream);
+        case 15: return gemm_tall_launch<15>(P, stream);
+    }
+    return fail(SHG_ERR_INVALID, "gemm_tall: %d columns", N);
 }
 
 }  // namespace shg

@@ -55,9 +55,10 @@ def test_gemm_seeded_random_shapes():
         np.testing.assert_array_equal(got[:, N:], C0[:, N:])            # the padding columns are untouched
 
 
-@pytest.mark.parametrize('M,N,K', [(2048, 240, 2048), (2049, 226, 2061), (3000, 240, 2500), (2176, 238, 2063), (4133, 232, 2048)])
+@pytest.mark.parametrize('M,N,K', [(2048, 240, 2048), (2049, 226, 2061), (3000, 240, 2500), (2176, 238, 2063), (4133, 232, 2048), (2500, 178, 2100), (2300, 200, 2049),
+                                   (2200, 224, 2064)])
 def test_gemm_tall_products(M, N, K):
-    """Tall products with 226 .. 240 columns take the whole-width stream-K kernel (gemm_tall.hip): rows and K that are no multiples of
+    """Tall products with 178 .. 240 columns take the whole-width stream-K kernel (gemm_tall.hip): rows and K that are no multiples of
     the tile, a partial last K tile, alpha / beta, row strides of all three operands, and the same bits on every run (the pieces of a
     cut tile are summed in a fixed order)."""
     rng = np.random.default_rng(M + N + K)
