@@ -30,6 +30,35 @@ __global__ __launch_bounds__(64 * WAVES) void store_kernel(double* G, int ntiles
         const int bt = tile / 45, it = tile % 45;
         const int epoch = bt * 4 + (wave & 3);
         double* Ge = G + (size_t)epoch * NLAT * NLON;
+        if (STYLE == 3) {
+            // pairs of adjacent column tiles in one wave: 4 rows x 256 B per instruction; the half tile behind them as 8 rows x 64 B
+            for (int pr = (WAVES == 8 ? wave >> 2 : 0); pr < 3; pr += (WAVES == 8 ? 2 : 1)) {
+#pragma unroll
+                for (int t = 0; t < 2 * R; ++t) {
+                    const int k = t < R ? t : t - R;
+                    int w = NLON / 2 + k * NR - (t < R ? 0 : ND);
+                    w = w >= NLON ? w - NLON : w;
+                    if (pr < 2) {
+                        const int col0 = t < R ? w + 32 * pr : w + ND - 32 * pr - 32;
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const int s = (lane >> 4) + 4 * h;
+                            const int row = s < 8 ? it * 8 + s : NLAT - 1 - (it * 8 + s - 8);
+                            STORE((double2_t){(double)t, (double)h}, (double2_t*)(Ge + (size_t)row * NLON + col0 + 2 * (lane & 15)));
+                        }
+                    } else {
+                        const int col0 = t < R ? w + 64 : w + ND - 72;
+#pragma unroll
+                        for (int h = 0; h < 1; ++h) {
+                            const int s = lane >> 2;
+                            const int row = s < 8 ? it * 8 + s : NLAT - 1 - (it * 8 + s - 8);
+                            STORE((double2_t){(double)t, (double)h}, (double2_t*)(Ge + (size_t)row * NLON + col0 + 2 * (lane & 3)));
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         for (int ct = (WAVES == 8 ? wave >> 2 : 0); ct < 5; ct += (WAVES == 8 ? 2 : 1)) {
             const int ncol = ct == 4 ? 8 : 16;
 #pragma unroll
@@ -94,6 +123,8 @@ int main() {
             run<0, 8>("8 B stores, 8 waves", G, grid, lds);
             run<1, 4>("16 B stores, 4 waves", G, grid, lds);
             run<1, 8>("16 B stores, 8 waves", G, grid, lds);
+            run<3, 4>("16 B stores, 256 B runs, 4 waves", G, grid, lds);
+            run<3, 8>("16 B stores, 256 B runs, 8 waves", G, grid, lds);
             run<2, 4>("contiguous 1 KB, 4 waves", G, grid, lds);
             run<2, 8>("contiguous 1 KB, 8 waves", G, grid, lds);
         }
