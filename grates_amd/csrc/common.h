@@ -24,6 +24,7 @@ int zero_fill(double* p, long long ld, long long cols, long long rows, hipStream
 int zero_fill(int* p, hipStream_t stream);
 // grow-only scratch of a stream (plan.hip), kept until shg_scratch_release(); one slot per buffer that is live at the same time
 enum ScratchSlot { kScratchSplitK = 0, kScratchAnaFold = 1, kScratchAnaTransform = 2, kScratchAnaSolution = 3, kScratchAnaFlag = 4,
+                   kScratchSeriesIn = 5, kScratchSeriesOut = 6 /* order-major copies of a batch in the reference layout (filters.hip) */,
                    kScratchBlocks = 8 /* and up: the workspaces of one block-matrix call (blockchol.hip) */ };
 class ScratchLease {          // the scratch buffers of one stream, held while the operations that use them are enqueued (plan.hip)
 public:
