@@ -380,35 +380,41 @@ __global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N,
         const double2_t zero2 = {0.0, 0.0};
         auto load_a = [&](int c) { return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff + (unsigned)c * 8u, 0, 0)); };
         auto load_x = [&](int q, int k) { return q < nq && k < n ? X[16 * (p0 + q) + (size_t)k * ldx] : zero2; };
-        double2_t a = load_a(0), x0[kOmPairsPerWave], x1[kOmPairsPerWave];
-#pragma unroll
-        for (int q = 0; q < kOmPairsPerWave; ++q) {
-            x0[q] = load_x(q, 2 * fk);
-            x1[q] = load_x(q, 2 * fk + 1);
-        }
-        for (int c = 0; c < n; c += 8) {
-            const double2_t an = load_a(c + 8);                      // (beyond the last step: within the packed blocks or zero by the range check)
-            double2_t xn0[kOmPairsPerWave], xn1[kOmPairsPerWave];
+        // three steps of eight columns per trip, every step's operands requested two steps ahead (three operand sets; steps beyond the
+        // block's columns multiply zeros: the packed blocks' range check and the row mask)
+        struct Step {
+            double2_t a, x0[kOmPairsPerWave], x1[kOmPairsPerWave];
+        };
+        auto load_step = [&](Step& st, int c) {
+            st.a = load_a(c);
 #pragma unroll
             for (int q = 0; q < kOmPairsPerWave; ++q) {
-                xn0[q] = load_x(q, c + 8 + 2 * fk);
-                xn1[q] = load_x(q, c + 9 + 2 * fk);
+                st.x0[q] = load_x(q, c + 2 * fk);
+                st.x1[q] = load_x(q, c + 2 * fk + 1);
             }
+        };
+        auto products = [&](const Step& st) {
 #pragma unroll
             for (int q = 0; q < kOmPairsPerWave; ++q) {
                 if (q < nq) {
-                    acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x0[q].x, acc[q][0][0], 0, 0, 0);      // even epochs, k-step 0
-                    acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x0[q].y, acc[q][1][0], 0, 0, 0);      // odd epochs
-                    acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x1[q].x, acc[q][0][1], 0, 0, 0);      // k-step 1
-                    acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x1[q].y, acc[q][1][1], 0, 0, 0);
+                    acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a.x, st.x0[q].x, acc[q][0][0], 0, 0, 0);      // even epochs, k-step 0
+                    acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a.x, st.x0[q].y, acc[q][1][0], 0, 0, 0);      // odd epochs
+                    acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a.y, st.x1[q].x, acc[q][0][1], 0, 0, 0);      // k-step 1
+                    acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a.y, st.x1[q].y, acc[q][1][1], 0, 0, 0);
                 }
             }
-            a = an;
-#pragma unroll
-            for (int q = 0; q < kOmPairsPerWave; ++q) {
-                x0[q] = xn0[q];
-                x1[q] = xn1[q];
-            }
+        };
+        Step s0, s1, s2;
+        load_step(s0, 0);
+        load_step(s1, 8);
+        load_step(s2, 16);
+        for (int c = 0; c < n; c += 24) {
+            products(s0);
+            load_step(s0, c + 24);
+            products(s1);
+            load_step(s1, c + 32);
+            products(s2);
+            load_step(s2, c + 40);
         }
 #pragma unroll
         for (int q = 0; q < kOmPairsPerWave; ++q) {
