@@ -2,7 +2,8 @@
 // 64 rows, a wave 16 of them; the quarter domain is walked in steps, every step reading the four images of the step's columns of every
 // row (x3 ascending from the row start, x1 ascending from the middle, x2 descending from the middle, x4 descending from the row end).
 // Variants: bytes that one load instruction takes from one row (64: 16 rows x 64 B as the MFMA operand layout has it, 128: 8 rows x
-// 128 B, 256, 512, 1024), and a fully contiguous reference (the same bytes as 1 KB runs).  No arithmetic beyond a checksum.
+// 128 B, 256), a fully contiguous reference (the same bytes as 1 KB runs), and the same with the transform's output written behind
+// the reads (193 slots x 64 rows per workgroup, 128-byte pieces).  No arithmetic beyond a checksum.
 //   hipcc -O3 --offload-arch=gfx950 tools/load_bench.hip -o tools/scratch/load_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -12,8 +13,8 @@ constexpr int NLAT = 360, NLON = 720, B = 240;
 constexpr long long ROWS = (long long)B * NLAT;
 
 // PIECE: bytes per row and instruction (64 .. 1024); DEPTH: steps in flight; CONTIG: ignore the row structure
-template <int PIECE, int DEPTH, bool CONTIG>
-__global__ __launch_bounds__(256, 2) void load_kernel(const double* __restrict__ V, double* __restrict__ out) {
+template <int PIECE, int DEPTH, bool CONTIG, bool WRITES>
+__global__ __launch_bounds__(256, 2) void load_kernel(const double* __restrict__ V, double* __restrict__ out, double* __restrict__ gt) {
     constexpr int LPR = PIECE / 16;            // lanes per row
     constexpr int RPI = 64 / LPR;              // rows per instruction
     constexpr int NI = 16 / RPI;               // instructions per image and step (16 rows of a wave)
@@ -66,22 +67,30 @@ __global__ __launch_bounds__(256, 2) void load_kernel(const double* __restrict__
         }
     }
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc.x + acc.y;
+    if (WRITES) {
+        // the transform's output: 193 slots x the workgroup's 64 rows, gt[slot][row]; a wave writes 16 rows (128 B) of 4 slots per instruction
+        const int fr = lane & 15, fk = lane >> 4;
+        for (int s0 = 0; s0 < 193; s0 += 4) {
+            const int slot = s0 + fk;
+            if (slot < 193) gt[(size_t)slot * ROWS + r0 + fr] = acc.x + slot;
+        }
+    }
 }
 
-template <int PIECE, int DEPTH, bool CONTIG>
-static void run(const char* name, const double* V, double* out) {
+template <int PIECE, int DEPTH, bool CONTIG, bool WRITES>
+static void run(const char* name, const double* V, double* out, double* gt) {
     const int blocks = (int)(ROWS / 64);
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((load_kernel<PIECE, DEPTH, CONTIG>), dim3(blocks), dim3(256), 0, 0, V, out);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((load_kernel<PIECE, DEPTH, CONTIG, WRITES>), dim3(blocks), dim3(256), 0, 0, V, out, gt);
     hipEventRecord(a);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((load_kernel<PIECE, DEPTH, CONTIG>), dim3(blocks), dim3(256), 0, 0, V, out);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((load_kernel<PIECE, DEPTH, CONTIG, WRITES>), dim3(blocks), dim3(256), 0, 0, V, out, gt);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms = 0;
     hipEventElapsedTime(&ms, a, b);
-    const double bytes = (double)ROWS * NLON * 8;
+    const double bytes = (double)ROWS * NLON * 8 + (WRITES ? (double)ROWS * 193 * 8 : 0.0);
     printf("%-28s %8.1f us  %6.2f TB/s\n", name, 1e3 * ms / 10, bytes / (ms / 10 * 1e-3) / 1e12);
     fflush(stdout);
 }
@@ -92,12 +101,15 @@ int main() {
     hipMalloc(&V, n * 8 + 65536);
     hipMalloc(&out, (size_t)(ROWS / 64) * 256 * 8);
     hipMemset(V, 0, n * 8 + 65536);
-    run<64, 2, false>("64 B pieces, depth 2", V, out);
-    run<64, 3, false>("64 B pieces, depth 3", V, out);
-    run<128, 2, false>("128 B pieces, depth 2", V, out);
-    run<128, 3, false>("128 B pieces, depth 3", V, out);
-    run<256, 2, false>("256 B pieces, depth 2", V, out);
-    run<128, 2, true>("contiguous, depth 2", V, out);
-    run<128, 3, true>("contiguous, depth 3", V, out);
+    double* gt;
+    hipMalloc(&gt, (size_t)ROWS * 193 * 8);
+    run<64, 2, false, false>("64 B pieces, depth 2", V, out, gt);
+    run<64, 3, false, false>("64 B pieces, depth 3", V, out, gt);
+    run<128, 2, false, false>("128 B pieces, depth 2", V, out, gt);
+    run<256, 2, false, false>("256 B pieces, depth 2", V, out, gt);
+    run<128, 2, true, false>("contiguous, depth 2", V, out, gt);
+    run<64, 2, false, true>("64 B pieces + gt writes", V, out, gt);
+    run<128, 2, false, true>("128 B pieces + gt writes", V, out, gt);
+    run<128, 2, true, true>("contiguous + gt writes", V, out, gt);
     return 0;
 }
