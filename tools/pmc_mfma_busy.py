@@ -6,7 +6,7 @@ import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 kernels = {'synthesis': ('synthesis_pmc', 'synthesis_rot_kernel'), 'covariance': ('covprop_pmc', 'gemm_f64_kernel<MODE_COVPROP>'),
-           'filters_block': ('filters_block_pmc', 'orderwise_filter_kernel'), 'filters_dense': ('filters_dense_pmc', 'gemm_tall_kernel (shg_dense_filter)')}
+           'filters_block': ('filters_block_pmc', 'orderwise_filter_om_kernel'), 'filters_dense': ('filters_dense_pmc', 'gemm_tall_kernel (shg_dense_filter)')}
 out = {'source': 'rocprofv3 --pmc, one pass per counter group beside --kernel-trace only (tools/pmc_summary.sh), per-dispatch averages', 'kernels': {}}
 for leg, (stem, kernel) in kernels.items():
     path = os.path.join(ROOT, 'profiles', '{0}_{1}.txt'.format(tag, stem))

@@ -39,7 +39,7 @@ PY
 }
 run_group ${tag}_synthesis_pmc synthesis_rot_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs synthesis --cpu-sample 0 --steps 20 --warmup 5 --ramp 50 --idle-pass 0
 run_group ${tag}_covprop_pmc gemm_f64_kernel python3 $GRAFT_REPO_ROOT/tools/gemm_phases.py --release-library 24
-run_group ${tag}_filters_block_pmc orderwise_filter_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs filters --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0
+run_group ${tag}_filters_block_pmc orderwise_filter_om_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs filters --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0
 cp $out/${tag}_filters_block_pmc.txt $out/${tag}_filters_tmp.txt
 run_group ${tag}_filters_dense_pmc gemm_tall_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs filters --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0
 rm -f $out/${tag}_filters_tmp.txt
