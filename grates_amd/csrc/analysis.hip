@@ -672,8 +672,11 @@ static int folded_transform(shg_plan* p, const double* grid, const double* area,
 static int analysis_pass(shg_plan* p, const double* grid, const double* area, int nmin, int B, int chunk, bool folded, double* wvt, double* gt,
                          double* X, double* anm, hipStream_t stream) {
     const int N = p->N, S = 2 * N + 1, nlat = p->nlat, nlon = p->nlon, R = N + 1;
-    hipLaunchKernelGGL(analysis_zero_kernel, dim3((unsigned)std::min<long long>(ceil_div64((long long)B * R * R, 2 * 256), 4096)), dim3(256), 0, stream,
-                       (long long)B * R * R, anm);
+    // degrees below min_degree stay zero; with min_degree 0 the slots write every entry of the output (C_nm at [n][m], n >= m, and S_nm at
+    // [m-1][n], n >= m >= 1, tile the (N+1) x (N+1) array exactly)
+    if (nmin > 0)
+        hipLaunchKernelGGL(analysis_zero_kernel, dim3((unsigned)std::min<long long>(ceil_div64((long long)B * R * R, 2 * 256), 4096)), dim3(256), 0, stream,
+                           (long long)B * R * R, anm);
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);
         const long long rows = (long long)nb * nlat;

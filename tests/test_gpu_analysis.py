@@ -96,6 +96,31 @@ def test_against_oracle_batched(N, nmin, dlon, dlat):
         assert relerr(out[e], ref) < TOL
 
 
+@pytest.mark.parametrize('N,nmin,dlon,dlat', [(12, 0, 7.5, 6), (12, 3, 7.5, 6), (40, 0, 2, 2), (127, 0, 1.25, 1.25), (127, 4, 1.25, 1.25)])
+def test_output_is_written_in_full(N, nmin, dlon, dlat):
+    """The library zero-fills the output only when min_degree > 0 (with min_degree 0 the slots write every entry): whatever the
+    allocator hands out as the output block -- here a block that held NaNs a moment ago -- the result is the oracle's, zeros
+    below min_degree included."""
+    import torch
+    grid = ga.grid.GeographicGrid(dlon, dlat)
+    rng = np.random.default_rng(N + nmin)
+    vals = rng.standard_normal((3, grid.parallels.size, grid.meridians.size))
+    ker = orc.KernelTable('potential')
+    colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel('potential'), N, grid.parallels, 3.9860044150e+14, 6.3781363000e+06,
+                                                   grid.semimajor_axis, grid.flattening)
+    plan = ga.engine.Plan(N, colat, kn, grid.meridians)
+    plan.analysis(vals, grid.area, nmin)                                       # operators built, caches warm
+    for _ in range(3):
+        poison = torch.full((3, N + 1, N + 1), float('nan'), dtype=torch.float64, device='cuda')
+        del poison                                                             # back to the caching allocator: the next block of this size
+        out = ga.engine.to_host(plan.analysis(vals, grid.area, nmin))
+        assert np.isfinite(out).all()
+    ref = orc.analysis_regular(vals[2].ravel(), grid.area, nmin, N, grid.meridians, grid.parallels, ker)
+    assert relerr(out[2], ref) < TOL
+    if nmin > 0:
+        assert not out[:, :nmin, :nmin].any()                                  # C_nm, n < min_degree (and the S_nm stored there)
+
+
 def test_operator_follows_weights_and_meridians():
     """The cached operator is rebuilt when the area weights change between calls (same plan, same min_degree), and grids
     without the four-fold meridian symmetry (here: shifted meridians, odd count) take the unfolded longitude transform."""
