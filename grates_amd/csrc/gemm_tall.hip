@@ -1,19 +1,19 @@
 // Tall-and-skinny fp64 product C = alpha A B + beta C with A [M x K] row-major (K-contiguous), B [K x N] row-major and N <= 240:
-// the dense form of the DDK filters, W [14637^2] X [14637 x 240] (grates/filter.py:  `NormalsFilter` / the full-matrix branch of
-// `FilterKernel.filter`, one numpy matmul per call in the reference).
+// the dense form of the DDK filters, W [14637^2] X [14637 x 240] (grates/filter.py:473-474, `GeneralMatrix.filter`: one numpy matmul per
+// epoch in the reference).
 //
 // Why a kernel of its own.  In square output tiles (blas.hip: gemm_ex_kernel) this shape pays three ways: the 240 columns fill 3.75
 // tiles of 64 (6 % of the MFMAs work on padding), the 916 tiles do not divide over the 768 workgroup slots of the card, and W crosses
 // LDS although no two waves of a workgroup share a row of it.  Here
-//   * an output tile is 16 WAVES rows x ALL columns (NF = ceil(N / 16) fragments of 16: no column padding beyond the last fragment);
-//   * the waves of a workgroup own 16 rows each (NF accumulator fragments = 8 NF registers): their rows of A go from global memory straight
+//   * an output tile is 128 rows x ALL columns (NF = ceil(N / 16) fragments of 16: no column padding beyond the last fragment);
+//   * the eight waves of a workgroup own 16 rows each (NF accumulator fragments = 8 NF registers): their rows of A go from global memory straight
 //     into the A-operand registers of the MFMAs -- lane (fr, fk) loads A[row fr][k0 + 2 fk .. + 1] and A[row fr][k0 + 8 + 2 fk .. + 1]
 //     (two 16-byte loads, each instruction covering 64 contiguous bytes of 16 rows) and uses its four values in the four k-steps of
 //     the K tile; B only has to present the SAME k to the lane, i.e. the k-step s of lane group fk reads row 2 fk + {0, 1, 8, 9}[s];
-//   * the K tile of B (16 rows x N) is shared by the four waves through LDS, copied there by LDS-DMA (no registers, no ds_write),
+//   * the K tile of B (16 rows x N) is shared by the eight waves through LDS, copied there by LDS-DMA (no registers, no ds_write),
 //     double-buffered, rows 16 NF + 8 doubles apart (conflict-free fragment reads); one barrier per K tile (4 NF = 60 MFMAs of a wave; K tiles of 32 rows measured no faster);
 //   * the work is dealt stream-K: the (tile, K tile) iterations of the whole product form one sequence that is cut into G equal
-//     ranges, one per workgroup (two per CU).  A range that covers a whole tile writes C itself; the at most two partial ends of a
+//     ranges, one per workgroup (one per CU).  A range that covers a whole tile writes C itself; the at most two partial ends of a
 //     range go to a workspace and a second kernel sums the pieces of every cut tile in the order of the ranges (a fixed order:
 //     the result does not depend on which workgroup ran when).
 #include <memory>
