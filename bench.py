@@ -82,7 +82,7 @@ def parse_args(argv=None):
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass of the staged path (0 = library default)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='seconds after which `--gpus N` run without a launcher kills its ranks (0 = never)')
-    ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'fused32', 'rot', 'pipe', 'fed', 'halves'], help='synthesis kernel path')
+    ap.add_argument('--path', default='auto', choices=['auto', 'staged', 'fused', 'fused32', 'rot'], help='synthesis kernel path')
     ap.add_argument('--cpu-sample', type=int, default=16, help='solutions timed on the CPU baseline (0 = skip all CPU baselines)')
     ap.add_argument('--cov-parallels', type=int, default=-1,
                     help='parallels of the covariance leg over all ranks (-1 = the whole 0.5 degree grid, 360; 0 = skip the leg)')
@@ -236,8 +236,8 @@ class GpuWorkload:
         self.batch = torch.from_numpy(self.batch_host).cuda()
         self.out = torch.empty((B, self.nlat, self.nlon), dtype=torch.float64, device='cuda')
         info = self.plan.info()
-        rot = bool(info['rotation_symmetry']) and self.args.path in ('auto', 'rot', 'pipe', 'fed', 'halves')
-        self.kernel_name = (('synthesis_pipe_kernel' if self.args.path in ('pipe', 'fed') else 'synthesis_rot_kernel') if rot else 'synthesis_fused_kernel') if info['fused'] else 'lon_stage_kernel<4>'
+        rot = bool(info['rotation_symmetry']) and self.args.path in ('auto', 'rot')
+        self.kernel_name = ('synthesis_rot_kernel' if rot else 'synthesis_fused_kernel') if info['fused'] else 'lon_stage_kernel<4>'
         self.config = {'fused_kernel': info['fused'], 'fourfold_symmetry': info['fourfold_symmetry'], 'rotation_folded_kernel': rot,
                        'rotations': info['rotations'] if rot else 0}
 

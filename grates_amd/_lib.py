@@ -29,6 +29,7 @@ PROTOTYPES = {
     'shg_plan_set_chunk': [c_plan_p, ctypes.c_int],
     'shg_plan_set_path': [c_plan_p, ctypes.c_int],
     'shg_plan_set_rotations': [c_plan_p, ctypes.c_int],
+    'shg_plan_set_stage_limit': [c_plan_p, ctypes.c_int],
     'shg_plan_info': [c_plan_p, ctypes.POINTER(ctypes.c_int64)],
     'shg_plan_profile': [c_plan_p, ctypes.c_int],
     'shg_plan_profile_read': [c_plan_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)],

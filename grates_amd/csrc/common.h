@@ -213,16 +213,10 @@ struct shg_plan {
     int* itemtab_d = nullptr;   // work items of the fused kernel's Legendre stage, [8 waves][nrec][4]
     int itemtab_nrec = 0, itemtab_ntrip = 0;
     int itemtab_rot = -1;       // panel slot convention of the work items: 0 = 4-fold kernel, R = rotation-folded kernel
-    int* itemtab2_d = nullptr;  // the same items for the four waves of the pipelined rotation-folded kernel, packed records
-    int itemtab2_nrec = 0, itemtab2_ntrip = 0;
-    double* ring_d = nullptr;   // fed pipeline (path 8): ring of panel images, hand-off words, the producer kernel's stream
-    size_t ring_bytes = 0, ring_image_bytes = 0;
-    int* handoff_d = nullptr;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t fork_event = nullptr, join_event = nullptr;
     const double* om_src = nullptr;   // set for the duration of shg_synthesis_om: the coefficient repack reads this order-major series
     int om_N = 0, om_Bpad = 0;
-    int* sem_d = nullptr;       // token counter of the rotation-folded kernels' Legendre stage (synthesis_rot.hip)
+    int* sem_d = nullptr;       // token counter of the rotation-folded kernel's Legendre stage (synthesis_rot.hip), allocated by rot_set_stage_limit
+    int stage_limit = 0;        // workgroups that may run their Legendre stage at once (0 = no limit, the default)
     int* blockmap_d = nullptr;  // XCD-aware (epoch tile, parallel tile) order of the fused kernel's workgroups
     int blockmap_nbt = 0, blockmap_nit = 0;
     std::vector<char> ns_badrow;    // per northern parallel: mirror image deviates too much to share the northern table
@@ -243,7 +237,7 @@ struct shg_plan {
     bool ana_rowconst = false;  // the weights of the cached operator are constant along every parallel (geographic and Gauss grids)
     double* ana_trig = nullptr; // trig table of the fused transform kernel in chunk order [chunk][8 columns][4 groups x MT x 16 orders], zero padded
     int ana_trig_mt = 0;
-    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 5 fused kernel with 32-row panels (two workgroups per CU), 6 rotation-folded fused kernel, 7 its pipelined variant (one wave per SIMD), 8 that variant fed by a Legendre-stage kernel on a second stream
+    int path = 0;               // 0 auto, 1 three-kernel path, 2 fused 4-fold kernel, 5 fused kernel with 32-row panels (two workgroups per CU), 6 rotation-folded fused kernel
 
     // users of the plan are serialised (PlanGuard): its tables are built lazily and its workspaces are per plan, not per stream
     std::mutex mtx;
@@ -273,10 +267,7 @@ int rot_choose(int nlon, const double* lon_h, int N);
 int rot_applicable(const shg_plan* p);
 int build_rot_trig(shg_plan* p, const double* lon_h);
 int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
-int pipe_applicable(const shg_plan* p);          // the pipelined variant of the rotation-folded kernel (synthesis_rot.hip, path 7)
-int synthesis_pipe(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
-int synthesis_fed(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
-int synthesis_rot_halves(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);    // path 9: two workgroups of two epochs per CU           // path 8: Legendre stage as a second kernel beside it
+int rot_set_stage_limit(shg_plan* p, int limit);
 int fused32_applicable(const shg_plan* p);
 int synthesis_fused32(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream);
 

@@ -540,13 +540,7 @@ extern "C" int shg_plan_destroy(shg_plan* p) {
     if (p->badmap_d) (void)hipFree(p->badmap_d);
     if (p->blockmap_d) (void)hipFree(p->blockmap_d);
     if (p->sem_d) (void)hipFree(p->sem_d);
-    if (p->ring_d) (void)hipFree(p->ring_d);
-    if (p->handoff_d) (void)hipFree(p->handoff_d);
-    if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
-    if (p->fork_event) (void)hipEventDestroy(p->fork_event);
-    if (p->join_event) (void)hipEventDestroy(p->join_event);
     if (p->itemtab_d) (void)hipFree(p->itemtab_d);
-    if (p->itemtab2_d) (void)hipFree(p->itemtab2_d);
     if (p->octinfo_d) (void)hipFree(p->octinfo_d);
     if (p->qoff32) (void)hipFree(p->qoff32);
     if (p->badmap32_d) (void)hipFree(p->badmap32_d);
@@ -567,14 +561,18 @@ extern "C" int shg_plan_set_chunk(shg_plan* p, int epochs_per_pass) {
 
 extern "C" int shg_plan_set_path(shg_plan* p, int path) {
     SHG_REQUIRE(p != nullptr, "shg_plan_set_path: NULL plan");
-    SHG_REQUIRE(path == 0 || path == 1 || path == 2 || path == 5 || path == 6 || path == 7 || path == 8 || path == 9, "shg_plan_set_path: path %d not in {0, 1, 2, 5, 6, 7, 8, 9}", path);
-    SHG_REQUIRE(path != 9 || rot_applicable(p), "shg_plan_set_path: rotation-folded kernel not applicable");
-    SHG_REQUIRE(path < 7 || path == 9 || pipe_applicable(p), "shg_plan_set_path: pipelined rotation-folded kernel not applicable (needs what path 6 needs and two trig buffers beside the panel in the LDS)");
+    SHG_REQUIRE(path == 0 || path == 1 || path == 2 || path == 5 || path == 6, "shg_plan_set_path: path %d not in {0, 1, 2, 5, 6}", path);
     SHG_REQUIRE(path != 5 || fused32_applicable(p), "shg_plan_set_path: the two-workgroup fused kernel needs both grid symmetries and K <= 416 (K = %d)", p->K);
     SHG_REQUIRE(path != 2 || fused_chunk_for(p) != 0, "shg_plan_set_path: fused kernel not applicable (needs 4-fold symmetric meridians and K <= 224, K = %d)", p->K);
     SHG_REQUIRE(path < 6 || rot_applicable(p), "shg_plan_set_path: rotation-folded kernel not applicable (needs equi-angular meridians with nlon %% 96 == 0 or nlon %% 48 == 0, nlon >= 192, and a panel within the LDS)");
     p->path = path;
     return SHG_OK;
+}
+
+extern "C" int shg_plan_set_stage_limit(shg_plan* p, int limit) {
+    SHG_REQUIRE(p != nullptr, "shg_plan_set_stage_limit: NULL plan");
+    std::unique_lock<std::mutex> lock(p->mtx);
+    return rot_set_stage_limit(p, limit);
 }
 
 extern "C" int shg_plan_set_rotations(shg_plan* p, int R) {

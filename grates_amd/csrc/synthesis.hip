@@ -259,9 +259,6 @@ extern "C" int shg_synthesis_om(shg_plan* p, const double* om, int Ns, int B, in
 
 static int synthesis_dispatch(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
     // degrees beyond the 64-row panel (d/o 127 ... ~210): the 32-row fused kernel still beats the three-kernel path
-    if (p->path == 9) return synthesis_rot_halves(p, anm, B, grid, stream);
-    if (p->path == 8) return synthesis_fed(p, anm, B, grid, stream);
-    if (p->path == 7) return synthesis_pipe(p, anm, B, grid, stream);
     if (p->path >= 6 || (p->path == 0 && rot_applicable(p))) return synthesis_rot(p, anm, B, grid, stream);
     if (p->path == 5 || (p->path == 0 && fused_chunk_for(p) == 0 && fused32_applicable(p))) return synthesis_fused32(p, anm, B, grid, stream);
     if (p->path >= 2 || (p->path == 0 && fused_chunk_for(p) != 0)) return synthesis_fused(p, anm, B, grid, stream);

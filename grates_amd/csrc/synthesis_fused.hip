@@ -713,45 +713,6 @@ static int build_item_table(shg_plan* p, int od, const std::vector<int>& qoff, i
         (void)hipFree(p->itemtab_d);
         p->itemtab_d = nullptr;
     }
-    if (p->itemtab2_d) {
-        (void)hipFree(p->itemtab2_d);
-        p->itemtab2_d = nullptr;
-    }
-    if (rotR) {
-        // the pipelined kernel (synthesis_rot.hip, synthesis_pipe_kernel): the same items in EIGHT lists (two per wave), records packed
-        // into two words (first octet | second octet << 16, panel slot | flags << 16), trips of four, padded by two trips
-        constexpr int nw2 = 8;
-        std::vector<std::vector<int>> rec2(nw2);
-        for (int m = 0; m <= N; ++m) {
-            int w = 0;
-            for (int v = 1; v < nw2; ++v)
-                if (rec2[v].size() < rec2[w].size()) w = v;
-            const int cnt = N + 1 - m, q = (cnt + od - 1) / od;
-            for (int j0 = 0; j0 < q; j0 += 2) {
-                const int o0 = qoff[m] + j0, o1 = o0 + (j0 + 1 < q ? 1 : 0);
-                const int flags = 1 | ((j0 + 1) * od < cnt ? 2 : 0) | (j0 + 2 >= q ? 4 : 0);
-                if (o1 >= 65536 || slot16[m] >= 65536) return fail(SHG_ERR_UNSUPPORTED, "work items of the pipelined kernel: octet index beyond 16 bits");
-                rec2[w].push_back(o0 | (o1 << 16));
-                rec2[w].push_back(slot16[m] | (flags << 16));
-            }
-        }
-        size_t longest2 = 0;
-        for (int w = 0; w < nw2; ++w) longest2 = std::max(longest2, rec2[w].size() / 2);
-        const int ntrip2 = (int)((longest2 + 3) / 4), nrec2 = 4 * (ntrip2 + 2);
-        std::vector<int> table2((size_t)nw2 * nrec2 * 2, 0);
-        for (int w = 0; w < nw2; ++w) {
-            const int pad = rec2[w].empty() ? 0 : (rec2[w][0] & 0xffff);
-            for (int t = 0; t < nrec2; ++t) {
-                const size_t src = (size_t)t * 2;
-                table2[((size_t)w * nrec2 + t) * 2] = src < rec2[w].size() ? rec2[w][src] : (pad | (pad << 16));
-                table2[((size_t)w * nrec2 + t) * 2 + 1] = src < rec2[w].size() ? rec2[w][src + 1] : 0;
-            }
-        }
-        if (hipMalloc((void**)&p->itemtab2_d, table2.size() * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "work item table allocation failed");
-        SHG_HIP(hipMemcpy(p->itemtab2_d, table2.data(), table2.size() * sizeof(int), hipMemcpyHostToDevice));
-        p->itemtab2_nrec = nrec2;
-        p->itemtab2_ntrip = ntrip2;
-    }
     if (hipMalloc((void**)&p->itemtab_d, table.size() * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "work item table allocation failed");
     SHG_HIP(hipMemcpyAsync(p->itemtab_d, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     SHG_HIP(hipStreamSynchronize(stream));                             // the host vector goes out of scope

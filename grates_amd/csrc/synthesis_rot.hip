@@ -87,15 +87,8 @@ struct RotParams {
     const double* pkf;
     const int4* itemtab;
     int nrec, ntrip;
-    double* ring;             // fed pipeline: images of the panels of `ring_tiles` tiles ((nslot + 1) KB each, padding slots zero)
-    int ring_tiles;
-    int fed_first;            // tiles 0 .. fed_first - 1 are not produced (every consumer workgroup makes the panel of its first tile itself)
-    int* produced;            // [ring_tiles] tile + 1 once the image of that tile's panel is complete
-    int* consumed;            // [ring_tiles] tile + 1 once the consumer has the image in its LDS (-1: slot given up for this launch)
     int* sem;                 // tokens of the Legendre stage in use (device-wide counter, 0 between launches)
     int sem_limit;            // at most this many workgroups run their Legendre stage at the same time (0 = no limit)
-    const int2* itemtab2;     // pipelined kernel: packed work items of its four waves (see build_item_table)
-    int nrec2, ntrip2;
 #ifdef SHG_TIMELINE
     unsigned long long* tl;
 #endif
@@ -315,8 +308,8 @@ struct RotStream {
 };
 
 // The issue side walks the column tiles of its wave on its own: (wave >> 2), + 2, ..., then again from the start for the next tile.
-// EP = epochs (= row tiles) of the workgroup: 4 (eight waves, one workgroup per CU) or 2 (four waves, two workgroups per CU)
-template <int EP>
+// EP = epochs (= row tiles) of the workgroup: eight waves, one workgroup per CU
+constexpr int EP = 4;
 __device__ __forceinline__ void rot_stream_init(RotStream& S, const RotParams& P, const double* As, int wave) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)As;
     S.ring_lds = lds0 + (unsigned)wave * (kRingSlots * 1024);
@@ -353,7 +346,7 @@ __device__ __forceinline__ void rot_issue_piece(RotStream& S, const RotParams& P
 // on the same column tile then drift apart and no longer share the trig pieces in the L1.)
 // On entry (S.tx, S.abx) hold the fragments of the first k-step; on exit those of the first k-step of column tile wave >> 2
 // again (trig part; the panel part is re-read by the caller once the next panel is there).
-template <bool NS, int R, int EP>
+template <bool NS, int R>
 __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As, const double2_t* panel, RotStream& S, int wave, int lane,
                                            int b0, int it) {
     constexpr int PR = 16 * EP;                        // panel rows
@@ -527,29 +520,7 @@ __device__ __forceinline__ void rot_phase2(const RotParams& P, const double* As,
 #undef ROT_FETCH
 }
 
-// Where a panel row goes: into the LDS panel of the tile, or (producer kernel of the fed pipeline) write-through into the image of a
-// tile's panel in global memory, from where another workgroup's LDS-DMA takes it (sc1 = aux 16: cdna_hip_programming.md guideline 16, R1)
-struct GlobalPanel {
-    __amdgpu_buffer_rsrc_t rsrc;
-    bool skip;
-};
 __device__ __forceinline__ void panel_put(double2_t* panel, int index, double2_t v) { panel[index] = v; }
-// the 32-row panel of a workgroup that keeps two of the tile's four epochs (index = slot * 64 + epoch * 16 + row of the full panel)
-struct HalfPanel {
-    double2_t* rows;
-    int half;
-};
-__device__ __forceinline__ void panel_put(const HalfPanel& panel, int index, double2_t v) {
-    const int row = index & 63;
-    if ((row >> 5) == panel.half) panel.rows[(index >> 6) * 32 + (row & 31)] = v;
-}
-__device__ __forceinline__ void panel_put(const GlobalPanel& panel, int index, double2_t v) {
-    if (panel.skip) {                       // (experiment builds: the producer without its stores)
-        asm volatile("" ::"v"(v));
-        return;
-    }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), panel.rsrc, (unsigned)index * 16u, 0, 16);
-}
 
 // Phase 1: Legendre stage of tile (bt, it) (see synthesis_fused.hip).  The orders of the tile are dealt to the waves that call this
 // (work-item records `recs`, one list per wave); the result of order m is one 16-byte pair (A_m, B'_m) per panel row, written to
@@ -698,7 +669,7 @@ __device__ __forceinline__ void legendre_token_acquire(int* sem, int limit) {
 }
 __device__ __forceinline__ void legendre_token_release(int* sem) { (void)__hip_atomic_fetch_add(sem, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <bool NS, int R, int EP>
+template <bool NS, int R>
 __global__ __launch_bounds__(128 * EP) void synthesis_rot_kernel(RotParams P) {
     constexpr int NW = 2 * EP, PR = 16 * EP;           // waves, panel rows
     using T = RotTraits<R>;
@@ -708,9 +679,7 @@ __global__ __launch_bounds__(128 * EP) void synthesis_rot_kernel(RotParams P) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nbt = (P.B + 3) >> 2;
-    // EP == 2: the workgroups b and b + 8 (one XCD) are the two halves of a tile: epochs 0, 1 and 2, 3
-    const int tile = EP == 4 ? (int)blockIdx.x : (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7));
-    const int half = EP == 4 ? 0 : (int)((blockIdx.x >> 3) & 1);
+    const int tile = (int)blockIdx.x;
     if (tile >= nbt * P.nit) return;
     const int bt = P.blockmap ? P.blockmap[2 * tile] : tile % nbt;
     const int it = P.blockmap ? P.blockmap[2 * tile + 1] : tile / nbt;
@@ -739,7 +708,7 @@ __global__ __launch_bounds__(128 * EP) void synthesis_rot_kernel(RotParams P) {
     // ---- trig stream of this wave.  The issue side runs kRingDepth pieces ahead of the consumer and never stops (when a wave has
     //      no further column tile it re-reads pieces), so that the count of DMAs in flight is the same at every wait.
     RotStream S;
-    rot_stream_init<EP>(S, P, As, wave);
+    rot_stream_init(S, P, As, wave);
 #pragma unroll
     for (int d = 0; d < kRingDepth; ++d) rot_issue_piece(S, P, (unsigned)lane * 16u);
 
@@ -748,15 +717,7 @@ __global__ __launch_bounds__(128 * EP) void synthesis_rot_kernel(RotParams P) {
         if (tid == 0) legendre_token_acquire(P.sem, P.sem_limit);
         __syncthreads();
     }
-    if (!SHG_DBG(P, 2)) {
-        if (EP == 4) {
-            rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
-        } else {                  // two of the eight item lists per wave; the rows of the other two epochs are computed and dropped
-            const HalfPanel hp = {panel, half};
-            rot_phase1<NS>(P, hp, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
-            rot_phase1<NS>(P, hp, P.itemtab + (size_t)(wave + 4) * P.nrec, bt, it, lane);
-        }
-    }
+    if (!SHG_DBG(P, 2)) rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
     ROT_STAMP(1);
     __syncthreads();          // panel complete; from here on it is read-only and the waves run independently
     if (P.sem_limit > 0 && tid == 0) legendre_token_release(P.sem);
@@ -777,7 +738,7 @@ __global__ __launch_bounds__(128 * EP) void synthesis_rot_kernel(RotParams P) {
         S.cslot = 1;
         S.abx = panel[(wave % EP) * 16 + fr + fk * PR];
         S.pf = P.npieces > 1 ? 1 : 0;
-        rot_phase2<NS, R, EP>(P, As, panel, S, wave, lane, bt * 4 + half * 2, it);
+        rot_phase2<NS, R>(P, As, panel, S, wave, lane, bt * 4, it);
         // The prefetched pieces of the stream must have landed before the LDS is released -- but not the stores: the 4 R stores of
         // the last unit are the youngest operations of the wave (its last LDS-DMA was issued in the last k-step, before them), and
         // the counter runs in order, so "at most 4 R outstanding" means every DMA is done.  The wave ends with its stores in flight
@@ -789,580 +750,6 @@ __global__ __launch_bounds__(128 * EP) void synthesis_rot_kernel(RotParams P) {
     ROT_STAMP(12);
 }
 
-// =====================================================================================================================
-// Pipelined variant (round 5): ONE wave per SIMD, the accumulators of a unit twice.
-//
-// What bounds synthesis_rot_kernel is not its instruction count but when it stores: every wave issues the 40 stores of a
-// unit in one burst at the end of the unit, all eight waves of a workgroup at about the same time, no wave stores anything
-// during the Legendre stage or the k-loop of a unit, and a wave's next k-loop waits for the acknowledgement of its burst
-// (one in-order vmcnt for stores and trig pieces).  Measured (tools/timeline.py, round 5): the no-store kernel takes 0.38 ms,
-// the stores alone 0.37 ms, together 0.50 ms; staggering workgroups or waves moves nothing (the chip falls back into step).
-//
-// Here a wave owns 512 registers: the 2 R images of unit u stay in registers while unit u + 1 accumulates into a second set,
-// and leave during that k-loop, a group of images behind every class of the K sequence (8-byte stores straight from the
-// accumulator registers, 4 rows x 128 bytes per instruction, wave-uniform address part in the scalar offset: no lane exchange
-// and no vector address arithmetic).  The trig stream no longer shares the in-order counter with the stores inside the
-// k-loop: the four waves of a workgroup (one row tile = one epoch each) walk the column tiles together, the pieces of column tile
-// ct + 1 are copied into the second half of a double buffer by LDS-DMA at the start of unit ct, and the only wait for them
-// stands at the end of the unit (all of the unit's stores are younger than they: vmcnt(63) never waits for a recent store),
-// followed by the workgroup's one barrier per unit.
-// =====================================================================================================================
-#ifndef SHG_LEGENDRE_TOKENS
-#define SHG_LEGENDRE_TOKENS -7      // > 0: that many; < 0: that many sixteenths of the device's CUs; 0: no limit
-#endif
-// Workgroups that may run their Legendre stage at once.  Measured (round 5, 240 x d/o 96 -> 0.25 degree, three boxes, alternating
-// processes): 96 .. 128 of 256 take 1.5 - 2 % off the kernel (0.497 / 0.472 / 0.497 against 0.505 / 0.480 / 0.508 ms), 64 cost 9 %.
-constexpr int kLegendreTokens = SHG_LEGENDRE_TOKENS;
-constexpr int kPipeWaves = 4;
-#ifndef SHG_PIPE_X
-#define SHG_PIPE_X 0           // experiment switches of the pipelined kernel's Legendre stage (timing only): 1 no arithmetic, 2 no operand loads
-#endif
-
-typedef int int8_v __attribute__((ext_vector_type(8)));
-
-// Legendre stage of the pipelined kernel.  With one wave per SIMD nothing hides the end of an order -- the last MFMA's latency, the
-// exchange between the hemispheres, the write of the panel row -- unless the wave itself has other work: every wave runs TWO
-// independent item lists (streams A and B, the lists of waves w and w + 4 of an eight-wave dealing) interleaved item by item,
-// each with its own accumulator pair and four operand sets (three items in flight per stream).  Records are packed into two words
-// (x = first octet | second octet << 16, y = panel slot | flags << 16; four records per 32-byte scalar load).
-constexpr int kPipeChunks = 8;          // the images still parked when a tile begins leave in this many groups during its Legendre stage
-
-template <bool NS, class Flush>
-__device__ __forceinline__ void pipe_phase1(const RotParams& P, double2_t* panel, const int2* recs_a, const int2* recs_b, int bt, int it, int lane,
-                                            bool pending, Flush&& flush_chunk) {
-    const int fr = lane & 15, fk = lane >> 4;
-    constexpr int ASTRIDE = NS ? 128 : 64;
-    typedef const int8_v __attribute__((address_space(4))) crec_t;
-    auto ld16 = [](__amdgpu_buffer_rsrc_t table, unsigned voff, unsigned soff) {
-        return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(table, voff, soff, 0));
-    };
-    const int bad = NS ? P.badmap[it] : -1;
-    __amdgpu_buffer_rsrc_t pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)it * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
-    const __amdgpu_buffer_rsrc_t cfu =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(NS ? P.cpk4 + (size_t)bt * P.Qtot * 128 : P.cpk4 + (size_t)bt * P.Qtot * 64), 0, 0xffffffffu, 0x00020000);
-    const unsigned pk_voff = (unsigned)lane * 16u;
-    const unsigned cf_voff = NS ? (unsigned)lane * 16u : (unsigned)(fk * 8 + (fr & 7)) * 16u;
-    int mode = NS && bad >= 0 ? 1 : 0;
-    int prow = lane;
-    const bool arow = NS || fr < 8;
-    double4_t accA0 = {0.0, 0.0, 0.0, 0.0}, accA1 = accA0, accB0 = accA0, accB1 = accA0;
-    const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-    double sgm = (mode == 0 && fr >= 8) ? -1.0 : 1.0;
-    bool freshA = true, freshB = true;
-
-#define PIPE_P1_ISSUE(rx, S)                                                                      \
-    do {                                                                                          \
-        const unsigned lo_ = (unsigned)(rx) & 0xffffu, hi_ = (unsigned)(rx) >> 16;                \
-        if (SHG_PIPE_X & 2) break;          /* experiment: no operand loads */                     \
-        al##S = ld16(cfu, cf_voff, lo_ * (ASTRIDE * 8u));                                         \
-        bl##S = ld16(pku, pk_voff, lo_ * 1024u);                                                  \
-        ah##S = ld16(cfu, cf_voff, hi_ * (ASTRIDE * 8u));                                         \
-        bh##S = ld16(pku, pk_voff, hi_ * 1024u);                                                  \
-    } while (0)
-
-#define PIPE_P1_CONSUME(ry, S, Q)                                                                                   \
-    do {                                                                                                            \
-        const int fl_ = (ry) >> 16;                                                                                 \
-        if (SHG_PIPE_X & 1) {               /* experiment: loads only */                                            \
-            asm volatile("" ::"v"(al##S.x), "v"(al##S.y), "v"(ah##S.x), "v"(ah##S.y), "v"(bl##S.x), "v"(bl##S.y), "v"(bh##S.x), "v"(bh##S.y)); \
-            break;                                                                                                  \
-        }                                                                                                           \
-        if (fl_ & 1) {                                                                                              \
-            const double ax_ = NS ? al##S.x : (arow ? al##S.x : 0.0), ay_ = NS ? al##S.y : (arow ? al##S.y : 0.0);  \
-            if (fresh##Q) {                                                                                         \
-                acc##Q##0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, bl##S.x, zero4, 0, 0, 0);                     \
-                acc##Q##1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, bl##S.y, zero4, 0, 0, 0);                     \
-            } else {                                                                                                \
-                acc##Q##0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, bl##S.x, acc##Q##0, 0, 0, 0);                 \
-                acc##Q##1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, bl##S.y, acc##Q##1, 0, 0, 0);                 \
-            }                                                                                                       \
-            fresh##Q = false;                                                                                       \
-        }                                                                                                           \
-        if (fl_ & 2) {                                                                                              \
-            const double ax_ = NS ? ah##S.x : (arow ? ah##S.x : 0.0), ay_ = NS ? ah##S.y : (arow ? ah##S.y : 0.0);  \
-            acc##Q##0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, bh##S.x, acc##Q##0, 0, 0, 0);                     \
-            acc##Q##1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, bh##S.y, acc##Q##1, 0, 0, 0);                     \
-        }                                                                                                           \
-        if (fl_ & 4) {                                  /* last item of an order: see rot_phase1 */                  \
-            double vc_ = acc##Q##0[0] + acc##Q##1[0], vs_ = acc##Q##0[1] + acc##Q##1[1];                            \
-            if (NS) {                                                                                               \
-                const double oc_ = acc##Q##0[2] + acc##Q##1[2], os_ = acc##Q##0[3] + acc##Q##1[3];                  \
-                const double xc_ = fr < 8 ? vc_ : oc_, xs_ = fr < 8 ? vs_ : os_;                                   \
-                const double rc_ = swap_half_row(xc_), rs_ = swap_half_row(xs_);                                   \
-                vc_ = fma(sgm, xc_, rc_);                                                                           \
-                vs_ = fma(sgm, xs_, rs_);                                                                           \
-            }                                                                                                       \
-            if (!NS || mode == 0 || fr < 8) panel[((ry) & 0xffff) * 64 + prow] = (double2_t){vc_, vs_};             \
-            fresh##Q = true;                                                                                        \
-        }                                                                                                           \
-    } while (0)
-
-    double2 al0 = {0, 0}, ah0 = {0, 0}, bl0 = {0, 0}, bh0 = {0, 0}, al1 = {0, 0}, ah1 = {0, 0}, bl1 = {0, 0}, bh1 = {0, 0};
-    double2 al2 = {0, 0}, ah2 = {0, 0}, bl2 = {0, 0}, bh2 = {0, 0}, al3 = {0, 0}, ah3 = {0, 0}, bl3 = {0, 0}, bh3 = {0, 0};
-    double2 al4 = {0, 0}, ah4 = {0, 0}, bl4 = {0, 0}, bh4 = {0, 0}, al5 = {0, 0}, ah5 = {0, 0}, bl5 = {0, 0}, bh5 = {0, 0};
-    double2 al6 = {0, 0}, ah6 = {0, 0}, bl6 = {0, 0}, bh6 = {0, 0}, al7 = {0, 0}, ah7 = {0, 0}, bl7 = {0, 0}, bh7 = {0, 0};
-    crec_t* ra = reinterpret_cast<crec_t*>(reinterpret_cast<unsigned long long>(recs_a));
-    crec_t* rb = reinterpret_cast<crec_t*>(reinterpret_cast<unsigned long long>(recs_b));
-    for (int pass = 0; pass < (mode == 0 ? 1 : 2); ++pass) {
-        if (pass == 1) {                                          // mirrored parallels of a polar block: their own table
-            mode = 2;
-            sgm = 1.0;
-            prow = lane + 8;
-            pku = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.pkf + (size_t)(P.nit + bad) * P.Qtot * 128), 0, 0xffffffffu, 0x00020000);
-        }
-        // per stream: records of the current trip (items 0 .. 3; items 0 .. 2 are in flight in sets 0 .. 2 / 4 .. 6) and of the next one
-        int8_v ca = ra[0], cb = rb[0], na = ra[1], nb = rb[1];
-        int chunk = pass == 0 && pending ? 0 : kPipeChunks, next_at = 0;
-        // (the scheduling barriers keep the order of the first loads: left alone hipcc sorts them so that the set the loop consumes first is
-        //  loaded LAST, and its wait-count analysis then drains every load at the head of every trip -- s_waitcnt vmcnt(4) instead of (24))
-        PIPE_P1_ISSUE(ca[0], 0);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_P1_ISSUE(cb[0], 4);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_P1_ISSUE(ca[2], 1);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_P1_ISSUE(cb[2], 5);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_P1_ISSUE(ca[4], 2);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_P1_ISSUE(cb[4], 6);
-        __builtin_amdgcn_sched_barrier(0);
-        for (int trip = 0; trip < P.ntrip2; ++trip) {
-            if (chunk < kPipeChunks && trip >= next_at) {          // (uniform) the next group of parked images leaves
-                flush_chunk(chunk);
-                ++chunk;
-                next_at = (chunk * P.ntrip2) / kPipeChunks;
-            }
-            PIPE_P1_ISSUE(ca[6], 3);
-            PIPE_P1_CONSUME(ca[1], 0, A);
-            PIPE_P1_ISSUE(cb[6], 7);
-            PIPE_P1_CONSUME(cb[1], 4, B);
-            PIPE_P1_ISSUE(na[0], 0);
-            PIPE_P1_CONSUME(ca[3], 1, A);
-            PIPE_P1_ISSUE(nb[0], 4);
-            PIPE_P1_CONSUME(cb[3], 5, B);
-            PIPE_P1_ISSUE(na[2], 1);
-            PIPE_P1_CONSUME(ca[5], 2, A);
-            PIPE_P1_ISSUE(nb[2], 5);
-            PIPE_P1_CONSUME(cb[5], 6, B);
-            PIPE_P1_ISSUE(na[4], 2);
-            PIPE_P1_CONSUME(ca[7], 3, A);
-            PIPE_P1_ISSUE(nb[4], 6);
-            PIPE_P1_CONSUME(cb[7], 7, B);
-            ca = na;
-            cb = nb;
-            na = ra[trip + 2];
-            nb = rb[trip + 2];
-        }
-        for (; chunk < kPipeChunks; ++chunk) flush_chunk(chunk);
-    }
-#undef PIPE_P1_ISSUE
-#undef PIPE_P1_CONSUME
-}
-
-// A value parked in the accumulator half of the register file.  gfx950 gives a wave 512 registers, but vector ALU instructions
-// address only the first 256 (the architectural VGPRs); the others (AGPRs) can be MFMA accumulators and the DATA of loads and
-// stores.  The images of a unit wait for their stores there: the empty statement ties its result to an AGPR, hipcc moves the
-// value across with v_accvgpr_write and the architectural registers are free for the next unit's sums.
-__device__ __forceinline__ double park(double v) {
-    double a;
-    asm volatile("; park" : "=a"(a) : "0"(v));
-    return a;
-}
-// 8-byte store as store_b64_soff with its data in AGPRs
-__device__ __forceinline__ void store_b64_soff_acc(double v, int4_s rsrc, unsigned voff, unsigned soff) {
-    // (s_mov + s_nop 3 = five wait states: hipcc may reload the DESCRIPTOR from a spill lane with v_readlane right in front of the
-    //  statement too, and a VALU-written SGPR must not be read by a vector memory instruction earlier)
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_store_dwordx2 %0, %1, %2, m0 offen nt"
-                 :
-                 : "a"(v), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
-}
-
-template <bool NS, int R>
-__device__ __forceinline__ void pipe_unit(const RotParams& P, double (&Y)[2 * R][4], const double2_t* tb, const double2_t* prow,
-                                          double4_t z4, bool pending, int4_s rs, const unsigned (&va)[4], const unsigned (&vd)[4], int ct_prev) {
-    double4_t X[2 * R];
-    using T = RotTraits<R>;
-    const double4_t kZero4 = {0.0, 0.0, 0.0, 0.0};
-    const int n2 = P.nlon >> 1, nR = P.nlon / R;
-    int pf = 0;
-    double2_t tx, abx, ty = {0.0, 0.0}, aby = {0.0, 0.0};
-#define PIPE_FETCH(T_, AB_)                        \
-    do {                                           \
-        T_ = tb[pf * 64];                          \
-        AB_ = prow[pf * 256];                      \
-        pf = pf + 1 < P.npieces ? pf + 1 : pf;     /* (the fetch behind the last k-step re-reads the last one) */ \
-    } while (0)
-#define PIPE_MFMA2(A0, T_, AB_)                                                                     \
-    X[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, X[A0], 0, 0, 0);                      \
-    X[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, X[A0 + 1], 0, 0, 0)
-#define PIPE_MFMA4(A0, T_, AB_)                                                                     \
-    X[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, X[A0], 0, 0, 0);                      \
-    X[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.y, X[A0 + 1], 0, 0, 0);              \
-    X[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, X[A0 + 2], 0, 0, 0);              \
-    X[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, X[A0 + 3], 0, 0, 0)
-#define PIPE_MFMA2_FIRST(A0, T_, AB_)                                                               \
-    X[A0] = (A0) == 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, X[A0], 0, 0, 0)            \
-                      : __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, kZero4, 0, 0, 0);         \
-    X[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, kZero4, 0, 0, 0)
-#define PIPE_MFMA4_FIRST(A0, T_, AB_)                                                               \
-    X[A0] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.x, kZero4, 0, 0, 0);                     \
-    X[A0 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.x, T_.y, kZero4, 0, 0, 0);                 \
-    X[A0 + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.x, kZero4, 0, 0, 0);                 \
-    X[A0 + 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(AB_.y, T_.y, kZero4, 0, 0, 0)
-    // one class: k-steps in pairs on the register sets (tx, abx) / (ty, aby), as in rot_phase2
-#define PIPE_CLASS(C, MF, A0, NACC)                                                                       \
-    if (!SHG_DBG(P, 8)) {                                                                                 \
-        const int nk_ = P.cls_nk[C];                                                                      \
-        int i_ = 0;                                                                                       \
-        if (nk_ >= 2) {                                                                                   \
-            PIPE_FETCH(ty, aby);                                                                          \
-            MF##_FIRST(A0, tx, abx);                                                                      \
-            PIPE_FETCH(tx, abx);                                                                          \
-            MF(A0, ty, aby);                                                                              \
-            i_ = 2;                                                                                       \
-        } else if (nk_ == 1) {                                                                            \
-            PIPE_FETCH(ty, aby);                                                                          \
-            MF##_FIRST(A0, tx, abx);                                                                      \
-            tx = ty;                                                                                      \
-            abx = aby;                                                                                    \
-            i_ = 1;                                                                                       \
-        } else {                                                                                          \
-            _Pragma("unroll") for (int z_ = ((A0) == 0 ? 1 : 0); z_ < (NACC); ++z_) X[(A0) + z_] = kZero4; \
-        }                                                                                                 \
-        for (; i_ + 2 <= nk_; i_ += 2) {                                                                  \
-            PIPE_FETCH(ty, aby);                                                                          \
-            MF(A0, tx, abx);                                                                              \
-            PIPE_FETCH(tx, abx);                                                                          \
-            MF(A0, ty, aby);                                                                              \
-        }                                                                                                 \
-        if (i_ < nk_) {                                                                                   \
-            PIPE_FETCH(ty, aby);                                                                          \
-            MF(A0, tx, abx);                                                                              \
-            tx = ty;                                                                                      \
-            abx = aby;                                                                                    \
-        }                                                                                                 \
-    }
-    PIPE_FETCH(tx, abx);                                     // fragments of the first k-step
-    X[0] = z4;                                               // order 0 does not depend on the longitude: start value of CA_0 (rows fk + 4 reg)
-#pragma unroll
-    for (int c = 0; c < T::kClasses; ++c) {
-        if (c < T::kTwo) {
-            PIPE_CLASS(c, PIPE_MFMA2, 2 * c, 2)
-        } else {
-            PIPE_CLASS(c, PIPE_MFMA4, 2 * T::kTwo + 4 * (c - T::kTwo), 4)
-        }
-        if (pending) {
-            // the images t = c, c + classes, ... of the previous unit leave
-#pragma unroll
-            for (int t = c; t < 2 * R; t += T::kClasses) {
-                const int k = t < R ? t : t - R;
-                const bool ascending = t < R;
-                int w = n2 + k * nR - (ascending ? 0 : P.nd);
-                w = w >= P.nlon ? w - P.nlon : w;
-                const unsigned soff = (unsigned)(ascending ? w + 16 * ct_prev : w + P.nd - 16 * ct_prev - 16) * 8u;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) store_b64_soff_acc(Y[t][r], rs, ascending ? va[r] : vd[r], soff);
-            }
-        }
-    }
-    if (!SHG_DBG(P, 8)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rot_images<R>(X, r);
-        // the images wait for their stores in the accumulator registers
-#pragma unroll
-        for (int t = 0; t < 2 * R; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Y[t][r] = park(X[t][r]);
-    }
-#undef PIPE_CLASS
-#undef PIPE_MFMA2
-#undef PIPE_MFMA4
-#undef PIPE_MFMA2_FIRST
-#undef PIPE_MFMA4_FIRST
-#undef PIPE_FETCH
-}
-
-// the images t = T0, T0 + STEP, ... of a unit as 8-byte stores (ncol = 16, or 8 for a half tile at the end of the fundamental domain)
-template <int R, int T0, int STEP>
-__device__ __forceinline__ void pipe_flush(const double (&Y)[2 * R][4], int4_s rs, const unsigned (&va)[4], const unsigned (&vd)[4], int nlon, int nd, int ct, int ncol) {
-    const int n2 = nlon >> 1, nR = nlon / R;
-#pragma unroll
-    for (int t = T0; t < 2 * R; t += STEP) {
-        const int k = t < R ? t : t - R;
-        const bool ascending = t < R;
-        int w = n2 + k * nR - (ascending ? 0 : nd);
-        w = w >= nlon ? w - nlon : w;
-        const unsigned soff = (unsigned)(ascending ? w + 16 * ct : w + nd - 16 * ct - ncol) * 8u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) store_b64_soff_acc(Y[t][r], rs, ascending ? va[r] : vd[r], soff);
-    }
-}
-
-// =====================================================================================================================
-// Fed pipeline (path 8): the Legendre stage as a kernel of its own that runs BESIDE the pipelined longitude kernel on every CU.
-//
-// Measured (round 5, one card): the longitude stage + stores of either rotation-folded kernel alone take 0.437 ms, 1.08 x the time the
-// HBM needs for the grids (0.405 ms, tools/store_bench.hip); the Legendre stage adds 0.07 - 0.11 ms because no wave of the workgroup
-// stores while it runs.  The pipelined kernel leaves 112 registers per SIMD free: one more wave, of another kernel.  So
-// `legendre_panel_kernel` (four waves of <= 104 registers, no LDS to speak of) computes the panels of the tiles in the consumer's
-// order into a ring of panel images in global memory (write-through stores; the ring lives in L2 / Infinity Cache), and the persistent
-// consumer takes each image into its LDS by LDS-DMA and goes straight to the longitude stage: its stores never stop, and the
-// Legendre stage's MFMAs fill the gaps of the longitude stage's on the same SIMDs.
-// Hand-off per tile, agent scope (cdna_hip_programming.md guideline 16, R1): producer -- sc1 stores, every wave drains, barrier, one
-// lane stores produced[slot] = tile + 1; consumer -- one lane polls that word, acquire, barrier, LDS-DMA, barrier, consumed[slot] =
-// tile + 1 (the ring slot may be overwritten).  Both waits are BOUNDED and nobody depends on them: a consumer that does not get its
-// image in time computes the panel itself (and poisons the slot for the rest of the launch: consumed = -1), a producer that does not
-// get its slot in time skips its tile.  Results do not depend on whether, or how far, the two kernels overlap.
-// =====================================================================================================================
-constexpr int kFedPollNaps = 400;          // x ~0.9 us: the consumer's patience for one panel image (the producer's for one ring slot)
-
-__device__ __forceinline__ bool wait_word_equals(int* word, int want, int naps) {
-    for (int i = 0; i < naps; ++i) {
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return true;
-        __builtin_amdgcn_s_sleep(32);
-    }
-    return false;
-}
-
-template <bool NS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(104))) void legendre_panel_kernel(RotParams P) {
-    __shared__ int go;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x + P.fed_first;            // (the consumers make the panels of their first tiles themselves: nothing to wait for at the start)
-    const int nbt = (P.B + 3) >> 2;
-    const int bt = P.blockmap ? P.blockmap[2 * tile] : tile % nbt;
-    const int it = P.blockmap ? P.blockmap[2 * tile + 1] : tile / nbt;
-    const int slot = tile % P.ring_tiles;
-    // This kernel has a third of the longitude kernel's arithmetic and should run AHEAD of it (up to the ring's length): its waves take
-    // every issue slot they can use, the longitude kernel's wave on the same SIMD fills the rest (priority, then age)
-    __builtin_amdgcn_s_setprio(3);
-    if (tid == 0) go = tile < P.ring_tiles + P.fed_first || wait_word_equals(P.consumed + slot, tile - P.ring_tiles + 1, kFedPollNaps) ? 1 : 0;
-    __syncthreads();
-    if (!go) return;                                   // (the consumer of this tile computes the panel itself)
-    const size_t image_doubles = (size_t)(P.nslot + 1) * 128;
-    GlobalPanel panel = {__builtin_amdgcn_make_buffer_rsrc(P.ring + (size_t)slot * image_doubles, 0, (unsigned)(image_doubles * 8), 0x00020000), (bool)SHG_DBG(P, 256)};
-    // the eight item lists of the rotation-folded kernel, two per wave
-    rot_phase1<NS>(P, panel, P.itemtab + (size_t)wave * P.nrec, bt, it, lane);
-    rot_phase1<NS>(P, panel, P.itemtab + (size_t)(wave + 4) * P.nrec, bt, it, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores ...
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(P.produced + slot, tile + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before ONE lane says so
-}
-
-#ifdef SHG_TIMELINE
-#define PIPE_STAMP(ev)                                                                                        \
-    do {                                                                                                      \
-        if (P.tl && lane == 0) P.tl[((size_t)tile * kWaves + wave) * 16 + (ev)] = wall_clock64();                  \
-        if (P.tl && lane == 0 && ((ev) == 0 || (ev) == 12))                                                   \
-            P.tl[((size_t)tile * kWaves + wave) * 16 + ((ev) == 0 ? 13 : 14)] = __builtin_amdgcn_s_memtime();       \
-    } while (0)
-#else
-#define PIPE_STAMP(ev)
-#endif
-
-template <bool NS, int R, bool FED>
-__global__ __launch_bounds__(64 * kPipeWaves, 1) void synthesis_pipe_kernel(RotParams P) {
-    using T = RotTraits<R>;
-    extern __shared__ __attribute__((aligned(16))) double As[];   // trig buffers [2][npieces][64][2], then panel [nslot + 1][64 rows][2]
-    __shared__ int fed_ready;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = row tile = epoch of the tile
-    const int rt = wave;
-    const int nbt = (P.B + 3) >> 2;
-    const int ntiles = nbt * P.nit;
-    const int fr = lane & 15, fk = lane >> 4;
-    const int tb_doubles = P.npieces * 128;
-    double2_t* const panel = reinterpret_cast<double2_t*>(As + 2 * tb_doubles);
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)As;
-    const unsigned lane_off = (unsigned)lane * 16u;
-    const int grid_bytes = P.nlat * P.nlon * 8;
-    const int nct = P.nct, ctl = nct - 1;
-    const int ncol_last = min(16, P.nd - 16 * ctl);                 // columns of the last column tile: 16, or 8 (half tile)
-    const double2_t* const prow = panel + rt * 16 + fr + fk * 64;  // + 256 p: k-step p
-    const double2_t* const tb0 = reinterpret_cast<const double2_t*>(As) + lane;
-    const double2_t* const tb1 = tb0 + P.npieces * 64;
-    // The trig pieces of a unit are issued before the unit's 8 R stores: "at most min(8 R, 63) operations outstanding" means they have landed
-    constexpr int kYounger = 8 * R < 63 ? 8 * R : 63;
-
-    // trig pieces of column tile ct -> buffer (ct & 1), dealt to the four waves
-    auto issue_trig = [&](int ct) {
-        const double* src = P.trig + (size_t)ct * P.npieces * 128;
-        const unsigned dst = lds0 + (unsigned)(ct & 1) * (unsigned)tb_doubles * 8u;
-        for (int j = wave; j < P.npieces; j += kPipeWaves) glds16(src + (size_t)j * 128, lane_off, dst + (unsigned)j * 1024u);
-    };
-
-    // ---- zero the padding slots of the panel (the Legendre stage never writes them)
-    {
-        int s0 = 0;
-        for (int c = 0; c < T::kClasses; ++c) {
-            for (int s = s0 + P.cls_cnt[c]; s < s0 + 4 * P.cls_nk[c]; ++s)
-                if (tid < 64) panel[s * 64 + tid] = (double2_t){0.0, 0.0};
-            s0 += 4 * P.cls_nk[c];
-        }
-    }
-
-#ifdef SHG_EXPERIMENT
-    if (P.stagger > 0) {             // experiment: the workgroups start up to P.stagger ticks apart (32 steps)
-        const long long ticks = (long long)P.stagger * (long long)(((blockIdx.x >> 3) * 13) & 31) / 32;
-        const long long t0 = wall_clock64();
-        for (int i = 0; i < 100000 && (long long)wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
-    double Y[T::kAcc][4];            // images of the previous unit, parked in AGPRs
-#pragma unroll
-    for (int t = 0; t < T::kAcc; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Y[t][r] = park(0.0);
-    bool have_last = false;          // the images of the previous tile's last unit are still parked
-
-    // The workgroup is persistent: it takes the tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the (XCD-aware) tile order, so that the
-    // images of a tile's last unit can leave during the Legendre stage of the next tile: the chip's store stream never stops.
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int bt = P.blockmap ? P.blockmap[2 * tile] : tile % nbt;
-        const int it = P.blockmap ? P.blockmap[2 * tile + 1] : tile / nbt;
-        PIPE_STAMP(0);
-        issue_trig(0);            // (buffer 0 is free: every wave has passed the barrier behind the last unit that read it)
-        auto grid_row_of = [&](int it_, int s_) { return NS ? (s_ < 8 ? it_ * 8 + s_ : P.nlat - 1 - (it_ * 8 + s_ - 8)) : it_ * 16 + s_; };
-        auto slot_valid_of = [&](int it_, int s_) { return NS ? it_ * 8 + (s_ & 7) < P.nh : it_ * 16 + s_ < P.nlat; };
-        auto descriptor_of = [&](int bt_) {
-            const int b_ = min(bt_ * 4 + rt, P.B - 1);
-            const unsigned long long g_ = (unsigned long long)(P.G + (size_t)b_ * P.nlat * P.nlon);
-            return (int4_s){(int)(unsigned)g_, (int)(unsigned)((g_ >> 32) & 0xffffu), grid_bytes, 0x00020000};
-        };
-        // what the parked images of the previous tile's last unit need to leave: its grid (descriptor) and its rows, from the tile order again
-        // (scalars carried around the tile loop end up in vector registers, which the store's descriptor operand cannot be)
-        const int tile_prev = max(tile - (int)gridDim.x, 0);
-        const int bt_prev = P.blockmap ? P.blockmap[2 * tile_prev] : tile_prev % nbt;
-        const int it_prev = P.blockmap ? P.blockmap[2 * tile_prev + 1] : tile_prev / nbt;
-        const int4_s rs_last = descriptor_of(bt_prev);
-        unsigned va_last[4], vd_last[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int sl = fk + 4 * r;
-            const unsigned ro = (unsigned)grid_row_of(it_prev, sl) * (unsigned)P.nlon * 8u;
-            const bool ok = slot_valid_of(it_prev, sl) && fr < ncol_last;
-            va_last[r] = ok ? ro + (unsigned)fr * 8u : 0x80000000u;
-            vd_last[r] = ok ? ro + (unsigned)(ncol_last - 1 - fr) * 8u : 0x80000000u;
-        }
-
-        // ---- phase 1: Legendre stage, the orders dealt to the four waves (two lists each); the parked images leave in groups meanwhile
-        auto flush_chunk = [&](int c) {
-            switch (c) {
-                case 0: pipe_flush<R, 0, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
-                case 1: pipe_flush<R, 1, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
-                case 2: pipe_flush<R, 2, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
-                case 3: pipe_flush<R, 3, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
-                case 4: pipe_flush<R, 4, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
-                case 5: pipe_flush<R, 5, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
-                case 6: pipe_flush<R, 6, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
-                default: pipe_flush<R, 7, kPipeChunks>(Y, rs_last, va_last, vd_last, P.nlon, P.nd, ctl, ncol_last); break;
-            }
-        };
-        bool self_made = !FED;
-        if (FED) {
-            // the image of this tile's panel: wait for it (one lane, bounded), acquire, LDS-DMA; the parked images leave meanwhile
-            const int slot = tile % P.ring_tiles;
-            if (tid == 0) {
-                const bool ok = tile >= P.fed_first && wait_word_equals(P.produced + slot, tile + 1, kFedPollNaps);
-                if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                fed_ready = ok ? 1 : 0;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (holds the barrier until the invalidate has completed)
-            }
-            __syncthreads();
-            if (fed_ready) {
-                const double* image = P.ring + (size_t)slot * (size_t)(P.nslot + 1) * 128;
-                const unsigned dst = lds0 + 2u * (unsigned)tb_doubles * 8u;
-                if (!SHG_DBG(P, 512))
-                    for (int j = wave; j <= P.nslot; j += kPipeWaves) glds16(image + (size_t)j * 128, lane_off, dst + (unsigned)j * 1024u);
-                if (have_last)
-                    for (int c = 0; c < kPipeChunks; ++c) flush_chunk(c);
-            } else {
-                self_made = true;
-#ifdef SHG_TIMELINE
-                if (P.tl && tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.tl) + ((size_t)ntiles * kWaves * 16), 1ull);       // images not in time
-#endif
-            }
-        }
-        if (self_made) {
-            if (P.sem_limit > 0) {
-                if (tid == 0) legendre_token_acquire(P.sem, P.sem_limit);
-                __syncthreads();
-            }
-            if (!SHG_DBG(P, 2))
-                pipe_phase1<NS>(P, panel, P.itemtab2 + (size_t)wave * P.nrec2, P.itemtab2 + (size_t)(wave + kPipeWaves) * P.nrec2, bt, it, lane, have_last, flush_chunk);
-            else if (have_last)
-                for (int c = 0; c < kPipeChunks; ++c) flush_chunk(c);
-        }
-        PIPE_STAMP(1);
-        // the trig pieces of column tile 0 (and the panel image) were issued before the 8 R stores of the parked images (if there were any)
-        if (have_last) wait_vmcnt<kYounger>(); else wait_vmcnt<0>();
-        __syncthreads();          // panel and trig buffer 0 complete
-        if (self_made && P.sem_limit > 0 && tid == 0) legendre_token_release(P.sem);
-        if (FED && tid == 0)      // the ring slot is free again -- or given up for this launch, if its image did not arrive in time
-            __hip_atomic_store(P.consumed + tile % P.ring_tiles, fed_ready || tile < P.fed_first ? tile + 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        PIPE_STAMP(2);
-
-        // ---- phase 2: longitude stage, wave = row tile
-        const bool epoch_ok = bt * 4 + rt < P.B && !SHG_DBG(P, 1);
-        const int4_s rs = descriptor_of(bt);
-        // lane parts of the store offsets: rows fk + 4 reg, column fr of a whole tile (ascending / mirrored images)
-        unsigned va[4], vd[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int sl = fk + 4 * r;
-            const unsigned ro = (unsigned)grid_row_of(it, sl) * (unsigned)P.nlon * 8u;
-            const bool ok = slot_valid_of(it, sl);
-            va[r] = ok ? ro + (unsigned)fr * 8u : 0x80000000u;
-            vd[r] = ok ? ro + (unsigned)(15 - fr) * 8u : 0x80000000u;
-        }
-        double4_t z4;
-        {
-            const double2_t* z = panel + P.nslot * 64 + rt * 16 + fk;         // order 0: rows fk + 4 reg
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z4[r] = z[4 * r].x;
-        }
-        if (!SHG_DBG(P, 4)) {
-            for (int ct = 0; ct < nct; ++ct) {
-                // unit ct: its sums accumulate while the images of unit ct - 1 leave; the trig pieces of unit ct + 1 arrive in the other buffer
-                if (ct + 1 < nct) issue_trig(ct + 1);
-                pipe_unit<NS, R>(P, Y, (ct & 1) ? tb1 : tb0, prow, z4, epoch_ok && ct > 0, rs, va, vd, ct - 1);
-                PIPE_STAMP(3 + min(ct, 4));
-                if (epoch_ok && ct > 0) wait_vmcnt<kYounger>(); else wait_vmcnt<0>();
-                __syncthreads();          // every wave is done with this unit's trig buffer (and, behind the last unit, with the panel)
-            }
-        }
-        have_last = epoch_ok && !SHG_DBG(P, 4);
-        PIPE_STAMP(12);
-    }
-    // ---- the images of the very last unit
-    if (have_last) {
-        const int done = (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x;           // tiles of this workgroup - 1
-        const int tile_last = (int)blockIdx.x + done * (int)gridDim.x;
-        const int bt_l = P.blockmap ? P.blockmap[2 * tile_last] : tile_last % nbt;
-        const int it_l = P.blockmap ? P.blockmap[2 * tile_last + 1] : tile_last / nbt;
-        const int b_ = min(bt_l * 4 + rt, P.B - 1);
-        const unsigned long long g_ = (unsigned long long)(P.G + (size_t)b_ * P.nlat * P.nlon);
-        const int4_s rs_l = {(int)(unsigned)g_, (int)(unsigned)((g_ >> 32) & 0xffffu), grid_bytes, 0x00020000};
-        unsigned va_l[4], vd_l[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int sl = fk + 4 * r;
-            const int row = NS ? (sl < 8 ? it_l * 8 + sl : P.nlat - 1 - (it_l * 8 + sl - 8)) : it_l * 16 + sl;
-            const bool ok = (NS ? it_l * 8 + (sl & 7) < P.nh : it_l * 16 + sl < P.nlat) && fr < ncol_last;
-            const unsigned ro = (unsigned)row * (unsigned)P.nlon * 8u;
-            va_l[r] = ok ? ro + (unsigned)fr * 8u : 0x80000000u;
-            vd_l[r] = ok ? ro + (unsigned)(ncol_last - 1 - fr) * 8u : 0x80000000u;
-        }
-        pipe_flush<R, 0, 1>(Y, rs_l, va_l, vd_l, P.nlon, P.nd, ctl, ncol_last);
-    }
-    // every LDS-DMA of this wave was waited for at the end of its unit; the stores may still be in flight when the wave ends
-}
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1496,47 +883,19 @@ int build_rot_trig(shg_plan* p, const double* lon_h) {
 }
 
 template <int R>
-static int launch_rot(shg_plan* p, bool ns, int mode, const RotParams& P, size_t lds, dim3 grid_dim, hipStream_t stream) {
-#define SHG_LAUNCH_PIPE(NS_, FED_)                                                                                                        \
-    do {                                                                                                                                  \
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_pipe_kernel<NS_, R, FED_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((synthesis_pipe_kernel<NS_, R, FED_>), grid_dim, dim3(64 * kPipeWaves), lds, stream, P);                        \
-    } while (0)
-    if (mode == 2) {
-        if (ns) SHG_LAUNCH_PIPE(true, true); else SHG_LAUNCH_PIPE(false, true);
-    } else if (mode == 1) {
-        if (ns) SHG_LAUNCH_PIPE(true, false); else SHG_LAUNCH_PIPE(false, false);
-    } else if (mode == 3) {           // two workgroups of two epochs per CU
-        if (ns) {
-            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((synthesis_rot_kernel<true, R, 2>), grid_dim, dim3(256), lds, stream, P);
-        } else {
-            SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<false, R, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((synthesis_rot_kernel<false, R, 2>), grid_dim, dim3(256), lds, stream, P);
-        }
-    } else if (ns) {
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((synthesis_rot_kernel<true, R, 4>), grid_dim, dim3(64 * kWaves), lds, stream, P);
+static int launch_rot(bool ns, const RotParams& P, size_t lds, dim3 grid_dim, hipStream_t stream) {
+    if (ns) {
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((synthesis_rot_kernel<true, R>), grid_dim, dim3(64 * kWaves), lds, stream, P);
     } else {
-        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<false, R, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((synthesis_rot_kernel<false, R, 4>), grid_dim, dim3(64 * kWaves), lds, stream, P);
+        SHG_HIP(hipFuncSetAttribute((const void*)synthesis_rot_kernel<false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((synthesis_rot_kernel<false, R>), grid_dim, dim3(64 * kWaves), lds, stream, P);
     }
-#undef SHG_LAUNCH_PIPE
     return SHG_OK;
 }
 
-// LDS of the pipelined kernel: two trig buffers of one column tile each, then the panel
-static size_t pipe_lds_bytes(int nslot) { return (size_t)(2 * (nslot / 4) + nslot + 1) * 1024; }
-
-int pipe_applicable(const shg_plan* p) {
-    if (!rot_applicable(p)) return 0;
-    int nk[kMaxClasses], cnt[kMaxClasses];
-    return pipe_lds_bytes(rot_layout(p->rotR, p->N, nk, cnt, nullptr)) <= 160 * 1024 ? 1 : 0;
-}
-
-static int synthesis_rot_launch(shg_plan* p, int mode, const double* anm, int B, double* grid, hipStream_t stream) {
-    const bool pipe = mode == 1 || mode == 2;
-    if (!(pipe ? pipe_applicable(p) : rot_applicable(p))) return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel not applicable to this plan");
+int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) {
+    if (!rot_applicable(p)) return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel not applicable to this plan");
     const int R = p->rotR;
     const bool ns = p->sym_ns;
     int rc = build_pkf_table(p, ns, R, stream);
@@ -1567,25 +926,11 @@ static int synthesis_rot_launch(shg_plan* p, int mode, const double* anm, int B,
     P.itemtab = reinterpret_cast<const int4*>(p->itemtab_d);
     P.nrec = p->itemtab_nrec;
     P.ntrip = p->itemtab_ntrip;
-    if (!p->sem_d) {
-        if (hipMalloc((void**)&p->sem_d, 256) != hipSuccess) return fail(SHG_ERR_NOMEM, "token counter allocation failed");
-        SHG_HIP(hipMemset(p->sem_d, 0, 256));
-    }
-    P.sem = p->sem_d;
-    P.sem_limit = kLegendreTokens;
-    if (kLegendreTokens < 0) {
-        int dev = 0, cus = 0;
-        SHG_HIP(hipGetDevice(&dev));
-        SHG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        P.sem_limit = std::max(1, cus * -kLegendreTokens / 16);
-    }
-    if (mode != 0) P.sem_limit = 0;          // (the other kernels: measured without gain)
+    P.sem = p->sem_d;                         // allocated and zeroed by rot_set_stage_limit; 0 again whenever a grid has drained
+    P.sem_limit = p->sem_d ? p->stage_limit : 0;
 #ifdef SHG_EXPERIMENT
-    if (getenv("SHG_SEM")) P.sem_limit = atoi(getenv("SHG_SEM"));
+    if (getenv("SHG_SEM") && p->sem_d) P.sem_limit = atoi(getenv("SHG_SEM"));
 #endif
-    P.itemtab2 = reinterpret_cast<const int2*>(p->itemtab2_d);
-    P.nrec2 = p->itemtab2_nrec;
-    P.ntrip2 = p->itemtab2_ntrip;
     P.badmap = p->badmap_d;
     P.blockmap = nullptr;
     if (!SHG_DBG(P, 2048)) {
@@ -1598,81 +943,39 @@ static int synthesis_rot_launch(shg_plan* p, int mode, const double* anm, int B,
 #ifdef SHG_TIMELINE
     P.tl = getenv("SHG_TIMELINE_PTR") ? (unsigned long long*)strtoull(getenv("SHG_TIMELINE_PTR"), nullptr, 0) : nullptr;
 #endif
-    // mode 3: four rings of kRingSlots KB, then the 32-row panel
-    const size_t lds = pipe ? pipe_lds_bytes(P.nslot) : mode == 3 ? (size_t)4 * kRingSlots * 1024 + (size_t)(P.nslot + 1) * 512 : rot_lds_bytes(P.nslot);
-    unsigned nwg_pipe = (unsigned)(nbt * nit);
-    if (pipe) {                                       // persistent workgroups, one per CU (the kernel's LDS admits no second one)
-        int dev = 0, cus = 0;
-        SHG_HIP(hipGetDevice(&dev));
-        SHG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        nwg_pipe = std::min(nwg_pipe, (unsigned)std::max(cus, 1));
-    }
-    P.fed_first = 0;
-    P.ring = nullptr;
-    P.ring_tiles = 0;
-    P.produced = P.consumed = nullptr;
-    if (mode == 2) {
-        // the ring of panel images, the hand-off words, the producer's stream; the words are zeroed before every launch
-        constexpr int kRingTiles = 512;
-        const size_t image_bytes = (size_t)(P.nslot + 1) * 1024;
-        if (p->ring_bytes < image_bytes * kRingTiles) {
-            SHG_HIP(hipDeviceSynchronize());
-            if (p->ring_d) (void)hipFree(p->ring_d);
-            p->ring_d = nullptr;
-            p->ring_bytes = 0;
-            if (hipMalloc((void**)&p->ring_d, image_bytes * kRingTiles) != hipSuccess) return fail(SHG_ERR_NOMEM, "panel ring allocation failed");
-            p->ring_bytes = image_bytes * kRingTiles;
-        }
-        if (p->ring_image_bytes != image_bytes) {                // (the padding slots of the images are never written: they must read as zero)
-            SHG_HIP(hipMemsetAsync(p->ring_d, 0, p->ring_bytes, stream));
-            p->ring_image_bytes = image_bytes;
-        }
-        if (!p->handoff_d && hipMalloc((void**)&p->handoff_d, 2 * kRingTiles * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "hand-off words allocation failed");
-        if (!p->side_stream) {
-            SHG_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
-            SHG_HIP(hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming));
-            SHG_HIP(hipEventCreateWithFlags(&p->join_event, hipEventDisableTiming));
-        }
-        P.ring = p->ring_d;
-        P.ring_tiles = kRingTiles;
-        P.produced = p->handoff_d;
-        P.consumed = p->handoff_d + kRingTiles;
-        P.fed_first = (int)std::min<unsigned>(nwg_pipe, (unsigned)(nbt * nit));
-    }
-    // (mode 3: the two halves of tile 8 j + x are the workgroups 16 j + x and 16 j + 8 + x)
-    const dim3 grid_dim(pipe ? nwg_pipe : mode == 3 ? (unsigned)(ceil_div(nbt * nit, 8) * 16) : (unsigned)(nbt * nit));
-    ProfileScope ps(p, 2, stream);          // (fed pipeline: from the fork to the join, i.e. both kernels)
-    if (mode == 2) {
-        SHG_HIP(hipMemsetAsync(p->handoff_d, 0, 2 * P.ring_tiles * sizeof(int), stream));
-        SHG_HIP(hipEventRecord(p->fork_event, stream));
-        SHG_HIP(hipStreamWaitEvent(p->side_stream, p->fork_event, 0));
-        const int produced_tiles = nbt * nit - P.fed_first;
-        if (produced_tiles > 0) {
-            if (ns)
-                hipLaunchKernelGGL(legendre_panel_kernel<true>, dim3((unsigned)produced_tiles), dim3(256), 0, p->side_stream, P);
-            else
-                hipLaunchKernelGGL(legendre_panel_kernel<false>, dim3((unsigned)produced_tiles), dim3(256), 0, p->side_stream, P);
-            SHG_HIP(hipGetLastError());
-        }
-        SHG_HIP(hipEventRecord(p->join_event, p->side_stream));
-    }
+    const size_t lds = rot_lds_bytes(P.nslot);
+    const dim3 grid_dim((unsigned)(nbt * nit));
+    ProfileScope ps(p, 2, stream);
     switch (R) {
-        case 10: rc = launch_rot<10>(p, ns, mode, P, lds, grid_dim, stream); break;
-        case 9: rc = launch_rot<9>(p, ns, mode, P, lds, grid_dim, stream); break;
-        case 6: rc = launch_rot<6>(p, ns, mode, P, lds, grid_dim, stream); break;
-        case 3: rc = launch_rot<3>(p, ns, mode, P, lds, grid_dim, stream); break;
+        case 10: rc = launch_rot<10>(ns, P, lds, grid_dim, stream); break;
+        case 9: rc = launch_rot<9>(ns, P, lds, grid_dim, stream); break;
+        case 6: rc = launch_rot<6>(ns, P, lds, grid_dim, stream); break;
+        case 3: rc = launch_rot<3>(ns, P, lds, grid_dim, stream); break;
         default: return fail(SHG_ERR_UNSUPPORTED, "rotation-folded synthesis kernel: no kernel for %d rotations", R);
     }
-    if (mode == 2) SHG_HIP(hipStreamWaitEvent(stream, p->join_event, 0));
-
     if (rc) return rc;
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
 
-int synthesis_rot(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 0, anm, B, grid, stream); }
-int synthesis_pipe(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 1, anm, B, grid, stream); }
-int synthesis_fed(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 2, anm, B, grid, stream); }
-int synthesis_rot_halves(shg_plan* p, const double* anm, int B, double* grid, hipStream_t stream) { return synthesis_rot_launch(p, 3, anm, B, grid, stream); }
+// Limit on the workgroups that run their Legendre stage at once (see legendre_token_acquire).  OFF by default: over six boxes of the
+// pool a limit of 7/16 of the CUs took 1.5 - 2 % off the kernel on the slower three and cost 2 - 4 % on the faster three (DESIGN.md
+// Appendix A) -- a tuning knob, not a default.  limit > 0: that many workgroups; < 0: that many sixteenths of the device's CUs;
+// 0: no limit.  The counter is allocated and zeroed here, synchronously, so that no launch can see it uninitialised.
+int rot_set_stage_limit(shg_plan* p, int limit) {
+    if (limit < 0) {
+        int dev = 0, cus = 0;
+        SHG_HIP(hipGetDevice(&dev));
+        SHG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        limit = std::max(1, cus * -limit / 16);
+    }
+    if (limit > 0 && !p->sem_d) {
+        if (hipMalloc((void**)&p->sem_d, 256) != hipSuccess) return fail(SHG_ERR_NOMEM, "token counter allocation failed");
+        SHG_HIP(hipMemset(p->sem_d, 0, 256));
+        SHG_HIP(hipDeviceSynchronize());
+    }
+    p->stage_limit = limit;
+    return SHG_OK;
+}
 
 }  // namespace shg

@@ -96,7 +96,12 @@ class Plan:
         """'auto', 'staged' (three kernels, any grid), 'fused' (single kernel on 4-fold symmetric meridians), 'fused32' (32-row
         panels) or 'rot' (rotation-folded kernel on equi-angular meridians with nlon % 96 == 0 or nlon % 48 == 0).  The fused
         kernels use the north-south symmetry of the parallels when the grid has it (their plain variants otherwise)."""
-        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'fused32': 5, 'rot': 6, 'pipe': 7, 'fed': 8, 'halves': 9}[path])
+        _lib.call('shg_plan_set_path', self._handle, {'auto': 0, 'staged': 1, 'fused': 2, 'fused32': 5, 'rot': 6}[path])
+
+    def set_stage_limit(self, limit):
+        """Rotation-folded kernel only: at most `limit` workgroups in their Legendre stage at once (< 0: sixteenths of the CUs, 0 = off,
+        the default).  A tuning knob whose sign differs between boxes (include/shg.h)."""
+        _lib.call('shg_plan_set_stage_limit', self._handle, int(limit))
 
     def set_rotations(self, R):
         """Rotation count of the rotation-folded kernel: 0 (the plan's own choice), 3, 6, 9 or 10; the meridians must be invariant

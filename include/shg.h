@@ -61,10 +61,13 @@ int shg_plan_set_chunk(shg_plan* plan, int epochs_per_pass);
  * degree <= ~210; chosen automatically above degree 126), 6 = single fused kernel for equi-angular cell-centred meridians that
  * folds the longitude stage over 6 (nlon a multiple of 96) or 3 (nlon a multiple of 48) rotations and the reflection of the
  * meridian set (degree <= ~110; the automatic choice where it applies).  Kernels 2 and 6 use the north-south symmetry of the
- * parallels when the grid has it and their plain variant otherwise; the variant is not a choice of the caller.
- * 7, 8, 9: variants of kernel 6 built and measured in round 5, all slower than it on MI355X: 7 one wave per SIMD with the images of
- * a unit stored during the next unit, 8 the same fed by a Legendre-stage kernel on a second stream, 9 two workgroups of two epochs per CU. */
+ * parallels when the grid has it and their plain variant otherwise; the variant is not a choice of the caller. */
 int shg_plan_set_path(shg_plan* plan, int path);
+
+/* Kernel 6 only: at most `limit` workgroups run their Legendre stage (in which they do not store) at the same time; limit < 0 = that many
+ * sixteenths of the device's CUs, 0 = no limit (the default).  A tuning knob: on MI355X -7 took 1.5-2 % off the d/o-96 / 0.25 degree
+ * kernel on some boxes and cost 2-4 % on others.  Waits for the device the first time a limit is set. */
+int shg_plan_set_stage_limit(shg_plan* plan, int limit);
 
 /* Rotation count R of kernel 6: the longitude sums are evaluated on nlon / (2 R) columns and the 2 R images of every column are
  * formed in registers.  0 = the plan's own choice (the default: 10 where nlon / 10 is a multiple of 16 -- the 0.25 degree grid --,
