@@ -248,6 +248,12 @@ static int launch_orderwise(int Nb, int N, int B, const double* blocks, const lo
 #define SHG_FILT_VIA_SERIES 1
 #endif
 constexpr int kSeriesMinEpochs = 64;
+#ifndef SHG_OM_EPOCH_GROUPS
+#define SHG_OM_EPOCH_GROUPS 2     // groups of 32 epochs per workgroup of orderwise_filter_om_kernel
+#endif
+// LDS of order_major_kernel: one row of the reference arrays for 16 epochs (above 64 KB the launch needs the opt-in attribute)
+constexpr size_t kOrderMajorMaxLds = 160 * 1024;
+static size_t order_major_lds_bytes(int N) { return (size_t)16 * (N + 2) * sizeof(double); }
 extern "C" int shg_order_major_pack(const double* anm, int N, int B, double* om, int Bpad, void* stream_);
 extern "C" int shg_order_major_unpack(const double* om, int N, int B, int Bpad, double* anm, void* stream_);
 extern "C" int shg_orderwise_filter_om(const double* blocks_packed, const int64_t* block_off, int Nb, int N, const double* om_in, int B, int Bpad,
@@ -271,11 +277,12 @@ extern "C" int shg_orderwise_filter(const double* blocks_packed, const int64_t* 
         ScratchLease lease(stream);
         double* om_in = (double*)lease.get(kScratchSeriesIn, bytes);
         double* om_out = (double*)lease.get(kScratchSeriesOut, bytes);
-        if (om_in && om_out) {
+        // (only where the row stage of the layout kernels fits the LDS; whatever fails on this way, the block kernel below still serves)
+        if (om_in && om_out && order_major_lds_bytes(N) <= kOrderMajorMaxLds) {
             int rc = shg_order_major_pack(anm_in, N, B, om_in, Bpad, stream_);
             if (!rc) rc = shg_orderwise_filter_om(blocks_packed, block_off, Nb, N, om_in, B, Bpad, om_out, stream_);
             if (!rc) rc = shg_order_major_unpack(om_out, N, B, Bpad, anm_out, stream_);
-            return rc;
+            if (!rc) return rc;
         }
     }
     // orders per workgroup: as many as the LDS stage allows (8: degree <= 143, 4: <= 295, 2: <= 591); every wave holds the results of
@@ -347,85 +354,115 @@ __global__ __launch_bounds__(256) void order_major_kernel(int N, int B, int Bpad
     }
 }
 
-// Y_s [n x Bpad] = W_s [n x n] X_s [n x Bpad] of one slot and one tile of 16 result rows per workgroup; the four waves share the
-// epochs, 64 each per pass.  A fragments (block entries) with one 16-byte range-checked buffer load per lane and pair of k-steps, as in
-// orderwise_filter_kernel.  B fragments straight from the series (L2: the rows of a slot are read by all its row tiles), two epochs per
-// lane and load: lane (j, k) reads X[k][32 p + 2 j .. + 1], the two values are the B operands of two MFMAs whose columns are the even
-// and the odd epochs of a group of 32 -- so that a lane also OWNS two adjacent epochs of four result rows and stores 16 bytes.
-// Degrees 0 and 1 keep the input (filter.py:189).
-constexpr int kOmPairsPerWave = 2;     // groups of 32 epochs of a wave at a time: 4 waves x 2 x 32 = 256 epochs per pass
-__global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N, int Bpad, int ntile_rows, const int* __restrict__ unit_slot, const int* __restrict__ unit_row0,
-                                                                  const double* __restrict__ blocks, const long long* __restrict__ block_off,
-                                                                  const double* __restrict__ in, double* __restrict__ out) {
-    const int unit = blockIdx.x;
-    if (unit >= ntile_rows) return;
-    const int s = unit_slot[unit], r0 = unit_row0[unit];
-    if (s < 0) return;
+// Y_s [n x Bpad] = W_s [n x n] X_s [n x Bpad], one workgroup per (slot s, slice of 32 EG epochs).  The slice of X_s is staged in the
+// LDS ONCE, in one burst of independent loads, and serves every row tile of the slot (wave w takes the tiles w, w + 4, ...); what is left
+// in the K loop is one 16-byte range-checked buffer load of block entries per lane and pair of k-steps, requested kOmDepth steps ahead,
+// and two ds_read_b128.  (Round 5 had one workgroup per (slot, row tile) with the rows of X read from L2 inside the K loop, three steps
+// in flight: the 16 dependent steps of the longest slots, each waiting out a memory round trip, were the critical path of the launch --
+// 30 us for 13 us of HBM time.)  The products and their order are those of orderwise_filter_kernel, the results bit-identical:
+// step c multiplies W[row][c + 2 fk], W[row][c + 2 fk + 1] with the rows c + 2 fk, c + 2 fk + 1 of X in two MFMAs per 16 epochs,
+// the two partial sums are added at the end.  A lane reads two adjacent epochs (16 bytes) of a row of X -- the B operands of two MFMAs
+// whose columns are the even and the odd epochs of a group of 32 -- and therefore also OWNS two adjacent epochs of four result rows: it
+// stores 16 bytes.  Degrees 0 and 1 keep the input (filter.py:189).
+// Workgroup b runs on XCD b % 8: all slices of a slot go to one XCD (they share the slot's block in its L2), the slots -- by decreasing
+// length, i.e. in their own order -- in a snake over the XCDs so that every XCD gets about the same arithmetic, the long ones first.
+// Slots whose rows do not fit the stage (kc rows) re-stage chunk by chunk for every pass of four row tiles.
+constexpr int kOmDepth = 4;            // steps of 8 columns whose block entries are in flight per wave
+template <int EG>
+__global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N, int Bpad, int nslice, int kc, const double* __restrict__ blocks,
+                                                                  const long long* __restrict__ block_off, const double* __restrict__ in,
+                                                                  double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double2_t om_stage[];      // [kc rows][16 EG pairs of epochs]
+    constexpr int PR = 16 * EG;                                                 // double2 per staged row
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int rank = seq / nslice, slice = seq % nslice;
+    const int s = 8 * rank + ((rank & 1) ? 7 - xcd : xcd);
+    if (s > 2 * N) return;
     const int m = (s + 1) >> 1, n = N + 1 - m, ld = Nb + 1 - m;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(blocks), 0, (int)((block_off[2 * Nb] + 1) * 8), 0x00020000);
-    const unsigned voff = (unsigned)(block_off[s] * 8) + (unsigned)((min(r0 + fr, n - 1) * ld + 2 * fk) * 8);
+    const int ldx = Bpad / 2;                                                   // double2 per row of the series
+    const int p0 = slice * PR;                                                  // first pair of epochs of the slice
+    const int npair = min(PR, ldx - p0);                                        // pairs that exist (a multiple of 16)
     const size_t row_first = (size_t)om_row(N, s);
-    const double2_t* X = reinterpret_cast<const double2_t*>(in + row_first * Bpad) + fr;       // + 16 p: group p of 32 epochs; + k Bpad / 2: row k
-    double2_t* Y = reinterpret_cast<double2_t*>(out + row_first * Bpad) + fr;
-    const int ldx = Bpad / 2, npair = Bpad / 32;
-    for (int p0 = wave * kOmPairsPerWave; p0 < npair; p0 += 4 * kOmPairsPerWave) {
-        double4_t acc[kOmPairsPerWave][2][2];
+    const double2_t* X = reinterpret_cast<const double2_t*>(in + row_first * Bpad) + p0;
+    double2_t* Y = reinterpret_cast<double2_t*>(out + row_first * Bpad) + p0;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(blocks), 0, (int)((block_off[2 * Nb] + 1) * 8), 0x00020000);
+    const int Kpad = (n + 7) & ~7, ntile = (n + 15) >> 4;
+    const bool resident = Kpad <= kc;                                           // the whole slice fits the stage: staged once
+    const double2_t zero2 = {0.0, 0.0};
+    // rows [k0, k0 + rows) of the slice -> stage; rows beyond the block and pairs beyond the series are zero
+    auto stage = [&](int k0, int rows) {
+        constexpr int RPP = 256 / PR;                                           // rows per pass of the workgroup
+        const int j = tid % PR, r_in = tid / PR;
+        for (int r = r_in; r < rows; r += 4 * RPP) {
+            double2_t v[4];
 #pragma unroll
-        for (int q = 0; q < kOmPairsPerWave; ++q) acc[q][0][0] = acc[q][0][1] = acc[q][1][0] = acc[q][1][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        const int nq = min(kOmPairsPerWave, npair - p0);
-        // columns c + 2 fk, c + 2 fk + 1 of the block rows (A fragments of two k-steps: beyond the packed blocks the range check returns 0;
-        // beyond the block's own columns the rows of X are masked instead); the operands of step c + 8 are loaded before the MFMAs of step c
-        const double2_t zero2 = {0.0, 0.0};
-        auto load_a = [&](int c) { return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff + (unsigned)c * 8u, 0, 0)); };
-        auto load_x = [&](int q, int k) { return q < nq && k < n ? X[16 * (p0 + q) + (size_t)k * ldx] : zero2; };
-        // three steps of eight columns per trip, every step's operands requested two steps ahead (three operand sets; steps beyond the
-        // block's columns multiply zeros: the packed blocks' range check and the row mask)
-        struct Step {
-            double2_t a, x0[kOmPairsPerWave], x1[kOmPairsPerWave];
-        };
-        auto load_step = [&](Step& st, int c) {
-            st.a = load_a(c);
-#pragma unroll
-            for (int q = 0; q < kOmPairsPerWave; ++q) {
-                st.x0[q] = load_x(q, c + 2 * fk);
-                st.x1[q] = load_x(q, c + 2 * fk + 1);
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + r + u * RPP;
+                v[u] = (r + u * RPP < rows && k < n && j < npair) ? X[(size_t)k * ldx + j] : zero2;
             }
-        };
-        auto products = [&](const Step& st) {
 #pragma unroll
-            for (int q = 0; q < kOmPairsPerWave; ++q) {
-                if (q < nq) {
-                    acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a.x, st.x0[q].x, acc[q][0][0], 0, 0, 0);      // even epochs, k-step 0
-                    acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a.x, st.x0[q].y, acc[q][1][0], 0, 0, 0);      // odd epochs
-                    acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a.y, st.x1[q].x, acc[q][0][1], 0, 0, 0);      // k-step 1
-                    acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a.y, st.x1[q].y, acc[q][1][1], 0, 0, 0);
+            for (int u = 0; u < 4; ++u)
+                if (r + u * RPP < rows) om_stage[(r + u * RPP) * PR + j] = v[u];
+        }
+    };
+    if (resident) {
+        stage(0, Kpad);
+        __syncthreads();
+    }
+    for (int t0 = 0; t0 < ntile; t0 += 4) {
+        const int tile = t0 + wave;
+        const bool active = tile < ntile;
+        const int r0 = 16 * tile;
+        const unsigned voff = (unsigned)(block_off[s] * 8) + (unsigned)((min(r0 + fr, n - 1) * ld + 2 * fk) * 8);
+        auto load_a = [&](int c) { return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff + (unsigned)c * 8u, 0, 0)); };
+        double4_t acc[EG][2][2];
+#pragma unroll
+        for (int q = 0; q < EG; ++q) acc[q][0][0] = acc[q][0][1] = acc[q][1][0] = acc[q][1][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < Kpad; k0 += kc) {
+            const int kend = min(k0 + kc, Kpad);
+            if (!resident) {
+                __syncthreads();
+                stage(k0, kend - k0);
+                __syncthreads();
+            }
+            if (active) {
+                double2_t a[kOmDepth];
+#pragma unroll
+                for (int d = 0; d < kOmDepth; ++d) a[d] = load_a(k0 + 8 * d);        // (beyond the packed blocks the range check returns 0)
+                for (int c = k0; c < kend; c += 8 * kOmDepth) {
+#pragma unroll
+                    for (int d = 0; d < kOmDepth; ++d) {
+                        const int cc = c + 8 * d;
+                        if (cc < kend) {
+                            const double2_t* xr = om_stage + (cc - k0 + 2 * fk) * PR + fr;
+#pragma unroll
+                            for (int q = 0; q < EG; ++q) {
+                                const double2_t x0 = xr[16 * q], x1 = xr[PR + 16 * q];
+                                acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].x, x0.x, acc[q][0][0], 0, 0, 0);      // even epochs, k-step 0
+                                acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].x, x0.y, acc[q][1][0], 0, 0, 0);      // odd epochs
+                                acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].y, x1.x, acc[q][0][1], 0, 0, 0);      // k-step 1
+                                acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].y, x1.y, acc[q][1][1], 0, 0, 0);
+                            }
+                        }
+                        a[d] = load_a(cc + 8 * kOmDepth);
+                    }
                 }
             }
-        };
-        Step s0, s1, s2;
-        load_step(s0, 0);
-        load_step(s1, 8);
-        load_step(s2, 16);
-        for (int c = 0; c < n; c += 24) {
-            products(s0);
-            load_step(s0, c + 24);
-            products(s1);
-            load_step(s1, c + 32);
-            products(s2);
-            load_step(s2, c + 40);
         }
+        if (active) {
 #pragma unroll
-        for (int q = 0; q < kOmPairsPerWave; ++q) {
-            if (q < nq) {
-                const double4_t even = acc[q][0][0] + acc[q][0][1], odd = acc[q][1][0] + acc[q][1][1];
+            for (int q = 0; q < EG; ++q) {
+                if (16 * q < npair) {
+                    const double4_t even = acc[q][0][0] + acc[q][0][1], odd = acc[q][1][0] + acc[q][1][1];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = r0 + fk + 4 * r;                            // C/D layout: row = fk + 4 reg, column = fr
-                    if (row < n) {
-                        const size_t at = (size_t)row * ldx + 16 * (p0 + q);
-                        Y[at] = m + row > 1 ? (double2_t){even[r], odd[r]} : X[at];
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = r0 + fk + 4 * r;                            // C/D layout: row = fk + 4 reg, column = fr
+                        if (row < n) {
+                            const size_t at = (size_t)row * ldx + 16 * q + fr;
+                            Y[at] = m + row > 1 ? (double2_t){even[r], odd[r]} : X[at];
+                        }
                     }
                 }
             }
@@ -439,7 +476,10 @@ extern "C" int shg_order_major_pack(const double* anm, int N, int B, double* om,
     SHG_REQUIRE(N >= 0 && B >= 0 && Bpad >= B && Bpad % 32 == 0, "shg_order_major_pack: need N >= 0, 0 <= B <= Bpad, Bpad a multiple of 32");
     if (B == 0) return SHG_OK;
     SHG_REQUIRE(anm && om, "shg_order_major_pack: NULL pointer");
-    hipLaunchKernelGGL(shg::order_major_kernel<true>, dim3(N + 1, Bpad / 16), dim3(256), (size_t)16 * (N + 2) * sizeof(double), (hipStream_t)stream_, N, B, Bpad, anm, om);
+    const size_t lds = order_major_lds_bytes(N);
+    SHG_REQUIRE(lds <= kOrderMajorMaxLds, "shg_order_major_pack: degree %d exceeds the LDS row stage of the layout kernel (max degree %d)", N, (int)(kOrderMajorMaxLds / 128) - 2);
+    if (lds > 64 * 1024) SHG_SET_LDS_ONCE(shg::order_major_kernel<true>, kOrderMajorMaxLds);
+    hipLaunchKernelGGL(shg::order_major_kernel<true>, dim3(N + 1, Bpad / 16), dim3(256), lds, (hipStream_t)stream_, N, B, Bpad, anm, om);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
@@ -448,7 +488,10 @@ extern "C" int shg_order_major_unpack(const double* om, int N, int B, int Bpad, 
     SHG_REQUIRE(N >= 0 && B >= 0 && Bpad >= B && Bpad % 32 == 0, "shg_order_major_unpack: need N >= 0, 0 <= B <= Bpad, Bpad a multiple of 32");
     if (B == 0) return SHG_OK;
     SHG_REQUIRE(anm && om, "shg_order_major_unpack: NULL pointer");
-    hipLaunchKernelGGL(shg::order_major_kernel<false>, dim3(N + 1, Bpad / 16), dim3(256), (size_t)16 * (N + 2) * sizeof(double), (hipStream_t)stream_, N, B, Bpad, om, anm);
+    const size_t lds = order_major_lds_bytes(N);
+    SHG_REQUIRE(lds <= kOrderMajorMaxLds, "shg_order_major_unpack: degree %d exceeds the LDS row stage of the layout kernel (max degree %d)", N, (int)(kOrderMajorMaxLds / 128) - 2);
+    if (lds > 64 * 1024) SHG_SET_LDS_ONCE(shg::order_major_kernel<false>, kOrderMajorMaxLds);
+    hipLaunchKernelGGL(shg::order_major_kernel<false>, dim3(N + 1, Bpad / 16), dim3(256), lds, (hipStream_t)stream_, N, B, Bpad, om, anm);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
 }
@@ -461,50 +504,15 @@ extern "C" int shg_orderwise_filter_om(const double* blocks_packed, const int64_
     SHG_REQUIRE(blocks_packed && block_off && om_in && om_out, "shg_orderwise_filter_om: NULL pointer");
     SHG_REQUIRE(om_in != om_out, "shg_orderwise_filter_om: in-place operation is not supported");
     hipStream_t stream = (hipStream_t)stream_;
-    // (slot, tile of 16 rows) units, the long slots first; the table is tiny (~1000 entries at d/o 120) and cached per degree
-    static std::mutex mtx;
-    static int cached_N = -1, cached_units = 0, cached_dev = -1;
-    static int* table_d = nullptr;
-    std::lock_guard<std::mutex> lock(mtx);
-    int dev = 0;
-    SHG_HIP(hipGetDevice(&dev));
-    if (cached_N != N || cached_dev != dev) {
-        // The row tiles of a slot read the same rows of the series: all of them go to ONE XCD (workgroups are dealt to the XCDs round
-        // robin by their linear index: entry i of the table runs on XCD i % 8), the slots by decreasing length in a snake over the XCDs
-        // so that every XCD gets about the same arithmetic; short lists are padded with empty units (slot -1).
-        std::vector<std::vector<int>> xs(8), xr(8);
-        std::vector<int> order(2 * N + 1);
-        for (int s = 0; s <= 2 * N; ++s) order[s] = s;                       // (already by decreasing length: orders ascend)
-        for (int i = 0; i <= 2 * N; ++i) {
-            const int s = order[i], m = (s + 1) >> 1;
-            const int x = (i / 8) % 2 == 0 ? i % 8 : 7 - i % 8;
-            for (int r0 = 0; r0 < N + 1 - m; r0 += 16) {
-                xs[x].push_back(s);
-                xr[x].push_back(r0);
-            }
-        }
-        size_t longest = 0;
-        for (int x = 0; x < 8; ++x) longest = std::max(longest, xs[x].size());
-        std::vector<int> slot(8 * longest, -1), row0(8 * longest, 0);
-        for (int x = 0; x < 8; ++x)
-            for (size_t j = 0; j < xs[x].size(); ++j) {
-                slot[8 * j + x] = xs[x][j];
-                row0[8 * j + x] = xr[x][j];
-            }
-        std::vector<int> table(slot);
-        table.insert(table.end(), row0.begin(), row0.end());
-        if (table_d) {
-            SHG_HIP(hipDeviceSynchronize());
-            (void)hipFree(table_d);
-            table_d = nullptr;
-        }
-        if (hipMalloc((void**)&table_d, table.size() * sizeof(int)) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_orderwise_filter_om: unit table allocation failed");
-        SHG_HIP(hipMemcpy(table_d, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
-        cached_N = N;
-        cached_dev = dev;
-        cached_units = (int)slot.size();
-    }
-    hipLaunchKernelGGL(shg::orderwise_filter_om_kernel, dim3((unsigned)cached_units), dim3(256), 0, stream, Nb, N, Bpad, cached_units, table_d, table_d + cached_units,
+    // slices of 32 EG epochs; the stage holds all rows of the longest slot when that fits (kOmStageMaxBytes), else chunks of kc rows
+    constexpr int EG = SHG_OM_EPOCH_GROUPS;
+    constexpr size_t kOmStageMaxBytes = 144 * 1024;
+    const int row_bytes = 32 * EG * (int)sizeof(double);
+    const int kc = std::min(round_up(N + 1, 8), (int)(kOmStageMaxBytes / row_bytes) / 8 * 8);
+    const size_t lds = (size_t)kc * row_bytes;
+    const int nslice = ceil_div(Bpad, 32 * EG);
+    if (lds > 64 * 1024) SHG_SET_LDS_ONCE(shg::orderwise_filter_om_kernel<EG>, kOmStageMaxBytes);
+    hipLaunchKernelGGL(shg::orderwise_filter_om_kernel<EG>, dim3((unsigned)(8 * ceil_div(2 * N + 1, 8) * nslice)), dim3(256), lds, stream, Nb, N, Bpad, nslice, kc,
                        blocks_packed, (const long long*)block_off, om_in, om_out);
     SHG_HIP(hipGetLastError());
     return SHG_OK;

@@ -62,6 +62,9 @@ __device__ inline int tall_owner(long long i, long long iters, int groups) {
 
 // LDS-DMA of one 16-byte piece per lane of `mask`: LDS address = lds_addr + 16 * lane (see synthesis_rot.hip: glds16).  The execution
 // mask is set inside the statement: a branch around a partial copy would end the scheduling region in the middle of the MFMAs.
+// exec is restored by the statement itself.  M0 is left overwritten and cannot be declared: hipcc treats it as reserved (a clobber entry
+// only draws -Winline-asm "clobber list contains reserved registers" and changes nothing) and reloads it in front of every use of its
+// own; gfx9 LDS instructions do not read it (synthesis_rot.hip: glds16).
 __device__ __forceinline__ void tall_glds16(const double* gbase, unsigned lane_off, unsigned lds_addr, unsigned long long mask) {
     unsigned long long saved;
     asm volatile(

@@ -635,16 +635,19 @@ class TikhonovRegularization(NormalEquations):
 def accumulate_normals(normal_equations, variance_factors):
     """Weighted sum of normal equation systems, N = sum_k N_k / s_k^2 (same for the right-hand side and l^T P l); the observation
     counts add up unweighted (grates/lstsq.py:1091-1119)."""
-    if len(normal_equations) != len(variance_factors) or len(normal_equations) == 0:
-        raise ValueError('accumulate_normals: one variance factor per system expected')
-    weights = [1.0 / factor for factor in variance_factors]
+    # as the reference: one factor per system is read (further factors are ignored, a missing one is an IndexError), the matrix is scaled
+    # by the reciprocal, right-hand side and square sum are DIVIDED by the factor (bit-equal to grates/lstsq.py:1106-1116)
+    factors = [variance_factors[k] for k in range(len(normal_equations))]
     matrix = normal_equations[0].matrix.copy()
-    matrix._scale(weights[0])
-    for part, weight in zip(normal_equations[1:], weights[1:]):
-        matrix._axpy(weight, part.matrix)
+    matrix._scale(1 / factors[0])
+    for part, factor in zip(normal_equations[1:], factors[1:]):
+        matrix._axpy(1 / factor, part.matrix)
     sides = [engine.to_host(part.right_hand_side) if _is_tensor(part.right_hand_side) else part.right_hand_side for part in normal_equations]
-    right_hand_side = sum((side * weight for side, weight in zip(sides[1:], weights[1:])), sides[0] * weights[0])
-    square_sum = sum(part.observation_square_sum * weight for part, weight in zip(normal_equations, weights))
+    right_hand_side = sides[0].copy() / factors[0]
+    square_sum = normal_equations[0].observation_square_sum / factors[0]
+    for part, side, factor in zip(normal_equations[1:], sides[1:], factors[1:]):
+        right_hand_side += side / factor
+        square_sum += part.observation_square_sum / factor
     count = sum(part.observation_count for part in normal_equations)
     return NormalEquations(matrix, right_hand_side, square_sum, count)
 

@@ -181,3 +181,52 @@ def basis_function_case(seed, count, min_degree, max_degree):
     p = (max_degree + 1) ** 2 - min_degree ** 2
     k_aniso = rng.standard_normal((p, p)) / p
     return lon, lat, values, k_rbf, k_aniso
+
+
+def api_probes(pkg):
+    """(label, thunk) pairs that exercise the error contract of the path's public API on `pkg` -- the reference package in
+    make_golden.py (which records the exception TYPE each one raises in g19_api.json), grates_amd in tests/test_api_signatures.py.  Every
+    thunk is cheap, host-only and needs no data file (the DDK normal blocks are absent from the reference mount)."""
+    gf = pkg.gravityfield.PotentialCoefficients()
+    gf.anm = coefficients(5, 6)
+    small = pkg.gravityfield.PotentialCoefficients()
+    small.anm = coefficients(6, 4)
+    grid = pkg.grid.GeographicGrid(30.0, 30.0)
+    blocks4 = orderwise_random_blocks(7, 4)
+    ewh = pkg.kernel.get_kernel('ewh')
+
+    def set_values(target, val):
+        target.values = val
+
+    return [
+        ('pc_add_str', lambda: gf + 'x'),
+        ('pc_sub_int', lambda: gf - 1),
+        ('pc_mul_pc', lambda: gf * gf),
+        ('pc_div_str', lambda: gf / 'x'),
+        ('pc_add_pc', lambda: gf + small),
+        ('pc_mul_float', lambda: gf * 2.0),
+        ('pc_values_2d', lambda: set_values(gf.copy(), np.zeros((7, 7)))),
+        ('pc_values_list', lambda: set_values(gf.copy(), [1.0, 2.0])),
+        ('pc_values_none_ok', lambda: set_values(gf.copy(), None)),
+        ('grid_values_2d', lambda: set_values(grid.copy(), np.zeros((6, 12)))),
+        ('grid_values_size', lambda: set_values(grid.copy(), np.zeros(5))),
+        ('grid_values_list', lambda: set_values(grid.copy(), [0.0] * 72)),
+        ('grid_values_ok', lambda: set_values(grid.copy(), np.zeros(72))),
+        ('grid_analysis_without_values', lambda: grid.copy().to_potential_coefficients(0, 2)),
+        ('get_kernel_unknown', lambda: pkg.kernel.get_kernel('no_such_kernel')),
+        ('get_kernel_geoid', lambda: pkg.kernel.get_kernel('geoid')),
+        ('kernel_shape_mismatch', lambda: ewh.inverse_coefficients(0, 4, np.full(3, 6.378e6), np.full(4, 1.0))),
+        ('kernel_list_input', lambda: ewh.inverse_coefficients(0, 4, [6.378e6], [1.0])),
+        ('kernel_scalar_ok', lambda: ewh.inverse_coefficients(0, 4, 6.378e6, 1.0)),
+        ('gaussian_filter_non_pc', lambda: pkg.filter.Gaussian(300).filter(5)),
+        ('orderwise_filter_non_pc', lambda: pkg.filter.OrderWiseFilter(blocks4).filter(np.zeros((5, 5)))),
+        ('orderwise_filter_degree_too_high', lambda: pkg.filter.OrderWiseFilter(blocks4).filter(gf)),
+        ('orderwise_filter_ok', lambda: pkg.filter.OrderWiseFilter(blocks4).filter(small)),
+        ('ddk_generic_level_0', lambda: pkg.filter.DDKGeneric(0)),
+        ('general_matrix_not_square', lambda: pkg.filter.GeneralMatrix(np.zeros((3, 4)), 0, 1)),
+        ('general_matrix_wrong_size', lambda: pkg.filter.GeneralMatrix(np.zeros((5, 5)), 0, 1)),
+        ('general_matrix_ok', lambda: pkg.filter.GeneralMatrix(np.eye(4), 0, 1)),
+        ('unravel_wrong_length', lambda: pkg.utilities.unravel_coefficients(np.zeros(7))),
+        ('ravel_ok', lambda: pkg.utilities.ravel_coefficients(np.zeros((4, 4)), 1, 3)),
+        ('legendre_scalar_colat', lambda: pkg.utilities.legendre_functions(3, np.array([0.4]))),
+    ]

@@ -564,8 +564,70 @@ def g18():
     save('g18_operators', **out)
 
 
+# ---- G19: the public API surface of the path: names, signatures, exception types -----------------------------------
+API_MODULES = ('utilities', 'kernel', 'gravityfield', 'grid', 'filter', 'lstsq', 'io', 'data')
+
+
+def g19():
+    """Names and inspect.signature strings of every public callable the reference defines in the modules of the path, the public methods /
+    properties of its classes, and the exception TYPE each probe of inputs.api_probes raises -- data about the interface, no code."""
+    import inspect
+    import json
+    import re
+
+    def describe(obj):
+        """[[name, kind, repr(default) | None], ...]; a default that is an object instance is recorded as '<instance of Type>'"""
+        try:
+            sig = inspect.signature(obj)
+        except (TypeError, ValueError):
+            return None
+        out = []
+        for prm in sig.parameters.values():
+            default = None
+            if prm.default is not inspect.Parameter.empty:
+                default = re.sub(r' at 0x[0-9a-f]+', '', repr(prm.default))
+                if ' object>' in default:
+                    default = '<instance of {0}>'.format(type(prm.default).__name__)
+            out.append([prm.name, prm.kind.name, default])
+        return out
+
+    api = {}
+    for modname in API_MODULES:
+        mod = getattr(grates, modname)
+        entry = {}
+        for name, obj in sorted(vars(mod).items()):
+            if name.startswith('_') or getattr(obj, '__module__', None) != mod.__name__:
+                continue
+            if inspect.isclass(obj):
+                members = {}
+                for mname, member in sorted(vars(obj).items()):
+                    if mname.startswith('_') and mname != '__init__':
+                        continue
+                    if isinstance(member, property):
+                        members[mname] = 'property' + ('+setter' if member.fset else '')
+                    elif isinstance(member, (staticmethod, classmethod)):
+                        members[mname] = [type(member).__name__] + (describe(member.__func__) or [])
+                    elif callable(member):
+                        members[mname] = describe(member)
+                entry[name] = {'kind': 'class', 'bases': [b.__name__ for b in obj.__mro__[1:-1]], 'members': members}
+            elif inspect.isfunction(obj):
+                entry[name] = {'kind': 'function', 'signature': describe(obj)}
+        api[modname] = entry
+    raised = {}
+    for label, thunk in inputs.api_probes(grates):
+        try:
+            thunk()
+            raised[label] = None
+        except Exception as err:            # noqa: BLE001 -- the TYPE is the datum
+            raised[label] = type(err).__name__
+    path = os.path.join(HERE, 'g19_api.json')
+    with open(path, 'w') as f:
+        json.dump({'modules': api, 'raises': raised}, f, indent=1, sort_keys=True)
+    print('{0:28s} {1:9.1f} KB'.format('g19_api.json', os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17, g18):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17, g18, g19):
         if not only or fn.__name__ in only:
             fn()

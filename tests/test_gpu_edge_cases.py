@@ -132,3 +132,19 @@ def test_shared_plan_on_two_streams_and_threads():
     for s in (0, 1):
         for got in results[s]:
             assert relerr(got[[0, 5]], refs[s]) < 1e-12
+
+
+def test_error_contract_of_the_reference_on_the_device():
+    """every probe of inputs.api_probes -- incl. the ones whose non-raising outcome runs a kernel -- raises the exception type that the
+    reference raised when tests/golden/make_golden.py recorded g19_api.json (the CPU half is tests/test_api_signatures.py)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g19_api.json')) as f:
+        expected = json.load(f)['raises']
+    for label, thunk in inputs.api_probes(ga):
+        try:
+            thunk()
+            got = None
+        except Exception as err:        # noqa: BLE001
+            got = type(err).__name__
+        assert got == expected[label], (label, got, expected[label])
