@@ -79,6 +79,7 @@ def parse_args(argv=None):
     ap.add_argument('--legs', default='all', help='comma separated subset of ' + ','.join(LEGS) + " (default: all; 'synthesis' always runs)")
     ap.add_argument('--ramp', type=int, default=300, help='untimed launches before the second measurement of the headline (device clock ramp)')
     ap.add_argument('--idle-pass', type=int, default=1, help='1: also time the contract pass straight behind the idle setup (roofline.value_idle_start)')
+    ap.add_argument('--stage-limit-pass', type=int, default=1, help='1: also time the headline with the Legendre-stage limit on (roofline.value_stage_limit_on)')
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass of the staged path (0 = library default)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='seconds after which `--gpus N` run without a launcher kills its ranks (0 = never)')
@@ -243,6 +244,9 @@ class GpuWorkload:
 
     def synthesis_step(self):
         self.plan.synthesis(self.batch, out=self.out)
+
+    def set_stage_limit(self, limit):
+        self.plan.set_stage_limit(limit)
 
     def profile(self, enable):
         # events around the dominant kernel only: the pair around the 16 us coefficient repack would cost every step another ~5 us
@@ -420,12 +424,15 @@ class GpuWorkload:
             state['block'] = flt.filter_batch(batch)
         step_block()
         el_block, _, ev_block = ctx.timed(step_block, args.warmup, args.steps, events=True)
-        # the same operator on the series kept on the device in order-major layout (engine.OrderMajorSeries): one product per block on whole
-        # matrices, no gather / scatter; the conversion from the reference arrays happens once, outside the timed steps
-        series = ga.engine.OrderMajorSeries.from_batch(batch)
+        # the same operator through the reference's classes on a device-resident series: filter.OrderWiseFilter.filter(TimeSeries) works on
+        # the engine.OrderMajorSeries the TimeSeries holds (one product per block on whole matrices, no gather / scatter) and returns a
+        # TimeSeries that stays on the device; the series is built once, outside the timed steps, like the batch above
+        import datetime
+        epochs = [datetime.datetime(2002, 4, 1) + datetime.timedelta(days=30 * e) for e in range(T)]
+        ts = ga.gravityfield.TimeSeries.from_series(batch, epochs)
 
         def step_series():
-            state['series'] = flt.filter_series(series)
+            state['series'] = flt.filter(ts)
         step_series()
         el_series, _, ev_series = ctx.timed(step_series, args.warmup, args.steps, events=True)
         nmin = 2
@@ -433,7 +440,7 @@ class GpuWorkload:
         dense = ga.filter.GeneralMatrix(flt.matrix(nmin, nmax), nmin, nmax)   # 14637 x 14637 full normal-type matrix, 1.7 GB
 
         def step_dense():
-            state['dense'] = dense.filter_batch(batch)
+            state['dense'] = dense.filter(ts)                                  # ONE product W_om X on the series (W permuted once, no ravel / unravel)
         step_dense()
         dense_steps = max(args.steps // 2, 1)
         el_dense, _, ev_dense = ctx.timed(step_dense, max(args.warmup // 2, 1), dense_steps, events=True)
@@ -450,8 +457,9 @@ class GpuWorkload:
         el_block, ev_block, el_dense, ev_dense, dense_steps = (st[k] for k in ('el_block', 'ev_block', 'el_dense', 'ev_dense', 'dense_steps'))
         block_bytes = 8.0 * (sum(b.size for b in blocks) + 2.0 * (nmax + 1) ** 2 * T)
         dense_flops = 2.0 * P * P * T
-        agree = float(((state['dense'] - state['block']).abs().max() / state['block'].abs().max()).item())
-        agree_series = float(((state['series'].to_batch() - state['block']).abs().max() / state['block'].abs().max()).item())
+        dense_batch = state['dense'].to_device().to_batch()
+        agree = float(((dense_batch - state['block']).abs().max() / state['block'].abs().max()).item())
+        agree_series = float(((state['series'].to_device().to_batch() - state['block']).abs().max() / state['block'].abs().max()).item())
         el_series, ev_series = st['el_series'], st['ev_series']
         out = {
             'block': {
@@ -466,7 +474,7 @@ class GpuWorkload:
                              'algorithmic_bytes_per_launch': block_bytes, 'avg_launch_ms': ev_block},
             },
             'order_major': {
-                'metric': 'the same filter on the series kept in order-major layout on the device (no gather / scatter)', 'value': ctx.world * T * args.steps / el_series,
+                'metric': 'the same filter through filter.OrderWiseFilter.filter(TimeSeries) on the device-resident series (order-major layout, no gather / scatter)', 'value': ctx.world * T * args.steps / el_series,
                 'unit': 'epochs/s', 'n_gpus': ctx.world, 'scaling': 'weak', 'ms_per_step': 1e3 * el_series / args.steps, 'dtype': 'f64',
                 'roofline': {'kernel': 'orderwise_filter_om_kernel', 'bound': 'hbm', 'achieved': block_bytes / (ev_series * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                              'unit': 'GB/s', 'frac': block_bytes / (ev_series * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -478,9 +486,9 @@ class GpuWorkload:
                 'metric': 'the same filter as full normal-matrix multiply W X, W {0} x {0}'.format(P), 'value': ctx.world * T * dense_steps / el_dense,
                 'unit': 'epochs/s', 'n_gpus': ctx.world, 'scaling': 'weak', 'ms_per_step': 1e3 * el_dense / dense_steps, 'dtype': 'f64',
                 'GFLOPs': dense_flops * dense_steps / el_dense / 1e9,
-                'config': {'workload': '{0} epochs per GPU: ravel, W [{1} x {1}] @ X [{1} x {0}], unravel'.format(T, P), 'max_degree': nmax, 'min_degree': nmin,
+                'config': {'workload': '{0} epochs per GPU: GeneralMatrix.filter(TimeSeries) = W [{1} x {1}] (+ 4 identity rows) @ X on the device-resident series'.format(T, P), 'max_degree': nmax, 'min_degree': nmin,
                            'epochs_per_gpu': T, 'flops_per_step': dense_flops},
-                'roofline': {'kernel': 'gemm_tall_kernel + gemm_tall_fixup_kernel (shg_dense_filter; the step also holds the ravel / unravel kernels)', 'bound': 'mfma',
+                'roofline': {'kernel': 'gemm_tall_kernel + gemm_tall_fixup_kernel (one product per step on the order-major series: no ravel / unravel)', 'bound': 'mfma',
                              'achieved': dense_flops / (ev_dense * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                              'frac': dense_flops / (ev_dense * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 'mfma_busy': pmc_mfma_busy('filters_dense'),
                              'traffic': pmc_traffic('filters', ['gemm_tall_kernel', 'gemm_tall_fixup_kernel'])[0],
@@ -505,7 +513,7 @@ class GpuWorkload:
             t0 = time.perf_counter()
             Y = W @ X
             dt = time.perf_counter() - t0
-            host_dense = state['dense'].cpu().numpy()
+            host_dense = dense_batch.cpu().numpy()
             ref0 = orc.general_matrix_filter(batch_host[0], W, nmin, nmax)
             err_dense = max(float(np.max(np.abs(host_dense[0] - ref0)) / np.max(np.abs(ref0))),
                             float(np.max(np.abs(orc.ravel_coefficients(host_dense[T - 1], nmin, nmax) - Y[:, T - 1])) / np.max(np.abs(Y[:, T - 1]))))
@@ -1004,6 +1012,14 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
         wl.synthesis_step()
     barrier()
     ramp_elapsed, ramp_prof = timed_steps(args.warmup, args.steps) if args.ramp > 0 else (elapsed, prof)
+    # the Legendre-stage limit (shg_plan_set_stage_limit, off by default) measured beside the default in the same steady state: what the
+    # knob is worth on THIS box is a number of the record (it took 1.5-2 % off on some boxes and cost 2-4 % on others in round 5)
+    limit_elapsed = limit_prof = None
+    if args.stage_limit_pass and hasattr(wl, 'set_stage_limit') and wl.config.get('rotation_folded_kernel'):
+        wl.set_stage_limit(-7)
+        barrier()
+        limit_elapsed, limit_prof = timed_steps(args.warmup, args.steps)
+        wl.set_stage_limit(0)
 
     line = None
     if rank == 0:
@@ -1019,6 +1035,7 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
         achieved, lon_avg_ms, epochs_per_launch = kernel_rate(prof)
         ramp_achieved, ramp_avg_ms, _ = kernel_rate(ramp_prof)
         idle_achieved, idle_avg_ms, _ = kernel_rate(idle_prof) if idle_prof is not None else (None, None, None)
+        limit_achieved, limit_avg_ms, _ = kernel_rate(limit_prof) if limit_prof is not None else (None, None, None)
         traffic, traffic_source = pmc_traffic('synthesis', [wl.kernel_name])
         kernels = {k: {'ms_total': round(v[0], 4), 'launches': int(v[1]), 'avg_us': round(1e3 * v[0] / max(v[1], 1), 3)} for k, v in prof.items()}
         config = {'workload': 'batch of {0} monthly solutions d/o {1} -> {2} deg GeographicGrid ({3}x{4}), kernel {5}, per GPU'.format(
@@ -1061,6 +1078,9 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
                 'value_idle_start': (world * B * args.steps / idle_elapsed) if idle_elapsed else None,
                 'frac_idle_start': (idle_achieved / HBM_PEAK_GBS) if idle_achieved else None,
                 'avg_launch_ms_idle_start': idle_avg_ms,
+                # the same steady state as `after_ramp`, with at most 7/16 of the CUs in their Legendre stage at once (the knob is OFF in `value`)
+                'value_stage_limit_on': (world * B * args.steps / limit_elapsed) if limit_elapsed else None,
+                'avg_launch_ms_stage_limit_on': limit_avg_ms,
             },
             'kernels': kernels,
         }

@@ -31,6 +31,7 @@ PROTOTYPES = {
     'shg_plan_set_rotations': [c_plan_p, ctypes.c_int],
     'shg_plan_set_stage_limit': [c_plan_p, ctypes.c_int],
     'shg_plan_info': [c_plan_p, ctypes.POINTER(ctypes.c_int64)],
+    'shg_analysis_info': [c_plan_p, c_double_p],
     'shg_plan_profile': [c_plan_p, ctypes.c_int],
     'shg_plan_profile_read': [c_plan_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)],
     'shg_synthesis': [c_plan_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],
@@ -54,6 +55,7 @@ PROTOTYPES = {
     'shg_order_major_pack': [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p],
     'shg_order_major_unpack': [c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_orderwise_filter_om': [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
+    'shg_degree_scale_om': [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_synthesis_om': [c_plan_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_void_p],
     'shg_ddk_blocks': [c_double_p, c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_void_p],
     'shg_dense_filter': [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_void_p],

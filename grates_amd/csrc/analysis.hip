@@ -96,6 +96,9 @@ __global__ __launch_bounds__(256) void weight_fold_kernel(int nb, int nlat, int 
 // (LDS [group][c][row]), D row = order fk + 4 reg, column = row fr.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
+#ifndef SHG_ANA_PARITY
+#define SHG_ANA_PARITY 1     // 0: A/B builds without the north-south parity split of the operator product
+#endif
 #ifndef SHG_ANA_X
 #define SHG_ANA_X 0    // experiment switches (timing only): 1 no MFMAs, 2 no global loads after the first chunk, 4 / 8 / 16 no weight / trig / value loads
 #endif
@@ -456,6 +459,173 @@ __global__ __launch_bounds__(256) void analysis_operator_kernel(int N, int nmin,
     }
 }
 
+// ---- North-south parity split of the operator product (round 6).
+// On parallels that are mirror images of each other (colat[nlat-1-i] = pi - colat[i], equal kernel factors) with mirror-symmetric weights,
+// P_nm(pi - theta) = (-1)^(n-m) P_nm(theta) makes the normal equations of a slot decouple by the parity of n - m, and the operator
+// inherits the symmetry: H_s[n][nlat-1-i] = (-1)^(n-m) H_s[n][i].  Then
+//     x_n = sum_i H_s[n][i] g[i] = sum_{i < nlat/2} Hp[n][i] (g[i] +- g[nlat-1-i]),      Hp[n][i] = (H_s[n][i] +- H_s[n][nlat-1-i]) / 2,
+// with + for even and - for odd n - m: half the products and half the operator bytes.  Hp is formed from the operator AS BUILT (from the
+// reference's own colatitudes, whose mirror images differ by ~1e-14 rad near the poles): the part of H_s that does not have the symmetry,
+// (H_s[n][i] -+ H_s[n][nlat-1-i]) / 2, is dropped, and its largest entry relative to the largest entry of H is measured while Hp is
+// formed -- the split is used when that defect is below kParityDefectMax (asymmetric weights or parallels show up as a defect of order
+// one and keep the full product).
+//   Hp [S][2 RE][nlat/2], RE = ceil((N+1)/2): rows j < dE of a slot hold the even rows a = e0 + 2 j (n = n0 + a), rows RE + j the odd ones.
+constexpr double kParityDefectMax = 5e-12;
+
+__device__ __forceinline__ void atomic_max_positive(double* addr, double v) {       // v >= 0: the bit patterns order like the values
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__builtin_bit_cast(long long, v));
+}
+
+__global__ __launch_bounds__(256) void analysis_parity_kernel(int N, int nmin, int nlat, const double* __restrict__ H, double* __restrict__ Hp,
+                                                              double* __restrict__ norms /* [2]: max |H|, max |dropped part| */) {
+    const int R = N + 1, RE = (R + 1) / 2, nh = nlat / 2;
+    const int s = blockIdx.y, row = blockIdx.x;                   // row of Hp: parity = row / RE, j = row % RE
+    const int m = (s + 1) >> 1, n0 = max(m, nmin), d = R - n0;
+    const int odd = row / RE, j = row % RE;
+    const int e0 = (n0 - m) & 1;                                   // first even row of the slot
+    const int a = (odd ? 1 - e0 : e0) + 2 * j;
+    double* out = Hp + ((size_t)s * 2 * RE + row) * nh;
+    double big = 0.0, drop = 0.0;
+    for (int i = threadIdx.x; i < nh; i += 256) {
+        double v = 0.0;
+        if (d > 0 && a < d) {
+            const double hn = H[((size_t)s * R + a) * nlat + i], hs = H[((size_t)s * R + a) * nlat + nlat - 1 - i];
+            v = odd ? 0.5 * (hn - hs) : 0.5 * (hn + hs);
+            big = fmax(big, fmax(fabs(hn), fabs(hs)));
+            drop = fmax(drop, fabs(odd ? 0.5 * (hn + hs) : 0.5 * (hn - hs)));
+        }
+        out[i] = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        big = fmax(big, __shfl_xor(big, o));
+        drop = fmax(drop, __shfl_xor(drop, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomic_max_positive(norms, big);
+        atomic_max_positive(norms + 1, drop);
+    }
+}
+
+// x_s = Hp_s (g_s +- mirrored g_s): the operator product on the northern half.  A workgroup takes one slot and 64 epochs as
+// analysis_operator_kernel does; the loader forms both combinations of a chunk of 16 northern parallels and their mirror images from
+// one read of the transform's output, the even row tiles multiply the sums, the odd ones the differences.
+__global__ __launch_bounds__(256) void analysis_operator_parity_kernel(int N, int nmin, int nlat, int nb, int b0, int ngroups, const double* __restrict__ Hp,
+                                                                       const double* __restrict__ gt, double* __restrict__ anm) {
+    __shared__ double AL[2][kOpKC][kOpRows + 2];
+    __shared__ double BL[2][2][kOpKC][kOpCols + 2];               // [stage][sum | difference]
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int s = 8 * (seq / ngroups) + xcd, cb = (seq % ngroups) * kOpCols;
+    if (s > 2 * N) return;
+    const int m = (s + 1) >> 1;
+    const bool sine = s > 0 && (s & 1) == 0;
+    const int n0 = max(m, nmin), R = N + 1, RE = (R + 1) / 2, nh = nlat / 2;
+    const int d = R - n0;
+    if (d <= 0) return;
+    const int e0 = (n0 - m) & 1;
+    const int dE = (d - e0 + 1) / 2, dO = d - dE;
+    const int tE = (dE + 15) >> 4, ntile = tE + ((dO + 15) >> 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const double* Hs = Hp + (size_t)s * 2 * RE * nh;
+    const double* gs = gt + (size_t)s * nb * nlat;                 // [nb][nlat]
+    const int kp = tid & 7, lrow = tid >> 3;                       // loader: 16-byte piece kp of row lrow (+ 32 per pass)
+    // The product is bound by the latency of its operand loads, not by its MFMAs (one chunk ahead: 3 TB/s of operands at two workgroups
+    // per CU): the operands of a chunk are requested TWO chunks ahead, in two register sets used in turn.
+    struct Operands {
+        double2_t ra[4], rn[2], rs[2];
+    };
+    Operands oa, ob;
+    auto fetch = [&](Operands& o, int k0) {
+        const int k = k0 + 2 * kp;
+        const bool kok = k < nh;                                   // nh is even: a pair is inside or outside
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = lrow + 32 * p;                         // row of the stage: even tiles first, then the odd ones
+            const bool even = row < 16 * tE;
+            const int j = even ? row : row - 16 * tE;
+            const bool ok = kok && (even ? j < dE : j < dO);
+            o.ra[p] = ok ? *reinterpret_cast<const double2_t*>(Hs + (size_t)((even ? 0 : RE) + j) * nh + k) : (double2_t){0.0, 0.0};
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int col = cb + lrow + 32 * p;
+            const bool ok = kok && col < nb;
+            o.rn[p] = ok ? *reinterpret_cast<const double2_t*>(gs + (size_t)col * nlat + k) : (double2_t){0.0, 0.0};
+            o.rs[p] = ok ? *reinterpret_cast<const double2_t*>(gs + (size_t)col * nlat + nlat - 2 - k) : (double2_t){0.0, 0.0};      // mirrors of k + 1, k
+        }
+    };
+    auto stage = [&](const Operands& o, int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (lrow + 32 * p < 16 * ntile) {
+                AL[buf][2 * kp][lrow + 32 * p] = o.ra[p].x;
+                AL[buf][2 * kp + 1][lrow + 32 * p] = o.ra[p].y;
+            }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            BL[buf][0][2 * kp][lrow + 32 * p] = o.rn[p].x + o.rs[p].y;
+            BL[buf][0][2 * kp + 1][lrow + 32 * p] = o.rn[p].y + o.rs[p].x;
+            BL[buf][1][2 * kp][lrow + 32 * p] = o.rn[p].x - o.rs[p].y;
+            BL[buf][1][2 * kp + 1][lrow + 32 * p] = o.rn[p].y - o.rs[p].x;
+        }
+    };
+    double4_t acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int nchunk = (nh + kOpKC - 1) / kOpKC;
+    auto products = [&](int buf) {
+        double fa[2][8], fb[2][2];
+        auto read_step = [&](int kk, int set) {
+            fb[set][0] = BL[buf][0][4 * kk + fk][16 * wave + fr];
+            fb[set][1] = BL[buf][1][4 * kk + fk][16 * wave + fr];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) fa[set][t] = AL[buf][4 * kk + fk][(t < ntile ? 16 * t : 0) + fr];
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk + 1 < 4) read_step(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][t], t < tE ? fb[kk & 1][0] : fb[kk & 1][1], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // chunk ch sits in stage ch & 1; `next` holds chunk ch + 1, `after` is free for chunk ch + 2
+    auto step = [&](int ch, Operands& next, Operands& after) {
+        if (ch + 2 < nchunk) fetch(after, (ch + 2) * kOpKC);
+        products(ch & 1);
+        if (ch + 1 < nchunk) stage(next, (ch & 1) ^ 1);
+        __syncthreads();
+    };
+    fetch(oa, 0);
+    if (nchunk > 1) fetch(ob, kOpKC);
+    stage(oa, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        step(ch, ob, oa);                          // chunk ch + 1 is in ob, chunk ch + 2 goes to oa
+        if (ch + 1 < nchunk) step(ch + 1, oa, ob);
+    }
+    const int b = cb + 16 * wave + fr;
+    if (b < nb) {
+        double* out = anm + (size_t)(b0 + b) * R * R;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < ntile) {
+                const bool even = t < tE;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int j = 16 * (even ? t : t - tE) + fk + 4 * reg;
+                    if (j < (even ? dE : dO)) {
+                        const int n = n0 + (even ? e0 : 1 - e0) + 2 * j;
+                        out[sine ? (size_t)(m - 1) * R + n : (size_t)n * R + m] = acc[t][reg];
+                    }
+                }
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void analysis_zero_kernel(long long n, double* __restrict__ x) {
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) x[e] = 0.0;
 }
@@ -492,6 +662,27 @@ __global__ __launch_bounds__(256) void analysis_matrix_kernel(int N, int nmin, i
     const double h = H[((size_t)s * (N + 1) + a) * nlat + i];
     double* out = F + row * ((size_t)nlat * nlon) + (size_t)i * nlon;
     for (int j = threadIdx.x; j < nlon; j += 256) out[j] = h * area[(size_t)i * nlon + j] * cs[(size_t)s * nlon + j];
+}
+
+// p->ana_Hp from p->ana_H where the parallels are mirror images of each other; p->ana_parity tells whether the product may use it
+static int build_parity_operator(shg_plan* p, int nmin, hipStream_t stream) {
+    const int N = p->N, S = 2 * N + 1, nlat = p->nlat, R = N + 1, RE = (R + 1) / 2;
+    p->ana_parity = false;
+    p->ana_parity_defect = -1.0;
+    if (!p->sym_ns || nlat % 4 != 0 || R > kOpRows) return SHG_OK;
+    const size_t count = (size_t)S * 2 * RE * (nlat / 2);
+    if (!p->ana_Hp && hipMalloc((void**)&p->ana_Hp, count * sizeof(double)) != hipSuccess) return fail(SHG_ERR_NOMEM, "analysis operator allocation failed");
+    double* norms = nullptr;
+    if (workspace_alloc((void**)&norms, 2 * sizeof(double), stream) != hipSuccess) return fail(SHG_ERR_NOMEM, "shg_analysis: workspace allocation failed");
+    SHG_HIP(hipMemsetAsync(norms, 0, 2 * sizeof(double), stream));
+    hipLaunchKernelGGL(analysis_parity_kernel, dim3(2 * RE, S), dim3(256), 0, stream, N, nmin, nlat, p->ana_H, p->ana_Hp, norms);
+    double host[2] = {0.0, 0.0};
+    SHG_HIP(hipMemcpyAsync(host, norms, sizeof(host), hipMemcpyDeviceToHost, stream));
+    SHG_HIP(hipStreamSynchronize(stream));
+    (void)hipFreeAsync(norms, stream);
+    p->ana_parity_defect = host[0] > 0.0 ? host[1] / host[0] : 0.0;
+    p->ana_parity = p->ana_parity_defect <= kParityDefectMax;
+    return SHG_OK;
 }
 
 // builds p->ana_H for the weights w2 (device, [S][nlat]); returns SHG_ERR_INVALID if a normal matrix is not positive definite
@@ -542,7 +733,7 @@ static int build_analysis_operator(shg_plan* p, const double* w2, int nmin, hipS
     (void)hipFreeAsync(info, stream);
     if (rc) return rc;
     if (bad) return fail(SHG_ERR_INVALID, "shg_analysis: a normal matrix is not positive definite (grid does not resolve the requested degrees)");
-    return SHG_OK;
+    return build_parity_operator(p, nmin, stream);
 }
 
 }  // namespace shg
@@ -611,6 +802,13 @@ static int ensure_analysis_operator(shg_plan* p, const double* area, int nmin, h
     return rebuild_analysis_operator(p, area, nmin, stream);
 }
 
+extern "C" int shg_analysis_info(const shg_plan* p, double info[2]) {
+    SHG_REQUIRE(p != nullptr && info != nullptr, "shg_analysis_info: NULL argument");
+    info[0] = p->ana_nmin < 0 ? -1.0 : (p->ana_parity && SHG_ANA_PARITY ? 1.0 : 0.0);
+    info[1] = p->ana_parity_defect;
+    return SHG_OK;
+}
+
 extern "C" int shg_analysis_matrix(shg_plan* p, const double* area, int nmin, double* F, void* stream_) {
     SHG_REQUIRE(p != nullptr, "shg_analysis_matrix: NULL plan");
     SHG_REQUIRE(nmin >= 0 && nmin <= p->N, "shg_analysis_matrix: min_degree %d out of range", nmin);
@@ -668,6 +866,24 @@ static int folded_transform(shg_plan* p, const double* grid, const double* area,
     return rc;
 }
 
+// The fused transform kernel for `nb` epochs starting at `values` -> gt [S][nb][nlat] (degrees up to 126, four-fold meridian symmetry)
+static int launch_fused_transform(shg_plan* p, const double* values, const double* area, int nb, double* gt, hipStream_t stream) {
+    const int N = p->N, nlat = p->nlat, nlon = p->nlon;
+    const unsigned blocks = (unsigned)ceil_div64((long long)nb * nlat, kAtRows);
+    const int mt = N <= 64 ? 2 : (N <= 96 ? 3 : 4);           // (N + 1) / 2 orders per group at most: 32 | 48 | 64
+    const int rc = ensure_transform_table(p, mt, stream);
+    if (rc) return rc;
+#define SHG_ANA_LAUNCH(MT_, RW_)                                                                                                       \
+    hipLaunchKernelGGL((analysis_transform_kernel<MT_, RW_>), dim3(blocks), dim3(256), 0, stream, nb, nlat, nlon, N, values, area, p->ana_trig, gt)
+    if (p->ana_rowconst) {
+        if (mt == 2) SHG_ANA_LAUNCH(2, true); else if (mt == 3) SHG_ANA_LAUNCH(3, true); else SHG_ANA_LAUNCH(4, true);
+    } else {
+        if (mt == 2) SHG_ANA_LAUNCH(2, false); else if (mt == 3) SHG_ANA_LAUNCH(3, false); else SHG_ANA_LAUNCH(4, false);
+    }
+#undef SHG_ANA_LAUNCH
+    return SHG_OK;
+}
+
 // one pass over all epochs with the operator in p->ana_H (workspaces sized for `chunk` epochs)
 static int analysis_pass(shg_plan* p, const double* grid, const double* area, int nmin, int B, int chunk, bool folded, double* wvt, double* gt,
                          double* X, double* anm, hipStream_t stream) {
@@ -687,20 +903,7 @@ static int analysis_pass(shg_plan* p, const double* grid, const double* area, in
             // output rows land in slot order; the two groups of a parity differ by one slot and form one batched call.
             if (N <= 126) {
                 ProfileScope ps(p, 4, stream);
-                const unsigned blocks = (unsigned)ceil_div64(rows, kAtRows);
-                const double* values = grid + (size_t)b0 * nlat * nlon;
-                const int mt = N <= 64 ? 2 : (N <= 96 ? 3 : 4);           // (N + 1) / 2 orders per group at most: 32 | 48 | 64
-                rc = ensure_transform_table(p, mt, stream);
-                if (rc) return rc;
-#define SHG_ANA_LAUNCH(MT_, RW_)                                                                                                       \
-    hipLaunchKernelGGL((analysis_transform_kernel<MT_, RW_>), dim3(blocks), dim3(256), 0, stream, nb, nlat, nlon, N, values, area, p->ana_trig, gt)
-                if (p->ana_rowconst) {
-                    if (mt == 2) SHG_ANA_LAUNCH(2, true); else if (mt == 3) SHG_ANA_LAUNCH(3, true); else SHG_ANA_LAUNCH(4, true);
-                } else {
-                    if (mt == 2) SHG_ANA_LAUNCH(2, false); else if (mt == 3) SHG_ANA_LAUNCH(3, false); else SHG_ANA_LAUNCH(4, false);
-                }
-#undef SHG_ANA_LAUNCH
-                rc = SHG_OK;
+                rc = launch_fused_transform(p, grid + (size_t)b0 * nlat * nlon, area, nb, gt, stream);
             } else {
                 rc = folded_transform(p, grid + (size_t)b0 * nlat * nlon, area, nb, wvt, gt, stream);
             }
@@ -712,7 +915,10 @@ static int analysis_pass(shg_plan* p, const double* grid, const double* area, in
         }
         if (rc) return rc;
         ProfileScope ps(p, 5, stream);
-        if (R <= kOpRows && nlat % 2 == 0) {
+        if (p->ana_parity && SHG_ANA_PARITY) {
+            hipLaunchKernelGGL(analysis_operator_parity_kernel, dim3((unsigned)(8 * ceil_div(S, 8) * ceil_div(nb, kOpCols))), dim3(256), 0, stream, N, nmin, nlat, nb, b0,
+                               ceil_div(nb, kOpCols), p->ana_Hp, gt, anm);
+        } else if (R <= kOpRows && nlat % 2 == 0) {
             hipLaunchKernelGGL(analysis_operator_kernel, dim3((unsigned)(8 * ceil_div(S, 8) * ceil_div(nb, kOpCols))), dim3(256), 0, stream, N, nmin, nlat, nb, b0,
                                ceil_div(nb, kOpCols), p->ana_H, gt, anm);
         } else {

@@ -232,6 +232,9 @@ struct shg_plan {
     size_t cpk4_zeroed = 0;
     // analysis operator cache (analysis.hip): H[S][N+1][nlat] for the area weights ana_area and min degree ana_nmin
     double* ana_H = nullptr;
+    double* ana_Hp = nullptr;   // north-south parity form of the operator [S][2 ceil((N+1)/2)][nlat/2] (analysis.hip), valid when ana_parity
+    bool ana_parity = false;
+    double ana_parity_defect = -1.0;   // largest dropped entry / largest entry of H when ana_Hp was formed (-1: not formed)
     double* ana_area = nullptr; // [nlat][nlon] copy of the area weights the operator was built for (compared on the device per call)
     int ana_nmin = -1;
     bool ana_rowconst = false;  // the weights of the cached operator are constant along every parallel (geographic and Gauss grids)

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void order_major_kernel(int N, int B, int Bpad
 
 // Y_s [n x Bpad] = W_s [n x n] X_s [n x Bpad], one workgroup per (slot s, slice of 32 EG epochs).  The slice of X_s is staged in the
 // LDS ONCE, in one burst of independent loads, and serves every row tile of the slot (wave w takes the tiles w, w + 4, ...); what is left
-// in the K loop is one 16-byte range-checked buffer load of block entries per lane and pair of k-steps, requested kOmDepth steps ahead,
+// in the K loop is one 16-byte range-checked buffer load of block entries per lane and pair of k-steps -- all of a row tile requested at once --
 // and two ds_read_b128.  (Round 5 had one workgroup per (slot, row tile) with the rows of X read from L2 inside the K loop, three steps
 // in flight: the 16 dependent steps of the longest slots, each waiting out a memory round trip, were the critical path of the launch --
 // 30 us for 13 us of HBM time.)  The products and their order are those of orderwise_filter_kernel, the results bit-identical:
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void order_major_kernel(int N, int B, int Bpad
 // Workgroup b runs on XCD b % 8: all slices of a slot go to one XCD (they share the slot's block in its L2), the slots -- by decreasing
 // length, i.e. in their own order -- in a snake over the XCDs so that every XCD gets about the same arithmetic, the long ones first.
 // Slots whose rows do not fit the stage (kc rows) re-stage chunk by chunk for every pass of four row tiles.
-constexpr int kOmDepth = 4;            // steps of 8 columns whose block entries are in flight per wave
+constexpr int kOmSteps = 16;           // steps of 8 columns whose block entries a wave requests at once: a whole row tile up to d/o 127
 template <int EG>
 __global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N, int Bpad, int nslice, int kc, const double* __restrict__ blocks,
                                                                   const long long* __restrict__ block_off, const double* __restrict__ in,
@@ -394,16 +394,17 @@ __global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N,
     // rows [k0, k0 + rows) of the slice -> stage; rows beyond the block and pairs beyond the series are zero
     auto stage = [&](int k0, int rows) {
         constexpr int RPP = 256 / PR;                                           // rows per pass of the workgroup
-        const int j = tid % PR, r_in = tid / PR;
-        for (int r = r_in; r < rows; r += 4 * RPP) {
-            double2_t v[4];
+        constexpr int UN = 16;                                                  // loads of a thread in flight: ALL rows of a d/o-120 slice at once
+        const int j = tid % PR, r_in = tid / PR;                                // (a staging loop of four loads at a time was four memory
+        for (int r = r_in; r < rows; r += UN * RPP) {                           //  round trips in a row: 10 us for the longest slots)
+            double2_t v[UN];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 const int k = k0 + r + u * RPP;
                 v[u] = (r + u * RPP < rows && k < n && j < npair) ? X[(size_t)k * ldx + j] : zero2;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < UN; ++u)
                 if (r + u * RPP < rows) om_stage[(r + u * RPP) * PR + j] = v[u];
         }
     };
@@ -428,13 +429,16 @@ __global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N,
                 __syncthreads();
             }
             if (active) {
-                double2_t a[kOmDepth];
+                // ALL block entries of this row tile for up to 128 columns are requested at once (16 loads of 16 bytes per lane): one memory
+                // round trip per row tile, where a window of four steps in flight was one round trip per step (the blocks come from HBM and
+                // a step is 0.2 us of MFMAs)
+                for (int k1 = k0; k1 < kend; k1 += 8 * kOmSteps) {
+                    double2_t a[kOmSteps];
 #pragma unroll
-                for (int d = 0; d < kOmDepth; ++d) a[d] = load_a(k0 + 8 * d);        // (beyond the packed blocks the range check returns 0)
-                for (int c = k0; c < kend; c += 8 * kOmDepth) {
+                    for (int d = 0; d < kOmSteps; ++d) a[d] = k1 + 8 * d < kend ? load_a(k1 + 8 * d) : zero2;       // (beyond the packed blocks the range check returns 0)
 #pragma unroll
-                    for (int d = 0; d < kOmDepth; ++d) {
-                        const int cc = c + 8 * d;
+                    for (int d = 0; d < kOmSteps; ++d) {
+                        const int cc = k1 + 8 * d;
                         if (cc < kend) {
                             const double2_t* xr = om_stage + (cc - k0 + 2 * fk) * PR + fr;
 #pragma unroll
@@ -446,7 +450,6 @@ __global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N,
                                 acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].y, x1.y, acc[q][1][1], 0, 0, 0);
                             }
                         }
-                        a[d] = load_a(cc + 8 * kOmDepth);
                     }
                 }
             }
@@ -471,6 +474,33 @@ __global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N,
 }
 
 }  // namespace shg
+
+namespace shg {
+// degree-wise scaling of an order-major series: row (slot s, k) holds degree n = m + k of all epochs; rows below `nfirst` are copied
+__global__ __launch_bounds__(256) void degree_scale_om_kernel(int N, int nfirst, int Bpad, const double* __restrict__ w, const double* __restrict__ in,
+                                                              double* __restrict__ out) {
+    const int s = blockIdx.x, m = (s + 1) >> 1, n = N + 1 - m;
+    const size_t first = (size_t)om_row(N, s) * Bpad;
+    const int pairs = Bpad / 2;
+    const double2_t* x = reinterpret_cast<const double2_t*>(in + first);
+    double2_t* y = reinterpret_cast<double2_t*>(out + first);
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < n * pairs; e += gridDim.y * 256) {
+        const int degree = m + e / pairs;
+        const double f = degree >= nfirst ? w[degree] : 1.0;
+        const double2_t v = x[e];
+        y[e] = degree >= nfirst ? (double2_t){v.x * f, v.y * f} : v;
+    }
+}
+}  // namespace shg
+
+extern "C" int shg_degree_scale_om(const double* w, int N, int nfirst, const double* om_in, int B, int Bpad, double* om_out, void* stream_) {
+    SHG_REQUIRE(N >= 0 && B >= 0 && Bpad >= B && Bpad % 32 == 0, "shg_degree_scale_om: need N >= 0, 0 <= B <= Bpad, Bpad a multiple of 32");
+    if (B == 0) return SHG_OK;
+    SHG_REQUIRE(w && om_in && om_out, "shg_degree_scale_om: NULL pointer");
+    hipLaunchKernelGGL(shg::degree_scale_om_kernel, dim3(2 * N + 1, 4), dim3(256), 0, (hipStream_t)stream_, N, nfirst, Bpad, w, om_in, om_out);
+    SHG_HIP(hipGetLastError());
+    return SHG_OK;
+}
 
 extern "C" int shg_order_major_pack(const double* anm, int N, int B, double* om, int Bpad, void* stream_) {
     SHG_REQUIRE(N >= 0 && B >= 0 && Bpad >= B && Bpad % 32 == 0, "shg_order_major_pack: need N >= 0, 0 <= B <= Bpad, Bpad a multiple of 32");

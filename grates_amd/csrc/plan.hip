@@ -534,7 +534,7 @@ extern "C" int shg_plan_create(shg_plan** out, int N, int nlat, const double* co
 extern "C" int shg_plan_destroy(shg_plan* p) {
     if (!p) return SHG_OK;
     double* ptrs[] = {p->ct, p->st, p->pmm, p->knT, p->arec, p->brec, p->trig, p->trig_f, p->lon, p->colat,
-                      p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->pkf, p->pkf32, p->cpk4, p->cov_partial, p->cov_pad, p->ana_H, p->ana_area, p->ana_trig, p->rot_trig};
+                      p->pk_deg, p->cs_slot, p->cpk, p->F, p->pk, p->pkf, p->pkf32, p->cpk4, p->cov_partial, p->cov_pad, p->ana_H, p->ana_Hp, p->ana_area, p->ana_trig, p->rot_trig};
     if (p->rslot) (void)hipFree(p->rslot);
     if (p->qoff) (void)hipFree(p->qoff);
     if (p->badmap_d) (void)hipFree(p->badmap_d);

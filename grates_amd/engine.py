@@ -257,6 +257,12 @@ class Plan:
     _analysis_token = None
     _analysis_weights = None
 
+    def analysis_info(self):
+        """{'parity_split': True | False | None (no operators yet), 'parity_defect': float} of the cached analysis operators (include/shg.h)"""
+        info = (ctypes.c_double * 2)()
+        _lib.call('shg_analysis_info', self._handle, ctypes.addressof(info))
+        return {'parity_split': None if info[0] < 0 else bool(info[0]), 'parity_defect': float(info[1])}
+
     def analysis_matrix(self, area, min_degree):
         """Dense analysis operator F [P, nlat * nlon] (device tensor) for the area weights `area`: F @ values = analysis(values)."""
         torch = _torch()
@@ -623,6 +629,70 @@ class OrderMajorSeries:
         out = torch.empty((B, N + 1, N + 1), dtype=torch.float64, device=self.data.device)
         _lib.call('shg_order_major_unpack', _ptr(self.data), N, B, self.padded_epochs, _ptr(out), _stream())
         return out
+
+    @property
+    def values(self):
+        """the coefficients of the epochs that exist, [(N+1)^2, B]: a view of `data` (row stride = padded epochs)"""
+        return self.data[:, :self.epochs]
+
+    def like(self, data):
+        return OrderMajorSeries(data, self.max_degree, self.epochs)
+
+    def truncated(self, max_degree):
+        """the series of the degrees up to `max_degree` (<= the own one): rows gathered on the device"""
+        if max_degree == self.max_degree:
+            return self
+        if max_degree > self.max_degree:
+            raise ValueError('the series holds degrees up to {0}'.format(self.max_degree))
+        torch = require_gpu()
+        N, M = self.max_degree, int(max_degree)
+        rows = np.concatenate([order_major_first_row(N, s) + np.arange(M + 1 - ((s + 1) >> 1)) for s in range(2 * M + 1)])
+        index = torch.from_numpy(rows.astype(np.int64)).to(self.data.device)
+        return OrderMajorSeries(self.data.index_select(0, index), M, self.epochs)
+
+    def to_array(self, min_degree=0):
+        """[B, P] device tensor of the degree-wise vectors (TimeSeries.to_array, grates/gravityfield.py:973-980)"""
+        torch = require_gpu()
+        index = torch.from_numpy(order_major_rows_of_degreewise(self.max_degree, min_degree)).to(self.data.device)
+        return self.values.index_select(0, index).t().contiguous()
+
+
+def order_major_first_row(N, s):
+    """first row of slot s (0: order 0 cosine, 2m - 1: order m cosine, 2m: order m sine) in a series of degree N (csrc/filters.hip: om_row)"""
+    if s == 0:
+        return 0
+    m = (s + 1) >> 1
+    cos_row = (N + 1) + 2 * ((m - 1) * (N + 1) - m * (m - 1) // 2)
+    return cos_row if s & 1 else cos_row + (N + 1 - m)
+
+
+_om_index_cache = {}
+
+
+def order_major_rows_of_degreewise(N, min_degree=0):
+    """int64 [P]: the row of an order-major series of degree N that holds entry p of the degree-wise vector of the degrees min_degree .. N
+    (the order of utilities.ravel_coefficients: C_n0, C_n1, S_n1, C_n2, ... per degree)"""
+    key = (int(N), int(min_degree))
+    if key not in _om_index_cache:
+        rows = []
+        for n in range(min_degree, N + 1):
+            rows.append(order_major_first_row(N, 0) + n)
+            for m in range(1, n + 1):
+                rows.append(order_major_first_row(N, 2 * m - 1) + n - m)
+                rows.append(order_major_first_row(N, 2 * m) + n - m)
+        _om_index_cache[key] = np.asarray(rows, dtype=np.int64)
+    return _om_index_cache[key]
+
+
+def degree_scale_series(series, weights, first_degree=0):
+    """degree-wise scaling (Gaussian / Butterworth) of every epoch of an OrderMajorSeries; degrees below `first_degree` are copied"""
+    torch = require_gpu()
+    w = to_device(weights)
+    if w.numel() != series.max_degree + 1:
+        raise ValueError('weights must have max_degree + 1 entries')
+    out = torch.empty_like(series.data)
+    _lib.call('shg_degree_scale_om', _ptr(w), series.max_degree, int(first_degree), _ptr(series.data), series.epochs, series.padded_epochs, _ptr(out), _stream())
+    return series.like(out)
 
 
 def orderwise_filter_series(blocks_packed, block_offsets, block_max_degree, series):

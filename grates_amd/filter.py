@@ -15,7 +15,7 @@ import numpy as np
 
 from . import data, engine, kernel as _kernel, utilities
 from . import gravityfield as _gravityfield
-from .gravityfield import PotentialCoefficients
+from .gravityfield import PotentialCoefficients, TimeSeries
 
 
 class SpatialFilter(metaclass=abc.ABCMeta):
@@ -52,6 +52,16 @@ class SpatialFilter(metaclass=abc.ABCMeta):
         result.anm = engine.to_host(self.filter_batch(gravityfield.anm[np.newaxis, :, :])[0])
         return result
 
+    def filter_series(self, series):
+        """Filter every epoch of an engine.OrderMajorSeries; the default goes through the reference arrays (`filter_batch`), the
+        order-wise, degree-wise and dense filters work on the series itself."""
+        return engine.OrderMajorSeries.from_batch(self.filter_batch(series.to_batch()))
+
+    def _filter_timeseries(self, series):
+        """`filter(TimeSeries)`: the series is filtered on the device, all epochs in one call, and stays there (extension of the
+        reference's `filter`, which takes one PotentialCoefficients: grates/filter.py:44-72, 153-191, 456-479)."""
+        return series._with_series(self.filter_series(series.to_device()))
+
 
 class _DegreeWiseFilter(SpatialFilter):
     """Filters that scale every coefficient by a factor w_n of its degree."""
@@ -66,7 +76,12 @@ class _DegreeWiseFilter(SpatialFilter):
         nmax = anm_batch.shape[-1] - 1
         return engine.degree_scale(anm_batch, self.weights(nmax), self.first_degree)
 
+    def filter_series(self, series):
+        return engine.degree_scale_series(series, self.weights(series.max_degree), self.first_degree)
+
     def filter(self, gravityfield):
+        if isinstance(gravityfield, TimeSeries):
+            return self._filter_timeseries(gravityfield)
         self._check(gravityfield)
         return self._filter_single(gravityfield)
 
@@ -145,7 +160,9 @@ class OrderWiseFilter(SpatialFilter):
 
     def filter(self, gravityfield):
         """Filtered copy; degrees 0 and 1 are restored from the input; ValueError above the block degree
-        (grates/filter.py:172-191)."""
+        (grates/filter.py:172-191).  A TimeSeries is filtered as a whole on the device (`filter_series`) and stays there."""
+        if isinstance(gravityfield, TimeSeries):
+            return self._filter_timeseries(gravityfield)
         self._check(gravityfield)
         return self._filter_single(gravityfield)
 
@@ -244,6 +261,7 @@ class GeneralMatrix(SpatialFilter):
         self.__nmin = min_degree
         self.__nmax = max_degree
         self.__device_W = None
+        self.__device_W_om = None
 
     def filter_batch(self, anm_batch):
         """
@@ -263,7 +281,37 @@ class GeneralMatrix(SpatialFilter):
         out[:, 0:k, 0:k] = x_in[:, 0:k, 0:k]
         return out
 
+    def _order_major_matrix(self):
+        """W in the row / column order of an order-major series of degree nmax, the identity on the degrees below min_degree (which the
+        filter restores from the input): one permuted copy on the device, built on first use"""
+        if self.__device_W_om is None:
+            torch = engine.require_gpu()
+            if self.__device_W is None:
+                self.__device_W = engine.to_device(self.__W)
+            n_all = (self.__nmax + 1) ** 2
+            rows = torch.from_numpy(engine.order_major_rows_of_degreewise(self.__nmax, self.__nmin)).to(self.__device_W.device)
+            W_om = torch.zeros((n_all, n_all), dtype=torch.float64, device=self.__device_W.device)
+            low = torch.from_numpy(engine.order_major_rows_of_degreewise(self.__nmax, 0)[0:self.__nmin ** 2]).to(rows.device)
+            W_om[low, low] = 1.0
+            W_om[rows[:, None], rows[None, :]] = self.__device_W
+            self.__device_W_om = W_om
+        return self.__device_W_om
+
+    def filter_series(self, series):
+        """Y = W X on the order-major series itself: the rows and columns of W are permuted once, every call is then ONE product on the
+        fp64 MFMA GEMM -- no ravel, no unravel.  (A series of another degree than the filter's goes through the reference arrays.)"""
+        if series.max_degree != self.__nmax:
+            return super(GeneralMatrix, self).filter_series(series)
+        torch = engine.require_gpu()
+        out = torch.empty_like(series.data)
+        if series.padded_epochs > series.epochs:
+            out[:, series.epochs:] = 0.0
+        engine.gemm(self._order_major_matrix(), series.values, out=out[:, :series.epochs])
+        return series.like(out)
+
     def filter(self, gravityfield):
+        if isinstance(gravityfield, TimeSeries):
+            return self._filter_timeseries(gravityfield)
         return self._filter_single(gravityfield)
 
     def matrix(self, min_degree, max_degree):

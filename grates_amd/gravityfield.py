@@ -297,7 +297,7 @@ def synthesize(anm_batch, grid, kernel='ewh', GM=3.9860044150e+14, R=6.378136300
     [B, nlat, nlon] for regular grids or [B, npts] for point lists.  This is the entry point the
     benchmark times; ``PotentialCoefficients.to_grid`` and ``TimeSeries.to_grid`` are thin wrappers.
     """
-    max_degree = anm_batch.shape[-1] - 1
+    max_degree = anm_batch.max_degree if isinstance(anm_batch, engine.OrderMajorSeries) else anm_batch.shape[-1] - 1
     ker = _kernel.get_kernel(kernel)
     try:
         parallels, meridians = grid.parallels, grid.meridians
@@ -307,6 +307,8 @@ def synthesize(anm_batch, grid, kernel='ewh', GM=3.9860044150e+14, R=6.378136300
             return colat, grid.longitude, kn
         colat, lon, kn = engine.cached_point_tables(max_degree, grid.latitude, grid.longitude,
                                                     (str(kernel), float(GM), float(R), float(grid.semimajor_axis), float(grid.flattening)), build)
+        if isinstance(anm_batch, engine.OrderMajorSeries):
+            anm_batch = anm_batch.to_batch()
         return engine.synthesis_points(max_degree, colat, lon, kn, anm_batch)
     colat, _, kn = surface_factors(ker, max_degree, parallels, GM, R, grid.semimajor_axis, grid.flattening)
     plan = engine.cached_plan(max_degree, colat, kn, meridians)
@@ -316,7 +318,12 @@ def synthesize(anm_batch, grid, kernel='ewh', GM=3.9860044150e+14, R=6.378136300
 class TimeSeries:
     """
     Time series of gravity fields of one type, sorted by epoch (grates/gravityfield.py:815-1052).
-    `to_array` / `to_grid` are the batching entry points of the GPU path.
+
+    Beside the reference's list of fields the series can live ON THE DEVICE as an `engine.OrderMajorSeries` (coefficients of all epochs,
+    epochs fastest, laid out for the order-wise operators): `to_device()` builds it once, `filter.*.filter(series)`, `detrend` and
+    `to_grid` then work on it without the coefficients ever passing through host arrays, and the fields are only materialised again
+    when something asks for them (`series[k]`, `items()`, arithmetic).  Whoever receives field objects may modify them, so handing
+    them out ends the device residency (the next device operator packs the fields again).
     """
 
     def __init__(self, data):
@@ -327,35 +334,107 @@ class TimeSeries:
                 raise ValueError("Found inconsistent data types (" + str(self.__dtype) + " and " + str(type(d)) + ")")
             if d.epoch is None:
                 raise ValueError("At least one data point has no valid time stamp")
+        self.__series = None            # engine.OrderMajorSeries in the order of the (sorted) epochs, or None
+        self.__meta = None              # (epochs, GM, R) of a series without materialised fields
         self.sort()
 
+    @classmethod
+    def from_series(cls, series, epochs, GM=3.9860044150e+14, R=6.3781363000e+06):
+        """A device-resident series of PotentialCoefficients: `series` an engine.OrderMajorSeries (or a coefficient batch
+        [T, N+1, N+1], packed here) whose epochs carry the time stamps `epochs` (ascending)."""
+        epochs = list(epochs)
+        if not isinstance(series, engine.OrderMajorSeries):
+            series = engine.OrderMajorSeries.from_batch(series)
+        if series.epochs != len(epochs) or len(epochs) == 0:
+            raise ValueError('one time stamp per epoch of the series expected')
+        if any(e is None for e in epochs):
+            raise ValueError("At least one data point has no valid time stamp")
+        if any(b < a for a, b in zip(epochs, epochs[1:])):
+            raise ValueError('the epochs of a device series must be ascending')
+        self = cls.__new__(cls)
+        self.__data = None
+        self.__dtype = PotentialCoefficients
+        self.__series = series
+        self.__meta = (epochs, GM, R)
+        return self
+
+    # ---- the two representations
+    def _fields(self, keep_series=False):
+        """the list of fields; built from the device series on first use.  Unless `keep_series`, the device copy is dropped: the
+        caller may change the fields it gets."""
+        if self.__data is None:
+            epochs, GM, R = self.__meta
+            host = engine.to_host(self.__series.to_batch())
+            self.__data = []
+            for k, epoch in enumerate(epochs):
+                gf = PotentialCoefficients(GM, R)
+                gf.anm = host[k].copy()
+                gf.epoch = epoch
+                self.__data.append(gf)
+        if not keep_series:
+            self.__series = None
+        return self.__data
+
+    @property
+    def on_device(self):
+        return self.__series is not None
+
+    def to_device(self):
+        """The series as engine.OrderMajorSeries (built on first use; PotentialCoefficients of one GM and R only, fields of a lower
+        degree zero-padded).  Stays valid until fields are handed out."""
+        if self.__series is None:
+            fields = self.__data
+            if self.__dtype is not PotentialCoefficients and not all(isinstance(d, PotentialCoefficients) for d in fields):
+                raise TypeError('only a series of PotentialCoefficients can be kept on the device')
+            GM, R = fields[0].GM, fields[0].R
+            if any(d.GM != GM or d.R != R for d in fields):
+                raise ValueError("batched operators need a common GM and R for all epochs")
+            self.__series = engine.OrderMajorSeries.from_batch(TimeSeries._stack(fields))
+            self.__meta = ([d.epoch for d in fields], GM, R)
+        return self.__series
+
+    def _constants(self):
+        if self.__data is not None:
+            return self.__data[0].GM, self.__data[0].R
+        return self.__meta[1], self.__meta[2]
+
+    def _with_series(self, series):
+        """a new device-resident series with the epochs and constants of this one (the result of a device operator)"""
+        GM, R = self._constants()
+        return TimeSeries.from_series(series, self.epochs(), GM, R)
+
     def __len__(self):
-        return len(self.__data)
+        return len(self.__data) if self.__data is not None else self.__series.epochs
 
     def __getitem__(self, index):
-        return self.__data[index]
+        return self._fields()[index]
 
     def __setitem__(self, index, value):
         if not isinstance(value, self.__dtype):
             raise ValueError("Inconsistent data types (" + str(self.__dtype) + " and " + str(type(value)) + ")")
-        self.__data[index] = value
+        self._fields()[index] = value
         self.sort()
 
     def copy(self):
+        if self.__data is None:
+            return self._with_series(self.__series.like(self.__series.data.clone()))
         return TimeSeries([d.copy() for d in self.__data])
 
     def __add__(self, other):
         if len(self) != len(other):
             raise ValueError("Length of time series differs")
+        mine = self._fields(keep_series=True)
         summed = []
         for k in range(len(self)):
-            if self.__data[k].epoch != other[k].epoch:
+            if mine[k].epoch != other[k].epoch:
                 raise ValueError("Time stamps of elements differ")
-            summed.append(self.__data[k] + other[k])
+            summed.append(mine[k] + other[k])
         return TimeSeries(summed)
 
     def __mul__(self, factor):
         _check_operand(self, factor, (int, float), '*')
+        if self.__data is None:
+            return self._with_series(self.__series.like(self.__series.data * factor))
         return TimeSeries([d.copy() * factor for d in self.__data])
 
     def __truediv__(self, divisor):
@@ -366,24 +445,32 @@ class TimeSeries:
         return self + other * -1
 
     def sort(self):
-        self.__data.sort(key=lambda d: d.epoch)
+        if self.__data is None:
+            return                                                  # (a device series is created with ascending epochs)
+        order = sorted(range(len(self.__data)), key=lambda k: self.__data[k].epoch)
+        if order != list(range(len(order))):
+            self.__data[:] = [self.__data[k] for k in order]
+            self.__series = None
 
     def items(self):
-        for d in self.__data:
+        for d in self._fields():
             yield d.epoch, d
 
     def epochs(self):
+        if self.__data is None:
+            return list(self.__meta[0])
         return [d.epoch for d in self.__data]
 
     def interpolate_to(self, epoch):
         """Piecewise linear interpolation to `epoch`; no extrapolation (grates/gravityfield.py:937-947)."""
-        t = np.array([d.epoch for d in self.__data])
+        data = self._fields(keep_series=True)
+        t = np.array([d.epoch for d in data])
         if t.size < 2:
             raise ValueError("at least two data points are required for interpolation")
         if not (t[0] <= epoch <= t[-1]):
             raise ValueError('{0} lies outside the series ({1} .. {2}): no extrapolation'.format(epoch, t[0], t[-1]))
         right = np.searchsorted(t, epoch)                     # first element at or after the epoch (as upstream: side='left')
-        before, after = self.__data[right - 1], self.__data[right]
+        before, after = data[right - 1], data[right]
         w = (epoch - before.epoch).total_seconds() / (after.epoch - before.epoch).total_seconds()
         blend = before * (1 - w) + after * w
         blend.epoch = epoch
@@ -394,6 +481,8 @@ class TimeSeries:
 
     def to_array(self):
         """Time series as (epochs, parameters) array of the degree-wise vectors (grates/gravityfield.py:973-980)."""
+        if self.__data is None:
+            return engine.to_host(self.__series.to_array())
         count = self.__data[0].values.size
         out = np.empty((len(self.__data), count))
         for k, d in enumerate(self.__data):
@@ -410,29 +499,35 @@ class TimeSeries:
 
     def to_coefficient_batch(self):
         """Stack anm of all epochs into [T, N+1, N+1] (zero-padded to the largest degree): GPU batch layout."""
+        if self.__data is None:
+            return engine.to_host(self.__series.to_batch())
         return TimeSeries._stack(self.__data)
 
     def to_grid(self, grid=None, kernel='ewh', as_tensor=False):
         """
-        Synthesize every epoch in one batched GPU call.  Returns a list of grids (copies of `grid` with
-        values and epoch set) or, with as_tensor=True, the device tensor [T, nlat, nlon].
-        All epochs must share GM and R.
+        Synthesize every epoch in one batched GPU call (from the device series when there is one: the coefficients never pass
+        through host arrays).  Returns a list of grids (copies of `grid` with values and epoch set) or, with as_tensor=True, the
+        device tensor [T, nlat, nlon].  All epochs must share GM and R.
         """
         from . import grid as _grid
         if grid is None:
             grid = _grid.GeographicGrid()
-        GM, R = self.__data[0].GM, self.__data[0].R
-        if any(d.GM != GM or d.R != R for d in self.__data):
-            raise ValueError("batched synthesis needs a common GM and R for all epochs")
-        values = synthesize(self.to_coefficient_batch(), grid, kernel, GM, R)
+        if self.__series is not None:
+            GM, R = self._constants()
+            values = synthesize(self.__series, grid, kernel, GM, R)
+        else:
+            GM, R = self.__data[0].GM, self.__data[0].R
+            if any(d.GM != GM or d.R != R for d in self.__data):
+                raise ValueError("batched synthesis needs a common GM and R for all epochs")
+            values = synthesize(self.to_coefficient_batch(), grid, kernel, GM, R)
         if as_tensor:
             return values
         host = engine.to_host(values)
         out = []
-        for k, d in enumerate(self.__data):
+        for k, epoch in enumerate(self.epochs()):
             g = grid.copy()
             g.values = host[k].ravel().copy()
-            g.epoch = d.epoch
+            g.epoch = epoch
             out.append(g)
         return out
 
@@ -440,16 +535,26 @@ class TimeSeries:
         """
         Estimate and remove a parametric temporal model in place (grates/gravityfield.py:1002-1012); `basis_functions` are
         `utilities.Polynomial` / `utilities.Oscillation` instances.  The pseudo-inverse of the [T, k] design matrix is host work;
-        the two products over all coefficients (k x T x P and T x k x P) run on the fp64 GEMM of the device.
+        the two products over all coefficients (k x T x P and T x k x P) run on the fp64 GEMM of the device -- on the device series
+        itself when there is one (the residuals stay there), else on the stacked degree-wise vectors of the fields.
         """
         t = self.epochs()
         design = np.hstack([bf.design_matrix(t) for bf in basis_functions])
+        pinv = np.linalg.pinv(design)
+        if self.__data is None:
+            series = self.__series
+            obs = series.values                                                       # [P rows, T], rows in order-major order
+            trend_t = engine.gemm(obs, pinv, transb=True)                             # [P, k] = obs pinv^T
+            engine.gemm(trend_t, design, transb=True, alpha=-1.0, beta=1.0, out=obs)  # obs -= trend^T design^T
+            rows = engine.order_major_rows_of_degreewise(series.max_degree)
+            return np.ascontiguousarray(engine.to_host(trend_t)[rows].T)
         observations = engine.to_device(self.to_array())
-        trend = engine.gemm(np.linalg.pinv(design), observations)
+        trend = engine.gemm(pinv, observations)
         engine.gemm(design, trend, alpha=-1.0, beta=1.0, out=observations)
         residuals = engine.to_host(observations)
         for k, d in enumerate(self.__data):
             d.values = residuals[k, :]
+        self.__series = None
         return engine.to_host(trend)
 
     def bin(self, bin_center_epochs, func=np.mean, no_data=np.nan):
@@ -460,11 +565,12 @@ class TimeSeries:
         never used).  As upstream, numpy.mean of PotentialCoefficients ends in a
         TypeError (division by a numpy integer): pass e.g. ``lambda v: sum(v[1:], v[0]) * (1.0 / len(v))``.
         """
+        data = self._fields(keep_series=True)
         centers = list(bin_center_epochs)
         nearest = [int(np.argmin([abs((e - c).total_seconds()) for c in centers])) for e in self.epochs()]
         binned = []
         for k, center in enumerate(centers):
-            members = [self.__data[i] for i, b in enumerate(nearest) if b == k]
+            members = [data[i] for i, b in enumerate(nearest) if b == k]
             if not members:
                 raise ValueError('no element of the time series falls into the bin centred at {0}'.format(center))
             value = func(members)
@@ -473,8 +579,9 @@ class TimeSeries:
         return TimeSeries(binned)
 
     def append(self, other):
+        data = self._fields()
         for _, d in other.items():
-            self.__data.append(d)
+            data.append(d)
         self.sort()
 
 

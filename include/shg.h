@@ -193,12 +193,14 @@ int shg_dense_filter(const double* W, int P, const double* X, int T, double* Y, 
  *   shg_order_major_pack / _unpack   from / to the reference arrays anm [B][N+1][N+1]
  *   shg_orderwise_filter_om          OrderWiseFilter.filter of all epochs: Y_s = W_s X_s per slot on whole matrices (no gather / scatter);
  *                                    degrees 0 and 1 keep the input, N <= Nb as in shg_orderwise_filter
+ *   shg_degree_scale_om              shg_degree_scale (Gaussian / Butterworth) of all epochs of a series
  *   shg_synthesis_om                 shg_synthesis of a series of degree Ns >= the plan's N (higher degrees are not read); fused kernels on
  *                                    parallels symmetric about the equator only (SHG_ERR_INVALID otherwise: unpack the series) */
 int shg_order_major_pack(const double* anm, int N, int B, double* om, int Bpad, void* stream);
 int shg_order_major_unpack(const double* om, int N, int B, int Bpad, double* anm, void* stream);
 int shg_orderwise_filter_om(const double* blocks_packed, const int64_t* block_off, int Nb, int N, const double* om_in, int B, int Bpad,
                             double* om_out, void* stream);
+int shg_degree_scale_om(const double* w /* [N+1] device */, int N, int nfirst, const double* om_in, int B, int Bpad, double* om_out, void* stream);
 int shg_synthesis_om(shg_plan* plan, const double* om, int Ns, int B, int Bpad, double* grid, void* stream);
 
 /* DDK block construction  W_k = (N_k + diag(w[m:]))^-1 N_k  for all 2Nb+1 order-wise normal blocks
@@ -299,6 +301,12 @@ int shg_block_multiply(int nb, const int* bounds, const int* rowptr, const int* 
  * waited for; an error if the plan holds no operators for this nmin.
  * ------------------------------------------------------------------------------------------------ */
 int shg_analysis(shg_plan* plan, const double* grid, const double* area, int nmin, int B, double* anm, void* stream);
+
+/* How the cached operators of a plan are applied: info[0] = 1 when the operator product uses the north-south parity split (parallels
+ * that are mirror images of each other, mirror-symmetric weights: x_n = sum over the northern parallels of Hp[n][i] (g[i] +- g[mirror i]),
+ * half the products), 0 for the full product, -1 when the plan holds no operators yet; info[1] = the largest entry of the operators
+ * that the split drops relative to their largest entry (the split is used below 5e-12; asymmetric weights give ~1). */
+int shg_analysis_info(const shg_plan* plan, double info[2]);
 
 /* ------------------------------------------------------------------------------------------------
  * Full-matrix forms of the operators

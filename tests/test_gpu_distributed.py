@@ -376,18 +376,6 @@ def test_bench_rehearsal_world2_and_world4_real_shard_sizes():
         run = subprocess.run(common + ['--gpus', str(world)] + extra, env=env, capture_output=True, text=True, timeout=900)
         assert run.returncode == 0, run.stderr[-2000:]
         lines[world] = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith('{')][-1])
-    # once more with the ranks taking turns on the card (smoother only): what every rank spends on its own segments, i.e. the time a
-    # rank with a GPU of its own would need
-    turns = {}
-    for world in (2, 4):
-        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-        env['GRATES_AMD_REHEARSAL_TURNS'] = '1'
-        run = subprocess.run(common + ['--gpus', str(world), '--backend', 'gloo', '--same-device', '--legs', 'smoother'], env=env, capture_output=True,
-                             text=True, timeout=900)
-        assert run.returncode == 0, run.stderr[-2000:]
-        line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith('{')][-1])
-        assert line['all_checks_ok']
-        turns[world] = line['smoother']['phases_s']['segment_work_s']
     one, two, four = lines[1], lines[2], lines[4]
     assert four['n_gpus'] == 4 and four['all_checks_ok'] and one['all_checks_ok'] and two['n_gpus'] == 2 and two['all_checks_ok']
     assert two['smoother']['config']['epochs_per_rank'] == [256] * 2 and two['smoother']['check']['residual'] < 1e-13
@@ -409,8 +397,6 @@ def test_bench_rehearsal_world2_and_world4_real_shard_sizes():
                            'seconds_world1': one['smoother']['seconds'], 'phases_world1': one['smoother']['phases_s'],
                            'seconds_world2_one_card': two['smoother']['seconds'], 'phases_world2': two['smoother']['phases_s'],
                            'residual_world2': two['smoother']['check']['residual'],
-                           'per_rank_segment_work_s_when_ranks_take_turns': {'world2': turns[2], 'world4': turns[4],
-                                                                            'note': 'max over ranks; single chain (world 1, two segments on two streams): seconds_world1'},
                            'residual_world4': four['smoother']['check']['residual'], 'identity_defect_world4': four['smoother']['check']['identity_defect_max'],
                            'solution_checksum_world1': a, 'solution_checksum_world4': b}}
     print(json.dumps(record))

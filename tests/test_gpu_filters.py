@@ -88,7 +88,7 @@ def test_order_major_series(golden, nmax, ngf, B):
 
 def test_order_major_series_to_grid():
     """DDK-type filter -> synthesis without leaving the device layout: series of degree 120 filtered, synthesised by plans of degree 96
-    and 120 (rotation-folded kernel and the pipelined variants) and by a plan that reads the reference arrays only."""
+    and 120 (rotation-folded and 4-fold kernels) and by a plan that reads the reference arrays only."""
     blocks = inputs.orderwise_random_blocks(7, 120)
     flt = ga.filter.OrderWiseFilter(blocks)
     B = 9
@@ -96,7 +96,7 @@ def test_order_major_series_to_grid():
     filtered = flt.filter_series(ga.engine.OrderMajorSeries.from_batch(batch))
     reference = ga.engine.to_host(flt.filter_batch(batch))
     ker = orc.KernelTable('potential')
-    for N, step, paths in ((96, 0.25, ('auto', 'pipe', 'fed', 'halves')), (120, 0.5, ('auto',)), (60, 3.0, ('auto', 'staged'))):
+    for N, step, paths in ((96, 0.25, ('auto', 'fused')), (120, 0.5, ('auto',)), (60, 3.0, ('auto', 'staged'))):
         grid = ga.grid.GeographicGrid(step, step)
         colat, _, kn = ga.gravityfield.surface_factors(ga.kernel.get_kernel('potential'), N, grid.parallels, 3.9860044150e+14, 6.3781363000e+06,
                                                        grid.semimajor_axis, grid.flattening)
@@ -179,6 +179,92 @@ def test_config3_ddk5_time_series_d120():
     dense = ga.filter.GeneralMatrix(flt.matrix(2, nmax), 2, nmax)             # 14637 x 14637 full normal-type matrix
     out_dense = ga.engine.to_host(dense.filter_batch(batch))
     assert relerr(out_dense, out_blocks) < 1e-12
+
+
+def _series(count, max_degree, seed=700):
+    import datetime as dt
+    fields = []
+    for e in range(count):
+        gf = make_pc(inputs.coefficients(seed + e, max_degree))
+        gf.epoch = dt.datetime(2005, 1, 1) + dt.timedelta(days=30 * e)
+        fields.append(gf)
+    return ga.gravityfield.TimeSeries(fields)
+
+
+def test_device_resident_time_series_chain(golden):
+    """The reference API carrying the device-resident series: `filter.*.filter(TimeSeries)` filters all epochs in
+    one call on an engine.OrderMajorSeries and returns a TimeSeries that stays on the device, `to_grid` reads it through
+    shg_synthesis_om.  The chained result is BIT-IDENTICAL to the per-epoch path of the reference API -- filter(field) and
+    to_grid(field) one epoch at a time --, for the order-wise (DDK-type) filter and the Gaussian; the golden values of the reference
+    at d/o 120; the dense filter to rounding.  Handing out fields ends the residency, nothing else does."""
+    g = golden('g10_filter')
+    nmax, T = 120, 70                                        # (>= 64 epochs: the batch entry point takes the order-major kernels too)
+    ts = _series(T, nmax)
+    assert not ts.on_device
+    flt = ga.filter.OrderWiseFilter(inputs.orderwise_random_blocks(42, nmax))
+    filtered = flt.filter(ts)
+    assert isinstance(filtered, ga.gravityfield.TimeSeries) and filtered.on_device and ts.on_device and len(filtered) == T
+    assert filtered.epochs() == ts.epochs()
+    grid = ga.grid.GeographicGrid(3.0, 3.0)
+    grids = ga.engine.to_host(filtered.to_grid(grid, kernel='ewh', as_tensor=True))
+    assert filtered.on_device                                # to_grid, to_array, epochs, len: no fields handed out
+    arr = filtered.to_array()
+    for e in (0, 1, 33, T - 1):
+        single = flt.filter(ts[e])
+        assert np.array_equal(arr[e], single.values), e                                   # filter: bit-identical to the per-epoch call
+        assert np.array_equal(grids[e], single.to_grid(grid, kernel='ewh').value_array), e   # ... and so is the grid
+    assert not ts.on_device                                  # ts[e] handed fields out
+    gold = make_pc(inputs.coefficients(43, nmax))
+    gold.epoch = ts.epochs()[0]
+    one = flt.filter(ga.gravityfield.TimeSeries([gold]))
+    assert relerr(one[0].anm, g['orderwise_120_120']) < TOL
+    # Gaussian on the series: the same products as the per-epoch call
+    gauss = ga.filter.Gaussian(300)
+    ts = _series(9, 60, seed=900)
+    smooth = gauss.filter(ts)
+    assert smooth.on_device
+    sm = smooth.to_array()
+    for e in (0, 8):
+        assert np.array_equal(sm[e], gauss.filter(_series(9, 60, seed=900)[e]).values)
+    # filters compose on the device; a grid list comes back with the epochs
+    both = gauss.filter(ga.filter.OrderWiseFilter(inputs.orderwise_random_blocks(42, 60)).filter(ts))
+    out = both.to_grid(ga.grid.GeographicGrid(10.0, 10.0), kernel='potential')
+    assert len(out) == 9 and out[3].epoch == ts.epochs()[3] and np.isfinite(out[3].values).all()
+    # dense filter on the series: one product with the permuted matrix
+    blocks20 = inputs.orderwise_random_blocks(42, 20)
+    dense = ga.filter.GeneralMatrix(ga.filter.OrderWiseFilter(blocks20).matrix(2, 20), 2, 20)
+    ts20 = _series(5, 20, seed=950)
+    d_series = dense.filter(ts20).to_array()
+    d_batch = ga.engine.to_host(dense.filter_batch(ts20.to_coefficient_batch()))
+    for e in range(5):
+        assert relerr(d_series[e], orc.ravel_coefficients(d_batch[e], 0, 20)) < TOL
+        assert np.array_equal(d_series[e][0:4], ts20.to_array()[e][0:4])                # degrees 0 and 1 restored
+    with pytest.raises(TypeError):
+        flt.filter(np.zeros((3, 3)))
+
+
+def test_device_resident_time_series_bookkeeping(golden):
+    """to_array / to_coefficient_batch / copy / scaling / detrend of a device-resident series equal those of the list of fields
+    (g10 `timeseries_array` pins the reference's to_array on the same inputs as tests/test_host_logic.py)."""
+    ts = _series(12, 15, seed=40)
+    host_array = ts.to_array()
+    dev = ga.gravityfield.TimeSeries.from_series(ts.to_coefficient_batch(), ts.epochs())
+    assert dev.on_device and len(dev) == 12
+    assert np.array_equal(dev.to_array(), host_array)
+    assert np.array_equal(dev.to_coefficient_batch(), ts.to_coefficient_batch())
+    assert np.array_equal((dev * 2.5).to_array(), (ts * 2.5).to_array())
+    assert np.array_equal(dev.copy().to_array(), host_array) and dev.on_device
+    basis = [ga.utilities.Polynomial(1, ts.epochs()[0])] if hasattr(ga.utilities, 'Polynomial') else None
+    if basis is not None:
+        a, b = ts.copy(), dev.copy()
+        trend_host, trend_dev = a.detrend(basis), b.detrend(basis)
+        assert b.on_device and relerr(trend_dev, trend_host) < 1e-12
+        assert relerr(b.to_array(), a.to_array()) < 1e-9        # (residuals: differences of nearly equal numbers, as in g14)
+    # fields handed out carry epoch, constants and coefficients; the device copy is rebuilt on demand
+    first = dev[0]
+    assert not dev.on_device and first.epoch == ts.epochs()[0] and np.array_equal(first.anm, ts[0].anm)
+    first.anm[2, 0] = 7.0
+    assert dev.to_device() is not None and dev.to_array()[0][4] == 7.0
 
 
 # ------------------------------------------------------------------------------------------------ SURVEY 8(f) rank 2

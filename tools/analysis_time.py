@@ -17,7 +17,7 @@ batch = torch.from_numpy(bench.coefficient_batch(20_000, B, N)).cuda()
 grids = plan.synthesis(batch)
 area = ga.engine.to_device(grid.area.reshape(nlat, nlon))
 out = plan.analysis(grids, area, 0)
-print('round trip max rel err', float(((out - batch).abs().max() / batch.abs().max()).item()))
+print('round trip max rel err', float(((out - batch).abs().max() / batch.abs().max()).item()), plan.analysis_info())
 for rnd in range(3):
     for _ in range(3): plan.analysis(grids, area, 0)
     torch.cuda.synchronize()
@@ -26,3 +26,7 @@ for rnd in range(3):
     for _ in range(20): plan.analysis(grids, area, 0)
     b.record(); torch.cuda.synchronize()
     print('round %d: %.1f us per call' % (rnd, 1e3 * a.elapsed_time(b) / 20), flush=True)
+plan.profile(True); plan.profile_read()
+for _ in range(10): plan.analysis(grids, area, 0)
+torch.cuda.synchronize()
+print({k: (round(1e3 * v[0] / max(v[1], 1), 1), v[1]) for k, v in plan.profile_read().items()}, 'us per launch, launches')

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 import grates_amd as ga
 import inputs
+if len(sys.argv) > 1 and sys.argv[1] != '-':
+    ga._lib.use_library(sys.argv[1])          # an A/B build (make -C grates_amd/csrc variant ...)
 N, B = 120, 240
 flt = ga.filter.OrderWiseFilter(inputs.orderwise_random_blocks(42, N))
 batch = torch.from_numpy(np.stack([inputs.coefficients(43 + e, N) for e in range(B)])).cuda()
