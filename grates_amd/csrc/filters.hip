@@ -249,7 +249,7 @@ static int launch_orderwise(int Nb, int N, int B, const double* blocks, const lo
 #endif
 constexpr int kSeriesMinEpochs = 64;
 #ifndef SHG_OM_EPOCH_GROUPS
-#define SHG_OM_EPOCH_GROUPS 2     // groups of 32 epochs per workgroup of orderwise_filter_om_kernel
+#define SHG_OM_EPOCH_GROUPS 1     // groups of 32 epochs per workgroup of orderwise_filter_om_kernel (1 with three waves per SIMD: 25.8 us; 2 with two: 28.5)
 #endif
 // LDS of order_major_kernel: one row of the reference arrays for 16 epochs (above 64 KB the launch needs the opt-in attribute)
 constexpr size_t kOrderMajorMaxLds = 160 * 1024;
@@ -354,26 +354,46 @@ __global__ __launch_bounds__(256) void order_major_kernel(int N, int B, int Bpad
     }
 }
 
-// Y_s [n x Bpad] = W_s [n x n] X_s [n x Bpad], one workgroup per (slot s, slice of 32 EG epochs).  The slice of X_s is staged in the
-// LDS ONCE, in one burst of independent loads, and serves every row tile of the slot (wave w takes the tiles w, w + 4, ...); what is left
-// in the K loop is one 16-byte range-checked buffer load of block entries per lane and pair of k-steps -- all of a row tile requested at once --
-// and two ds_read_b128.  (Round 5 had one workgroup per (slot, row tile) with the rows of X read from L2 inside the K loop, three steps
-// in flight: the 16 dependent steps of the longest slots, each waiting out a memory round trip, were the critical path of the launch --
-// 30 us for 13 us of HBM time.)  The products and their order are those of orderwise_filter_kernel, the results bit-identical:
-// step c multiplies W[row][c + 2 fk], W[row][c + 2 fk + 1] with the rows c + 2 fk, c + 2 fk + 1 of X in two MFMAs per 16 epochs,
-// the two partial sums are added at the end.  A lane reads two adjacent epochs (16 bytes) of a row of X -- the B operands of two MFMAs
-// whose columns are the even and the odd epochs of a group of 32 -- and therefore also OWNS two adjacent epochs of four result rows: it
-// stores 16 bytes.  Degrees 0 and 1 keep the input (filter.py:189).
+// Y_s [n x Bpad] = W_s [n x n] X_s [n x Bpad], one workgroup per (slot s, slice of 32 EG epochs); wave w takes the row tiles w, w + 4, ...
+// (a pass of four row tiles at a time).  The K loop is a pipeline over chunks of kOmChunk rows of the slice: the chunk in use sits in one of
+// two LDS buffers, the next one in registers (written to the other buffer behind the products), the one after that is in flight -- and so
+// are the block entries of those chunks (one 16-byte range-checked buffer load per lane and step of eight columns).  The barrier of the
+// pipeline waits for the LDS only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads would drain the loads in flight.
+// History of this kernel (kernel time per 240 epochs at d/o 120; 66 MB of algorithmic traffic = 8 us of HBM time, 9 us of MFMA time):
+//   round 5: one workgroup per (slot, row tile), rows of X from L2 inside the K loop, three steps in flight                       30 us
+//   round 6: the slice of X staged in the LDS at once, then all products -- whatever the staging (4 or 16 loads in flight), the
+//            window of block entries (4 steps or a whole row tile) or the slice width (32 | 64 epochs)                            27-29 us
+//            (every workgroup of a round stages at the same time -- 32 MB in one burst, nothing computes --, then every workgroup computes
+//            and the HBM idles: SQ counters show the MFMA pipe busy 33 % of the time, the waves waiting half of theirs)
+//   this form: loads and products of a workgroup overlap, workgroups in different phases share a CU                                25.8 us
+//            (32 epochs per workgroup, three waves per SIMD; 64 epochs at two waves per SIMD 28.5, 32 epochs at four 29.5)
+// Knock-outs of this form (SHG_OM_X): without the products 15.3 us, without the loads of X 23.5, without the block entries 24.5: the
+// kernel takes the SUM of its memory time (66 MB at 4.3 TB/s) and its MFMA time (338 000 MFMAs = 9 us on 1024 SIMDs), not their maximum.
+// The products and their order are those of orderwise_filter_kernel, the results bit-identical: step c multiplies W[row][c + 2 fk],
+// W[row][c + 2 fk + 1] with the rows c + 2 fk, c + 2 fk + 1 of X in two MFMAs per 16 epochs, the two partial sums are added at the end.  A
+// lane reads two adjacent epochs (16 bytes) of a row of X -- the B operands of two MFMAs whose columns are the even and the odd epochs of
+// a group of 32 -- and therefore also OWNS two adjacent epochs of four result rows: it stores 16 bytes.  Degrees 0 and 1 keep the input
+// (filter.py:189).
 // Workgroup b runs on XCD b % 8: all slices of a slot go to one XCD (they share the slot's block in its L2), the slots -- by decreasing
 // length, i.e. in their own order -- in a snake over the XCDs so that every XCD gets about the same arithmetic, the long ones first.
-// Slots whose rows do not fit the stage (kc rows) re-stage chunk by chunk for every pass of four row tiles.
-constexpr int kOmSteps = 16;           // steps of 8 columns whose block entries a wave requests at once: a whole row tile up to d/o 127
+#ifndef SHG_OM_X
+#define SHG_OM_X 0      // experiment switches (timing only, wrong results): 1 no products, 2 no stores, 4 no loads of X, 8 no loads of block entries
+#endif
+constexpr int kOmChunk = 32;           // rows of the slice per pipeline stage = four steps of eight columns
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifndef SHG_OM_WAVES_PER_EU
+#define SHG_OM_WAVES_PER_EU 3
+#endif
 template <int EG>
-__global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N, int Bpad, int nslice, int kc, const double* __restrict__ blocks,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHG_OM_WAVES_PER_EU, SHG_OM_WAVES_PER_EU))) void orderwise_filter_om_kernel(int Nb, int N, int Bpad, int nslice, const double* __restrict__ blocks,
                                                                   const long long* __restrict__ block_off, const double* __restrict__ in,
                                                                   double* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) double2_t om_stage[];      // [kc rows][16 EG pairs of epochs]
     constexpr int PR = 16 * EG;                                                 // double2 per staged row
+    constexpr int RPP = 256 / PR;                                               // rows per pass of the loader threads
+    constexpr int NLD = kOmChunk / RPP;                                         // loads of a thread per chunk
+    constexpr int NST = kOmChunk / 8;                                           // steps per chunk
+    __shared__ __attribute__((aligned(16))) double2_t om_stage[2][kOmChunk * PR];
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
     const int rank = seq / nslice, slice = seq % nslice;
     const int s = 8 * rank + ((rank & 1) ? 7 - xcd : xcd);
@@ -389,79 +409,88 @@ __global__ __launch_bounds__(256) void orderwise_filter_om_kernel(int Nb, int N,
     double2_t* Y = reinterpret_cast<double2_t*>(out + row_first * Bpad) + p0;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(blocks), 0, (int)((block_off[2 * Nb] + 1) * 8), 0x00020000);
     const int Kpad = (n + 7) & ~7, ntile = (n + 15) >> 4;
-    const bool resident = Kpad <= kc;                                           // the whole slice fits the stage: staged once
+    const int nchunk = (Kpad + kOmChunk - 1) / kOmChunk;
     const double2_t zero2 = {0.0, 0.0};
-    // rows [k0, k0 + rows) of the slice -> stage; rows beyond the block and pairs beyond the series are zero
-    auto stage = [&](int k0, int rows) {
-        constexpr int RPP = 256 / PR;                                           // rows per pass of the workgroup
-        constexpr int UN = 16;                                                  // loads of a thread in flight: ALL rows of a d/o-120 slice at once
-        const int j = tid % PR, r_in = tid / PR;                                // (a staging loop of four loads at a time was four memory
-        for (int r = r_in; r < rows; r += UN * RPP) {                           //  round trips in a row: 10 us for the longest slots)
-            double2_t v[UN];
+    const int lj = tid % PR, lr = tid / PR;                                     // loader: pair lj of the rows lr, lr + RPP, ...
+    const bool pair_ok = lj < npair;
+    struct Chunk {
+        double2_t x[NLD];                   // this thread's part of the chunk's rows of X
+        double2_t a[NST];                   // this lane's block entries of the chunk's steps
+    };
+    for (int t0 = 0; t0 < ntile; t0 += 4) {
+        // (the tiles of a pass go to the waves in an order that turns with the workgroup: wave w of every workgroup runs on SIMD w, and a slot of 5 row
+        //  tiles has 2, 1, 1, 1 of them for its four waves -- unturned, SIMD 0 carried 1.25 times the average and SIMD 3 0.7 times)
+        const int tile = t0 + ((wave + rank + slice) & 3);
+        const bool active = tile < ntile;
+        const int r0 = 16 * min(tile, ntile - 1);                               // (idle waves load the last tile's entries: the same count of loads in every wave)
+        const unsigned voff = (unsigned)(block_off[s] * 8) + (unsigned)((min(r0 + fr, n - 1) * ld + 2 * fk) * 8);
+        auto fetch = [&](Chunk& c, int j) {                                     // (beyond the packed blocks the range check returns 0; rows beyond the block are zero)
+            const int k0 = j * kOmChunk;
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int k = k0 + r + u * RPP;
-                v[u] = (r + u * RPP < rows && k < n && j < npair) ? X[(size_t)k * ldx + j] : zero2;
+            for (int u = 0; u < NLD; ++u) {
+                const int k = k0 + lr + u * RPP;
+                c.x[u] = (k < n && pair_ok && !(SHG_OM_X & 4)) ? X[(size_t)k * ldx + lj] : zero2;
             }
 #pragma unroll
-            for (int u = 0; u < UN; ++u)
-                if (r + u * RPP < rows) om_stage[(r + u * RPP) * PR + j] = v[u];
-        }
-    };
-    if (resident) {
-        stage(0, Kpad);
-        __syncthreads();
-    }
-    for (int t0 = 0; t0 < ntile; t0 += 4) {
-        const int tile = t0 + wave;
-        const bool active = tile < ntile;
-        const int r0 = 16 * tile;
-        const unsigned voff = (unsigned)(block_off[s] * 8) + (unsigned)((min(r0 + fr, n - 1) * ld + 2 * fk) * 8);
-        auto load_a = [&](int c) { return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff + (unsigned)c * 8u, 0, 0)); };
+            for (int d = 0; d < NST; ++d)
+                c.a[d] = (SHG_OM_X & 8) ? (double2_t){1.0, 1.0} : __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff + (unsigned)(k0 + 8 * d) * 8u, 0, 0));
+        };
+        auto stage = [&](const Chunk& c, int buf) {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) om_stage[buf][(lr + u * RPP) * PR + lj] = c.x[u];
+        };
         double4_t acc[EG][2][2];
 #pragma unroll
         for (int q = 0; q < EG; ++q) acc[q][0][0] = acc[q][0][1] = acc[q][1][0] = acc[q][1][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < Kpad; k0 += kc) {
-            const int kend = min(k0 + kc, Kpad);
-            if (!resident) {
-                __syncthreads();
-                stage(k0, kend - k0);
-                __syncthreads();
-            }
-            if (active) {
-                // ALL block entries of this row tile for up to 128 columns are requested at once (16 loads of 16 bytes per lane): one memory
-                // round trip per row tile, where a window of four steps in flight was one round trip per step (the blocks come from HBM and
-                // a step is 0.2 us of MFMAs)
-                for (int k1 = k0; k1 < kend; k1 += 8 * kOmSteps) {
-                    double2_t a[kOmSteps];
+        auto products = [&](const double2_t (&a)[NST], int j, int buf) {
+            const int steps = min(NST, (Kpad - j * kOmChunk) / 8);
 #pragma unroll
-                    for (int d = 0; d < kOmSteps; ++d) a[d] = k1 + 8 * d < kend ? load_a(k1 + 8 * d) : zero2;       // (beyond the packed blocks the range check returns 0)
+            for (int d = 0; d < NST; ++d) {
+                if (d < steps) {
+                    const double2_t* xr = om_stage[buf] + (8 * d + 2 * fk) * PR + fr;
 #pragma unroll
-                    for (int d = 0; d < kOmSteps; ++d) {
-                        const int cc = k1 + 8 * d;
-                        if (cc < kend) {
-                            const double2_t* xr = om_stage + (cc - k0 + 2 * fk) * PR + fr;
-#pragma unroll
-                            for (int q = 0; q < EG; ++q) {
-                                const double2_t x0 = xr[16 * q], x1 = xr[PR + 16 * q];
-                                acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].x, x0.x, acc[q][0][0], 0, 0, 0);      // even epochs, k-step 0
-                                acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].x, x0.y, acc[q][1][0], 0, 0, 0);      // odd epochs
-                                acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].y, x1.x, acc[q][0][1], 0, 0, 0);      // k-step 1
-                                acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].y, x1.y, acc[q][1][1], 0, 0, 0);
-                            }
-                        }
+                    for (int q = 0; q < EG; ++q) {
+                        const double2_t x0 = xr[16 * q], x1 = xr[PR + 16 * q];
+                        acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].x, x0.x, acc[q][0][0], 0, 0, 0);      // even epochs, k-step 0
+                        acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].x, x0.y, acc[q][1][0], 0, 0, 0);      // odd epochs
+                        acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].y, x1.x, acc[q][0][1], 0, 0, 0);      // k-step 1
+                        acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d].y, x1.y, acc[q][1][1], 0, 0, 0);
                     }
                 }
             }
+        };
+        // chunk j sits in stage j & 1, its block entries in `cur_a`; `next` holds chunk j + 1, `after` takes chunk j + 2
+        double2_t cur_a[NST];
+        auto step = [&](int j, Chunk& next, Chunk& after) {
+            if (j + 2 < nchunk) fetch(after, j + 2);
+            if (active && !(SHG_OM_X & 1)) products(cur_a, j, j & 1);
+            if (j + 1 < nchunk) {
+                stage(next, (j & 1) ^ 1);
+#pragma unroll
+                for (int d = 0; d < NST; ++d) cur_a[d] = next.a[d];
+            }
+            lds_barrier();
+        };
+        Chunk ca, cb;
+        fetch(ca, 0);
+        if (nchunk > 1) fetch(cb, 1);
+        lds_barrier();                               // (a second pass: every wave is done with the stages of the first)
+        stage(ca, 0);
+#pragma unroll
+        for (int d = 0; d < NST; ++d) cur_a[d] = ca.a[d];
+        lds_barrier();
+        for (int j = 0; j < nchunk; j += 2) {
+            step(j, cb, ca);                         // chunk j + 1 is in cb, chunk j + 2 goes to ca
+            if (j + 1 < nchunk) step(j + 1, ca, cb);
         }
-        if (active) {
+        if (active && !(SHG_OM_X & 2)) {
 #pragma unroll
             for (int q = 0; q < EG; ++q) {
                 if (16 * q < npair) {
                     const double4_t even = acc[q][0][0] + acc[q][0][1], odd = acc[q][1][0] + acc[q][1][1];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = r0 + fk + 4 * r;                            // C/D layout: row = fk + 4 reg, column = fr
+                        const int row = 16 * tile + fk + 4 * r;                     // C/D layout: row = fk + 4 reg, column = fr
                         if (row < n) {
                             const size_t at = (size_t)row * ldx + 16 * q + fr;
                             Y[at] = m + row > 1 ? (double2_t){even[r], odd[r]} : X[at];
@@ -534,15 +563,9 @@ extern "C" int shg_orderwise_filter_om(const double* blocks_packed, const int64_
     SHG_REQUIRE(blocks_packed && block_off && om_in && om_out, "shg_orderwise_filter_om: NULL pointer");
     SHG_REQUIRE(om_in != om_out, "shg_orderwise_filter_om: in-place operation is not supported");
     hipStream_t stream = (hipStream_t)stream_;
-    // slices of 32 EG epochs; the stage holds all rows of the longest slot when that fits (kOmStageMaxBytes), else chunks of kc rows
-    constexpr int EG = SHG_OM_EPOCH_GROUPS;
-    constexpr size_t kOmStageMaxBytes = 144 * 1024;
-    const int row_bytes = 32 * EG * (int)sizeof(double);
-    const int kc = std::min(round_up(N + 1, 8), (int)(kOmStageMaxBytes / row_bytes) / 8 * 8);
-    const size_t lds = (size_t)kc * row_bytes;
+    constexpr int EG = SHG_OM_EPOCH_GROUPS;            // slices of 32 EG epochs
     const int nslice = ceil_div(Bpad, 32 * EG);
-    if (lds > 64 * 1024) SHG_SET_LDS_ONCE(shg::orderwise_filter_om_kernel<EG>, kOmStageMaxBytes);
-    hipLaunchKernelGGL(shg::orderwise_filter_om_kernel<EG>, dim3((unsigned)(8 * ceil_div(2 * N + 1, 8) * nslice)), dim3(256), lds, stream, Nb, N, Bpad, nslice, kc,
+    hipLaunchKernelGGL(shg::orderwise_filter_om_kernel<EG>, dim3((unsigned)(8 * ceil_div(2 * N + 1, 8) * nslice)), dim3(256), 0, stream, Nb, N, Bpad, nslice,
                        blocks_packed, (const long long*)block_off, om_in, om_out);
     SHG_HIP(hipGetLastError());
     return SHG_OK;
