@@ -61,6 +61,7 @@ KERNEL = 'ewh'
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 COV_DEGREE = 180
 COV_GRID_STEP = 0.5
+ANALYSIS_KERNELS = ['analysis_transform_kernel', 'analysis_operator_parity_kernel']
 BLOCK_FORM_KERNELS = ['order_major_kernel<true>', 'orderwise_filter_om_kernel', 'order_major_kernel<false>']      # of the filters leg's block form
 MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (spec); measured 77.3 TFLOP/s (profiles/r01_microbench.txt)
 GM, R_EARTH = 3.9860044150e+14, 6.3781363000e+06
@@ -80,6 +81,7 @@ def parse_args(argv=None):
     ap.add_argument('--ramp', type=int, default=300, help='untimed launches before the second measurement of the headline (device clock ramp)')
     ap.add_argument('--idle-pass', type=int, default=1, help='1: also time the contract pass straight behind the idle setup (roofline.value_idle_start)')
     ap.add_argument('--stage-limit-pass', type=int, default=1, help='1: also time the headline with the Legendre-stage limit on (roofline.value_stage_limit_on)')
+    ap.add_argument('--api-chain', type=int, default=1, help='1: also time filter(TimeSeries) -> to_grid through the classes (roofline.api_chain_solutions_per_s)')
     ap.add_argument('--epochs', type=int, default=EPOCHS, help='epochs per GPU per step (default: BASELINE config 2)')
     ap.add_argument('--chunk', type=int, default=0, help='epochs per internal pass of the staged path (0 = library default)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='seconds after which `--gpus N` run without a launcher kills its ranks (0 = never)')
@@ -248,6 +250,38 @@ class GpuWorkload:
     def set_stage_limit(self, limit):
         self.plan.set_stage_limit(limit)
 
+    def api_chain(self, ctx):
+        """The same 240 x d/o 96 -> 0.25 degree workload through the reference's CLASSES on a device-resident series:
+        filter.OrderWiseFilter.filter(TimeSeries) (DDK5-type blocks of d/o 96) -> TimeSeries.to_grid(grid, 'ewh', as_tensor=True); the
+        coefficients never pass through host arrays (round 5: the class API moved every epoch over PCIe, <= 7.5 k solutions/s)."""
+        import datetime
+        import numpy as np
+        ga, args = self.ga, self.args
+        B = args.epochs
+        weights = DDK_LEVEL_SCALE * np.arange(MAX_DEGREE + 1, dtype=float) ** 4
+        weights[0] = 1
+        flt = ga.filter.OrderWiseFilter(ga.engine.ddk_blocks(orderwise_normal_blocks(44, MAX_DEGREE), weights))
+        epochs = [datetime.datetime(2002, 4, 1) + datetime.timedelta(days=30 * e) for e in range(B)]
+        ts = ga.gravityfield.TimeSeries.from_series(self.batch, epochs, GM, R_EARTH)
+        state = {}
+
+        def step():
+            state['grids'] = flt.filter(ts).to_grid(self.grid, KERNEL, as_tensor=True)
+        step()
+        elapsed, _, step_ms = ctx.timed(step, max(args.warmup // 2, 1), max(args.steps // 2, 1), events=True)
+        steps = max(args.steps // 2, 1)
+        # one epoch against the per-epoch calls of the same classes (bit-identical by construction: tests/test_gpu_filters.py)
+        e = B // 2
+        gf = ga.gravityfield.PotentialCoefficients(GM, R_EARTH)
+        gf.anm = self.batch_host[e].copy()
+        single = flt.filter(gf).to_grid(self.grid, kernel=KERNEL).value_array
+        same = bool(np.array_equal(state['grids'][e].cpu().numpy(), single))
+        del state['grids']
+        self.torch.cuda.empty_cache()
+        return {'what': 'OrderWiseFilter.filter(TimeSeries) -> TimeSeries.to_grid(as_tensor=True) on the device-resident series, {0} epochs d/o {1} -> {2} deg'.format(B, MAX_DEGREE, GRID_STEP),
+                'solutions_per_s': ctx.world * B * steps / elapsed, 'ms_per_step': 1e3 * elapsed / steps, 'gpu_ms_per_step': step_ms,
+                'bit_identical_to_per_epoch_calls': same}
+
     def profile(self, enable):
         # events around the dominant kernel only: the pair around the 16 us coefficient repack would cost every step another ~5 us
         self.plan.profile(enable, kinds=('lon_stage',) if self.plan.info()['fused'] else None)
@@ -367,13 +401,12 @@ class GpuWorkload:
             'ms_per_step': 1e3 * elapsed / args.steps, 'dtype': 'f64',
             'config': {'workload': '{0} epochs per GPU, grids resident in HBM, kernel {1}, min_degree 0'.format(B, KERNEL), 'max_degree': N,
                        'grid': [nlat, nlon], 'epochs_per_gpu': B},
-            'roofline': {'kernel': 'analysis_transform_kernel + analysis_operator_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'roofline': {'kernel': 'analysis_transform_kernel + analysis_operator_parity_kernel (north-south parity split of the operator product)', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None,
-                         'traffic': pmc_traffic('analysis', ['analysis_transform_kernel', 'analysis_operator_kernel'])[0],
-                         'traffic_source': pmc_traffic('analysis', ['analysis_transform_kernel', 'analysis_operator_kernel'])[1],
+                         'traffic': pmc_traffic('analysis', ANALYSIS_KERNELS)[0], 'traffic_source': pmc_traffic('analysis', ANALYSIS_KERNELS)[1],
                          'algorithmic_bytes_per_launch': per_epoch * B, 'avg_launch_ms': per_call_ms,
                          'kernels': {'analysis_transform_kernel': {'avg_us': 1e3 * k_lon[0] / max(k_lon[1], 1), 'launches': int(k_lon[1])},
-                                     'analysis_operator_kernel': {'avg_us': 1e3 * k_solve[0] / max(k_solve[1], 1), 'launches': int(k_solve[1])}},
+                                     'analysis_operator_parity_kernel': {'avg_us': 1e3 * k_solve[0] / max(k_solve[1], 1), 'launches': int(k_solve[1])}},
                          'mfma_floor_ms': mfma_flops / (MFMA_F64_PEAK_TFLOPS * 1e12) * 1e3},
             'check': {'roundtrip_max_rel_err': roundtrip, 'tolerance': 1e-11, 'ok': bool(roundtrip < 1e-11),
                       'what': 'coefficients of the timed output buffer against the band-limited input of all {0} epochs'.format(B)},
@@ -686,28 +719,44 @@ def pmc_traffic(leg, kernels):
     """HBM-side bytes per launch of the named kernels of a leg (summed) from the committed rocprofv3 --pmc summary of the same workload
     (profiles/r04_pmc_traffic.json, tools/pmc_legs.sh), with its origin: counters cannot be collected inside a timed run.  A kernel
     name matches when the recorded name starts with it.  -> (bytes or None, source or None)"""
-    table = rows = None
-    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json'):          # the newest summary that holds the leg
+    table = rows = summary = None
+    for name in PMC_TRAFFIC_SUMMARIES:                                      # the newest summary that holds the leg
         path = os.path.join(ROOT, 'profiles', name)
         try:
             with open(path) as f:
                 table = json.load(f)
-            rows = table['legs'][leg]
+            rows, summary = table['legs'][leg], name
             break
         except Exception:
             rows = None
     if rows is None:
         return None, None
+    # counter figures are quoted only while the kernel sources they were measured on are unchanged (hashes recorded in the summary)
+    if not _source_hashes().unchanged(_get(table, 'sources', leg), leg):
+        return None, 'profiles/{0}: the kernel sources of this leg have changed since these counters were collected (build of {1}): not quoted'.format(
+            summary, table.get('commit', 'unrecorded'))
     total, found = 0.0, []
     for want in kernels:
-        hit = [(name, r) for name, r in rows.items() if name.startswith(want)]
+        hit = [(kname, r) for kname, r in rows.items() if kname.startswith(want)]
         if not hit:
             return None, None
-        name, r = max(hit, key=lambda kv: kv[1]['dispatches'])
+        kname, r = max(hit, key=lambda kv: kv[1]['dispatches'])
         total += r['bytes']
-        found.append(name.split('<')[0])
-    return total, 'profiles/' + name + ' ({0}; {1}; build of {2}): {3}'.format(table.get('source', ''), table.get('correction', ''),
-                                                                                  table.get('commit', 'round 4'), ' + '.join(found))
+        found.append(kname.split('<')[0])
+    return total, 'profiles/' + summary + ' ({0}; {1}; build of {2}): {3}'.format(table.get('source', ''), table.get('correction', ''),
+                                                                                     table.get('commit', 'unrecorded'), ' + '.join(found))
+
+
+PMC_TRAFFIC_SUMMARIES = ('r06_pmc_traffic.json',)
+PMC_BUSY_SUMMARIES = ('r06_mfma_busy.json',)
+
+
+def _source_hashes():
+    tools = os.path.join(ROOT, 'tools')
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import source_hashes
+    return source_hashes
 
 
 def _get(d, *path):
@@ -845,10 +894,13 @@ def compact_line(line, limit=LINE_LIMIT):
 def pmc_mfma_busy(leg):
     """MFMA-busy share of a leg's dominant kernel from the committed SQ counter summary (tools/pmc_summary.sh, tools/pmc_mfma_busy.py):
     counters cannot be collected inside a timed run.  -> fraction or None"""
-    for name in ('r05_mfma_busy.json',):
+    for name in PMC_BUSY_SUMMARIES:
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
-                return float(json.load(f)['kernels'][leg]['mfma_busy'])
+                table = json.load(f)
+            if not _source_hashes().unchanged(_get(table, 'sources', leg), leg):
+                return None                                                  # stale: the kernel has changed since the counter pass
+            return float(table['kernels'][leg]['mfma_busy'])
         except Exception:
             pass
     return None
@@ -1020,6 +1072,7 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
         barrier()
         limit_elapsed, limit_prof = timed_steps(args.warmup, args.steps)
         wl.set_stage_limit(0)
+    chain = wl.api_chain(ctx) if args.api_chain and hasattr(wl, 'api_chain') else None
 
     line = None
     if rank == 0:
@@ -1081,7 +1134,10 @@ def run_rank(args, workload_factory=GpuWorkload, emit=print):
                 # the same steady state as `after_ramp`, with at most 7/16 of the CUs in their Legendre stage at once (the knob is OFF in `value`)
                 'value_stage_limit_on': (world * B * args.steps / limit_elapsed) if limit_elapsed else None,
                 'avg_launch_ms_stage_limit_on': limit_avg_ms,
+                'api_chain_solutions_per_s': chain['solutions_per_s'] if chain else None,
+                'api_chain_bit_identical': chain['bit_identical_to_per_epoch_calls'] if chain else None,
             },
+            'api_chain': chain,
             'kernels': kernels,
         }
         sample = min(args.cpu_sample, B) if world == 1 else min(args.cpu_sample, 1)

@@ -44,11 +44,9 @@ def main(out, tag):
                           'fetch_bytes_raw': fetch_kb * 1024.0, 'fetch_bytes_doubled': fetch_kb * 2048.0, 'write_bytes': write_kb * 1024.0,
                           'fetch_factor': factor, 'bytes': fetch_kb * 1024.0 * factor + write_kb * 1024.0}
         table[leg] = rows
-    try:
-        commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
-    except Exception:
-        commit = ''
-    summary = {'commit': commit or 'the tree the passes ran on (no git on the GPU box)', 'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes per leg (tools/pmc_legs.sh), averages per dispatch',
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import source_hashes
+    summary = {'commit': source_hashes.commit(), 'sources': {leg: source_hashes.leg_hashes(leg) for leg in legs}, 'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes per leg (tools/pmc_legs.sh), averages per dispatch',
                'correction': 'counters in KB; fetch doubled (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes for wide coalesced reads) except for the '
                              'kernels that gather 8-byte elements (fetch_factor 1, calibrated on their known byte counts); WRITE_SIZE as counted; '
                              'Infinity-Cache hits are counted',

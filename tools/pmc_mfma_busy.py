@@ -7,7 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 kernels = {'synthesis': ('synthesis_pmc', 'synthesis_rot_kernel'), 'covariance': ('covprop_pmc', 'gemm_f64_kernel<MODE_COVPROP>'),
            'filters_block': ('filters_block_pmc', 'orderwise_filter_om_kernel'), 'filters_dense': ('filters_dense_pmc', 'gemm_tall_kernel (shg_dense_filter)')}
-out = {'source': 'rocprofv3 --pmc, one pass per counter group beside --kernel-trace only (tools/pmc_summary.sh), per-dispatch averages', 'kernels': {}}
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import source_hashes
+out = {'commit': source_hashes.commit(), 'sources': {leg: source_hashes.leg_hashes(leg) for leg in ('synthesis', 'covariance', 'filters_block', 'filters_dense')},
+       'source': 'rocprofv3 --pmc, one pass per counter group beside --kernel-trace only (tools/pmc_summary.sh), per-dispatch averages', 'kernels': {}}
 for leg, (stem, kernel) in kernels.items():
     path = os.path.join(ROOT, 'profiles', '{0}_{1}.txt'.format(tag, stem))
     if not os.path.exists(path):
