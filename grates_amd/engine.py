@@ -302,6 +302,28 @@ def cached_plan(max_degree, colat, kn, meridians):
     return plan
 
 
+_grid_plan_cache = {}
+
+
+def plan_by_grid(scalars, axes, build):
+    """The plan of a regular grid found by what defines it -- kernel name, degree, constants (`scalars`, hashable) and the two axes
+    (`axes`: parallels, meridians; hashed: 17 KB on the 0.25 degree grid) -- without building the kernel table first; `build()` makes
+    the plan on a miss.  Least recently used of _PLAN_CACHE_LIMIT entries goes first."""
+    torch = require_gpu()
+    h = hashlib.blake2b(digest_size=16)
+    h.update(repr((scalars, torch.cuda.current_device())).encode())
+    for a in axes:
+        h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    key = h.hexdigest()
+    plan = _grid_plan_cache.pop(key, None)
+    if plan is None:
+        if len(_grid_plan_cache) >= _PLAN_CACHE_LIMIT:
+            _grid_plan_cache.pop(next(iter(_grid_plan_cache)))
+        plan = build()
+    _grid_plan_cache[key] = plan
+    return plan
+
+
 _table_cache = {}
 
 

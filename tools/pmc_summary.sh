@@ -2,7 +2,7 @@
 # SQ / TCP / TCC counters of the two headline kernels, one rocprofv3 --pmc pass per counter group (never combined with a trace
 # domain other than --kernel-trace).  Run on a GPU box from the repository root:
 #   tools/pmc_summary.sh r05        -> gpurun_out/r05_synthesis_pmc.txt, r05_covprop_pmc.txt, r05_filters_block_pmc.txt, r05_filters_dense_pmc.txt
-tag=${1:-r05}
+tag=${1:-r06}
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -37,9 +37,11 @@ for c, v in sorted(agg.items()):
 PY
   done
 }
-run_group ${tag}_synthesis_pmc synthesis_rot_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs synthesis --cpu-sample 0 --steps 20 --warmup 5 --ramp 50 --idle-pass 0
+run_group ${tag}_synthesis_pmc synthesis_rot_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs synthesis --cpu-sample 0 --steps 20 --warmup 5 --ramp 50 --idle-pass 0 --api-chain 0 --stage-limit-pass 0
 run_group ${tag}_covprop_pmc gemm_f64_kernel python3 $GRAFT_REPO_ROOT/tools/gemm_phases.py --release-library 24
-run_group ${tag}_filters_block_pmc orderwise_filter_om_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs filters --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0
+run_group ${tag}_filters_block_pmc orderwise_filter_om_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs filters --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0 --api-chain 0 --stage-limit-pass 0
+run_group ${tag}_analysis_transform_pmc analysis_transform_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs analysis --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0 --api-chain 0 --stage-limit-pass 0
+run_group ${tag}_analysis_operator_pmc analysis_operator_parity_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs analysis --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0 --api-chain 0 --stage-limit-pass 0
 cp $out/${tag}_filters_block_pmc.txt $out/${tag}_filters_tmp.txt
-run_group ${tag}_filters_dense_pmc gemm_tall_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs filters --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0
+run_group ${tag}_filters_dense_pmc gemm_tall_kernel python3 $GRAFT_REPO_ROOT/bench.py --legs filters --cpu-sample 0 --steps 10 --warmup 2 --ramp 0 --idle-pass 0 --api-chain 0 --stage-limit-pass 0
 rm -f $out/${tag}_filters_tmp.txt
