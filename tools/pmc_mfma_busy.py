@@ -4,12 +4,13 @@ kernel's duration in shader cycles), the MFMA counter over the 1024 SIMDs (64 cy
     python3 tools/pmc_mfma_busy.py r05"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 kernels = {'synthesis': ('synthesis_pmc', 'synthesis_rot_kernel'), 'covariance': ('covprop_pmc', 'gemm_f64_kernel<MODE_COVPROP>'),
-           'filters_block': ('filters_block_pmc', 'orderwise_filter_om_kernel'), 'filters_dense': ('filters_dense_pmc', 'gemm_tall_kernel (shg_dense_filter)')}
+           'filters_block': ('filters_block_pmc', 'orderwise_filter_om_kernel'), 'filters_dense': ('filters_dense_pmc', 'gemm_tall_kernel (shg_dense_filter)'),
+           'analysis': ('analysis_transform_pmc', 'analysis_transform_kernel'), 'analysis_operator': ('analysis_operator_pmc', 'analysis_operator_parity_kernel')}
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import source_hashes
-out = {'commit': source_hashes.commit(), 'sources': {leg: source_hashes.leg_hashes(leg) for leg in ('synthesis', 'covariance', 'filters_block', 'filters_dense')},
+out = {'commit': source_hashes.commit(), 'sources': {leg: source_hashes.leg_hashes(leg) for leg in ('synthesis', 'covariance', 'filters_block', 'filters_dense', 'analysis')},
        'source': 'rocprofv3 --pmc, one pass per counter group beside --kernel-trace only (tools/pmc_summary.sh), per-dispatch averages', 'kernels': {}}
 for leg, (stem, kernel) in kernels.items():
     path = os.path.join(ROOT, 'profiles', '{0}_{1}.txt'.format(tag, stem))
