@@ -181,6 +181,26 @@ def test_config3_ddk5_time_series_d120():
     assert relerr(out_dense, out_blocks) < 1e-12
 
 
+def test_order_major_layout_above_degree_510():
+    """Degrees from 511 on: the row stage of the layout kernels (16 epochs x (N + 2) doubles) exceeds the 64 KB a launch gets without the
+    opt-in attribute.  Round 5 launched it regardless, and shg_orderwise_filter -- which takes the order-major kernels for 64 epochs and
+    more -- returned the launch error instead of falling back (advisor, round 5).  Pack / unpack round trip, the filter through both
+    layouts (blocks 0.5 I: every coefficient of degree >= 2 halved, degrees 0 and 1 kept), ragged epoch count."""
+    import torch
+    N, B = 520, 70
+    rng = np.random.default_rng(520)
+    batch = torch.from_numpy(rng.standard_normal((B, N + 1, N + 1))).cuda()
+    series = ga.engine.OrderMajorSeries.from_batch(batch)
+    assert series.padded_epochs == 96 and torch.equal(series.to_batch(), batch)
+    flt = ga.filter.OrderWiseFilter([0.5 * np.eye(N + 1)] + [0.5 * np.eye(N + 1 - m) for m in range(1, N + 1) for _ in (0, 1)])
+    out = flt.filter_batch(batch)                                 # 70 epochs: pack -> products -> unpack
+    small = flt.filter_batch(batch[0:3])                          # 3 epochs: the kernel on the reference layout
+    want = 0.5 * batch
+    want[:, 0:2, 0:2] = batch[:, 0:2, 0:2]
+    assert torch.equal(out, want) and torch.equal(small, want[0:3])
+    assert torch.equal(flt.filter_series(series).to_batch(), want)
+
+
 def _series(count, max_degree, seed=700):
     import datetime as dt
     fields = []
