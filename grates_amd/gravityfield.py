@@ -428,17 +428,24 @@ class TimeSeries:
     def __add__(self, other):
         if len(self) != len(other):
             raise ValueError("Length of time series differs")
+        if isinstance(other, TimeSeries) and self.__series is not None and other.__series is not None and \
+                self.__series.max_degree == other.__series.max_degree and self._constants() == other._constants():
+            # both on the device, same degree and constants (the reference's rescaling factor (R2 / R1)^n GM2 / GM1 is exactly 1): one sum
+            if self.epochs() != other.epochs():
+                raise ValueError("Time stamps of elements differ")
+            return self._with_series(self.__series.like(self.__series.data + other.__series.data))
         mine = self._fields(keep_series=True)
+        theirs = other._fields(keep_series=True) if isinstance(other, TimeSeries) else other      # (no field leaves either series)
         summed = []
         for k in range(len(self)):
-            if mine[k].epoch != other[k].epoch:
+            if mine[k].epoch != theirs[k].epoch:
                 raise ValueError("Time stamps of elements differ")
-            summed.append(mine[k] + other[k])
+            summed.append(mine[k] + theirs[k])
         return TimeSeries(summed)
 
     def __mul__(self, factor):
         _check_operand(self, factor, (int, float), '*')
-        if self.__data is None:
+        if self.__series is not None:
             return self._with_series(self.__series.like(self.__series.data * factor))
         return TimeSeries([d.copy() * factor for d in self.__data])
 

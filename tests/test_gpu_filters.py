@@ -274,6 +274,9 @@ def test_device_resident_time_series_bookkeeping(golden):
     assert np.array_equal(dev.to_coefficient_batch(), ts.to_coefficient_batch())
     assert np.array_equal((dev * 2.5).to_array(), (ts * 2.5).to_array())
     assert np.array_equal(dev.copy().to_array(), host_array) and dev.on_device
+    both = dev + dev * 0.5
+    assert both.on_device and np.array_equal(both.to_array(), (ts + ts * 0.5).to_array())
+    assert np.array_equal((dev - dev).to_array(), np.zeros_like(host_array)) and dev.on_device
     basis = [ga.utilities.Polynomial(1, ts.epochs()[0])] if hasattr(ga.utilities, 'Polynomial') else None
     if basis is not None:
         a, b = ts.copy(), dev.copy()
