@@ -59,7 +59,10 @@ class SpatialFilter(metaclass=abc.ABCMeta):
 
     def _filter_timeseries(self, series):
         """`filter(TimeSeries)`: the series is filtered on the device, all epochs in one call, and stays there (extension of the
-        reference's `filter`, which takes one PotentialCoefficients: grates/filter.py:44-72, 153-191, 456-479)."""
+        reference's `filter`, which takes one PotentialCoefficients: grates/filter.py:44-72, 153-191, 456-479).  A series of fields of
+        different degrees is filtered field by field, as the reference's call would (every result keeps its field's degree)."""
+        if not series.uniform_degree:
+            return TimeSeries([self.filter(field) for _, field in series.items()])
         return series._with_series(self.filter_series(series.to_device()))
 
 

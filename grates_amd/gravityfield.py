@@ -384,6 +384,12 @@ class TimeSeries:
     def on_device(self):
         return self.__series is not None
 
+    @property
+    def uniform_degree(self):
+        """whether all fields have one maximum degree (a device series pads lower ones with zeros: fine for `to_grid`, but a filter with
+        dense blocks would fill the padding, where the per-field call of the reference keeps every field's own degree)"""
+        return self.__data is None or len({d.max_degree for d in self.__data}) == 1
+
     def to_device(self):
         """The series as engine.OrderMajorSeries (built on first use; PotentialCoefficients of one GM and R only, fields of a lower
         degree zero-padded).  Stays valid until fields are handed out."""

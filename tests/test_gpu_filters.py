@@ -261,6 +261,11 @@ def test_device_resident_time_series_chain(golden):
         assert np.array_equal(d_series[e][0:4], ts20.to_array()[e][0:4])                # degrees 0 and 1 restored
     with pytest.raises(TypeError):
         flt.filter(np.zeros((3, 3)))
+    # fields of different degrees: filtered field by field like the reference's call (a padded series would fill the padding)
+    mixed = ga.gravityfield.TimeSeries([_series(1, 12, seed=960)[0], _series(2, 20, seed=961)[1]])
+    out = ga.filter.OrderWiseFilter(blocks20).filter(mixed)
+    assert not mixed.uniform_degree and [f.max_degree for _, f in out.items()] == [12, 20]
+    assert np.array_equal(out[0].anm, ga.filter.OrderWiseFilter(blocks20).filter(mixed[0]).anm)
 
 
 def test_device_resident_time_series_bookkeeping(golden):
